@@ -1,0 +1,97 @@
+/*
+ * tma.h -- C ABI of libtma_hip.so: the MI355X (gfx950) vector-env + PPO hot path for
+ * lukehollis/three-mlagents.  Plain pointers and sizes only; every device pointer is HBM on the
+ * handle's device; `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * The reference has no FFI: its boundary is a Python API.  Each entry point cites
+ * the reference interface (path:line under /root/reference/) whose work it replaces.  The Python
+ * shim (three-mlagents_amd/_lib.py) binds these with ctypes and mirrors the reference's operator
+ * names; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Every function returns a TMA_* status; tma_last_error() gives the message (thread-local).
+ * Status -> Python exception in the shim:  INVALID -> ValueError (registry.py:368-369,
+ * training.py:105-114), UNKNOWN_TASK -> KeyError (registry.py:359-362), HIP -> RuntimeError.
+ */
+#ifndef TMA_H
+#define TMA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMA_VERSION 100
+
+enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
+
+/* task ids (backend/mlagents/registry.py:52-116,225-240) */
+enum { TMA_TASK_BASIC = 0, TMA_TASK_GRIDWORLD = 1, TMA_TASK_BALL3D = 2, TMA_TASK_PUSH = 3, TMA_TASK_CRAWLER = 4, TMA_NUM_TASKS = 5 };
+
+/* dtype of the `actions` buffer handed to tma_env_step */
+enum { TMA_ACT_I32 = 0, TMA_ACT_I64 = 1, TMA_ACT_F32 = 2 };
+
+/* episode k of (global) env i is reset with numpy-legacy seed  base + i + k * TMA_EP_STRIDE  (mod 2^32);
+ * k = 0 is the reference's `seed + rank` (backend/mlagents/training.py:80,84). */
+#define TMA_EP_STRIDE (1u << 20)
+
+int tma_version(void);
+const char *tma_last_error(void);
+
+/* ---- task metadata: spaces declared by make_*_env (backend/mlagents/envs.py:35-44,162-199,274-277) ---- */
+int tma_task_id(const char *name, int *task_out);
+int tma_task_obs_dim(int task);           /* 21 / 4 / 6 / 4 / 172 */
+int tma_task_num_actions(int task);       /* Discrete(n); 0 for a Box action space */
+int tma_task_act_dim(int task);           /* Box action dim (crawler: 20), else 1 */
+int tma_task_state_dim(int task);         /* doubles per env in the flat get/set_state layout */
+int tma_task_max_episode_steps(int task); /* 50 / 100 / 200 / 120 / 1000 */
+
+/* ---- vector env: replaces make_vector_env + DummyVecEnv + Monitor + LegacySingleAgentGymAdapter +
+ *      the task step()/reset() (backend/mlagents/training.py:71-89; backend/mlagents/envs.py:30-159;
+ *      backend/examples/{gridworld.py:40-95, ball3d.py:47-113, push.py:39-125}) ---- */
+typedef struct tma_env tma_env;
+
+/* env_offset = global index of this shard's env 0 (data-parallel sharding); ring_depth = look-ahead of
+ * pre-drawn reset states per env (>= 2; the MT19937 reset states of future episodes are produced by a
+ * separate refill kernel every ring_depth steps). */
+int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, uint32_t env_offset, int ring_depth,
+                   tma_env **out);
+int tma_env_destroy(tma_env *h);
+/* VecEnv.seed(seed): env i -> seed + i at the next reset (SB3 DummyVecEnv) */
+int tma_env_seed(tma_env *h, uint32_t seed_base);
+/* VecEnv.reset(): every env starts episode 0;  obs_out f32[num_envs][obs_dim] */
+int tma_env_reset(tma_env *h, float *obs_out, void *stream);
+/*
+ * VecEnv.step_wait() for n_steps consecutive vector steps in ONE launch (n_steps = 1 is the plain
+ * VecEnv.step).  actions: [n_steps][num_envs] (I32/I64) or [n_steps][num_envs][act_dim] (F32); if NULL the
+ * counter-based tape a(i,t) = mix32(tape_seed, global_i, tape_t0 + s) % n_actions is generated on device.
+ * Outputs are [n_steps][num_envs][...]; obs is the post-auto-reset observation (what DummyVecEnv
+ * returns), term_obs the pre-reset observation where done (info["terminal_observation"]), ep_ret/ep_len the
+ * Monitor episode sum/length where done (else 0).  rew/term/trunc/term_obs/ep_ret/ep_len may be NULL.
+ * n_steps must not exceed tma_env_steps_until_refill().
+ */
+int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tape_seed, uint32_t tape_t0, int n_steps,
+                 float *obs_out, float *rew_out, uint8_t *term_out, uint8_t *trunc_out, float *term_obs_out,
+                 double *ep_ret_out, int32_t *ep_len_out, void *stream);
+int tma_env_steps_until_refill(tma_env *h, int *out);
+/* re-draw the reset states consumed since the last refill (exact numpy MT19937 legacy stream) */
+int tma_env_refill(tma_env *h, void *stream);
+/* flat float64 state [num_envs][state_dim] in the oracle's layout (state injection for parity tests;
+ * also BasicMoveToGoalEnv.reset(options={"position": p}), backend/mlagents/envs.py:54-57) */
+int tma_env_get_state(tma_env *h, double *state_out, void *stream);
+int tma_env_set_state(tma_env *h, const double *state_in, void *stream);
+int tma_env_episode_index(tma_env *h, uint32_t *out, void *stream);
+/* Monitor aggregate since the last call: out[0]=sum of episode returns, out[1]=sum of lengths, out[2]=count.
+ * Synchronises `stream`. */
+int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream);
+
+/* ---- GAE: replaces SB3 RolloutBuffer.compute_returns_and_advantage (3P, constructed at
+ *      backend/mlagents/training.py:150; hyper-parameters training.py:383-384).  All [T][N] f32. ---- */
+int tma_gae(const float *rewards, const float *values, const float *episode_starts, const float *last_values,
+            const uint8_t *dones, double gamma, double gae_lambda, int T, int64_t N, float *adv_out, float *ret_out,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

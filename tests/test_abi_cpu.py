@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/tma.h
+declares; status codes map to the reference's exception types; no compute is attempted without a GPU."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from three_mlagents_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "tma.h")).read()
+    declared = set(re.findall(r"\b(tma_[a-z0-9_]+)\s*\(", header))
+    declared -= {"tma_last_error"} - {"tma_last_error"}
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libtma_hip.so does not export {name}"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert L.tma_version() == 100
+
+
+def test_task_metadata_matches_reference_spaces():
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    # backend/mlagents/envs.py:38-44,166-199 ; max_episode_steps envs.py:35 + examples MAX_STEPS_PER_EP
+    expect = {"basic": (21, 3, 50), "gridworld": (4, 5, 100), "ball3d": (6, 5, 200), "push": (4, 5, 120), "crawler": (172, 0, 1000)}
+    for name, (d, a, m) in expect.items():
+        t = _lib.task_id(name)
+        assert (L.tma_task_obs_dim(t), L.tma_task_num_actions(t), L.tma_task_max_episode_steps(t)) == (d, a, m)
+    assert _lib.task_id("ant") == _lib.task_id("crawler")
+
+
+def test_status_codes_map_to_reference_exception_types():
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    with pytest.raises(KeyError):
+        _lib.task_id("definitely-not-a-task")
+    h = C.c_void_p()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().tma_env_create(1, 0, 0, 1, 0, 8, C.byref(h)))
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().tma_gae(None, None, None, None, None, 0.99, 0.95, 4, 4, None, None, None))
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from three_mlagents_amd.vec_env import HipEnvEngine
+
+    with pytest.raises(RuntimeError):
+        HipEnvEngine("gridworld", 8)

@@ -1,0 +1,224 @@
+"""GPU parity tests of the HIP vector-env engine (through the C ABI) against the golden vectors captured from
+the reference and against the CPU oracle.  Integer tasks: bit-exact.  Ball3D: <= 1e-5 (north_star tolerance),
+with the bit-exact mismatch count reported."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TASKS = ["basic", "gridworld", "push", "ball3d"]
+FLOAT_TOL = 1e-5  # north_star: float tasks within 1e-5
+
+
+def _engine(task, n, **kw):
+    from three_mlagents_amd.vec_env import HipEnvEngine
+
+    return HipEnvEngine(task, n, **kw)
+
+
+def _cmp(task, name, got, ref, ctx):
+    got, ref = np.asarray(got), np.asarray(ref)
+    if task in ("ball3d", "crawler") and got.dtype.kind == "f":
+        assert np.allclose(got, ref, rtol=0, atol=FLOAT_TOL), (task, name, ctx, np.abs(got - ref).max())
+        return int((got != ref).sum())
+    assert np.array_equal(got, ref), (task, name, ctx)
+    return 0
+
+
+def _run_golden(task, g, prefix, ring_depth):
+    n, T, base, tape, n_act, D = [int(x) for x in g[prefix + "meta"]]
+    eng = _engine(task, n, seed=base, ring_depth=ring_depth)
+    inexact = _cmp(task, "reset_obs", eng.reset().cpu().numpy(), g[prefix + "reset_obs"], 0)
+    actions = torch.from_numpy(g[prefix + "actions"]).cuda()
+    for t in range(T):
+        o = eng.step(actions[t])
+        inexact += _cmp(task, "obs", o["obs"][0].cpu(), g[prefix + "obs"][t], t)
+        inexact += _cmp(task, "rew", o["rew"][0].cpu(), g[prefix + "rewards_f32"][t], t)
+        assert np.array_equal(o["term"][0].cpu().numpy().astype(bool), g[prefix + "terminated"][t]), (task, t)
+        assert np.array_equal(o["trunc"][0].cpu().numpy().astype(bool), g[prefix + "truncated"][t]), (task, t)
+        done = g[prefix + "terminated"][t] | g[prefix + "truncated"][t]
+        inexact += _cmp(task, "term_obs", o["term_obs"][0].cpu().numpy()[done], g[prefix + "terminal_obs"][t][done], t)
+        inexact += _cmp(task, "ep_ret", o["ep_ret"][0].cpu(), g[prefix + "ep_ret"][t], t)
+        assert np.array_equal(o["ep_len"][0].cpu().numpy(), g[prefix + "ep_len"][t]), (task, t)
+    assert np.array_equal(eng.episode_index().cpu().numpy(), g[prefix + "episodes_per_env"])
+    eng.close()
+    return inexact
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_rollouts_from_reference(golden, task):
+    g = golden(task)
+    inexact = _run_golden(task, g, "", ring_depth=8)
+    inexact += _run_golden(task, g, "b_", ring_depth=2)
+    print(f"[{task}] elements not bit-identical to the reference: {inexact}")
+    if task != "ball3d":
+        assert inexact == 0
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_seeded_resets(golden, task):
+    g = golden(task)
+    seeds = g["reset_seeds"]
+    for s, obs_ref, st_ref in list(zip(seeds, g["reset_seed_obs"], g["reset_seed_state"]))[::7]:
+        eng = _engine(task, 1, seed=int(s), ring_depth=2)
+        obs = eng.reset().cpu().numpy()[0]
+        st = eng.get_state().cpu().numpy()[0]
+        assert np.array_equal(obs, obs_ref), (task, s)
+        assert np.array_equal(st[: len(st_ref)], st_ref), (task, s)
+        eng.close()
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_transitions_state_injection(golden, task):
+    g = golden(task)
+    tin, tout, tobs = g["tr_in"], g["tr_out"], g["tr_obs"]
+    n = len(tin)
+    sdim = {"basic": 2, "gridworld": 8, "push": 6, "ball3d": 8}[task]
+    eng = _engine(task, n, seed=1, ring_depth=2)
+    eng.reset()
+    eng.set_state(tin[:, :sdim].astype(np.float64))
+    act = torch.from_numpy(tin[:, sdim].astype(np.int32)).cuda()
+    o = eng.step(act, want_terminal_obs=True)
+    done = (o["term"][0] | o["trunc"][0]).cpu().numpy().astype(bool)
+    # the observation the legacy step returns is the terminal obs where the episode ended, else the new obs
+    obs = np.where(done[:, None], o["term_obs"][0].cpu().numpy(), o["obs"][0].cpu().numpy())
+    if task == "ball3d":
+        assert np.allclose(obs, tobs, rtol=0, atol=FLOAT_TOL)
+        assert np.allclose(o["rew"][0].cpu().numpy(), tout[:, 7].astype(np.float32), rtol=0, atol=FLOAT_TOL)
+        legacy_done = tout[:, 8].astype(bool)
+    else:
+        assert np.array_equal(obs, tobs)
+        rcol = {"basic": 2, "gridworld": 3, "push": 5}[task]
+        assert np.array_equal(o["rew"][0].cpu().numpy(), tout[:, rcol].astype(np.float32))
+        legacy_done = (tout[:, rcol + 1] + (tout[:, rcol + 2] if task == "basic" else 0)).astype(bool)
+    assert np.array_equal(done, legacy_done)
+    eng.close()
+
+
+@pytest.mark.parametrize("task", TASKS + ["crawler"])
+@pytest.mark.parametrize("mode", ["actions", "tape_multi"])
+def test_against_oracle_many_envs(task, mode):
+    n, T, base, tape_seed, offset, depth = 1000, 192, 7, 99, 5000, 16
+    eng = _engine(task, n, seed=base, env_offset=offset, ring_depth=depth)
+    ref = orc.OracleVecEnv(task, n, seed=base, env_offset=offset)
+    inexact = _cmp(task, "reset", eng.reset().cpu().numpy(), ref.reset(), 0)
+    n_act = orc.num_actions(task)
+    if task == "crawler":
+        rng = np.random.default_rng(3)
+        actions = rng.uniform(-1.3, 1.3, size=(T, n, 20)).astype(np.float32)
+    else:
+        actions = orc.action_tape(tape_seed, n, T, n_act, env_offset=offset)
+    outs = []
+    if mode == "actions" or task == "crawler":
+        dev_actions = torch.from_numpy(actions).cuda()
+        for t in range(T):
+            o = eng.step(dev_actions[t])
+            outs.append({k: v[0].cpu().numpy() for k, v in o.items()})
+    else:  # device-generated tape, `depth` steps per launch
+        for t0 in range(0, T, depth):
+            o = eng.step(None, n_steps=depth, tape_seed=tape_seed, tape_t0=t0)
+            for s in range(depth):
+                outs.append({k: v[s].cpu().numpy() for k, v in o.items()})
+    for t in range(T):
+        r = ref.step(actions[t])
+        o = outs[t]
+        done = (r["term"] | r["trunc"]).astype(bool)
+        inexact += _cmp(task, "obs", o["obs"], r["obs"], t)
+        inexact += _cmp(task, "rew", o["rew"], r["rew32"], t)
+        assert np.array_equal(o["term"], r["term"]) and np.array_equal(o["trunc"], r["trunc"]), (task, t)
+        inexact += _cmp(task, "term_obs", o["term_obs"][done], r["term_obs"][done], t)
+        inexact += _cmp(task, "ep_ret", o["ep_ret"], r["ep_ret"], t)
+        assert np.array_equal(o["ep_len"], r["ep_len"]), (task, t)
+    assert np.array_equal(eng.episode_index().cpu().numpy().astype(np.uint32), ref.episode_index())
+    st = eng.get_state().cpu().numpy()
+    inexact += _cmp(task, "state", st, ref.get_state(), "final")
+    print(f"[{task}/{mode}] not bit-identical to oracle: {inexact}")
+    if task in ("basic", "gridworld", "push"):
+        assert inexact == 0
+    eng.close()
+
+
+def test_sharding_equals_one_big_env():
+    """env_offset sharding: two shards of 512 reproduce envs [0,512) and [512,1024) of one 1024-env engine."""
+    T, tape = 64, 5
+    big = _engine("gridworld", 1024, seed=11, ring_depth=16)
+    a = _engine("gridworld", 512, seed=11, env_offset=0, ring_depth=16)
+    b = _engine("gridworld", 512, seed=11, env_offset=512, ring_depth=16)
+    ob, oa, obb = big.reset(), a.reset(), b.reset()
+    assert torch.equal(ob[:512], oa) and torch.equal(ob[512:], obb)
+    for t0 in range(0, T, 16):
+        rb = big.step(None, n_steps=16, tape_seed=tape, tape_t0=t0)
+        ra = a.step(None, n_steps=16, tape_seed=tape, tape_t0=t0)
+        rbb = b.step(None, n_steps=16, tape_seed=tape, tape_t0=t0)
+        for k in ("obs", "rew", "term", "trunc"):
+            assert torch.equal(rb[k][:, :512], ra[k]) and torch.equal(rb[k][:, 512:], rbb[k]), k
+
+
+def test_full_size_properties_gridworld():
+    """BASELINE config 2 size (4096 envs x 1024 steps): structural invariants + determinism + Monitor aggregate."""
+    N, T, depth = 4096, 1024, 32
+    runs = []
+    for _ in range(2):
+        eng = _engine("gridworld", N, seed=1, ring_depth=depth)
+        eng.reset()
+        n_done = 0
+        sum_len = 0
+        rew_sum = 0.0
+        chk = 0
+        for t0 in range(0, T, depth):
+            o = eng.step(None, n_steps=depth, tape_seed=1, tape_t0=t0)
+            done = (o["term"] | o["trunc"]).bool()
+            assert not (o["term"] & o["trunc"]).any()
+            n_done += int(done.sum())
+            sum_len += int(o["ep_len"].sum())
+            assert int(o["ep_len"].max()) <= 100
+            rew_sum += float(o["rew"].double().sum())
+            obs = o["obs"]
+            assert bool(((obs[..., 2] + obs[..., 3]) == 1.0).all()) and float(obs[..., :2].abs().max()) <= 1.0
+            chk = (chk * 1000003 + int(o["obs"].view(torch.int32).sum().item()) + int(o["rew"].view(torch.int32).sum().item())) % (2**61 - 1)
+        s_ret, s_len, cnt = eng.pop_episode_stats()
+        assert cnt == n_done and int(s_len) == sum_len
+        assert int(eng.episode_index().sum()) == n_done
+        runs.append((n_done, sum_len, chk))
+        eng.close()
+    assert runs[0] == runs[1]
+    assert 20 < N * T / runs[0][0] < 45  # random-policy episodes are ~31 steps
+
+
+def test_gae_matches_oracle_bit_exact():
+    from three_mlagents_amd import _lib
+
+    rng = np.random.default_rng(0)
+    for T, N in [(1, 1), (7, 3), (128, 257), (1024, 64)]:
+        r = rng.normal(size=(T, N)).astype(np.float32)
+        v = rng.normal(size=(T, N)).astype(np.float32)
+        es = (rng.random((T, N)) < 0.1).astype(np.float32)
+        lv = rng.normal(size=N).astype(np.float32)
+        d = (rng.random(N) < 0.3).astype(np.uint8)
+        adv_ref, ret_ref = orc.gae(r, v, es, lv, d, 0.99, 0.95)
+        tr, tv, tes, tlv, td = (torch.from_numpy(x).cuda() for x in (r, v, es, lv, d))
+        adv = torch.empty_like(tr)
+        ret = torch.empty_like(tr)
+        _lib.check(_lib.lib().tma_gae(_lib.ptr(tr), _lib.ptr(tv), _lib.ptr(tes), _lib.ptr(tlv), _lib.ptr(td), 0.99, 0.95, T, N,
+                                      _lib.ptr(adv), _lib.ptr(ret), _lib.stream_ptr()))
+        assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref), (T, N)
+
+
+def test_error_mapping_on_gpu():
+    from three_mlagents_amd.vec_env import HipEnvEngine
+
+    with pytest.raises(KeyError):
+        HipEnvEngine("no-such-task", 4)
+    with pytest.raises(ValueError):
+        HipEnvEngine("gridworld", 0)
+    eng = HipEnvEngine("gridworld", 4, ring_depth=4)
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(4, dtype=torch.int32, device="cuda"))  # step before reset
+    eng.reset()
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(4, dtype=torch.float32, device="cuda"))  # wrong dtype for Discrete
+    with pytest.raises(ValueError):
+        eng.step(None, n_steps=5)  # exceeds steps until refill

@@ -1,0 +1,99 @@
+"""ctypes binding of csrc/libtma_hip.so (the C ABI declared in include/tma.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object is missing this
+module raises ImportError telling the user to build it (`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libtma_hip.so")
+
+TMA_OK, TMA_ERR_INVALID, TMA_ERR_UNKNOWN_TASK, TMA_ERR_HIP = 0, 1, 2, 3
+ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2
+EP_STRIDE = 1 << 20
+
+_vp, _i32, _i64, _u32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_double
+
+# name -> (restype, argtypes); every symbol include/tma.h declares
+SIGNATURES = {
+    "tma_version": (_i32, []),
+    "tma_last_error": (C.c_char_p, []),
+    "tma_task_id": (_i32, [C.c_char_p, C.POINTER(_i32)]),
+    "tma_task_obs_dim": (_i32, [_i32]),
+    "tma_task_num_actions": (_i32, [_i32]),
+    "tma_task_act_dim": (_i32, [_i32]),
+    "tma_task_state_dim": (_i32, [_i32]),
+    "tma_task_max_episode_steps": (_i32, [_i32]),
+    "tma_env_create": (_i32, [_i32, _i64, _i32, _u32, _u32, _i32, C.POINTER(_vp)]),
+    "tma_env_destroy": (_i32, [_vp]),
+    "tma_env_seed": (_i32, [_vp, _u32]),
+    "tma_env_reset": (_i32, [_vp, _vp, _vp]),
+    "tma_env_step": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tma_env_steps_until_refill": (_i32, [_vp, C.POINTER(_i32)]),
+    "tma_env_refill": (_i32, [_vp, _vp]),
+    "tma_env_get_state": (_i32, [_vp, _vp, _vp]),
+    "tma_env_set_state": (_i32, [_vp, _vp, _vp]),
+    "tma_env_episode_index": (_i32, [_vp, _vp, _vp]),
+    "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
+    "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtma_hip.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: the HIP extension is the only compute path of three-mlagents_amd. "
+                "Build it with `make -C three-mlagents_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)."
+            )
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().tma_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int) -> None:
+    """Map a TMA_* status to the exception type the reference raises for the same condition."""
+    if status == TMA_OK:
+        return
+    msg = last_error()
+    if status == TMA_ERR_UNKNOWN_TASK:
+        raise KeyError(msg)  # registry.get_task: backend/mlagents/registry.py:359-362
+    if status == TMA_ERR_INVALID:
+        raise ValueError(msg)  # registry.make_env / train_task: registry.py:368-369, training.py:105-114
+    raise RuntimeError(msg)  # HIP / RCCL failures
+
+
+def task_id(name: str) -> int:
+    out = _i32(0)
+    check(lib().tma_task_id(name.encode(), C.byref(out)))
+    return out.value
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return t.ctypes.data_as(C.c_void_p)
+
+
+def stream_ptr(device=None):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,495 @@
+// tma_env.hip -- batched vector-env engine for gfx950: reset / step (+auto-reset, terminal obs, Monitor
+// episode sums) / reset-ring refill (exact numpy MT19937 legacy stream) / state get+set.
+//
+// Layout in HBM (per env handle): packed state words struct-of-arrays st[w][N]; reset ring
+// ring[slot][w][N]; ep_ret f64[N]; cur_ep u32[N]; filled_hi u32[N].  One thread per env, 64 consecutive
+// envs per wavefront, every state load/store is one coalesced 256-B row per word.
+//
+// Replaces (reference, paths under /root/reference/): DummyVecEnv/Monitor semantics constructed by
+// backend/mlagents/training.py:71-89; LegacySingleAgentGymAdapter backend/mlagents/envs.py:87-159;
+// task dynamics backend/mlagents/envs.py:30-84, backend/examples/gridworld.py:33-95,
+// backend/examples/ball3d.py:41-113, backend/examples/push.py:27-125.
+#include "tma_tasks.h"
+
+#include <cstring>
+#include <new>
+
+namespace tma {
+
+char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+struct EnvView {
+    int64_t N;
+    int D;  // ring depth
+    uint32_t seed_base, env_offset;
+    uint32_t *st, *ring, *cur_ep, *filled_hi;
+    double *ep_ret, *stats;
+};
+
+template <int OBS>
+__device__ __forceinline__ void store_obs(float *dst, const float *o) {
+    if constexpr (OBS == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (OBS % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < OBS; k += 2) *reinterpret_cast<float2 *>(dst + k) = make_float2(o[k], o[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < OBS; k++) dst[k] = o[k];
+    }
+}
+
+// obs of state s -> dst row (wide obs are written straight from the task, narrow ones staged in registers)
+template <class T>
+__device__ __forceinline__ void emit_obs(const typename T::S &s, float *dst) {
+    if constexpr (T::OBS > 32) {
+        T::obs(s, dst);
+    } else {
+        float o[T::OBS];
+        T::obs(s, o);
+        store_obs<T::OBS>(dst, o);
+    }
+}
+
+enum { ACT_I32 = 0, ACT_I64 = 1, ACT_F32 = 2, ACT_TAPE = 3 };
+
+// ------------------------------------------------------------------------------------------
+// step kernel: n_steps vector steps with the state held in registers.
+// ------------------------------------------------------------------------------------------
+template <class T, int ACTMODE>
+__global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__restrict__ actions, uint32_t tape_seed, uint32_t tape_t0,
+                                                   int n_steps, float *__restrict__ obs_out, float *__restrict__ rew_out,
+                                                   uint8_t *__restrict__ term_out, uint8_t *__restrict__ trunc_out,
+                                                   float *__restrict__ term_obs_out, double *__restrict__ ep_ret_out,
+                                                   int32_t *__restrict__ ep_len_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    if (i < v.N) {
+        typename T::S s;
+        T::unpack(v.st, v.N, i, s);
+        double er = v.ep_ret[i];
+        uint32_t ce = v.cur_ep[i];
+        const uint32_t gi = v.env_offset + (uint32_t)i;
+        for (int k = 0; k < n_steps; k++) {
+            const int64_t off = (int64_t)k * v.N + i;
+            int a = 0;
+            float fa[T::ADIM];
+            if constexpr (T::NACT > 0) {
+                if constexpr (ACTMODE == ACT_I32) a = static_cast<const int32_t *>(actions)[off];
+                else if constexpr (ACTMODE == ACT_I64) a = (int)static_cast<const int64_t *>(actions)[off];
+                else if constexpr (ACTMODE == ACT_TAPE) a = (int)(mix32(tape_seed, gi, tape_t0 + (uint32_t)k) % (uint32_t)T::NACT);
+                a = clampi(a, 0, T::NACT - 1);
+            } else {
+                if constexpr (ACTMODE == ACT_TAPE) {
+#pragma unroll
+                    for (int j = 0; j < T::ADIM; j++) {
+                        uint32_t h = mix32(tape_seed ^ (0x9E37u * (uint32_t)(j + 1)), gi, tape_t0 + (uint32_t)k);
+                        fa[j] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+                    }
+                } else {
+                    const float4 *src = reinterpret_cast<const float4 *>(static_cast<const float *>(actions) + off * T::ADIM);
+#pragma unroll
+                    for (int j = 0; j < T::ADIM / 4; j++) {
+                        float4 q = src[j];
+                        fa[4 * j] = q.x, fa[4 * j + 1] = q.y, fa[4 * j + 2] = q.z, fa[4 * j + 3] = q.w;
+                    }
+                }
+            }
+            double r;
+            bool done;
+            T::step(s, a, fa, r, done);
+            const int steps = T::steps(s);
+            bool te, tr;
+            if constexpr (T::NATIVE_TRUNC_RULE) {  // backend/mlagents/envs.py:76
+                te = done;
+                tr = (steps >= T::MAXSTEPS) && !te;
+            } else {  // adapter rule, backend/mlagents/envs.py:139-145
+                const bool hit = steps >= T::MAXSTEPS;
+                te = done && !hit;
+                tr = hit;
+            }
+            er += r;  // Monitor: sum of float(reward) in order
+            if (rew_out) rew_out[off] = (float)r;
+            if (term_out) term_out[off] = (uint8_t)te;
+            if (trunc_out) trunc_out[off] = (uint8_t)tr;
+            if (te || tr) {
+                if (term_obs_out) emit_obs<T>(s, term_obs_out + off * T::OBS);
+                if (ep_ret_out) ep_ret_out[off] = er;
+                if (ep_len_out) ep_len_out[off] = steps;
+                sret += er, slen += (double)steps, scnt += 1.0;
+                er = 0.0;
+                ce += 1;
+                if constexpr (T::USES_MT) {
+                    uint32_t rec[T::RW > 0 ? T::RW : 1];
+                    const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * v.N + i;
+#pragma unroll
+                    for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * v.N];
+                    T::from_rec(rec, s);
+                } else {
+                    T::reset_inline(episode_seed(v.seed_base, gi, ce), s);
+                }
+            } else {
+                if (ep_ret_out) ep_ret_out[off] = 0.0;
+                if (ep_len_out) ep_len_out[off] = 0;
+            }
+            emit_obs<T>(s, obs_out + off * T::OBS);
+        }
+        T::pack(v.st, v.N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    // Monitor aggregate: wavefront shuffle reduction, one atomic triple per wave that finished an episode
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sret += __shfl_down(sret, o, 64);
+        slen += __shfl_down(slen, o, 64);
+        scnt += __shfl_down(scnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && scnt > 0.0) {
+        atomicAdd(&v.stats[0], sret);
+        atomicAdd(&v.stats[1], slen);
+        atomicAdd(&v.stats[2], scnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// seed kernel: mode 0 = VecEnv.reset (episode 0 -> state, episodes 1..D -> ring),
+//              mode 1 = refill (episodes consumed since the last refill -> ring).
+// One thread per env (grid-stride over G threads); MT19937 state in lane-interleaved global scratch.
+// ------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void seed_kernel(EnvView v, uint32_t *mt_scratch, int64_t G, int mode, float *obs_out) {
+    __shared__ uint8_t lds_js[36 * 256];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    MT mt{mt_scratch + tid, G, 0};
+    for (int64_t i = tid; i < v.N; i += G) {
+        const uint32_t gi = v.env_offset + (uint32_t)i;
+        if constexpr (T::USES_MT) {
+            uint32_t lo, hi;
+            if (mode == 0) {
+                lo = 0;
+                hi = (uint32_t)v.D;
+                v.cur_ep[i] = 0;
+                v.ep_ret[i] = 0.0;
+            } else {
+                lo = v.filled_hi[i];
+                hi = v.cur_ep[i] + (uint32_t)v.D;
+            }
+            for (uint32_t e = lo; e <= hi && e >= lo; e++) {
+                uint32_t rec[T::RW > 0 ? T::RW : 1];
+                mt.seed(episode_seed(v.seed_base, gi, e));
+                // adapter.reset(seed): env_ctor() resets once, then env.reset() -- the second draw is the visible one
+                T::draw(mt, lds_js + threadIdx.x, (int)blockDim.x, rec);
+                T::draw(mt, lds_js + threadIdx.x, (int)blockDim.x, rec);
+                if (mode == 0 && e == 0) {
+                    typename T::S s;
+                    T::from_rec(rec, s);
+                    T::pack(v.st, v.N, i, s);
+                    if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
+                } else {
+                    uint32_t *slot = v.ring + ((int64_t)(e % (uint32_t)v.D) * T::RW) * v.N + i;
+#pragma unroll
+                    for (int w = 0; w < T::RW; w++) slot[(int64_t)w * v.N] = rec[w];
+                }
+            }
+            v.filled_hi[i] = hi + 1;
+        } else {
+            if (mode == 0) {
+                typename T::S s;
+                T::reset_inline(episode_seed(v.seed_base, gi, 0), s);
+                T::pack(v.st, v.N, i, s);
+                v.cur_ep[i] = 0;
+                v.ep_ret[i] = 0.0;
+                if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void get_state_kernel(EnvView v, double *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N) return;
+    typename T::S s;
+    T::unpack(v.st, v.N, i, s);
+    double f[T::SDIM];
+    T::to_flat(s, f);
+#pragma unroll
+    for (int k = 0; k < T::SDIM; k++) out[i * T::SDIM + k] = f[k];
+}
+
+template <class T>
+__global__ void set_state_kernel(EnvView v, const double *in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N) return;
+    double f[T::SDIM];
+#pragma unroll
+    for (int k = 0; k < T::SDIM; k++) f[k] = in[i * T::SDIM + k];
+    typename T::S s;
+    T::from_flat(f, s);
+    T::pack(v.st, v.N, i, s);
+}
+
+__global__ void copy_u32_kernel(const uint32_t *src, uint32_t *dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+struct TaskMeta {
+    const char *name;
+    int obs, nact, adim, sdim, maxsteps, sw, rw;
+    bool uses_mt;
+};
+template <class T>
+constexpr TaskMeta meta_of(const char *n) {
+    return TaskMeta{n, T::OBS, T::NACT, T::ADIM, T::SDIM, T::MAXSTEPS, T::SW, T::RW, T::USES_MT};
+}
+static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_of<GridTask>("gridworld"), meta_of<BallTask>("ball3d"),
+                                              meta_of<PushTask>("push"), meta_of<CrawlerTask>("crawler")};
+
+}  // namespace tma
+
+using namespace tma;
+
+struct tma_env {
+    int task, device;
+    EnvView v;
+    uint32_t *mt_scratch;
+    int64_t G;  // threads of the seed kernel grid
+    int steps_since_refill;
+    bool is_reset;
+};
+
+template <class F>
+static int dispatch_task(int task, F &&f) {
+    switch (task) {
+    case TMA_TASK_BASIC: return f(BasicTask{});
+    case TMA_TASK_GRIDWORLD: return f(GridTask{});
+    case TMA_TASK_BALL3D: return f(BallTask{});
+    case TMA_TASK_PUSH: return f(PushTask{});
+    case TMA_TASK_CRAWLER: return f(CrawlerTask{});
+    }
+    return fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
+}
+
+static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
+    return dispatch_task(h->task, [&](auto t) {
+        using T = decltype(t);
+        if (mode == 1 && !T::USES_MT) return (int)TMA_OK;
+        seed_kernel<T><<<dim3((unsigned)(h->G / 256)), dim3(256), 0, s>>>(h->v, h->mt_scratch, h->G, mode, obs_out);
+        TMA_LAUNCH_CHECK();
+        return (int)TMA_OK;
+    });
+}
+
+template <class T, int MODE>
+static void launch_step(tma_env *h, const void *actions, uint32_t tape_seed, uint32_t t0, int n_steps, float *obs, float *rew, uint8_t *te,
+                        uint8_t *tr, float *tobs, double *epr, int32_t *epl, hipStream_t s) {
+    const unsigned blocks = (unsigned)ceil_div(h->v.N, 256);
+    step_kernel<T, MODE><<<dim3(blocks), dim3(256), 0, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl);
+}
+
+extern "C" {
+
+int tma_version(void) { return TMA_VERSION; }
+const char *tma_last_error(void) { return err_buf(); }
+
+int tma_task_id(const char *name, int *task_out) {
+    if (!name || !task_out) return fail(TMA_ERR_INVALID, "tma_task_id: null argument");
+    for (int t = 0; t < TMA_NUM_TASKS; t++)
+        if (strcmp(kMeta[t].name, name) == 0) {
+            *task_out = t;
+            return TMA_OK;
+        }
+    if (strcmp(name, "ant") == 0) {  // registry id of the Crawler demo (backend/mlagents/registry.py:225)
+        *task_out = TMA_TASK_CRAWLER;
+        return TMA_OK;
+    }
+    return fail(TMA_ERR_UNKNOWN_TASK, "Unknown task '%s'. Available: ball3d, basic, crawler, gridworld, push", name);
+}
+#define META_GETTER(fn, field)                                 \
+    int fn(int task) {                                         \
+        if (task < 0 || task >= TMA_NUM_TASKS) return -1;      \
+        return kMeta[task].field;                              \
+    }
+META_GETTER(tma_task_obs_dim, obs)
+META_GETTER(tma_task_num_actions, nact)
+META_GETTER(tma_task_act_dim, adim)
+META_GETTER(tma_task_state_dim, sdim)
+META_GETTER(tma_task_max_episode_steps, maxsteps)
+
+int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, uint32_t env_offset, int ring_depth, tma_env **out) {
+    if (!out) return fail(TMA_ERR_INVALID, "tma_env_create: out is null");
+    if (task < 0 || task >= TMA_NUM_TASKS) return fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
+    if (num_envs < 1) return fail(TMA_ERR_INVALID, "num_envs must be >= 1 (got %lld)", (long long)num_envs);
+    if (ring_depth < 2 || ring_depth > 4096) return fail(TMA_ERR_INVALID, "ring_depth must be in [2, 4096] (got %d)", ring_depth);
+    TMA_HIP(hipSetDevice(device));
+    const TaskMeta &m = kMeta[task];
+    tma_env *h = new (std::nothrow) tma_env();
+    if (!h) return fail(TMA_ERR_INVALID, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->task = task;
+    h->device = device;
+    EnvView &v = h->v;
+    v.N = num_envs;
+    v.D = ring_depth;
+    v.seed_base = seed_base;
+    v.env_offset = env_offset;
+    const size_t n = (size_t)num_envs;
+    TMA_HIP(hipMalloc(&v.st, sizeof(uint32_t) * n * m.sw));
+    TMA_HIP(hipMemset(v.st, 0, sizeof(uint32_t) * n * m.sw));
+    if (m.uses_mt) TMA_HIP(hipMalloc(&v.ring, sizeof(uint32_t) * n * m.rw * ring_depth));
+    TMA_HIP(hipMalloc(&v.cur_ep, sizeof(uint32_t) * n));
+    TMA_HIP(hipMalloc(&v.filled_hi, sizeof(uint32_t) * n));
+    TMA_HIP(hipMalloc(&v.ep_ret, sizeof(double) * n));
+    TMA_HIP(hipMalloc(&v.stats, sizeof(double) * 4));
+    TMA_HIP(hipMemset(v.cur_ep, 0, sizeof(uint32_t) * n));
+    TMA_HIP(hipMemset(v.filled_hi, 0, sizeof(uint32_t) * n));
+    TMA_HIP(hipMemset(v.ep_ret, 0, sizeof(double) * n));
+    TMA_HIP(hipMemset(v.stats, 0, sizeof(double) * 4));
+    // seed-kernel grid: one thread per env up to 128K threads (2.5 KB of MT19937 scratch each)
+    int64_t G = ceil_div(num_envs, 256) * 256;
+    if (G > 131072) G = 131072;
+    h->G = G;
+    if (m.uses_mt) TMA_HIP(hipMalloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)G));
+    *out = h;
+    return TMA_OK;
+}
+
+int tma_env_destroy(tma_env *h) {
+    if (!h) return TMA_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->v.st);
+    (void)hipFree(h->v.ring);
+    (void)hipFree(h->v.cur_ep);
+    (void)hipFree(h->v.filled_hi);
+    (void)hipFree(h->v.ep_ret);
+    (void)hipFree(h->v.stats);
+    (void)hipFree(h->mt_scratch);
+    delete h;
+    return TMA_OK;
+}
+
+int tma_env_seed(tma_env *h, uint32_t seed_base) {
+    if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    h->v.seed_base = seed_base;
+    h->is_reset = false;
+    return TMA_OK;
+}
+
+int tma_env_reset(tma_env *h, float *obs_out, void *stream) {
+    if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    if (!obs_out) return fail(TMA_ERR_INVALID, "tma_env_reset: obs_out is null");
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    TMA_HIP(hipMemsetAsync(h->v.stats, 0, sizeof(double) * 4, s));
+    int rc = launch_seed(h, 0, obs_out, s);
+    if (rc) return rc;
+    h->steps_since_refill = 0;
+    h->is_reset = true;
+    return TMA_OK;
+}
+
+int tma_env_refill(tma_env *h, void *stream) {
+    if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    if (!h->is_reset) return fail(TMA_ERR_INVALID, "tma_env_refill before tma_env_reset");
+    TMA_HIP(hipSetDevice(h->device));
+    int rc = launch_seed(h, 1, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    h->steps_since_refill = 0;
+    return TMA_OK;
+}
+
+int tma_env_steps_until_refill(tma_env *h, int *out) {
+    if (!h || !out) return fail(TMA_ERR_INVALID, "null argument");
+    *out = kMeta[h->task].uses_mt ? h->v.D - h->steps_since_refill : (1 << 30);
+    return TMA_OK;
+}
+
+int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tape_seed, uint32_t tape_t0, int n_steps, float *obs_out,
+                 float *rew_out, uint8_t *term_out, uint8_t *trunc_out, float *term_obs_out, double *ep_ret_out, int32_t *ep_len_out,
+                 void *stream) {
+    if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    if (!h->is_reset) return fail(TMA_ERR_INVALID, "tma_env_step before tma_env_reset");
+    if (!obs_out) return fail(TMA_ERR_INVALID, "tma_env_step: obs_out is null");
+    if (n_steps < 1) return fail(TMA_ERR_INVALID, "n_steps must be >= 1 (got %d)", n_steps);
+    const TaskMeta &m = kMeta[h->task];
+    if (m.uses_mt && h->steps_since_refill + n_steps > h->v.D)
+        return fail(TMA_ERR_INVALID, "n_steps=%d exceeds the %d steps left before a reset-ring refill is due", n_steps,
+                    h->v.D - h->steps_since_refill);
+    if (actions) {
+        const bool discrete = m.nact > 0;
+        if (discrete && action_dtype != TMA_ACT_I32 && action_dtype != TMA_ACT_I64)
+            return fail(TMA_ERR_INVALID, "task '%s' has Discrete(%d) actions: pass int32 or int64", m.name, m.nact);
+        if (!discrete && action_dtype != TMA_ACT_F32) return fail(TMA_ERR_INVALID, "task '%s' has Box actions: pass float32", m.name);
+    }
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int mode = actions ? action_dtype : ACT_TAPE;
+    int rc = dispatch_task(h->task, [&](auto t) {
+        using T = decltype(t);
+#define TMA_STEP_ARGS h, actions, tape_seed, tape_t0, n_steps, obs_out, rew_out, term_out, trunc_out, term_obs_out, ep_ret_out, ep_len_out, s
+        if constexpr (T::NACT > 0) {
+            if (mode == ACT_I32) launch_step<T, ACT_I32>(TMA_STEP_ARGS);
+            else if (mode == ACT_I64) launch_step<T, ACT_I64>(TMA_STEP_ARGS);
+            else launch_step<T, ACT_TAPE>(TMA_STEP_ARGS);
+        } else {
+            if (mode == ACT_F32) launch_step<T, ACT_F32>(TMA_STEP_ARGS);
+            else launch_step<T, ACT_TAPE>(TMA_STEP_ARGS);
+        }
+#undef TMA_STEP_ARGS
+        TMA_LAUNCH_CHECK();
+        return (int)TMA_OK;
+    });
+    if (rc) return rc;
+    if (m.uses_mt) {
+        h->steps_since_refill += n_steps;
+        if (h->steps_since_refill >= h->v.D) return tma_env_refill(h, stream);
+    }
+    return TMA_OK;
+}
+
+int tma_env_get_state(tma_env *h, double *state_out, void *stream) {
+    if (!h || !state_out) return fail(TMA_ERR_INVALID, "null argument");
+    TMA_HIP(hipSetDevice(h->device));
+    return dispatch_task(h->task, [&](auto t) {
+        using T = decltype(t);
+        get_state_kernel<T><<<dim3((unsigned)ceil_div(h->v.N, 256)), dim3(256), 0, (hipStream_t)stream>>>(h->v, state_out);
+        TMA_LAUNCH_CHECK();
+        return (int)TMA_OK;
+    });
+}
+
+int tma_env_set_state(tma_env *h, const double *state_in, void *stream) {
+    if (!h || !state_in) return fail(TMA_ERR_INVALID, "null argument");
+    TMA_HIP(hipSetDevice(h->device));
+    return dispatch_task(h->task, [&](auto t) {
+        using T = decltype(t);
+        set_state_kernel<T><<<dim3((unsigned)ceil_div(h->v.N, 256)), dim3(256), 0, (hipStream_t)stream>>>(h->v, state_in);
+        TMA_LAUNCH_CHECK();
+        return (int)TMA_OK;
+    });
+}
+
+int tma_env_episode_index(tma_env *h, uint32_t *out, void *stream) {
+    if (!h || !out) return fail(TMA_ERR_INVALID, "null argument");
+    TMA_HIP(hipSetDevice(h->device));
+    copy_u32_kernel<<<dim3((unsigned)ceil_div(h->v.N, 256)), dim3(256), 0, (hipStream_t)stream>>>(h->v.cur_ep, out, h->v.N);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream) {
+    if (!h || !out3_host) return fail(TMA_ERR_INVALID, "null argument");
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    TMA_HIP(hipMemcpyAsync(out3_host, h->v.stats, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemsetAsync(h->v.stats, 0, sizeof(double) * 4, s));
+    TMA_HIP(hipStreamSynchronize(s));
+    return TMA_OK;
+}
+
+}  // extern "C"

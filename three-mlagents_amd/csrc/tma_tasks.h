@@ -1,0 +1,567 @@
+// tma_tasks.h -- device-side task definitions (state packing, numpy-legacy reset draws, step, obs).
+//
+// One struct per registry task.  The arithmetic restates, operation by operation, the reference's
+// scalar Python (citations relative to /root/reference/); the build is compiled with
+// -ffp-contract=off so no multiply-add is ever fused (NumPy never fuses).
+//
+//   S          register-resident env state
+//   SW         packed 32-bit state words per env in HBM (struct-of-arrays: word w of env i at st[w*N+i])
+//   RW         32-bit words of one pre-drawn reset record in the reset ring (0: reset needs no MT19937)
+//   SDIM       doubles in the flat get/set_state layout (identical to oracle/tma_oracle.c)
+#pragma once
+#include "tma_common.h"
+
+namespace tma {
+
+// ------------------------------------------------------------------------------------------
+// numpy legacy global RNG on device.  MT19937 state lives in a lane-interleaved global scratch
+// array (word k of thread t at p[k*stride]) so every access of a wavefront is one coalesced row.
+// Outputs are generated lazily in place (bit-identical to the bulk twist).
+// Call sites restated: np.random.seed / shuffle / choice / randint / uniform as used by
+// backend/mlagents/envs.py:117-119, backend/examples/gridworld.py:45,50, push.py:41,46, ball3d.py:49-57.
+// ------------------------------------------------------------------------------------------
+struct MT {
+    uint32_t *p;
+    int64_t stride;
+    int idx;
+    __device__ __forceinline__ uint32_t &at(int k) { return p[(int64_t)k * stride]; }
+    __device__ void seed(uint32_t s) {  // init_genrand
+        uint32_t prev = s;
+        at(0) = prev;
+        for (int k = 1; k < 624; k++) {
+            prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)k;
+            at(k) = prev;
+        }
+        idx = 0;
+    }
+    __device__ uint32_t next() {
+        int k = idx;
+        int k1 = (k == 623) ? 0 : k + 1;
+        int km = (k < 227) ? k + 397 : k - 227;
+        uint32_t y = (at(k) & 0x80000000u) | (at(k1) & 0x7fffffffu);
+        uint32_t v = at(km) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        at(k) = v;
+        idx = (k == 623) ? 0 : k + 1;
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        return v;
+    }
+    __device__ uint32_t interval(uint32_t max) {  // legacy rk_interval (masked rejection)
+        if (max == 0) return 0;
+        uint32_t mask = max;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        uint32_t v;
+        do {
+            v = next() & mask;
+        } while (v > max);
+        return v;
+    }
+    __device__ double dbl() {  // legacy rk_double
+        uint32_t a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ double uniform(double lo, double hi) {
+        double scale = hi - lo;
+        double pr = scale * dbl();
+        return lo + pr;
+    }
+};
+
+__device__ __forceinline__ uint32_t episode_seed(uint32_t base, uint32_t gi, uint32_t ep) { return base + gi + ep * TMA_EP_STRIDE; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Fisher-Yates of numpy's legacy shuffle, reduced to what the envs read: draw j_i for i = n-1..1 (kept in an
+// LDS byte column per thread), then walk the swaps backwards to find which original cell ends at position p.
+template <int NCELL>
+struct ShuffleTrace {
+    uint8_t *js;  // LDS column base for this thread, element k at js[k * blockDim.x]
+    int bs;
+    __device__ void draw(MT &mt) {
+        for (int i = NCELL - 1; i >= 1; i--) js[(i - 1) * bs] = (uint8_t)mt.interval((uint32_t)i);
+    }
+    __device__ int final_at(int p) const {
+        int c = p;
+        for (int i = 1; i <= NCELL - 1; i++) {
+            int j = js[(i - 1) * bs];
+            c = (c == i) ? j : ((c == j) ? i : c);
+        }
+        return c;
+    }
+};
+
+// ==========================================================================================
+// Basic -- backend/mlagents/envs.py:17-27 (constants, one-hot), :48-58 (reset), :60-81 (step)
+// ==========================================================================================
+struct BasicTask {
+    static constexpr int ID = TMA_TASK_BASIC, OBS = 21, NACT = 3, ADIM = 1, MAXSTEPS = 50, SW = 1, RW = 0, SDIM = 2;
+    static constexpr bool USES_MT = false, NATIVE_TRUNC_RULE = true;
+    struct S {
+        int pos, steps;
+    };
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+        uint32_t w = st[i];
+        s.pos = w & 31;
+        s.steps = (w >> 5) & 127;
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) { st[i] = (uint32_t)s.pos | ((uint32_t)s.steps << 5); }
+    __device__ static void reset_inline(uint32_t, S &s) {
+        s.pos = 10;
+        s.steps = 0;
+    }
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        int delta = a - 1;  // (-1, 0, 1)[a]
+        s.pos = clampi(s.pos + delta, 0, 20);
+        s.steps += 1;
+        double rew = -0.01;
+        bool term = false;
+        if (s.pos == 7) {
+            rew = rew + 0.1;
+            term = true;
+        } else if (s.pos == 17) {
+            rew = rew + 1.0;
+            term = true;
+        }
+        r = rew;
+        done = term;
+    }
+    __device__ static void obs(const S &s, float *o) {
+#pragma unroll
+        for (int k = 0; k < 21; k++) o[k] = (k == s.pos) ? 1.0f : 0.0f;
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        f[0] = s.pos;
+        f[1] = s.steps;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        s.pos = clampi((int)f[0], 0, 20);
+        s.steps = (int)f[1];
+    }
+};
+
+// ==========================================================================================
+// GridWorld -- backend/examples/gridworld.py:14-30 (constants), :40-52 (reset), :55-64 (obs), :67-95 (step)
+// ==========================================================================================
+struct GridTask {
+    static constexpr int ID = TMA_TASK_GRIDWORLD, OBS = 4, NACT = 5, ADIM = 1, MAXSTEPS = 100, SW = 1, RW = 1, SDIM = 8;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    struct S {
+        int ax, ay, gx, gy, rx, ry, gt, steps;
+    };
+    __device__ static void from_word(uint32_t w, S &s) {
+        s.ax = w & 7;
+        s.ay = (w >> 3) & 7;
+        s.gx = (w >> 6) & 7;
+        s.gy = (w >> 9) & 7;
+        s.rx = (w >> 12) & 7;
+        s.ry = (w >> 15) & 7;
+        s.gt = (w >> 18) & 1;
+        s.steps = (w >> 19) & 255;
+    }
+    __device__ static uint32_t to_word(const S &s) {
+        return (uint32_t)s.ax | ((uint32_t)s.ay << 3) | ((uint32_t)s.gx << 6) | ((uint32_t)s.gy << 9) | ((uint32_t)s.rx << 12) |
+               ((uint32_t)s.ry << 15) | ((uint32_t)s.gt << 18) | ((uint32_t)s.steps << 19);
+    }
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) { from_word(st[i], s); }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) { st[i] = to_word(s); }
+    __device__ static void from_rec(const uint32_t *rec, S &s) { from_word(rec[0], s); }
+    // one GridWorldEnv.reset(): shuffle 25 cells (x-major), take cells 0,1,2, then choice([0,1])
+    __device__ static void draw(MT &mt, uint8_t *lds_col, int bs, uint32_t *rec) {
+        ShuffleTrace<25> sh{lds_col, bs};
+        sh.draw(mt);
+        uint32_t gt = mt.interval(1);
+        int a = sh.final_at(0), g = sh.final_at(1), r = sh.final_at(2);
+        S s{a / 5, a % 5, g / 5, g % 5, r / 5, r % 5, (int)gt, 0};
+        rec[0] = to_word(s);
+    }
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        int dx = (a == 4) - (a == 3), dy = (a == 1) - (a == 2);
+        s.ax = clampi(s.ax + dx, 0, 4);
+        s.ay = clampi(s.ay + dy, 0, 4);
+        s.steps += 1;
+        double rew = -0.01;
+        bool d = false;
+        if (s.ax == s.gx && s.ay == s.gy) {
+            rew = (s.gt == 0) ? 1.0 : -1.0;
+            d = true;
+        } else if (s.ax == s.rx && s.ay == s.ry) {
+            rew = (s.gt == 1) ? 1.0 : -1.0;
+            d = true;
+        }
+        if (s.steps >= 100) d = true;
+        r = rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        int tx = s.gt == 0 ? s.gx : s.rx, ty = s.gt == 0 ? s.gy : s.ry;
+        o[0] = (float)((double)(tx - s.ax) / 4.0);
+        o[1] = (float)((double)(ty - s.ay) / 4.0);
+        o[2] = s.gt == 0 ? 1.0f : 0.0f;
+        o[3] = s.gt == 0 ? 0.0f : 1.0f;
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        f[0] = s.ax, f[1] = s.ay, f[2] = s.gx, f[3] = s.gy, f[4] = s.rx, f[5] = s.ry, f[6] = s.gt, f[7] = s.steps;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        s = S{(int)f[0], (int)f[1], (int)f[2], (int)f[3], (int)f[4], (int)f[5], (int)f[6], (int)f[7]};
+    }
+};
+
+// ==========================================================================================
+// Push -- backend/examples/push.py:10-24 (constants), :39-50 (reset), :53-59 (obs), :62-125 (step)
+// ==========================================================================================
+struct PushTask {
+    static constexpr int ID = TMA_TASK_PUSH, OBS = 4, NACT = 5, ADIM = 1, MAXSTEPS = 120, SW = 1, RW = 1, SDIM = 6;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    struct S {
+        int ax, ay, bx, by, gx, steps;
+    };
+    __device__ static void from_word(uint32_t w, S &s) {
+        s.ax = w & 7;
+        s.ay = (w >> 3) & 7;
+        s.bx = (w >> 6) & 7;
+        s.by = (w >> 9) & 7;
+        s.gx = (w >> 12) & 7;
+        s.steps = (w >> 15) & 255;
+    }
+    __device__ static uint32_t to_word(const S &s) {
+        return (uint32_t)s.ax | ((uint32_t)s.ay << 3) | ((uint32_t)s.bx << 6) | ((uint32_t)s.by << 9) | ((uint32_t)s.gx << 12) |
+               ((uint32_t)s.steps << 15);
+    }
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) { from_word(st[i], s); }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) { st[i] = to_word(s); }
+    __device__ static void from_rec(const uint32_t *rec, S &s) { from_word(rec[0], s); }
+    __device__ static void draw(MT &mt, uint8_t *lds_col, int bs, uint32_t *rec) {
+        ShuffleTrace<36> sh{lds_col, bs};
+        sh.draw(mt);
+        uint32_t gx = mt.interval(5);  // np.random.randint(0, 6)
+        int a = sh.final_at(0), b = sh.final_at(1);
+        S s{a / 6, a % 6, b / 6, b % 6, (int)gx, 0};
+        rec[0] = to_word(s);
+    }
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static int iabs(int v) { return v < 0 ? -v : v; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        int dx = (a == 4) - (a == 3), dy = (a == 1) - (a == 2);
+        int nax = clampi(s.ax + dx, 0, 5), nay = clampi(s.ay + dy, 0, 5);
+        int nbx = s.bx, nby = s.by;
+        int prev_bg = iabs(s.gx - s.bx) + iabs(5 - s.by);
+        int prev_ab = iabs(s.bx - s.ax) + iabs(s.by - s.ay);
+        bool invalid = false;
+        if (nax == s.bx && nay == s.by) {
+            int tx = s.bx + dx, ty = s.by + dy;
+            if (0 <= tx && tx < 6 && 0 <= ty && ty < 6) {
+                nbx = tx;
+                nby = ty;
+            } else {
+                nax = s.ax;
+                nay = s.ay;
+                invalid = true;
+            }
+        }
+        s.ax = nax, s.ay = nay, s.bx = nbx, s.by = nby;
+        s.steps += 1;
+        int bg = iabs(s.gx - nbx) + iabs(5 - nby);
+        int ab = iabs(nbx - nax) + iabs(nby - nay);
+        double rew = -0.01;
+        double t1 = 0.05 * (double)(prev_ab - ab);
+        rew = rew + t1;
+        double t2 = 0.3 * (double)(prev_bg - bg);
+        rew = rew + t2;
+        if (invalid) rew = rew - 0.05;
+        bool d = false;
+        if (nby == 5) {
+            rew = 1.0;
+            d = true;
+        }
+        if (s.steps >= 120) d = true;
+        r = rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        o[0] = (float)((double)(s.bx - s.ax) / 5.0);
+        o[1] = (float)((double)(s.by - s.ay) / 5.0);
+        o[2] = (float)((double)(s.gx - s.bx) / 5.0);
+        o[3] = (float)((double)(5 - s.by) / 5.0);
+    }
+    __device__ static void to_flat(const S &s, double *f) { f[0] = s.ax, f[1] = s.ay, f[2] = s.bx, f[3] = s.by, f[4] = s.gx, f[5] = s.steps; }
+    __device__ static void from_flat(const double *f, S &s) { s = S{(int)f[0], (int)f[1], (int)f[2], (int)f[3], (int)f[4], (int)f[5]}; }
+};
+
+// ==========================================================================================
+// Ball3D -- backend/examples/ball3d.py:10-38 (constants), :47-59 (reset), :61-72 (obs), :74-113 (step)
+// mixed f32/f64 recipe: SURVEY.md Appendix A.3.
+// ==========================================================================================
+struct BallTask {
+    static constexpr int ID = TMA_TASK_BALL3D, OBS = 6, NACT = 5, ADIM = 1, MAXSTEPS = 200, SW = 9, RW = 6, SDIM = 8;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    static constexpr double MAX_TILT = 0.4363323129985824;     // np.deg2rad(25.0)
+    static constexpr double TILT_DELTA = 0.05235987755982989;  // np.deg2rad(3.0)
+    struct S {
+        double rot[2];
+        float pos[2], vel[2];
+        int steps;
+        bool first;
+    };
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+        for (int k = 0; k < 2; k++) {
+            uint32_t lo = st[(2 * k) * N + i], hi = st[(2 * k + 1) * N + i];
+            s.rot[k] = __longlong_as_double(((long long)hi << 32) | lo);
+        }
+        s.pos[0] = __uint_as_float(st[4 * N + i]);
+        s.pos[1] = __uint_as_float(st[5 * N + i]);
+        s.vel[0] = __uint_as_float(st[6 * N + i]);
+        s.vel[1] = __uint_as_float(st[7 * N + i]);
+        uint32_t w = st[8 * N + i];
+        s.steps = w & 0xffff;
+        s.first = (w >> 16) & 1;
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) {
+        for (int k = 0; k < 2; k++) {
+            unsigned long long b = (unsigned long long)__double_as_longlong(s.rot[k]);
+            st[(2 * k) * N + i] = (uint32_t)b;
+            st[(2 * k + 1) * N + i] = (uint32_t)(b >> 32);
+        }
+        st[4 * N + i] = __float_as_uint(s.pos[0]);
+        st[5 * N + i] = __float_as_uint(s.pos[1]);
+        st[6 * N + i] = __float_as_uint(s.vel[0]);
+        st[7 * N + i] = __float_as_uint(s.vel[1]);
+        st[8 * N + i] = (uint32_t)s.steps | ((uint32_t)s.first << 16);
+    }
+    __device__ static void from_rec(const uint32_t *rec, S &s) {
+        s.rot[0] = (double)__uint_as_float(rec[0]);
+        s.rot[1] = (double)__uint_as_float(rec[1]);
+        s.pos[0] = __uint_as_float(rec[2]);
+        s.pos[1] = __uint_as_float(rec[3]);
+        s.vel[0] = __uint_as_float(rec[4]);
+        s.vel[1] = __uint_as_float(rec[5]);
+        s.steps = 0;
+        s.first = true;
+    }
+    __device__ static void draw(MT &mt, uint8_t *, int, uint32_t *rec) {
+        const double half = MAX_TILT * 0.5;
+        rec[0] = __float_as_uint((float)mt.uniform(-half, half));
+        rec[1] = __float_as_uint((float)mt.uniform(-half, half));
+        rec[2] = __float_as_uint((float)mt.uniform(-1.5, 1.5));
+        rec[3] = __float_as_uint((float)mt.uniform(-1.5, 1.5));
+        rec[4] = __float_as_uint((float)mt.uniform(-1.0, 1.0));
+        rec[5] = __float_as_uint((float)mt.uniform(-1.0, 1.0));
+    }
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        double del[2];
+        del[0] = (a == 0) ? TILT_DELTA : ((a == 1) ? -TILT_DELTA : 0.0);
+        del[1] = (a == 2) ? TILT_DELTA : ((a == 3) ? -TILT_DELTA : 0.0);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            double rr = s.rot[k] + del[k];
+            if (s.first) rr = (double)(float)rr;  // rot += delta in place on the float32 array (first step after reset)
+            rr = rr < -MAX_TILT ? -MAX_TILT : rr;
+            rr = rr > MAX_TILT ? MAX_TILT : rr;
+            s.rot[k] = rr;
+            double acc = 9.81 * sin(rr);
+            double accdt = acc * 0.02;
+            float v = (float)((double)s.vel[k] + accdt);
+            v = v * 0.98f;
+            float stp = v * 0.02f;
+            s.vel[k] = v;
+            s.pos[k] = s.pos[k] + stp;
+        }
+        s.steps += 1;
+        s.first = false;
+        bool off = (fabsf(s.pos[0]) > 3.0f) || (fabsf(s.pos[1]) > 3.0f);
+        bool timeout = s.steps >= 200;
+        bool d = off || timeout;
+        float s0 = s.pos[0] * s.pos[0], s1 = s.pos[1] * s.pos[1];
+        float norm = sqrtf(s0 + s1);
+        float q = norm / 3.0f;
+        float rew = 1.0f - q;
+        if (d) rew = (timeout && !off) ? 1.0f : -1.0f;
+        float pen = -0.02f * norm;
+        rew = rew + pen;
+        r = (double)rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        o[0] = (float)s.rot[0];
+        o[1] = (float)s.rot[1];
+        o[2] = s.pos[0];
+        o[3] = s.pos[1];
+        o[4] = s.vel[0];
+        o[5] = s.vel[1];
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        f[0] = s.rot[0], f[1] = s.rot[1], f[2] = s.pos[0], f[3] = s.pos[1], f[4] = s.vel[0], f[5] = s.vel[1], f[6] = s.steps, f[7] = s.first ? 1.0 : 0.0;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        s.rot[0] = f[0], s.rot[1] = f[1];
+        s.pos[0] = (float)f[2], s.pos[1] = (float)f[3], s.vel[0] = (float)f[4], s.vel[1] = (float)f[5];
+        s.steps = (int)f[6];
+        s.first = f[7] != 0.0;
+    }
+};
+
+// ==========================================================================================
+// Crawler-shape (BUILD-DEFINED, parity unpinned against the reference: the reference's "ant" task is
+// gym.make("Ant-v5") over MuJoCo, backend/mlagents/envs.py:274-277, backend/examples/crawler.py:31-85).
+// 172-dim obs, Box(-1,1,(20,)) actions, 1000-step limit.  Restated 1:1 from oracle/tma_oracle.c.
+// ==========================================================================================
+struct CrawlerTask {
+    static constexpr int NJ = 20;
+    static constexpr int ID = TMA_TASK_CRAWLER, OBS = 172, NACT = 0, ADIM = NJ, MAXSTEPS = 1000, SW = 3 * NJ + 9, RW = 0, SDIM = 3 * NJ + 9;
+    static constexpr bool USES_MT = false, NATIVE_TRUNC_RULE = false;
+    struct S {
+        float q[NJ], qd[NJ], pa[NJ], root[8];
+        int steps;
+    };
+    __device__ static float csin(float x) {
+        float x2 = x * x;
+        float p = 2.7557319e-06f;
+        p = p * x2 + -1.9841270e-04f;
+        p = p * x2 + 8.3333333e-03f;
+        p = p * x2 + -1.6666667e-01f;
+        p = p * x2;
+        p = p * x;
+        return x + p;
+    }
+    __device__ static float ccos(float x) {
+        float x2 = x * x;
+        float p = -2.7557319e-07f;
+        p = p * x2 + 2.4801587e-05f;
+        p = p * x2 + -1.3888889e-03f;
+        p = p * x2 + 4.1666668e-02f;
+        p = p * x2 + -0.5f;
+        p = p * x2;
+        return 1.0f + p;
+    }
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            s.q[j] = __uint_as_float(st[(int64_t)j * N + i]);
+            s.qd[j] = __uint_as_float(st[(int64_t)(NJ + j) * N + i]);
+            s.pa[j] = __uint_as_float(st[(int64_t)(2 * NJ + j) * N + i]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.root[k] = __uint_as_float(st[(int64_t)(3 * NJ + k) * N + i]);
+        s.steps = (int)st[(int64_t)(3 * NJ + 8) * N + i];
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            st[(int64_t)j * N + i] = __float_as_uint(s.q[j]);
+            st[(int64_t)(NJ + j) * N + i] = __float_as_uint(s.qd[j]);
+            st[(int64_t)(2 * NJ + j) * N + i] = __float_as_uint(s.pa[j]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) st[(int64_t)(3 * NJ + k) * N + i] = __float_as_uint(s.root[k]);
+        st[(int64_t)(3 * NJ + 8) * N + i] = (uint32_t)s.steps;
+    }
+    __device__ static void reset_inline(uint32_t seed, S &s) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            uint32_t h0 = mix32(seed, (uint32_t)j, 0x51u), h1 = mix32(seed, (uint32_t)j, 0x52u);
+            float u0 = (float)(h0 >> 8) * (1.0f / 16777216.0f), u1 = (float)(h1 >> 8) * (1.0f / 16777216.0f);
+            s.q[j] = (u0 - 0.5f) * 0.2f;
+            s.qd[j] = (u1 - 0.5f) * 0.2f;
+            s.pa[j] = 0.0f;
+        }
+        s.root[0] = 0.55f;
+#pragma unroll
+        for (int k = 1; k < 8; k++) s.root[k] = 0.0f;
+        s.steps = 0;
+    }
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+    __device__ static void step(S &s, int, const float *act, double &r, bool &done) {
+        const float dt = 0.05f, gear = 8.0f, kq = 4.0f, cq = 1.5f, kc = 1.0f;
+        float a[NJ], nq[NJ], nqd[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) a[j] = clipf(act[j], -1.0f, 1.0f);
+        float thrust_x = 0.0f, thrust_y = 0.0f, asym = 0.0f, ctrl = 0.0f, lift = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            float ql = s.q[(j + NJ - 1) % NJ], qr = s.q[(j + 1) % NJ];
+            float lap = (ql + qr) - 2.0f * s.q[j];
+            float acc = gear * a[j];
+            acc = acc - kq * s.q[j];
+            acc = acc - cq * s.qd[j];
+            acc = acc + kc * lap;
+            float v = s.qd[j] + dt * acc;
+            float p = s.q[j] + dt * v;
+            if (p > 1.2f) {
+                p = 1.2f;
+                v = 0.0f;
+            }
+            if (p < -1.2f) {
+                p = -1.2f;
+                v = 0.0f;
+            }
+            nq[j] = p;
+            nqd[j] = v;
+            float c = ccos(p), sn = csin(p);
+            float side = (j & 1) ? -1.0f : 1.0f;
+            float w = (j < NJ / 2) ? 1.0f : -1.0f;
+            thrust_x = thrust_x + (side * v) * c;
+            thrust_y = thrust_y + (w * v) * c;
+            asym = asym + side * sn;
+            lift = lift + c;
+            ctrl = ctrl + a[j] * a[j];
+        }
+        float z = s.root[0], vx = s.root[1], vy = s.root[2], pitch = s.root[3], roll = s.root[4], pr = s.root[5], rr = s.root[6], x = s.root[7];
+        vx = vx + dt * (0.15f * thrust_x - 0.8f * vx);
+        vy = vy + dt * (0.15f * thrust_y - 0.8f * vy);
+        pr = pr + dt * (0.3f * asym - 6.0f * pitch - 1.2f * pr);
+        rr = rr + dt * (0.05f * thrust_y - 6.0f * roll - 1.2f * rr);
+        pitch = pitch + dt * pr;
+        roll = roll + dt * rr;
+        z = 0.25f + 0.015f * lift;
+        x = x + dt * vx;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            s.q[j] = nq[j];
+            s.qd[j] = nqd[j];
+            s.pa[j] = a[j];
+        }
+        s.root[0] = z, s.root[1] = vx, s.root[2] = vy, s.root[3] = pitch, s.root[4] = roll, s.root[5] = pr, s.root[6] = rr, s.root[7] = x;
+        s.steps += 1;
+        bool unhealthy = (z < 0.38f) || (fabsf(pitch) > 1.0f) || (fabsf(roll) > 1.0f);
+        float rew = 1.0f + vx;
+        rew = rew - 0.5f * ctrl * 0.05f;
+        r = (double)rew;
+        done = unhealthy || s.steps >= 1000;
+    }
+    // writes straight to the destination row (172 floats) -- too wide to stage in registers
+    __device__ static void obs(const S &s, float *o) {
+        float pitch = s.root[3], roll = s.root[4];
+        o[0] = s.root[0], o[1] = s.root[1], o[2] = s.root[2], o[3] = pitch, o[4] = roll, o[5] = s.root[5], o[6] = s.root[6];
+        o[7] = csin(pitch), o[8] = ccos(pitch), o[9] = csin(roll), o[10] = ccos(roll), o[11] = s.root[0] - 0.55f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            float qj = s.q[j], qn = s.q[(j + 1) % NJ];
+            float sn = csin(qj), c = ccos(qj);
+            float side = (j & 1) ? -1.0f : 1.0f;
+            float contact = -(sn + side * pitch * 0.5f);
+            float *p = o + 12 + 8 * j;
+            p[0] = qj, p[1] = s.qd[j] * 0.1f, p[2] = sn, p[3] = c, p[4] = s.pa[j], p[5] = qn - qj, p[6] = contact > 0.0f ? contact : 0.0f, p[7] = qj * qj;
+        }
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        for (int j = 0; j < NJ; j++) f[j] = s.q[j], f[NJ + j] = s.qd[j], f[2 * NJ + j] = s.pa[j];
+        for (int k = 0; k < 8; k++) f[3 * NJ + k] = s.root[k];
+        f[3 * NJ + 8] = s.steps;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        for (int j = 0; j < NJ; j++) s.q[j] = (float)f[j], s.qd[j] = (float)f[NJ + j], s.pa[j] = (float)f[2 * NJ + j];
+        for (int k = 0; k < 8; k++) s.root[k] = (float)f[3 * NJ + k];
+        s.steps = (int)f[3 * NJ + 8];
+    }
+};
+
+}  // namespace tma
