@@ -91,6 +91,89 @@ int tma_gae(const float *rewards, const float *values, const float *episode_star
             const uint8_t *dones, double gamma, double gae_lambda, int T, int64_t N, float *adv_out, float *ret_out,
             void *stream);
 
+/* ---- actor-critic MLP + PPO update: replaces the SB3 objects PPO("MlpPolicy", env, **kwargs) builds at
+ *      backend/mlagents/training.py:150 (policy_kwargs net_arch pi/vf = [H, H], training.py:363-365; hyper-parameters
+ *      training.py:377-390) and model.learn() drives at training.py:166-170.  Third-party semantics: SURVEY.md App. C. ---- */
+typedef struct {
+    int obs_dim;    /* D */
+    int hidden;     /* H: two tanh layers of width H for both the policy and the value net (multiple of 64) */
+    int act_dim;    /* Discrete(n): n (2..16); Box: action dimension (1..32) */
+    int continuous; /* 0: Categorical head; 1: DiagGaussian head with a state-independent log_std */
+} tma_policy_dims;
+
+/* parameter buffer = n_total floats: [0, n_trainable) trainable, [in][out] layout, order
+ * pi.W1 pi.b1 pi.W2 pi.b2 pi.W3(action_net) pi.b3 vf.W1 vf.b1 vf.W2 vf.b2 vf.W3(value_net) vf.b3 [log_std];
+ * the rest are [out][in] copies maintained by tma_policy_sync / tma_ppo_adam_step. */
+int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total);
+int tma_policy_param_offsets(const tma_policy_dims *d, int32_t *out13);
+int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream);
+/* ActorCriticPolicy.forward(obs, deterministic): actions i32[n] (Discrete) or f32[n][act_dim] (Box, unclipped),
+ * values f32[n], log_prob f32[n].  Sampling uses the counter-based stream (rng_seed, env_offset + row, rng_step). */
+int tma_policy_act(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
+                   uint32_t env_offset, int deterministic, void *actions_out, float *values_out, float *logp_out, void *stream);
+/* ActorCriticPolicy.predict_values */
+int tma_policy_values(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, float *values_out, void *stream);
+/* collect_rollouts timeout bootstrap: rewards[i] += gamma * V(terminal_obs[i]) where truncated[i] */
+int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const float *terminal_obs, const uint8_t *truncated, int64_t n,
+                         double gamma, float *rewards_inout, void *stream);
+
+typedef struct {
+    const float *obs;       /* [T][N][D]                                  RolloutBuffer.observations */
+    const void *actions;    /* i32 [T][N] (Discrete) or f32 [T][N][A] (Box)              .actions    */
+    const float *log_probs; /* [T][N]                                                     .log_probs  */
+    const float *advantages;
+    const float *returns;
+    int T;
+    int64_t N;
+} tma_rollout;
+
+typedef struct {
+    const int64_t *indices; /* optional explicit permutation of the env-major flat index f = i*T + t (SB3 swap_and_flatten);
+                               NULL -> on-device Feistel permutation keyed by (perm_seed, perm_epoch) */
+    uint32_t perm_seed, perm_epoch;
+    int64_t start, count;   /* this minibatch = permuted rows [start, start + count) */
+} tma_minibatch;
+
+typedef struct {
+    double clip_range, ent_coef, vf_coef;
+    int normalize_advantage;
+} tma_ppo_hparams;
+
+int64_t tma_ppo_workspace_bytes(void);
+/* PPO.train inner loop body up to loss.backward(): accumulates d(loss)/d(params) into grad[n_trainable] (caller zeroes it
+ * once; tma_ppo_adam_step re-zeroes it) and loss statistics into the workspace. */
+int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mb,
+                           const tma_ppo_hparams *hp, float *grad, void *workspace, void *stream);
+/* clip_grad_norm_(max_grad_norm) + Adam.step() (+ refresh of the [out][in] copies).  grad_scale multiplies the gradient
+ * first (1/world_size after an all-reduce(sum)). */
+int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
+                      double beta1, double beta2, double eps, double max_grad_norm, double grad_scale, void *workspace, void *stream);
+/* out8: sums since the last call of {policy_loss, value_sq_err, entropy, approx_kl, clipped, n_samples}, then the last
+ * total grad norm and clip coefficient.  Synchronises `stream`. */
+int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream);
+
+/* ---- native rollout loop: SB3 OnPolicyAlgorithm.collect_rollouts driven by model.learn()
+ *      (backend/mlagents/training.py:166-170; SURVEY.md §3.1 loop A) without a host round-trip per step ---- */
+typedef struct {
+    float *obs;            /* [T+1][N][D]; slot t is the observation acted on at step t, slot T the final new_obs */
+    void *actions;         /* [T][N] i32 or [T][N][A] f32 */
+    float *rewards;        /* [T][N], timeout bootstrap already applied */
+    float *values;         /* [T][N] */
+    float *log_probs;      /* [T][N] */
+    uint8_t *terminated;   /* [T][N] */
+    uint8_t *truncated;    /* [T][N] */
+    float *terminal_obs;   /* [N][D] scratch, rewritten every step */
+    float *last_values;    /* [N] */
+    int64_t N;
+} tma_rollout_buffers;
+int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin, int t_end,
+                        int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma, int compute_last_values,
+                        void *stream);
+/* GAE from done flags (episode_starts[t+1] == terminated[t] | truncated[t]): same arithmetic as tma_gae */
+int tma_gae_flags(const float *rewards, const float *values, const uint8_t *terminated, const uint8_t *truncated,
+                  const float *last_values, double gamma, double gae_lambda, int T, int64_t N, float *adv_out, float *ret_out,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

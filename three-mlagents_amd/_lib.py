@@ -17,6 +17,31 @@ EP_STRIDE = 1 << 20
 
 _vp, _i32, _i64, _u32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_double
 
+
+
+class PolicyDims(C.Structure):
+    _fields_ = [("obs_dim", _i32), ("hidden", _i32), ("act_dim", _i32), ("continuous", _i32)]
+
+
+class Rollout(C.Structure):
+    _fields_ = [("obs", _vp), ("actions", _vp), ("log_probs", _vp), ("advantages", _vp), ("returns", _vp), ("T", _i32), ("N", _i64)]
+
+
+class Minibatch(C.Structure):
+    _fields_ = [("indices", _vp), ("perm_seed", _u32), ("perm_epoch", _u32), ("start", _i64), ("count", _i64)]
+
+
+class PPOHParams(C.Structure):
+    _fields_ = [("clip_range", _f64), ("ent_coef", _f64), ("vf_coef", _f64), ("normalize_advantage", _i32)]
+
+
+class RolloutBuffers(C.Structure):
+    _fields_ = [("obs", _vp), ("actions", _vp), ("rewards", _vp), ("values", _vp), ("log_probs", _vp), ("terminated", _vp),
+                ("truncated", _vp), ("terminal_obs", _vp), ("last_values", _vp), ("N", _i64)]
+
+
+_pd = C.POINTER(PolicyDims)
+
 # name -> (restype, argtypes); every symbol include/tma.h declares
 SIGNATURES = {
     "tma_version": (_i32, []),
@@ -39,6 +64,18 @@ SIGNATURES = {
     "tma_env_episode_index": (_i32, [_vp, _vp, _vp]),
     "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
     "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
+    "tma_gae_flags": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
+    "tma_policy_param_count": (_i32, [_pd, C.POINTER(_i64), C.POINTER(_i64)]),
+    "tma_policy_param_offsets": (_i32, [_pd, C.POINTER(_i32)]),
+    "tma_policy_sync": (_i32, [_vp, _pd, _vp]),
+    "tma_policy_act": (_i32, [_vp, _pd, _vp, _i64, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
+    "tma_policy_values": (_i32, [_vp, _pd, _vp, _i64, _vp, _vp]),
+    "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
+    "tma_ppo_workspace_bytes": (_i64, []),
+    "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
+    "tma_ppo_adam_step": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
+    "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
+    "tma_rollout_collect": (_i32, [_vp, _vp, _pd, C.POINTER(RolloutBuffers), _i32, _i32, _i32, _u32, _u32, _u32, _f64, _i32, _vp]),
 }
 
 _lib = None

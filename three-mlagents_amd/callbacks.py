@@ -1,0 +1,182 @@
+"""Callback protocol the reference relies on (SB3 BaseCallback / CallbackList / EvalCallback).
+
+The reference builds `CallbackList([EvalCallback(...), user_callback])` (/root/reference/backend/mlagents/training.py:151-170)
+and its WebSocket bridge subclasses BaseCallback reading `self.num_timesteps` / `self.model`
+(/root/reference/backend/mlagents/websocket_training.py:19-51).  Any object with `init_callback(model)` and
+`on_step() -> bool` works; returning False stops training.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import numpy as np
+
+
+class BaseCallback:
+    def __init__(self, verbose: int = 0):
+        self.model = None
+        self.training_env = None
+        self.n_calls = 0
+        self.num_timesteps = 0
+        self.verbose = verbose
+        self.locals: dict[str, Any] = {}
+        self.globals: dict[str, Any] = {}
+        self.parent = None
+
+    def init_callback(self, model) -> None:
+        self.model = model
+        self.training_env = model.get_env()
+        self._init_callback()
+
+    def _init_callback(self) -> None:
+        pass
+
+    def on_training_start(self, locals_=None, globals_=None) -> None:
+        self.locals, self.globals = locals_ or {}, globals_ or {}
+        self.num_timesteps = self.model.num_timesteps
+        self._on_training_start()
+
+    def _on_training_start(self) -> None:
+        pass
+
+    def on_rollout_start(self) -> None:
+        self._on_rollout_start()
+
+    def _on_rollout_start(self) -> None:
+        pass
+
+    def _on_step(self) -> bool:
+        return True
+
+    def on_step(self) -> bool:
+        self.n_calls += 1
+        self.num_timesteps = self.model.num_timesteps
+        return self._on_step()
+
+    def on_rollout_end(self) -> None:
+        self._on_rollout_end()
+
+    def _on_rollout_end(self) -> None:
+        pass
+
+    def on_training_end(self) -> None:
+        self._on_training_end()
+
+    def _on_training_end(self) -> None:
+        pass
+
+
+class CallbackList(BaseCallback):
+    def __init__(self, callbacks):
+        super().__init__()
+        self.callbacks = [as_callback(c) for c in callbacks]
+
+    def _init_callback(self) -> None:
+        for c in self.callbacks:
+            c.init_callback(self.model)
+
+    def _on_training_start(self) -> None:
+        for c in self.callbacks:
+            c.on_training_start(self.locals, self.globals)
+
+    def _on_rollout_start(self) -> None:
+        for c in self.callbacks:
+            c.on_rollout_start()
+
+    def _on_step(self) -> bool:
+        ok = True
+        for c in self.callbacks:
+            ok = c.on_step() and ok
+        return ok
+
+    def _on_rollout_end(self) -> None:
+        for c in self.callbacks:
+            c.on_rollout_end()
+
+    def _on_training_end(self) -> None:
+        for c in self.callbacks:
+            c.on_training_end()
+
+
+class _Duck(BaseCallback):
+    """Adapts any object exposing a subset of the protocol (e.g. an SB3-style callback written against the reference)."""
+
+    def __init__(self, obj):
+        super().__init__()
+        self.obj = obj
+
+    def _call(self, name, *a):
+        fn = getattr(self.obj, name, None)
+        return fn(*a) if callable(fn) else None
+
+    def init_callback(self, model) -> None:
+        self.model = model
+        if self._call("init_callback", model) is None and hasattr(self.obj, "model"):
+            self.obj.model = model
+
+    def on_training_start(self, l=None, g=None) -> None:
+        self._call("on_training_start", l or {}, g or {})
+
+    def on_rollout_start(self) -> None:
+        self._call("on_rollout_start")
+
+    def on_step(self) -> bool:
+        if hasattr(self.obj, "num_timesteps"):
+            try:
+                self.obj.num_timesteps = self.model.num_timesteps
+            except AttributeError:
+                pass
+        r = self._call("on_step")
+        return True if r is None else bool(r)
+
+    def on_rollout_end(self) -> None:
+        self._call("on_rollout_end")
+
+    def on_training_end(self) -> None:
+        self._call("on_training_end")
+
+
+def as_callback(cb) -> BaseCallback:
+    if cb is None:
+        return BaseCallback()
+    if isinstance(cb, BaseCallback):
+        return cb
+    if isinstance(cb, (list, tuple)):
+        return CallbackList(cb)
+    return _Duck(cb)
+
+
+class EvalCallback(BaseCallback):
+    """Periodic deterministic evaluation (SB3 EvalCallback as configured at training.py:152-161): every `eval_freq`
+    calls, run `n_eval_episodes`, append to `<log_path>/evaluations.npz`, keep the best model."""
+
+    def __init__(self, eval_env, best_model_save_path=None, log_path=None, eval_freq=10000, n_eval_episodes=5, deterministic=True, verbose=0, warn=True):
+        super().__init__(verbose)
+        self.eval_env, self.best_model_save_path, self.log_path = eval_env, best_model_save_path, log_path
+        self.eval_freq, self.n_eval_episodes, self.deterministic = int(eval_freq), int(n_eval_episodes), deterministic
+        self.best_mean_reward = -np.inf
+        self.last_mean_reward = -np.inf
+        self.evaluations_timesteps, self.evaluations_results, self.evaluations_length = [], [], []
+
+    def _on_step(self) -> bool:
+        if self.eval_freq > 0 and self.n_calls % self.eval_freq == 0:
+            from .evaluation import evaluate_policy
+
+            rewards, lengths = evaluate_policy(self.model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
+                                               return_episode_rewards=True)
+            self.evaluations_timesteps.append(self.num_timesteps)
+            self.evaluations_results.append(rewards)
+            self.evaluations_length.append(lengths)
+            if self.log_path is not None:
+                os.makedirs(self.log_path, exist_ok=True)
+                np.savez(os.path.join(self.log_path, "evaluations"), timesteps=self.evaluations_timesteps, results=self.evaluations_results,
+                         ep_lengths=self.evaluations_length)
+            self.last_mean_reward = float(np.mean(rewards))
+            if self.verbose >= 1:
+                print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
+            if self.last_mean_reward > self.best_mean_reward:
+                self.best_mean_reward = self.last_mean_reward
+                if self.best_model_save_path is not None:
+                    self.model.save(os.path.join(self.best_model_save_path, "best_model"))
+        return True

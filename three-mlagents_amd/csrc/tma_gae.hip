@@ -12,15 +12,21 @@ namespace tma {
 
 constexpr int GAE_UNROLL = 8;
 
+// FLAGS=false: SB3 layout (float episode_starts[T][N] + final dones[N]).  FLAGS=true: engine layout, done flags
+// terminated/truncated[T][N] where episode_starts[t+1] == done[t], so next_non_terminal at step t is 1 - done[t].
+template <bool FLAGS>
 __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rewards, const float *__restrict__ values,
                                                   const float *__restrict__ episode_starts, const float *__restrict__ last_values,
-                                                  const uint8_t *__restrict__ dones, float gamma, float gl, int T, int64_t N,
+                                                  const uint8_t *__restrict__ dones, const uint8_t *__restrict__ term,
+                                                  const uint8_t *__restrict__ trunc, float gamma, float gl, int T, int64_t N,
                                                   float *__restrict__ adv, float *__restrict__ ret) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float last = 0.0f;
     float next_v = last_values[i];
-    float next_nnt = 1.0f - (dones[i] ? 1.0f : 0.0f);
+    float next_nnt;
+    if constexpr (FLAGS) next_nnt = 1.0f - ((term[(int64_t)(T - 1) * N + i] | trunc[(int64_t)(T - 1) * N + i]) ? 1.0f : 0.0f);
+    else next_nnt = 1.0f - (dones[i] ? 1.0f : 0.0f);
     int t = T - 1;
     for (; t >= GAE_UNROLL - 1; t -= GAE_UNROLL) {
         float r[GAE_UNROLL], v[GAE_UNROLL], es[GAE_UNROLL];
@@ -29,7 +35,12 @@ __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rewa
             const int64_t off = (int64_t)(t - u) * N + i;
             r[u] = rewards[off];
             v[u] = values[off];
-            es[u] = episode_starts[off];
+            if constexpr (FLAGS) {  // flag of the PREVIOUS step is this step's episode_start
+                const int tp = t - u - 1;
+                es[u] = tp >= 0 ? ((term[(int64_t)tp * N + i] | trunc[(int64_t)tp * N + i]) ? 1.0f : 0.0f) : 0.0f;
+            } else {
+                es[u] = episode_starts[off];
+            }
         }
 #pragma unroll
         for (int u = 0; u < GAE_UNROLL; u++) {
@@ -49,7 +60,10 @@ __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rewa
     }
     for (; t >= 0; t--) {
         const int64_t off = (int64_t)t * N + i;
-        const float rr = rewards[off], vv = values[off], ee = episode_starts[off];
+        const float rr = rewards[off], vv = values[off];
+        float ee;
+        if constexpr (FLAGS) ee = t >= 1 ? ((term[(int64_t)(t - 1) * N + i] | trunc[(int64_t)(t - 1) * N + i]) ? 1.0f : 0.0f) : 0.0f;
+        else ee = episode_starts[off];
         float a = gamma * next_v;
         a = a * next_nnt;
         float delta = rr + a;
@@ -75,8 +89,22 @@ extern "C" int tma_gae(const float *rewards, const float *values, const float *e
     if (T < 1 || N < 1) return fail(TMA_ERR_INVALID, "tma_gae: T and N must be >= 1 (got T=%d N=%lld)", T, (long long)N);
     // SB3 multiplies the python floats gamma*gae_lambda in float64, then the product meets the float32 arrays
     const float gl = (float)(gamma * gae_lambda);
-    gae_kernel<<<dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream>>>(rewards, values, episode_starts, last_values, dones,
-                                                                                         (float)gamma, gl, T, N, adv_out, ret_out);
+    gae_kernel<false><<<dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rewards, values, episode_starts, last_values, dones, nullptr, nullptr, (float)gamma, gl, T, N, adv_out, ret_out);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+extern "C" int tma_gae_flags(const float *rewards, const float *values, const uint8_t *terminated, const uint8_t *truncated,
+                             const float *last_values, double gamma, double gae_lambda, int T, int64_t N, float *adv_out, float *ret_out,
+                             void *stream) {
+    using namespace tma;
+    if (!rewards || !values || !terminated || !truncated || !last_values || !adv_out || !ret_out)
+        return fail(TMA_ERR_INVALID, "tma_gae_flags: null buffer");
+    if (T < 1 || N < 1) return fail(TMA_ERR_INVALID, "tma_gae_flags: T and N must be >= 1 (got T=%d N=%lld)", T, (long long)N);
+    const float gl = (float)(gamma * gae_lambda);
+    gae_kernel<true><<<dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        rewards, values, nullptr, last_values, nullptr, terminated, truncated, (float)gamma, gl, T, N, adv_out, ret_out);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }

@@ -1,0 +1,211 @@
+// tma_mlp.h -- wavefront-level actor-critic MLP building blocks on the gfx950 f32-input MFMA
+// (v_mfma_f32_16x16x4_f32: exact f32, bitwise a k-ordered fmaf chain).
+//
+// Unit of work: ONE wavefront owns a tile of 16 samples and carries it through every layer.  Activations of the
+// tile live in the wave's private LDS region ([16][H+2] f32, +2 floats of padding = conflict-free A-fragment reads);
+// weights are read straight from HBM/L2 as B fragments (every wave reads the same <= 0.9 MB, so they stay L2/L1
+// resident) in the [in][out] layout for the forward pass and the [out][in] copy for the input-gradient pass, so that
+// 16 consecutive lanes always touch 64 contiguous bytes.
+//
+// Fragment maps (cdna_hip_programming.md §3): A: lane l holds A[row=l&15][k=l>>4];  B: B[k=l>>4][col=l&15];
+// C/D: reg r of lane l is C[row=(l>>4)*4+r][col=l&15].
+//
+// Mirrors stable-baselines3 2.9.0 ActorCriticPolicy(MlpPolicy) with net_arch=dict(pi=[H,H], vf=[H,H]), tanh
+// (third-party; built by PPO("MlpPolicy", ...) at /root/reference/backend/mlagents/training.py:150 with the
+// policy_kwargs of training.py:363-365).  SURVEY.md Appendix C.3.
+#pragma once
+#include "tma_common.h"
+
+namespace tma {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// Flat parameter buffer (floats).  [0, P) is the trainable region in [in][out] ("t") layout; [P, total) holds the
+// [out][in] copies of the matrices whose input gradient is needed (layer 2 and the heads).
+struct PLayout {
+    int D, H, A, cont;
+    int pW1t, pb1, pW2t, pb2, pW3t, pb3, vW1t, vb1, vW2t, vb2, vW3t, vb3, log_std, P;
+    int pW2, pW3, vW2, vW3, total;
+};
+
+__host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont) {
+    PLayout L;
+    L.D = D, L.H = H, L.A = A, L.cont = cont;
+    int o = 0;
+    L.pW1t = o, o += D * H;
+    L.pb1 = o, o += H;
+    L.pW2t = o, o += H * H;
+    L.pb2 = o, o += H;
+    L.pW3t = o, o += H * A;
+    L.pb3 = o, o += A;
+    L.vW1t = o, o += D * H;
+    L.vb1 = o, o += H;
+    L.vW2t = o, o += H * H;
+    L.vb2 = o, o += H;
+    L.vW3t = o, o += H;
+    L.vb3 = o, o += 1;
+    L.log_std = o, o += cont ? A : 0;
+    L.P = o;
+    L.pW2 = o, o += H * H;
+    L.pW3 = o, o += A * H;
+    L.vW2 = o, o += H * H;
+    L.vW3 = o, o += H;
+    L.total = o;
+    return L;
+}
+
+// out[16][N] = tanh(in[16][K] . Wt[K][N] + b)   (N % 64 == 0; in/out are wave-private LDS tiles)
+__device__ __forceinline__ void dense_tanh(const float *in, int ldi, int K, const float *__restrict__ Wt, const float *__restrict__ b, int N,
+                                           float *out, int ldo, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int KS = (K + 3) >> 2;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float bias = b[n0 + 16 * j + r16];
+            acc[j] = f32x4{bias, bias, bias, bias};
+        }
+        for (int ks = 0; ks < KS; ks++) {
+            const int k = 4 * ks + g;
+            const bool ok = k < K;
+            const float a = ok ? in[r16 * ldi + k] : 0.0f;
+            const float *wrow = Wt + (int64_t)k * N + n0 + r16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float w = ok ? wrow[16 * j] : 0.0f;
+                acc[j] = mfma16(a, w, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + n0 + 16 * j + r16] = tanhf(acc[j][r]);
+    }
+}
+
+// acc[NT] (C layout, columns 16*j + (lane&15)) = in[16][K] . Wt[K][N] + b, columns >= N are zero
+template <int NT>
+__device__ __forceinline__ void dense_head(const float *in, int ldi, int K, const float *__restrict__ Wt, const float *__restrict__ b, int N,
+                                           f32x4 (&acc)[NT], int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int col = 16 * j + r16;
+        const float bias = col < N ? b[col] : 0.0f;
+        acc[j] = f32x4{bias, bias, bias, bias};
+    }
+    for (int ks = 0; ks < (K >> 2); ks++) {
+        const int k = 4 * ks + g;
+        const float a = in[r16 * ldi + k];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = 16 * j + r16;
+            const float w = col < N ? Wt[(int64_t)k * N + col] : 0.0f;
+            acc[j] = mfma16(a, w, acc[j]);
+        }
+    }
+}
+
+// dzout[16][K] = (dzin[16][N] . W[N][K]) * (1 - hprev^2)      (K % 64 == 0)
+__device__ __forceinline__ void dense_bwd_input(const float *dzin, int ldz, int N, const float *__restrict__ W, int K, const float *hprev,
+                                                int ldh, float *dzout, int ldo, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int NS = (N + 3) >> 2;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ns = 0; ns < NS; ns++) {
+            const int n = 4 * ns + g;
+            const bool ok = n < N;
+            const float a = ok ? dzin[r16 * ldz + n] : 0.0f;
+            const float *wrow = W + (int64_t)n * K + k0 + r16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float w = ok ? wrow[16 * j] : 0.0f;
+                acc[j] = mfma16(a, w, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = g * 4 + r, col = k0 + 16 * j + r16;
+                const float h = hprev[row * ldh + col];
+                const float d1 = 1.0f - h * h;
+                dzout[row * ldo + col] = acc[j][r] * d1;
+            }
+    }
+}
+
+// gWt[K][N] += xin[16][K]^T . dz[16][N] ;  gb[N] += column sums of dz   (float atomics into the gradient buffer)
+__device__ __forceinline__ void dense_bwd_weight(const float *xin, int ldx, int K, const float *dz, int ldz, int N, float *gWt, float *gb,
+                                                 int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        const int col = n0 + r16;
+        float bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) bf[s] = col < N ? dz[(4 * s + g) * ldz + col] : 0.0f;
+        float cs = (bf[0] + bf[1]) + (bf[2] + bf[3]);
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        if (g == 0 && col < N) atomicAdd(gb + col, cs);
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int krow = k0 + r16;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float a = krow < K ? xin[(4 * s + g) * ldx + krow] : 0.0f;
+                acc = mfma16(a, bf[s], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = k0 + g * 4 + r;
+                if (k < K && col < N) atomicAdd(gWt + (int64_t)k * N + col, acc[r]);
+            }
+        }
+    }
+}
+
+// reductions inside one 16-lane group (lanes sharing lane>>4): xor masks 1,2,4,8 never leave the group
+__device__ __forceinline__ float gsum16(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float gmax16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+
+// minibatch permutation: 4-round Feistel network over [0, 2^b) with cycle walking down to [0, n).  Stands in for
+// np.random.permutation in SB3's RolloutBuffer.get (the reference draws it from the process-global MT19937 that the
+// envs also consume, so its order is not reproducible for a vectorised run anyway -- SURVEY.md §7.3-1).
+__host__ __device__ inline uint32_t perm_index(uint32_t seed, uint32_t epoch, uint32_t j, uint32_t n) {
+    uint32_t b = 2;
+    while ((1ull << b) < (unsigned long long)n) b += 2;
+    const uint32_t half = b >> 1, mask = (1u << half) - 1u;
+    const uint32_t key = seed ^ (epoch * 0x9E3779B9u);
+    uint32_t x = j;
+    do {
+        uint32_t L = x >> half, R = x & mask;
+        for (uint32_t rd = 0; rd < 4; rd++) {
+            const uint32_t t = R;
+            R = L ^ (mix32(key, R, rd) & mask);
+            L = t;
+        }
+        x = (L << half) | R;
+    } while (x >= n);
+    return x;
+}
+
+}  // namespace tma

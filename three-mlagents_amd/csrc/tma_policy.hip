@@ -1,0 +1,687 @@
+// tma_policy.hip -- actor-critic MLP forward (act / values / timeout bootstrap), PPO clipped-surrogate
+// forward+backward over a minibatch, global-norm clip + Adam.  gfx950, f32-input MFMA (exact f32).
+//
+// Replaces stable-baselines3 2.9.0 (third-party, pinned by /root/reference/backend/uv.lock:1686-1687) pieces that
+// PPO("MlpPolicy", env, **kwargs) at /root/reference/backend/mlagents/training.py:150 constructs and
+// model.learn() at training.py:166-170 drives:
+//   ActorCriticPolicy.forward / predict_values / evaluate_actions / _predict      -> policy_act_kernel, values kernels
+//   OnPolicyAlgorithm.collect_rollouts timeout bootstrap (rewards += gamma * V(terminal_obs))  -> bootstrap_kernel
+//   RolloutBuffer.get (minibatch permutation + gather)                            -> perm_index + gather in ppo_grad_kernel
+//   PPO.train loss (clipped surrogate, value MSE, entropy bonus) + autograd       -> ppo_grad_kernel
+//   clip_grad_norm_(max_grad_norm) + torch.optim.Adam(eps=1e-5).step()            -> grad_sumsq_kernel + adam_kernel
+// Formulas: SURVEY.md Appendix C.3 / C.5.  "Parity unpinned" at this boundary (SB3 is not importable here); checked
+// against a torch-CPU autograd restatement in tests/.
+#include "tma_mlp.h"
+
+#include <cmath>
+#include <vector>
+
+namespace tma {
+
+constexpr int WS_ADV = 0;             // float[2]: minibatch advantage mean, std
+constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-squares partials
+constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
+constexpr int WS_STATS = 4096;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
+constexpr int MAX_GRAD_BLOCKS = 2048;
+constexpr int64_t WS_BYTES = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;
+
+struct Net {
+    const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
+};
+__device__ __forceinline__ Net pi_net(const float *p, const PLayout &L) {
+    return Net{p + L.pW1t, p + L.pb1, p + L.pW2t, p + L.pb2, p + L.pW3t, p + L.pb3, p + L.pW2, p + L.pW3};
+}
+__device__ __forceinline__ Net vf_net(const float *p, const PLayout &L) {
+    return Net{p + L.vW1t, p + L.vb1, p + L.vW2t, p + L.vb2, p + L.vW3t, p + L.vb3, p + L.vW2, p + L.vW3};
+}
+
+__global__ void sync_transposed_kernel(float *params, PLayout L) {
+    const int H = L.H, A = L.A;
+    const int total = 2 * H * H + A * H + H;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int x = e;
+        if (x < H * H) {  // pW2[n][k] = pW2t[k][n]
+            const int n = x / H, k = x % H;
+            params[L.pW2 + x] = params[L.pW2t + k * H + n];
+            continue;
+        }
+        x -= H * H;
+        if (x < A * H) {
+            const int n = x / H, k = x % H;
+            params[L.pW3 + x] = params[L.pW3t + k * A + n];
+            continue;
+        }
+        x -= A * H;
+        if (x < H * H) {
+            const int n = x / H, k = x % H;
+            params[L.vW2 + x] = params[L.vW2t + k * H + n];
+            continue;
+        }
+        x -= H * H;
+        params[L.vW3 + x] = params[L.vW3t + x];
+    }
+}
+
+// stage a [16][D] tile of rows (gathered through row_off[]) into LDS, zero rows that are out of range
+__device__ __forceinline__ void load_obs_tile(const float *__restrict__ src, const int64_t *row_off_lds, int D, float *X, int ldx, int lane) {
+    const int total = 16 * D;
+    for (int e = lane; e < total; e += 64) {
+        const int row = e / D, c = e - row * D;
+        const int64_t off = row_off_lds[row];
+        X[row * ldx + c] = off >= 0 ? src[off * D + c] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------------------------------
+// policy_act: obs[n][D] -> sampled (or deterministic) actions, values, log-probs.  One wave per 16 rows.
+// MODE: 0 act (actions+values+logp), 1 values only, 2 timeout bootstrap (rewards[i] += gamma * V(term_obs[i]) where trunc[i])
+// ------------------------------------------------------------------------------------------
+template <bool CONT, int MODE>
+__global__ __launch_bounds__(256) void policy_fwd_kernel(const float *__restrict__ params, PLayout L, const float *__restrict__ obs, int64_t n,
+                                                         uint32_t rng_seed, uint32_t rng_step, uint32_t env_offset, int deterministic,
+                                                         void *__restrict__ actions_out, float *__restrict__ values_out,
+                                                         float *__restrict__ logp_out, const uint8_t *__restrict__ trunc, float gamma,
+                                                         float *__restrict__ rewards) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, H = L.H, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2, ld = H + 2;
+    const int per_wave = 16 * (ldx + 2 * ld) + 32;
+    float *X = smem + (int64_t)wave * per_wave;
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(h2 + 16 * ld);
+    const int64_t n_tiles = (n + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
+        const int64_t row0 = tile << 4;
+        if constexpr (MODE == 2) {  // skip tiles without a truncated env
+            const int64_t rr = row0 + r16;
+            const bool t = (rr < n) && trunc[rr] != 0;
+            if (__ballot(t) == 0ull) continue;
+        }
+        if (lane < 16) row_off[lane] = (row0 + lane < n) ? row0 + lane : -1;
+        load_obs_tile(obs, row_off, D, X, ldx, lane);
+        const Net V = vf_net(params, L);
+        dense_tanh(X, ldx, D, V.W1t, V.b1, H, h1, ld, lane);
+        dense_tanh(h1, ld, H, V.W2t, V.b2, H, h2, ld, lane);
+        f32x4 vacc[1];
+        dense_head<1>(h2, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        if constexpr (MODE == 1) {
+            if (r16 == 0)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + g * 4 + r;
+                    if (row < n) values_out[row] = vacc[0][r];
+                }
+            continue;
+        }
+        if constexpr (MODE == 2) {
+            if (r16 == 0)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + g * 4 + r;
+                    if (row < n && trunc[row]) {
+                        const float gv = gamma * vacc[0][r];  // SB3: rewards[idx] += self.gamma * terminal_value (float32)
+                        rewards[row] = rewards[row] + gv;
+                    }
+                }
+            continue;
+        }
+        if constexpr (MODE == 0) {
+            const Net P = pi_net(params, L);
+            dense_tanh(X, ldx, D, P.W1t, P.b1, H, h1, ld, lane);
+            dense_tanh(h1, ld, H, P.W2t, P.b2, H, h2, ld, lane);
+            if constexpr (!CONT) {
+                f32x4 acc[1];
+                dense_head<1>(h2, ld, H, P.W3t, P.b3, A, acc, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + g * 4 + r;
+                    const bool colok = r16 < A;
+                    const float x = colok ? acc[0][r] : -INFINITY;
+                    const float m = gmax16(x);
+                    const float e = colok ? expf(x - m) : 0.0f;
+                    const float s = gsum16(e);
+                    const float lse = m + logf(s);
+                    const float lp = x - lse;
+                    int act;
+                    if (deterministic) {
+                        const float cand = (colok && x == m) ? (float)r16 : 99.0f;
+                        float mn = cand;
+                        mn = fminf(mn, __shfl_xor(mn, 1, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 2, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 4, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                        act = (int)mn;
+                    } else {
+                        float c = e / s;
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) {
+                            const float up = __shfl_up(c, d, 16);
+                            if (r16 >= d) c += up;
+                        }
+                        const uint32_t gi = env_offset + (uint32_t)row;
+                        const float u = uniform01(mix32(rng_seed, gi, rng_step));
+                        const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                        act = min((int)cnt, A - 1);
+                    }
+                    const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                    const float vrow = __shfl(vacc[0][r], lane & 48, 64);  // value sits in column 0 of the group
+                    if (r16 == r && row < n) {
+                        static_cast<int32_t *>(actions_out)[row] = act;
+                        logp_out[row] = lpa;
+                        values_out[row] = vrow;
+                    }
+                }
+            } else {
+                f32x4 acc[2];
+                dense_head<2>(h2, ld, H, P.W3t, P.b3, A, acc, lane);
+                const float *ls = params + L.log_std;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + g * 4 + r;
+                    const uint32_t gi = env_offset + (uint32_t)row;
+                    float lpsum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int col = 16 * j + r16;
+                        if (col < A) {
+                            const float mu = acc[j][r], lsd = ls[col], sd = expf(lsd);
+                            float a = mu;
+                            if (!deterministic) {
+                                const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rng_step)), 5.9604645e-08f);
+                                const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rng_step));
+                                const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+                                a = mu + sd * z;
+                            }
+                            const float d = a - mu;
+                            lpsum += -(d * d) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                            if (row < n) static_cast<float *>(actions_out)[row * A + col] = a;
+                        }
+                    }
+                    lpsum = gsum16(lpsum);
+                    const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                    if (r16 == r && row < n) {
+                        logp_out[row] = lpsum;
+                        values_out[row] = vrow;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// minibatch advantage statistics (mean, unbiased std) -- one block; SB3 PPO.train normalize_advantage
+// ------------------------------------------------------------------------------------------
+struct Minibatch {
+    const int64_t *indices;  // optional explicit flat (env-major: f = i*T + t) indices
+    uint32_t perm_seed, perm_epoch;
+    int64_t start, count, total;  // rows [start, start+count) of the permuted buffer of `total` samples
+};
+
+__device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {
+    const int64_t f = mb.indices ? mb.indices[j] : (int64_t)perm_index(mb.perm_seed, mb.perm_epoch, (uint32_t)j, (uint32_t)mb.total);
+    const int64_t i = f / T, t = f - i * T;  // swap_and_flatten: (T, N) -> env-major
+    return t * N + i;
+}
+
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, float *ws_adv) {
+    __shared__ double s1[16], s2[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t j = threadIdx.x; j < mb.count; j += blockDim.x) {
+        const double x = (double)adv[sample_offset(mb, mb.start + j, T, N)];
+        a += x;
+        b += x * x;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = a, s2[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0.0, sb = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) sa += s1[w], sb += s2[w];
+        const double n = (double)mb.count;
+        const double mean = sa / n;
+        double var = n > 1.0 ? (sb - n * mean * mean) / (n - 1.0) : 0.0;
+        if (var < 0.0) var = 0.0;
+        ws_adv[0] = (float)mean;
+        ws_adv[1] = (float)sqrt(var);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PPO minibatch forward + loss + backward.  One wave per 16 samples, gradient accumulated with float atomics.
+// ------------------------------------------------------------------------------------------
+struct Rollout {
+    const float *obs;
+    const void *actions;
+    const float *log_probs, *advantages, *returns;
+    int T;
+    int64_t N;
+};
+struct HParams {
+    float clip_range, ent_coef, vf_coef;
+    int normalize_advantage;
+};
+
+template <bool CONT>
+__global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                       const float *__restrict__ ws_adv, float *__restrict__ grad, double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, H = L.H, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2, ld = H + 2, ld3 = 34;
+    const int per_wave = 16 * (ldx + 6 * ld + ld3) + 16 * 8;
+    float *X = smem + (int64_t)wave * per_wave;
+    float *h1p = X + 16 * ldx, *h2p = h1p + 16 * ld, *h1v = h2p + 16 * ld, *h2v = h1v + 16 * ld;
+    float *dzA = h2v + 16 * ld, *dzB = dzA + 16 * ld, *dz3 = dzB + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);  // 16 x int64 = 32 floats
+    float *meta = reinterpret_cast<float *>(row_off + 16);           // [16][4]: old_logp, adv, ret, action(bits)
+    const float invB = 1.0f / (float)mb.count;
+    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
+    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    const Net P = pi_net(params, L), V = vf_net(params, L);
+    double st_pl = 0.0, st_vl = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
+    const int64_t n_tiles = (mb.count + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
+        if (lane < 16) {
+            const int64_t j = (tile << 4) + lane;
+            int64_t off = -1;
+            meta[lane * 4 + 0] = meta[lane * 4 + 1] = meta[lane * 4 + 2] = meta[lane * 4 + 3] = 0.0f;
+            if (j < mb.count) {
+                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                meta[lane * 4 + 0] = rb.log_probs[off];
+                meta[lane * 4 + 1] = rb.advantages[off];
+                meta[lane * 4 + 2] = rb.returns[off];
+                if constexpr (!CONT) meta[lane * 4 + 3] = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+            }
+            row_off[lane] = off;
+        }
+        load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
+        // ---- forward ----
+        dense_tanh(X, ldx, D, P.W1t, P.b1, H, h1p, ld, lane);
+        dense_tanh(h1p, ld, H, P.W2t, P.b2, H, h2p, ld, lane);
+        dense_tanh(X, ldx, D, V.W1t, V.b1, H, h1v, ld, lane);
+        dense_tanh(h1v, ld, H, V.W2t, V.b2, H, h2v, ld, lane);
+        f32x4 vacc[1];
+        dense_head<1>(h2v, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        float dlsd[2] = {0.0f, 0.0f};  // continuous: per-column log_std gradient partials
+        if constexpr (!CONT) {
+            f32x4 acc[1];
+            dense_head<1>(h2p, ld, H, P.W3t, P.b3, A, acc, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = g * 4 + r;
+                const bool valid = row_off[row] >= 0;
+                const bool colok = r16 < A;
+                const float x = colok ? acc[0][r] : -INFINITY;
+                const float m = gmax16(x);
+                const float e = colok ? expf(x - m) : 0.0f;
+                const float s = gsum16(e);
+                const float lse = m + logf(s);
+                const float lp = colok ? x - lse : 0.0f;
+                const float p = e / s;
+                const int act = __float_as_int(meta[row * 4 + 3]);
+                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                const float ent = -gsum16(p * lp);
+                const float old = meta[row * 4 + 0];
+                const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+                const float ratio = expf(lpa - old);
+                const float pl1 = advn * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+                const float pl2 = advn * rc;
+                const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+                float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
+                dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
+                dz3[row * ld3 + r16] = colok ? dl : 0.0f;
+                if (valid && r16 == 0) {
+                    st_pl += (double)(-fminf(pl1, pl2));
+                    st_ent += (double)ent;
+                    st_kl += (double)((ratio - 1.0f) - (lpa - old));
+                    st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+                    st_n += 1.0;
+                }
+            }
+        } else {
+            f32x4 acc[2];
+            dense_head<2>(h2p, ld, H, P.W3t, P.b3, A, acc, lane);
+            const float *lsp = params + L.log_std;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = g * 4 + r;
+                const int64_t off = row_off[row];
+                const bool valid = off >= 0;
+                float lpsum = 0.0f, d[2] = {0.0f, 0.0f}, sd[2] = {1.0f, 1.0f}, entsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = 16 * j + r16;
+                    if (col < A) {
+                        const float lsd = lsp[col];
+                        sd[j] = expf(lsd);
+                        const float a = valid ? static_cast<const float *>(rb.actions)[off * A + col] : 0.0f;
+                        d[j] = a - acc[j][r];
+                        lpsum += -(d[j] * d[j]) / (2.0f * (sd[j] * sd[j])) - lsd - 0.9189385332046727f;
+                        entsum += 1.4189385332046727f + lsd;
+                    }
+                }
+                const float lpa = gsum16(lpsum);
+                const float ent = gsum16(entsum);
+                const float old = meta[row * 4 + 0];
+                const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+                const float ratio = expf(lpa - old);
+                const float pl1 = advn * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+                const float pl2 = advn * rc;
+                const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = 16 * j + r16;
+                    const float var = sd[j] * sd[j];
+                    dz3[row * ld3 + col] = (col < A) ? g_lp * (d[j] / var) : 0.0f;
+                    if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
+                }
+                if (valid && r16 == 0) {
+                    st_pl += (double)(-fminf(pl1, pl2));
+                    st_ent += (double)ent;
+                    st_kl += (double)((ratio - 1.0f) - (lpa - old));
+                    st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+                    st_n += 1.0;
+                }
+            }
+            // log_std gradient: sum the 4 row-groups (lanes sharing lane&15), one atomic per column
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float v = dlsd[j];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int col = 16 * j + r16;
+                if (g == 0 && col < A) atomicAdd(grad + L.log_std + col, v);
+            }
+        }
+        // ---- backward: policy net ----
+        dense_bwd_weight(h2p, ld, H, dz3, ld3, A, grad + L.pW3t, grad + L.pb3, lane);
+        dense_bwd_input(dz3, ld3, A, P.W3, H, h2p, ld, dzA, ld, lane);
+        dense_bwd_weight(h1p, ld, H, dzA, ld, H, grad + L.pW2t, grad + L.pb2, lane);
+        dense_bwd_input(dzA, ld, H, P.W2, H, h1p, ld, dzB, ld, lane);
+        dense_bwd_weight(X, ldx, D, dzB, ld, H, grad + L.pW1t, grad + L.pb1, lane);
+        // ---- value loss + backward: value net ----
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = g * 4 + r;
+            const bool valid = row_off[row] >= 0;
+            const float v = vacc[0][r], ret = meta[row * 4 + 2];
+            const float diff = v - ret;
+            dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+            if (valid && r16 == 0) st_vl += (double)(diff * diff);
+        }
+        dense_bwd_weight(h2v, ld, H, dz3, ld3, 1, grad + L.vW3t, grad + L.vb3, lane);
+        dense_bwd_input(dz3, ld3, 1, V.W3, H, h2v, ld, dzA, ld, lane);
+        dense_bwd_weight(h1v, ld, H, dzA, ld, H, grad + L.vW2t, grad + L.vb2, lane);
+        dense_bwd_input(dzA, ld, H, V.W2, H, h1v, ld, dzB, ld, lane);
+        dense_bwd_weight(X, ldx, D, dzB, ld, H, grad + L.vW1t, grad + L.vb1, lane);
+    }
+    // loss statistics: wave shuffle reduction -> LDS -> this block's slot (plain RMW, summed on the host when logged)
+    double st[6] = {st_pl, st_vl, st_ent, st_kl, st_clip, st_n};
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0)
+        for (int q = 0; q < 6; q++) red[wave * 6 + q] = st[q];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double s = 0.0;
+        for (int w = 0; w < wpb; w++) s += red[w * 6 + threadIdx.x];
+        stat_slots[(int64_t)blockIdx.x * 8 + threadIdx.x] += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict__ grad, int P, float scale, double *partials) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P; e += gridDim.x * blockDim.x) {
+        const float gv = grad[e] * scale;
+        s += (double)gv * (double)gv;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                                   int P, float scale, const double *__restrict__ partials, int n_partials, float max_norm, float lr_step,
+                                                   float beta1, float beta2, float bc2_sqrt, float eps, double *norm_out) {
+    double tot = 0.0;
+    for (int b = 0; b < n_partials; b++) tot += partials[b];
+    const float total_norm = (float)sqrt(tot);
+    float coef = max_norm / (total_norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (max_norm <= 0.0f) coef = 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        norm_out[0] = (double)total_norm;
+        norm_out[1] = (double)coef;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P; e += gridDim.x * blockDim.x) {
+        const float gv = (grad[e] * scale) * coef;
+        grad[e] = 0.0f;  // ready for the next minibatch
+        float mm = m[e], vv = v[e];
+        mm = mm + (gv - mm) * (1.0f - beta1);         // exp_avg.lerp_(grad, 1 - beta1)
+        vv = vv * beta2 + (gv * gv) * (1.0f - beta2);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        m[e] = mm;
+        v[e] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        params[e] = params[e] - lr_step * (mm / denom);  // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
+static int check_dims(const tma_policy_dims *d) {
+    if (!d) return fail(TMA_ERR_INVALID, "policy dims is null");
+    if (d->obs_dim < 1 || d->obs_dim > 4096) return fail(TMA_ERR_INVALID, "obs_dim out of range: %d", d->obs_dim);
+    if (d->hidden < 64 || d->hidden % 64 != 0 || d->hidden > 1024)
+        return fail(TMA_ERR_INVALID, "hidden width must be a multiple of 64 in [64, 1024] (got %d)", d->hidden);
+    if (d->continuous) {
+        if (d->act_dim < 1 || d->act_dim > 32) return fail(TMA_ERR_INVALID, "Box action dim must be in [1, 32] (got %d)", d->act_dim);
+    } else if (d->act_dim < 2 || d->act_dim > 16)
+        return fail(TMA_ERR_INVALID, "Discrete action count must be in [2, 16] (got %d)", d->act_dim);
+    return TMA_OK;
+}
+
+static int fwd_smem_bytes(const PLayout &L, int wpb) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    return wpb * (16 * (ldx + 2 * ld) + 32) * 4;
+}
+static int grad_smem_bytes(const PLayout &L, int wpb) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    return wpb * (16 * (ldx + 6 * ld + 34) + 16 * 8) * 4;
+}
+
+template <int MODE>
+static int launch_fwd(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t seed, uint32_t step, uint32_t env_offset,
+                      int deterministic, void *actions, float *values, float *logp, const uint8_t *trunc, float gamma, float *rewards,
+                      hipStream_t s) {
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const int64_t tiles = ceil_div(n, 16);
+    int wpb = tiles >= 1024 ? 4 : 1;  // small batches: one wave per block so every CU gets work
+    while (wpb > 1 && fwd_smem_bytes(L, wpb) > 64 * 1024) wpb >>= 1;
+    const int smem = fwd_smem_bytes(L, wpb);
+    int64_t blocks = ceil_div(tiles, wpb);
+    if (blocks > 8192) blocks = 8192;
+    if (d->continuous) {
+        auto k = policy_fwd_kernel<true, MODE>;
+        if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp,
+                                                               trunc, gamma, rewards);
+    } else {
+        auto k = policy_fwd_kernel<false, MODE>;
+        if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp,
+                                                               trunc, gamma, rewards);
+    }
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+}  // namespace tma
+
+using namespace tma;
+
+extern "C" {
+
+int64_t tma_ppo_workspace_bytes(void) { return WS_BYTES; }
+
+int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    if (n_trainable) *n_trainable = L.P;
+    if (n_total) *n_total = L.total;
+    return TMA_OK;
+}
+
+int tma_policy_param_offsets(const tma_policy_dims *d, int32_t *out13) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!out13) return fail(TMA_ERR_INVALID, "out13 is null");
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const int o[13] = {L.pW1t, L.pb1, L.pW2t, L.pb2, L.pW3t, L.pb3, L.vW1t, L.vb1, L.vW2t, L.vb2, L.vW3t, L.vb3, L.log_std};
+    for (int i = 0; i < 13; i++) out13[i] = o[i];
+    return TMA_OK;
+}
+
+int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params) return fail(TMA_ERR_INVALID, "params is null");
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const int total = 2 * L.H * L.H + L.A * L.H + L.H;
+    sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(params, L);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_policy_act(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
+                   uint32_t env_offset, int deterministic, void *actions_out, float *values_out, float *logp_out, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !obs || !actions_out || !values_out || !logp_out) return fail(TMA_ERR_INVALID, "tma_policy_act: null buffer");
+    if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act: n must be >= 1");
+    return launch_fwd<0>(params, d, obs, n, rng_seed, rng_step, env_offset, deterministic, actions_out, values_out, logp_out, nullptr, 0.0f, nullptr,
+                         (hipStream_t)stream);
+}
+
+int tma_policy_values(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, float *values_out, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !obs || !values_out) return fail(TMA_ERR_INVALID, "tma_policy_values: null buffer");
+    if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_values: n must be >= 1");
+    return launch_fwd<1>(params, d, obs, n, 0, 0, 0, 1, nullptr, values_out, nullptr, nullptr, 0.0f, nullptr, (hipStream_t)stream);
+}
+
+int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const float *terminal_obs, const uint8_t *truncated, int64_t n, double gamma,
+                         float *rewards_inout, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !terminal_obs || !truncated || !rewards_inout) return fail(TMA_ERR_INVALID, "tma_policy_bootstrap: null buffer");
+    if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_bootstrap: n must be >= 1");
+    return launch_fwd<2>(params, d, terminal_obs, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, truncated, (float)gamma, rewards_inout, (hipStream_t)stream);
+}
+
+int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
+                           float *grad, void *workspace, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !rb || !mbi || !hp || !grad || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_minibatch_grad: null argument");
+    if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
+    if (rb->T < 1 || rb->N < 1) return fail(TMA_ERR_INVALID, "rollout view: T and N must be >= 1");
+    const int64_t total = (int64_t)rb->T * rb->N;
+    if (total > 0x7fffffffLL) return fail(TMA_ERR_INVALID, "rollout of %lld samples exceeds the 2^31 minibatch index range", (long long)total);
+    if (mbi->count < 1 || mbi->start < 0 || mbi->start + mbi->count > total)
+        return fail(TMA_ERR_INVALID, "minibatch [%lld, +%lld) outside the %lld-sample rollout", (long long)mbi->start, (long long)mbi->count, (long long)total);
+    hipStream_t s = (hipStream_t)stream;
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
+    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total};
+    HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, (hp->normalize_advantage && mbi->count > 1) ? 1 : 0};
+    char *ws = static_cast<char *>(workspace);
+    float *ws_adv = reinterpret_cast<float *>(ws + WS_ADV);
+    double *slots = reinterpret_cast<double *>(ws + WS_STATS);
+    if (hpar.normalize_advantage) {
+        adv_stats_kernel<<<dim3(1), dim3(1024), 0, s>>>(rb->advantages, M, rb->T, rb->N, ws_adv);
+        TMA_LAUNCH_CHECK();
+    }
+    const int64_t tiles = ceil_div(mbi->count, 16);
+    int wpb = tiles >= 1024 ? 4 : 1;
+    while (wpb > 1 && grad_smem_bytes(L, wpb) > 150 * 1024) wpb >>= 1;
+    const int smem = grad_smem_bytes(L, wpb);
+    if (smem > 160 * 1024) return fail(TMA_ERR_INVALID, "policy too wide for the LDS-resident tile (needs %d bytes)", smem);
+    int64_t blocks = ceil_div(tiles, wpb);
+    if (blocks > MAX_GRAD_BLOCKS) blocks = MAX_GRAD_BLOCKS;
+    if (d->continuous) {
+        auto k = ppo_grad_kernel<true>;
+        if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
+    } else {
+        auto k = ppo_grad_kernel<false>;
+        if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
+    }
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr, double beta1,
+                      double beta2, double eps, double max_grad_norm, double grad_scale, void *workspace, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step: null buffer");
+    if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    char *ws = static_cast<char *>(workspace);
+    double *partials = reinterpret_cast<double *>(ws + WS_NORM_PART);
+    double *norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
+    int nb = (int)ceil_div(L.P, 1024);
+    if (nb > 256) nb = 256;
+    grad_sumsq_kernel<<<dim3(nb), dim3(256), 0, s>>>(grad, L.P, (float)grad_scale, partials);
+    TMA_LAUNCH_CHECK();
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
+    adam_kernel<<<dim3(nb), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L.P, (float)grad_scale, partials, nb, (float)max_grad_norm,
+                                               (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
+    TMA_LAUNCH_CHECK();
+    const int total = 2 * L.H * L.H + L.A * L.H + L.H;
+    sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s>>>(params, L);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {
+    if (!workspace || !out8_host) return fail(TMA_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<double> tmpv(MAX_GRAD_BLOCKS * 8 + 2);
+    double *tmp = tmpv.data();
+    char *ws = static_cast<char *>(workspace);
+    TMA_HIP(hipMemcpyAsync(tmp, ws + WS_STATS, sizeof(double) * MAX_GRAD_BLOCKS * 8, hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemcpyAsync(tmp + MAX_GRAD_BLOCKS * 8, ws + WS_NORM_OUT, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemsetAsync(ws + WS_STATS, 0, sizeof(double) * MAX_GRAD_BLOCKS * 8, s));
+    TMA_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < 6; q++) out8_host[q] = 0.0;
+    for (int b = 0; b < MAX_GRAD_BLOCKS; b++)
+        for (int q = 0; q < 6; q++) out8_host[q] += tmp[b * 8 + q];
+    out8_host[6] = tmp[MAX_GRAD_BLOCKS * 8];
+    out8_host[7] = tmp[MAX_GRAD_BLOCKS * 8 + 1];
+    return TMA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,405 @@
+"""PPO engine with the Stable-Baselines3 `PPO` surface the reference drives.
+
+Drop-in for `ALGORITHMS["ppo"](policy, env, seed=seed, **kwargs)` + `.learn()/.predict()/.save()/.load()` as used at
+/root/reference/backend/mlagents/training.py:150,166-170,175,269,278.  Every arithmetic step of the hot path -- policy
+forward and sampling, env step, timeout bootstrap, GAE, minibatch forward/backward of the clipped-surrogate loss,
+global-norm clipping and Adam -- is a HIP kernel reached through the C ABI (include/tma.h); this file is host plumbing
+(buffers, loop order, callbacks, artefacts).  Semantics follow SB3 2.9.0; deviations, all
+forced by running thousands of envs on a GPU, are listed in DESIGN.md §"Deviations":
+  * action sampling and the minibatch permutation use counter-based device RNGs instead of torch/numpy global RNGs;
+  * per-(env, episode) reset seeds.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import json
+import math
+import os
+import platform
+import time
+import zipfile
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _lib
+from .vec_env import HipVecEnv
+
+SB3_KEYS = [
+    "mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias",
+    "mlp_extractor.policy_net.2.weight", "mlp_extractor.policy_net.2.bias",
+    "action_net.weight", "action_net.bias",
+    "mlp_extractor.value_net.0.weight", "mlp_extractor.value_net.0.bias",
+    "mlp_extractor.value_net.2.weight", "mlp_extractor.value_net.2.bias",
+    "value_net.weight", "value_net.bias",
+]
+
+
+def _hidden_from_net_arch(net_arch) -> int:
+    """SB3 net_arch -> H.  Supported: dict(pi=[H,H], vf=[H,H]) or [H,H] (SB3 default is [64,64]; the reference passes
+    dict(pi=[256,256], vf=[256,256]), backend/mlagents/training.py:363-365)."""
+    if net_arch is None:
+        return 64
+    if isinstance(net_arch, dict):
+        pi, vf = list(net_arch.get("pi", [])), list(net_arch.get("vf", []))
+    else:
+        pi = vf = list(net_arch)
+    if len(pi) != 2 or len(vf) != 2 or len(set(pi + vf)) != 1:
+        raise ValueError(f"three-mlagents_amd supports net_arch with two equal hidden layers for pi and vf, got {net_arch}")
+    H = int(pi[0])
+    if H % 64 or not 64 <= H <= 1024:
+        raise ValueError(f"hidden width must be a multiple of 64 in [64, 1024], got {H}")
+    return H
+
+
+class HipActorCriticPolicy:
+    """Parameters of SB3's ActorCriticPolicy(MlpPolicy) in one flat HBM buffer + the forward kernels."""
+
+    def __init__(self, obs_dim: int, act_dim: int, continuous: bool, hidden: int, device, seed: int = 0):
+        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0)
+        self.obs_dim, self.act_dim, self.continuous, self.hidden = int(obs_dim), int(act_dim), bool(continuous), int(hidden)
+        self.device = torch.device(device)
+        nt, ntot = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().tma_policy_param_count(C.byref(self.dims), C.byref(nt), C.byref(ntot)))
+        self.n_trainable, self.n_total = nt.value, ntot.value
+        offs = (C.c_int32 * 13)()
+        _lib.check(_lib.lib().tma_policy_param_offsets(C.byref(self.dims), offs))
+        self.offsets = list(offs)
+        self.params = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        self.load_state_dict(self._orthogonal_init(seed))
+
+    # -- init / (de)serialisation in SB3's state_dict naming -------------------------------
+    def _orthogonal_init(self, seed: int) -> dict[str, torch.Tensor]:
+        gen = torch.Generator().manual_seed(int(seed))
+        D, H, A = self.obs_dim, self.hidden, self.act_dim
+
+        def ortho(o, i, gain):
+            w = torch.empty(o, i)
+            torch.nn.init.orthogonal_(w, gain=gain, generator=gen)
+            return w
+
+        g2 = math.sqrt(2.0)
+        sd = {
+            SB3_KEYS[0]: ortho(H, D, g2), SB3_KEYS[1]: torch.zeros(H), SB3_KEYS[2]: ortho(H, H, g2), SB3_KEYS[3]: torch.zeros(H),
+            SB3_KEYS[4]: ortho(A, H, 0.01), SB3_KEYS[5]: torch.zeros(A),
+            SB3_KEYS[6]: ortho(H, D, g2), SB3_KEYS[7]: torch.zeros(H), SB3_KEYS[8]: ortho(H, H, g2), SB3_KEYS[9]: torch.zeros(H),
+            SB3_KEYS[10]: ortho(1, H, 1.0), SB3_KEYS[11]: torch.zeros(1),
+        }
+        if self.continuous:
+            sd["log_std"] = torch.zeros(A)
+        return sd
+
+    def _segments(self):
+        D, H, A = self.obs_dim, self.hidden, self.act_dim
+        shapes = [(H, D), (H,), (H, H), (H,), (A, H), (A,), (H, D), (H,), (H, H), (H,), (1, H), (1,)]
+        return list(zip(SB3_KEYS, self.offsets[:12], shapes))
+
+    def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
+        flat = torch.zeros(self.n_trainable, dtype=torch.float32)
+        for key, off, shape in self._segments():
+            w = sd[key].detach().to(torch.float32).cpu().reshape(shape)
+            w = w.t().contiguous() if len(shape) == 2 else w  # kernels use the [in][out] layout
+            flat[off:off + w.numel()] = w.reshape(-1)
+        if self.continuous:
+            flat[self.offsets[12]:self.offsets[12] + self.act_dim] = sd["log_std"].detach().float().cpu()
+        self.params[: self.n_trainable].copy_(flat.to(self.device))
+        _lib.check(_lib.lib().tma_policy_sync(_lib.ptr(self.params), C.byref(self.dims), _lib.stream_ptr(self.device)))
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        flat = self.params[: self.n_trainable].detach().cpu()
+        sd = {}
+        for key, off, shape in self._segments():
+            n = int(np.prod(shape))
+            w = flat[off:off + n]
+            sd[key] = (w.reshape(shape[1], shape[0]).t().contiguous() if len(shape) == 2 else w.clone())
+        if self.continuous:
+            sd["log_std"] = flat[self.offsets[12]:self.offsets[12] + self.act_dim].clone()
+        return sd
+
+    # -- kernels ---------------------------------------------------------------------------
+    def act(self, obs: torch.Tensor, *, rng_seed: int = 0, rng_step: int = 0, env_offset: int = 0, deterministic: bool = False):
+        obs = obs.to(self.device, torch.float32).contiguous()
+        n = obs.shape[0]
+        if self.continuous:
+            actions = torch.empty((n, self.act_dim), dtype=torch.float32, device=self.device)
+        else:
+            actions = torch.empty((n,), dtype=torch.int32, device=self.device)
+        values = torch.empty((n,), dtype=torch.float32, device=self.device)
+        logp = torch.empty((n,), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().tma_policy_act(_lib.ptr(self.params), C.byref(self.dims), _lib.ptr(obs), n, int(rng_seed) & 0xFFFFFFFF,
+                                             int(rng_step) & 0xFFFFFFFF, int(env_offset) & 0xFFFFFFFF, 1 if deterministic else 0,
+                                             _lib.ptr(actions), _lib.ptr(values), _lib.ptr(logp), _lib.stream_ptr(self.device)))
+        return actions, values, logp
+
+    def predict_values(self, obs: torch.Tensor) -> torch.Tensor:
+        obs = obs.to(self.device, torch.float32).contiguous()
+        values = torch.empty((obs.shape[0],), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().tma_policy_values(_lib.ptr(self.params), C.byref(self.dims), _lib.ptr(obs), obs.shape[0], _lib.ptr(values),
+                                                _lib.stream_ptr(self.device)))
+        return values
+
+
+class PPO:
+    """SB3-shaped PPO whose compute is libtma_hip.so.  Constructor/learn/predict/save/load keep SB3's names and defaults."""
+
+    def __init__(self, policy: str = "MlpPolicy", env: HipVecEnv | None = None, learning_rate: float = 3e-4, n_steps: int = 2048,
+                 batch_size: int = 64, n_epochs: int = 10, gamma: float = 0.99, gae_lambda: float = 0.95, clip_range: float = 0.2,
+                 clip_range_vf=None, normalize_advantage: bool = True, ent_coef: float = 0.0, vf_coef: float = 0.5,
+                 max_grad_norm: float = 0.5, policy_kwargs: dict | None = None, tensorboard_log: str | None = None, verbose: int = 0,
+                 seed: int | None = None, device="auto", _init_setup_model: bool = True, **unused):
+        if policy not in ("MlpPolicy", "MultiInputPolicy"):
+            raise ValueError(f"three-mlagents_amd PPO supports MlpPolicy (vector observations), got '{policy}'")
+        if clip_range_vf is not None:
+            raise ValueError("clip_range_vf is not supported (the reference leaves it None)")
+        if callable(learning_rate) or callable(clip_range):
+            raise ValueError("schedules are not supported: pass constant learning_rate / clip_range (the reference does)")
+        self.policy_class = policy
+        self.env = env
+        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = float(learning_rate), int(n_steps), int(batch_size), int(n_epochs)
+        self.gamma, self.gae_lambda, self.clip_range = float(gamma), float(gae_lambda), float(clip_range)
+        self.normalize_advantage, self.ent_coef, self.vf_coef = bool(normalize_advantage), float(ent_coef), float(vf_coef)
+        self.max_grad_norm = float(max_grad_norm)
+        self.policy_kwargs = dict(policy_kwargs or {})
+        self.tensorboard_log, self.verbose = tensorboard_log, int(verbose)
+        self.seed = 0 if seed is None else int(seed)
+        self.num_timesteps = 0
+        self._n_updates = 0
+        self._adam_step = 0
+        self._epoch_counter = 0
+        self._rollout_counter = 0
+        self.logger_values: dict[str, float] = {}
+        self.ep_info: list[tuple[float, float]] = []
+        self.policy: HipActorCriticPolicy | None = None
+        self._last_obs_valid = False
+        from . import dist as _dist
+
+        self.world_size, self.rank = _dist.world_size(), _dist.rank()
+        if env is not None and _init_setup_model:
+            self._setup_model()
+
+    # ------------------------------------------------------------------------------------
+    def _setup_model(self) -> None:
+        env = self.env
+        if not isinstance(env, HipVecEnv):
+            raise ValueError("env must be a three_mlagents_amd HipVecEnv (use training.make_vector_env)")
+        eng = env.engine
+        self.device = eng.device
+        self.n_envs = env.num_envs
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        H = _hidden_from_net_arch(self.policy_kwargs.get("net_arch"))
+        cont = eng.num_actions == 0
+        A = eng.act_dim if cont else eng.num_actions
+        self.policy = HipActorCriticPolicy(eng.obs_dim, A, cont, H, self.device, seed=self.seed)
+        env.seed(self.seed)  # BaseAlgorithm.set_random_seed -> env.seed(seed): env i gets seed + i
+        T, N, D, dev = self.n_steps, self.n_envs, eng.obs_dim, self.device
+        f32 = torch.float32
+        self.buf = dict(
+            obs=torch.zeros((T + 1, N, D), dtype=f32, device=dev),
+            actions=torch.zeros((T, N, A), dtype=f32, device=dev) if cont else torch.zeros((T, N), dtype=torch.int32, device=dev),
+            rewards=torch.zeros((T, N), dtype=f32, device=dev), values=torch.zeros((T, N), dtype=f32, device=dev),
+            log_probs=torch.zeros((T, N), dtype=f32, device=dev), terminated=torch.zeros((T, N), dtype=torch.uint8, device=dev),
+            truncated=torch.zeros((T, N), dtype=torch.uint8, device=dev), terminal_obs=torch.zeros((N, D), dtype=f32, device=dev),
+            last_values=torch.zeros((N,), dtype=f32, device=dev), advantages=torch.zeros((T, N), dtype=f32, device=dev),
+            returns=torch.zeros((T, N), dtype=f32, device=dev),
+        )
+        P = self.policy.n_trainable
+        self.grad = torch.zeros(P, dtype=f32, device=dev)
+        self.exp_avg = torch.zeros(P, dtype=f32, device=dev)
+        self.exp_avg_sq = torch.zeros(P, dtype=f32, device=dev)
+        self.workspace = torch.zeros(int(_lib.lib().tma_ppo_workspace_bytes()), dtype=torch.uint8, device=dev)
+        b = self.buf
+        self._rb = _lib.RolloutBuffers(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["rewards"]), _lib.ptr(b["values"]),
+                                       _lib.ptr(b["log_probs"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]), _lib.ptr(b["terminal_obs"]),
+                                       _lib.ptr(b["last_values"]), N)
+        self._rollout_view = _lib.Rollout(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["log_probs"]), _lib.ptr(b["advantages"]),
+                                          _lib.ptr(b["returns"]), T, N)
+        self._hp = _lib.PPOHParams(self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0)
+
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def get_env(self):
+        return self.env
+
+    # -- rollout --------------------------------------------------------------------------
+    def collect_rollouts(self, callback=None, chunk: int | None = None) -> bool:
+        """SB3 OnPolicyAlgorithm.collect_rollouts: n_steps vector steps through the native driver, then GAE."""
+        L, T, eng = _lib.lib(), self.n_steps, self.env.engine
+        if not self._last_obs_valid:
+            eng.reset(self.buf["obs"][0])
+            self._last_obs_valid = True
+        else:
+            self.buf["obs"][0].copy_(self.buf["obs"][T])
+        chunk = T if (chunk is None or callback is None) else max(1, int(chunk))
+        t = 0
+        keep_going = True
+        while t < T and keep_going:
+            te = min(T, t + chunk)
+            _lib.check(L.tma_rollout_collect(eng._h, _lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rb), t, te, T,
+                                             self.seed & 0xFFFFFFFF, (self._rollout_counter * T) & 0xFFFFFFFF, eng.env_offset & 0xFFFFFFFF,
+                                             self.gamma, 1, self._stream()))
+            for _ in range(te - t):
+                self.num_timesteps += self.n_envs * self.world_size
+                if callback is not None and not callback.on_step():
+                    keep_going = False
+                    break
+            t = te
+        if not keep_going:
+            return False
+        self._rollout_counter += 1
+        b = self.buf
+        _lib.check(L.tma_gae_flags(_lib.ptr(b["rewards"]), _lib.ptr(b["values"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]),
+                                   _lib.ptr(b["last_values"]), self.gamma, self.gae_lambda, T, self.n_envs, _lib.ptr(b["advantages"]),
+                                   _lib.ptr(b["returns"]), self._stream()))
+        return True
+
+    # -- update ---------------------------------------------------------------------------
+    def train(self) -> None:
+        """SB3 PPO.train: n_epochs passes over the permuted rollout in minibatches of batch_size."""
+        L = _lib.lib()
+        total = self.n_steps * self.n_envs
+        scale = 1.0 / self.world_size
+        for _ in range(self.n_epochs):
+            for start in range(0, total, self.batch_size):
+                mb = _lib.Minibatch(None, (self.seed * 2654435761 + 12345) & 0xFFFFFFFF, self._epoch_counter & 0xFFFFFFFF, start,
+                                    min(self.batch_size, total - start))
+                _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
+                                                    C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
+                if self.world_size > 1:
+                    import torch.distributed as tdist
+
+                    tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
+                self._adam_step += 1
+                _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                               C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5, self.max_grad_norm,
+                                               scale, _lib.ptr(self.workspace), self._stream()))
+            self._epoch_counter += 1
+        self._n_updates += self.n_epochs
+
+    def pop_train_stats(self) -> dict[str, float]:
+        out = (C.c_double * 8)()
+        _lib.check(_lib.lib().tma_ppo_pop_stats(_lib.ptr(self.workspace), out, self._stream()))
+        n = max(out[5], 1.0)
+        return {"train/policy_gradient_loss": out[0] / n, "train/value_loss": out[1] / n, "train/entropy_loss": -out[2] / n,
+                "train/approx_kl": out[3] / n, "train/clip_fraction": out[4] / n, "train/grad_norm": out[6], "train/n_samples": out[5]}
+
+    # -- learn ----------------------------------------------------------------------------
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 1, tb_log_name: str = "PPO", reset_num_timesteps: bool = True,
+              progress_bar: bool = False):
+        from .callbacks import as_callback
+
+        cb = as_callback(callback)
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        self._total_timesteps = int(total_timesteps)
+        cb.init_callback(self)
+        cb.on_training_start(locals(), globals())
+        t0 = time.time()
+        iteration = 0
+        while self.num_timesteps < total_timesteps:
+            cb.on_rollout_start()
+            if not self.collect_rollouts(cb if callback is not None else None, chunk=getattr(cb, "chunk_steps", None)):
+                break
+            cb.on_rollout_end()
+            iteration += 1
+            self.train()
+            if log_interval is not None and iteration % log_interval == 0:
+                s_ret, s_len, cnt = self.env.engine.pop_episode_stats()
+                stats = self.pop_train_stats()
+                fps = self.num_timesteps / max(time.time() - t0, 1e-9)
+                stats.update({"time/fps": fps, "time/iterations": iteration, "time/total_timesteps": self.num_timesteps,
+                              "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
+                              "rollout/episodes": cnt, "train/n_updates": self._n_updates})
+                self.logger_values = stats
+                if self.verbose >= 1 and self.rank == 0:
+                    print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+        cb.on_training_end()
+        return self
+
+    # -- inference ------------------------------------------------------------------------
+    def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
+        """BaseAlgorithm.predict: obs [D] or [n, D] (numpy or tensor) -> (action(s), None)."""
+        obs = torch.as_tensor(np.asarray(observation, dtype=np.float32) if not torch.is_tensor(observation) else observation)
+        single = obs.dim() == 1
+        if single:
+            obs = obs.unsqueeze(0)
+        self._predict_counter = getattr(self, "_predict_counter", 0) + 1
+        actions, _, _ = self.policy.act(obs, rng_seed=self.seed ^ 0x5EED, rng_step=self._predict_counter, deterministic=deterministic)
+        a = actions.cpu().numpy()
+        if self.policy.continuous:
+            a = np.clip(a, -1.0, 1.0)
+        else:
+            a = a.astype(np.int64)
+        return (a[0] if single else a), None
+
+    # -- artefacts (SB3 zip member names) ---------------------------------------
+    def _data(self) -> dict[str, Any]:
+        return {
+            "policy_class": self.policy_class, "engine": "three-mlagents_amd", "task_id": getattr(self.env, "task_id", None),
+            "obs_dim": self.policy.obs_dim, "act_dim": self.policy.act_dim, "continuous": self.policy.continuous, "hidden": self.policy.hidden,
+            "learning_rate": self.learning_rate, "n_steps": self.n_steps, "batch_size": self.batch_size, "n_epochs": self.n_epochs,
+            "gamma": self.gamma, "gae_lambda": self.gae_lambda, "clip_range": self.clip_range, "normalize_advantage": self.normalize_advantage,
+            "ent_coef": self.ent_coef, "vf_coef": self.vf_coef, "max_grad_norm": self.max_grad_norm, "policy_kwargs": self.policy_kwargs,
+            "seed": self.seed, "num_timesteps": self.num_timesteps, "_n_updates": self._n_updates, "_adam_step": self._adam_step,
+            "n_envs": getattr(self, "n_envs", None),
+        }
+
+    def save(self, path, exclude=None, include=None) -> None:
+        path = str(path)
+        if not os.path.splitext(path)[1]:
+            path += ".zip"
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+        def _pth(obj) -> bytes:
+            bio = io.BytesIO()
+            torch.save(obj, bio)
+            return bio.getvalue()
+
+        sd = self.policy.state_dict()
+        opt = {"state": {}, "param_groups": [{"lr": self.learning_rate, "betas": (0.9, 0.999), "eps": 1e-5, "weight_decay": 0,
+                                               "amsgrad": False, "params": list(range(len(sd)))}],
+               "tma_flat": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self._adam_step}}
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+            z.writestr("data", json.dumps(self._data(), indent=2, default=str))
+            z.writestr("policy.pth", _pth(sd))
+            z.writestr("policy.optimizer.pth", _pth(opt))
+            z.writestr("pytorch_variables.pth", _pth({}))
+            z.writestr("_stable_baselines3_version", "2.9.0+three-mlagents_amd")
+            z.writestr("system_info.txt", f"OS: {platform.platform()}\nPython: {platform.python_version()}\nPyTorch: {torch.__version__}\nGPU Enabled: True\n")
+
+    @classmethod
+    def load(cls, path, env=None, device="auto", **kwargs) -> "PPO":
+        path = str(path)
+        if not os.path.exists(path) and os.path.exists(path + ".zip"):
+            path += ".zip"
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Model not found: {path}")
+        with zipfile.ZipFile(path) as z:
+            data = json.loads(z.read("data").decode())
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+            opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=False)
+        model = cls(data.get("policy_class", "MlpPolicy"), None, learning_rate=data["learning_rate"], n_steps=data["n_steps"],
+                    batch_size=data["batch_size"], n_epochs=data["n_epochs"], gamma=data["gamma"], gae_lambda=data["gae_lambda"],
+                    clip_range=data["clip_range"], normalize_advantage=data["normalize_advantage"], ent_coef=data["ent_coef"],
+                    vf_coef=data["vf_coef"], max_grad_norm=data["max_grad_norm"], policy_kwargs=data.get("policy_kwargs"), seed=data.get("seed"),
+                    _init_setup_model=False)
+        model.num_timesteps, model._n_updates, model._adam_step = data.get("num_timesteps", 0), data.get("_n_updates", 0), data.get("_adam_step", 0)
+        if env is not None:
+            model.env = env
+            model._setup_model()
+            model.policy.load_state_dict(sd)
+            flat = opt.get("tma_flat")
+            if flat is not None:
+                model.exp_avg.copy_(flat["exp_avg"].to(model.device))
+                model.exp_avg_sq.copy_(flat["exp_avg_sq"].to(model.device))
+        else:
+            from .vec_env import _require_gpu
+
+            dev = _require_gpu(None if device == "auto" else device)
+            model.device = dev
+            model.policy = HipActorCriticPolicy(data["obs_dim"], data["act_dim"], data["continuous"], data["hidden"], dev, seed=0)
+            model.policy.load_state_dict(sd)
+        return model
+
