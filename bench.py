@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of full PPO iterations on GridWorld, 4096 envs per MI355X (BASELINE.json configs[1]).
+
+One "step" = one complete PPO iteration of the hot path on one GPU:
+    rollout of n_steps vector steps (policy forward + sampling, batched env step with auto-reset / terminal obs /
+    Monitor sums, timeout bootstrap, MT19937 reset-ring refills) -> GAE -> n_epochs x minibatches of
+    (advantage stats, forward+backward of the clipped-surrogate loss, [RCCL all-reduce of the flat gradient], clip + Adam).
+Nothing is skipped inside the timed region.  `value` = env-steps of all ranks / max-over-ranks wall time.
+
+Run:  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per env-step of the step kernel as this build lays it out: state words in+out,
+# Monitor sum in+out, episode index in+out, action in, obs + reward + 2 flags out.  SURVEY.md §8d's formula (i32 fields)
+# is reported next to it.
+LAYOUT_BYTES = {"gridworld": 4 + 4 + 4 + 8 + 8 + 4 + 4 + 16 + 4 + 2, "push": 58, "basic": 4 + 8 + 16 + 8 + 84 + 6, "ball3d": 4 + 72 + 16 + 8 + 24 + 6}
+SURVEY_BYTES = {"gridworld": 90, "push": 74, "basic": 110, "ball3d": 114}
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+
+
+def mlp_flops_per_sample(D, H, A):
+    fwd = 2 * ((D * H + H * H) * 2 + H * A + H)
+    return fwd, 3 * fwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--task", default="gridworld")
+    ap.add_argument("--n-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--n-steps", type=int, default=1024)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--n-epochs", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=0, help="0 -> 32 minibatches per epoch (the reference's default schedule: 8 envs x 1024 / 256)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sweep", action="store_true", help="also run the env-count sweep of the step kernel (extra JSON field)")
+    return ap.parse_args()
+
+
+def timed_kernel_us(fn, reps, stream_sync):
+    """Average duration of one launch, HIP events recorded on the launch stream around each launch."""
+    import torch
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    stream_sync()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(args, seconds):
+    """Oracle (C port, OpenMP over envs) + torch-CPU restatement of the SB3 policy/update, on a bounded sample of the workload."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle as orc
+    from oracle import sb3_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N, D, A, H = args.n_envs, orc.obs_dim(args.task), orc.num_actions(args.task), args.hidden
+    T = 16
+    env = orc.OracleVecEnv(args.task, N, seed=args.seed, threads=cores)
+    sd = sb3_ref.init_policy(D, H, A, False, seed=args.seed)
+    obs = torch.from_numpy(env.reset())
+    t0 = time.perf_counter()
+    iters = 0
+    env_only_t = 0.0
+    while True:
+        b_obs, b_act, b_lp, b_val, b_rew, b_done = [], [], [], [], [], []
+        for _ in range(T):
+            with torch.no_grad():
+                logits, values = sb3_ref.forward(sd, obs)
+                dist = torch.distributions.Categorical(logits=logits)
+                act = dist.sample()
+                lp = dist.log_prob(act)
+            e0 = time.perf_counter()
+            o = env.step(act.numpy().astype(np.int32))
+            env_only_t += time.perf_counter() - e0
+            b_obs.append(obs), b_act.append(act), b_lp.append(lp), b_val.append(values), b_rew.append(torch.from_numpy(o["rew32"]))
+            b_done.append(torch.from_numpy((o["term"] | o["trunc"]).astype(np.float32)))
+            obs = torch.from_numpy(o["obs"])
+        with torch.no_grad():
+            _, last_v = sb3_ref.forward(sd, obs)
+        rew, val, done = torch.stack(b_rew).numpy(), torch.stack(b_val).numpy(), torch.stack(b_done).numpy()
+        es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
+        adv, ret = orc.gae(rew, val, es, last_v.numpy(), done[-1].astype(np.uint8))
+        tr = sb3_ref.RefTrainer(sd)
+        fo, fa, fl = torch.cat(b_obs), torch.cat(b_act), torch.cat(b_lp)
+        fadv, fret = torch.from_numpy(adv).reshape(-1), torch.from_numpy(ret).reshape(-1)
+        total = T * N
+        bs = args.batch_size if args.batch_size > 0 else max(256, total // 32)
+        for _ in range(args.n_epochs):
+            perm = torch.randperm(total)
+            for s in range(0, total, bs):
+                idx = perm[s:s + bs]
+                tr.step(fo[idx], fa[idx], fl[idx], fadv[idx], fret[idx], clip_range=0.2, ent_coef=0.01, vf_coef=0.5)
+        sd = {k: v.detach() for k, v in tr.sd.items()}
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > seconds:
+            break
+    return {
+        "value": iters * T * N / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{iters} reduced PPO iterations of {T} vector steps x {N} envs ({args.task}, MLP {H}x{H}, {args.n_epochs} epochs): C oracle env "
+                  f"(OpenMP, {cores} threads) + torch-CPU restatement of SB3 policy/GAE/update ({cores} threads)",
+        "env_only_steps_per_s": iters * T * N / max(env_only_t, 1e-9),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    from three_mlagents_amd import dist
+
+    rank, local_rank, world = dist.init_from_env()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from three_mlagents_amd import _lib
+    from three_mlagents_amd.ppo import PPO
+    from three_mlagents_amd.training import make_vector_env
+
+    N, T = args.n_envs, args.n_steps
+    total = N * T
+    batch = args.batch_size if args.batch_size > 0 else max(256, total // 32)
+    env = make_vector_env(args.task, n_envs=N, seed=args.seed, device=dev, env_offset=rank * N)
+    model = PPO("MlpPolicy", env, learning_rate=3e-4, n_steps=T, batch_size=batch, n_epochs=args.n_epochs, gamma=0.99, gae_lambda=0.95,
+                clip_range=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, seed=args.seed,
+                policy_kwargs={"net_arch": {"pi": [args.hidden] * 2, "vf": [args.hidden] * 2}})
+    D, A = model.policy.obs_dim, model.policy.act_dim
+
+    def iteration():
+        model.collect_rollouts()
+        model.train()
+
+    for _ in range(args.warmup):
+        iteration()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    t_roll = 0.0
+    for _ in range(args.steps):
+        r0 = time.perf_counter()
+        model.collect_rollouts()
+        torch.cuda.synchronize()
+        t_roll += time.perf_counter() - r0
+        model.train()
+    torch.cuda.synchronize()
+    dist.barrier()
+    el_local = time.perf_counter() - t0
+    el = dist.allreduce_max_float(el_local, device=dev)
+    t_roll = dist.allreduce_max_float(t_roll, device=dev)
+    env_steps = world * total * args.steps
+    updates = args.steps * args.n_epochs * ((total + batch - 1) // batch)
+    train_stats = model.pop_train_stats()
+
+    out = {
+        "metric": "env_steps_per_sec", "value": env_steps / el, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.task} (5x5 GridWorld), {N} envs/GPU, full PPO iterations: n_steps={T}, MLP pi/vf {args.hidden}x{args.hidden} tanh, "
+                        f"n_epochs={args.n_epochs}, batch_size={batch} ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
+                        f"gae_lambda=0.95, clip=0.2, ent=0.01, vf=0.5, max_grad_norm=0.5",
+            "envs_per_gpu": N, "n_steps": T, "batch_size": batch, "n_epochs": args.n_epochs, "hidden": args.hidden,
+            "parallelism": f"dp{world} (envs sharded, all-reduce of the flat f32 gradient per minibatch)" if world > 1 else "single GPU",
+        },
+        "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9), "ppo_updates_per_iteration": updates // args.steps,
+        "rollout_env_steps_per_sec": env_steps / max(t_roll, 1e-9), "rollout_ms": t_roll / args.steps * 1e3,
+        "update_ms": (el - t_roll) / args.steps * 1e3, "train_stats": {k: round(v, 6) for k, v in train_stats.items()},
+    }
+
+    if rank == 0:
+        # ---- per-kernel durations with HIP events on the launch stream (rank 0, after the timed region) ----
+        import ctypes as C
+
+        eng = env.engine
+        sync = lambda: torch.cuda.current_stream(dev).synchronize()  # noqa: E731
+        b = model.buf
+        L = _lib.lib()
+        # batched step kernel exactly as the rollout launches it (1 vector step, policy actions, terminal obs captured)
+        acts = b["actions"][0].contiguous()
+        outs = dict(obs=torch.empty((1, N, D), device=dev), rew=torch.empty((1, N), device=dev), term=torch.empty((1, N), dtype=torch.uint8, device=dev),
+                    trunc=torch.empty((1, N), dtype=torch.uint8, device=dev), term_obs=torch.empty((1, N, D), device=dev))
+
+        def step_once():
+            if eng.steps_until_refill() == 0:
+                raise RuntimeError("refill bookkeeping broke")
+            eng.step(acts, outputs=outs, want_episode=False)
+
+        reps = 4 * eng.ring_depth - 8
+        avg_us, med_us = timed_kernel_us(step_once, reps, sync)  # includes the refill launch once per ring_depth steps
+        # exclude launches that also carried a refill: use the median for the pure step kernel
+        lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
+        step_gbps = N * lay / (med_us * 1e-6) / 1e9
+        out["roofline"] = {
+            "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs)", "bound": "hbm", "achieved": step_gbps, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_env_step": lay, "launch_us": med_us,
+            "survey_formula_bytes_per_env_step": sv, "survey_formula_GBps": N * sv / (med_us * 1e-6) / 1e9,
+            "note": "4096 envs move 0.24 MB per launch: the launch is latency-bound, not HBM-bound (SURVEY.md §7.3-4); see roofline_saturated",
+        }
+        # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
+        try:
+            from three_mlagents_amd.vec_env import HipEnvEngine
+
+            Nb = 1 << 22
+            big = HipEnvEngine(args.task, Nb, seed=args.seed, ring_depth=8)
+            big.reset()
+            bo = {k: v for k, v in big._out(1).items() if k in ("obs", "rew", "term", "trunc")}
+            tt = [0]
+
+            def big_step():
+                big.step(None, n_steps=1, tape_seed=1, tape_t0=tt[0], outputs=bo, want_terminal_obs=False, want_episode=False)
+                tt[0] += 1
+
+            for _ in range(8):
+                big_step()
+            _, med_big = timed_kernel_us(big_step, 40, sync)
+            bytes_big = lay - 4  # tape: no action read
+            gb = Nb * bytes_big / (med_big * 1e-6) / 1e9
+            out["roofline_saturated"] = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm",
+                                         "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS, "launch_us": med_big,
+                                         "bytes_per_env_step": bytes_big, "env_steps_per_s_kernel_only": Nb / (med_big * 1e-6),
+                                         "survey_formula_GBps": Nb * (sv - 4) / (med_big * 1e-6) / 1e9}
+            big.close()
+            del big, bo
+        except Exception as exc:  # noqa: BLE001
+            out["roofline_saturated"] = {"error": str(exc)}
+        # PPO minibatch forward+backward kernel (the kernel that dominates wall time of the iteration)
+        mb = _lib.Minibatch(None, 1, 0, 0, min(batch, total))
+        flops_fwd, flops_fb = mlp_flops_per_sample(D, args.hidden, A)
+
+        def grad_once():
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(model._rollout_view), C.byref(mb),
+                                                C.byref(model._hp), _lib.ptr(model.grad), _lib.ptr(model.workspace), model._stream()))
+
+        for _ in range(2):
+            grad_once()
+        g_avg, g_med = timed_kernel_us(grad_once, 10, sync)
+        model.grad.zero_()
+        tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
+        out["roofline_update"] = {"kernel": "tma::adv_stats_kernel + tma::ppo_grad_kernel (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",
+                                  "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                  "launch_us": g_med, "samples": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb, "traffic": None}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": str(exc)}
+        if args.sweep:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import env_sweep
+
+            out["env_sweep"] = [env_sweep.run(args.task, n, 32, 3, pl) for n in (4096, 65536, 1 << 20, 1 << 22) for pl in (1, 32)]
+        print(json.dumps(out), flush=True)
+    env.close()
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""GPU mirror of the reference's env-contract / construct-and-predict tests and of the CLI train/evaluate path
+(/root/reference/backend/tests/test_mlagents.py:32-45,51-101; cli.py:70-95)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_basic_env_reset_and_step():  # test_mlagents.py:32-45
+    from three_mlagents_amd.registry import make_env
+
+    env = make_env("basic")
+    try:
+        obs, info = env.reset(seed=1)
+        assert obs.shape == env.observation_space.shape and info["position"] == 10
+        next_obs, reward, terminated, truncated, info = env.step(2)
+        assert next_obs.shape == env.observation_space.shape and isinstance(reward, float) and reward == -0.01
+        assert terminated is False and truncated is False and info["position"] == 11
+        obs, info = env.reset(options={"position": 16})
+        _, reward, terminated, truncated, info = env.step(2)
+        assert terminated and not truncated and info["position"] == 17 and abs(reward - 0.99) < 1e-6
+    finally:
+        env.close()
+
+
+def test_trainable_env_contracts_match_declared_spaces():  # test_mlagents.py:51-72
+    from three_mlagents_amd.registry import list_tasks, make_env
+
+    for task in list_tasks(include_roadmap=False):
+        env = make_env(task.id)
+        try:
+            obs, _ = env.reset(seed=123)
+            assert env.observation_space.contains(obs), task.id
+            next_obs, reward, terminated, truncated, _ = env.step(env.action_space.sample())
+            assert env.observation_space.contains(next_obs), task.id
+            assert isinstance(float(reward), float) and isinstance(terminated, bool) and isinstance(truncated, bool)
+        finally:
+            env.close()
+
+
+def test_single_env_matches_reference_seeded_reset(golden):
+    from three_mlagents_amd.registry import make_env
+
+    g = golden("gridworld")
+    env = make_env("gridworld")
+    for s, obs_ref in list(zip(g["reset_seeds"], g["reset_seed_obs"]))[:5]:
+        obs, info = env.reset(seed=int(s))
+        assert np.array_equal(obs, obs_ref) and info == {"steps": 0}
+    # /root/reference probe quoted in SURVEY.md §8c: reset(seed=7) -> [0.25,-0.75,1,0]; 100 no-ops -> truncated, not terminated
+    obs, _ = env.reset(seed=7)
+    assert obs.tolist() == [0.25, -0.75, 1.0, 0.0]
+    for _ in range(100):
+        obs, r, te, tr, info = env.step(0)
+    assert tr and not te and info["steps"] == 100
+    env.close()
+
+
+def test_registered_algorithms_construct_and_predict():  # test_mlagents.py:74-101
+    from three_mlagents_amd.registry import list_tasks
+    from three_mlagents_amd.training import ALGORITHMS, _default_model_kwargs, _default_policy, make_vector_env
+
+    for task in list_tasks(include_roadmap=False):
+        vec_env = make_vector_env(task.id, n_envs=2, seed=321)
+        try:
+            kwargs = _default_model_kwargs("ppo", train_env=vec_env, task=task, total_timesteps=64, tensorboard_log="/tmp/three-mlagents-test-tb", verbose=0)
+            kwargs["n_steps"] = 16
+            model = ALGORITHMS["ppo"](_default_policy(task), vec_env, seed=321, **kwargs)
+            action, _ = model.predict(vec_env.reset(), deterministic=True)
+            assert action is not None and len(action) == 2
+            obs, rew, dones, infos = vec_env.step(action)
+            assert obs.shape == (2,) + vec_env.observation_space.shape and rew.dtype == np.float32 and dones.dtype == bool and len(infos) == 2
+        finally:
+            vec_env.close()
+
+
+def test_vec_env_infos_carry_sb3_keys():
+    from three_mlagents_amd.vec_env import HipVecEnv, HipVectorEnv
+
+    env = HipVecEnv("gridworld", 64, seed=3)
+    env.reset()
+    rng = np.random.default_rng(0)
+    seen = False
+    for _ in range(150):
+        obs, rew, dones, infos = env.step(rng.integers(0, 5, 64))
+        for i in np.nonzero(dones)[0]:
+            info = infos[i]
+            assert set(info) >= {"terminal_observation", "TimeLimit.truncated", "episode"} and set(info["episode"]) == {"r", "l", "t"}
+            assert info["terminal_observation"].shape == (4,) and info["episode"]["l"] <= 100
+            seen = True
+    assert seen
+    env.close()
+    genv = HipVectorEnv("push", 8, seed=1)
+    obs, infos = genv.reset(seed=5)
+    obs, rew, term, trunc, infos = genv.step(np.zeros(8, np.int64))
+    assert obs.shape == (8, 4) and term.dtype == bool and trunc.dtype == bool
+    genv.close()
+
+
+def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 ; artefacts training.py:172-207
+    monkeypatch.chdir(tmp_path)
+    from three_mlagents_amd import cli
+
+    cli.main(["train", "basic", "--algorithm", "ppo", "--n-envs", "8", "-t", "4096", "--eval-episodes", "4", "--eval-freq", "2048", "--run-name", "t1", "--quiet"])
+    out = json.loads(capsys.readouterr().out)
+    assert out["task_id"] == "basic" and out["algorithm"] == "ppo" and out["model_filename"] == "basic_policy_t1.zip"
+    assert os.path.exists(tmp_path / "policies" / "basic_policy_t1.zip")
+    meta = json.loads((tmp_path / "runs" / "basic" / "t1" / "metadata.json").read_text())
+    assert meta["run_id"] == "t1" and len(meta["episode_rewards"]) == 4 and meta["task"]["id"] == "basic"
+    assert os.path.exists(tmp_path / "runs" / "basic" / "t1" / "eval" / "evaluations.npz")
+    cli.main(["evaluate", "basic", "basic_policy_t1.zip", "--episodes", "3"])
+    ev = json.loads(capsys.readouterr().out)
+    assert ev["episodes"] == 3 and len(ev["episode_lengths"]) == 3
+    from three_mlagents_amd.training import predict_action
+
+    assert predict_action("basic", np.eye(21, dtype=np.float32)[10], "basic_policy_t1.zip") in (0, 1, 2)

@@ -217,8 +217,8 @@ def test_timeout_bootstrap():
     rew = torch.randn(n, generator=g)
     _, v_ref = sb3_ref.forward(sd, tobs)
     expect = torch.where(trunc.bool(), rew + np.float32(0.99) * v_ref, rew)
-    r = rew.cuda()
-    _lib.check(_lib.lib().tma_policy_bootstrap(_lib.ptr(pol.params), C.byref(pol.dims), _lib.ptr(tobs.cuda()), _lib.ptr(trunc.cuda()), n, 0.99,
+    r, tobs_d, trunc_d = rew.cuda(), tobs.cuda(), trunc.cuda()  # keep the device tensors alive across the launch
+    _lib.check(_lib.lib().tma_policy_bootstrap(_lib.ptr(pol.params), C.byref(pol.dims), _lib.ptr(tobs_d), _lib.ptr(trunc_d), n, 0.99,
                                                _lib.ptr(r), _lib.stream_ptr()))
     assert torch.allclose(r.cpu(), expect, rtol=0, atol=1e-5)
     assert torch.equal(r.cpu()[~trunc.bool()], rew[~trunc.bool()])

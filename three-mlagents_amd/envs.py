@@ -1,0 +1,118 @@
+"""Single-environment Gymnasium surface over the HIP engine (a 1-env shard of the vector engine).
+
+Mirrors what the reference's factories return (/root/reference/backend/mlagents/envs.py:162-199,274-277): an object with
+`observation_space`, `action_space`, `reset(*, seed=None, options=None) -> (obs, info)` and
+`step(action) -> (obs, reward: float, terminated: bool, truncated: bool, info)`.
+`reset(seed=s)` reproduces `LegacySingleAgentGymAdapter.reset(seed=s)` (np.random.seed(s), constructor reset, explicit
+reset; envs.py:110-123) bit for bit; an unseeded `reset()` starts the next episode of the per-episode seed contract.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+
+class HipSingleEnv:
+    metadata = {"render_modes": []}
+    render_mode = None
+    spec = None
+
+    def __init__(self, task: str, *, seed: int = 0, device=None):
+        from .vec_env import HipEnvEngine
+
+        self.engine = HipEnvEngine(task, 1, seed=seed, device=device, ring_depth=8)
+        self.task_id = self.engine.task_name
+        self.observation_space = self.engine.observation_space
+        self.action_space = self.engine.action_space
+        self.max_episode_steps = self.engine.max_episode_steps
+        self.steps = 0
+        self._started = False
+        self._pending_obs = None  # observation of the auto-started next episode, handed out by the next reset()
+
+    def _info(self, steps: int) -> dict[str, Any]:
+        info = {"steps": int(steps)}
+        if self.task_id == "basic":
+            info["position"] = int(self.engine.get_state()[0, 0].item())
+        return info
+
+    def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):
+        if seed is not None:
+            self.engine.seed(int(seed))
+            self.action_space.seed(int(seed))
+        if seed is not None or not self._started:
+            obs = self.engine.reset().cpu().numpy()[0]
+            self._started = True
+        elif self._pending_obs is not None:
+            obs = self._pending_obs
+        else:  # reset in the middle of an episode: abandon it and start episode 0 of the current seed again
+            obs = self.engine.reset().cpu().numpy()[0]
+        self._pending_obs = None
+        self.steps = 0
+        if self.task_id == "basic" and options and "position" in options:  # envs.py:54-57
+            pos = int(np.clip(int(options["position"]), 0, 20))
+            self.engine.set_state(np.array([[float(pos), 0.0]]))
+            obs = np.zeros(21, np.float32)
+            obs[pos] = 1.0
+        return obs.astype(np.float32), self._info(0)
+
+    def step(self, action):
+        if not self._started:
+            raise RuntimeError("step() called before reset()")
+        if self.engine.num_actions > 0:
+            a = torch.tensor([int(action)], dtype=torch.int64)
+        else:
+            a = torch.as_tensor(np.asarray(action, np.float32).reshape(1, -1))
+        out = self.engine.step(a.to(self.engine.device))
+        term = bool(out["term"][0, 0].item())
+        trunc = bool(out["trunc"][0, 0].item())
+        reward = float(out["rew"][0, 0].item()) if self.task_id == "ball3d" else self._reward64(out)
+        self.steps += 1
+        if term or trunc:
+            obs = out["term_obs"][0, 0].cpu().numpy()
+            self._pending_obs = out["obs"][0, 0].cpu().numpy()
+            info = {"steps": int(out["ep_len"][0, 0].item())}
+            if self.task_id == "basic":
+                info["position"] = int(np.argmax(obs))
+        else:
+            obs = out["obs"][0, 0].cpu().numpy()
+            info = self._info(self.steps)
+        return obs.astype(np.float32), reward, term, trunc, info
+
+    def _reward64(self, out) -> float:
+        """The reference returns python floats computed in float64 (e.g. -0.01, 0.09000000000000001); the kernel's float32
+        reward is the float32 rounding of one of a small set of float64 values per task, recovered here."""
+        r32 = float(out["rew"][0, 0].item())
+        r6 = round(r32, 6)
+        return r6 if np.float32(r6) == np.float32(r32) else r32
+
+    def close(self) -> None:
+        self.engine.close()
+
+    def render(self):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+def make_basic_env() -> HipSingleEnv:
+    return HipSingleEnv("basic")
+
+
+def make_ball3d_env() -> HipSingleEnv:
+    return HipSingleEnv("ball3d")
+
+
+def make_gridworld_env() -> HipSingleEnv:
+    return HipSingleEnv("gridworld")
+
+
+def make_push_env() -> HipSingleEnv:
+    return HipSingleEnv("push")
+
+
+def make_ant_env() -> HipSingleEnv:
+    return HipSingleEnv("crawler")
