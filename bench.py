@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # CPU-baseline leg: OpenMP (oracle) and torch pools must not spin against each other
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -54,6 +56,10 @@ def parse():
     return ap.parse_args()
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def timed_kernel_us(fn, reps, stream_sync):
     """Average duration of one launch, HIP events recorded on the launch stream around each launch."""
     import torch
@@ -76,8 +82,9 @@ def cpu_baseline(args, seconds):
     from oracle import oracle as orc
     from oracle import sb3_ref
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # threads actually used by both the OpenMP oracle and torch
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, budget {seconds:.0f} s")
     N, D, A, H = args.n_envs, orc.obs_dim(args.task), orc.num_actions(args.task), args.hidden
     T = 16
     env = orc.OracleVecEnv(args.task, N, seed=args.seed, threads=cores)
@@ -115,6 +122,8 @@ def cpu_baseline(args, seconds):
             for s in range(0, total, bs):
                 idx = perm[s:s + bs]
                 tr.step(fo[idx], fa[idx], fl[idx], fadv[idx], fret[idx], clip_range=0.2, ent_coef=0.01, vf_coef=0.5)
+            if iters > 0 and time.perf_counter() - t0 > 3 * seconds:
+                break  # hard bound: never let the baseline leg run away
         sd = {k: v.detach() for k, v in tr.sd.items()}
         iters += 1
         el = time.perf_counter() - t0
@@ -160,8 +169,10 @@ def main():
         model.collect_rollouts()
         model.train()
 
+    log(f"rank {rank}/{world}: engine ready, N={N} T={T} batch={batch}")
     for _ in range(args.warmup):
         iteration()
+    log("warmup done")
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -177,6 +188,7 @@ def main():
     el_local = time.perf_counter() - t0
     el = dist.allreduce_max_float(el_local, device=dev)
     t_roll = dist.allreduce_max_float(t_roll, device=dev)
+    log(f"timed region done: {el:.3f} s for {args.steps} iterations")
     env_steps = world * total * args.steps
     updates = args.steps * args.n_epochs * ((total + batch - 1) // batch)
     train_stats = model.pop_train_stats()
@@ -217,6 +229,7 @@ def main():
         reps = 4 * eng.ring_depth - 8
         avg_us, med_us = timed_kernel_us(step_once, reps, sync)  # includes the refill launch once per ring_depth steps
         # exclude launches that also carried a refill: use the median for the pure step kernel
+        log(f"step kernel: avg {avg_us:.2f} us, median {med_us:.2f} us")
         lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
         step_gbps = N * lay / (med_us * 1e-6) / 1e9
         out["roofline"] = {
@@ -241,7 +254,9 @@ def main():
 
             for _ in range(8):
                 big_step()
+            log("saturated engine ready")
             _, med_big = timed_kernel_us(big_step, 40, sync)
+            log(f"saturated step kernel median {med_big:.1f} us")
             bytes_big = lay - 4  # tape: no action read
             gb = Nb * bytes_big / (med_big * 1e-6) / 1e9
             out["roofline_saturated"] = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm",
@@ -263,6 +278,7 @@ def main():
         for _ in range(2):
             grad_once()
         g_avg, g_med = timed_kernel_us(grad_once, 10, sync)
+        log(f"grad kernel median {g_med:.1f} us")
         model.grad.zero_()
         tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
         out["roofline_update"] = {"kernel": "tma::adv_stats_kernel + tma::ppo_grad_kernel (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",

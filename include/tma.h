@@ -139,7 +139,8 @@ typedef struct {
     int normalize_advantage;
 } tma_ppo_hparams;
 
-int64_t tma_ppo_workspace_bytes(void);
+/* bytes of the update workspace for a policy shape (loss-stat slots, norm partials, partial-gradient slabs) */
+int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d);
 /* PPO.train inner loop body up to loss.backward(): accumulates d(loss)/d(params) into grad[n_trainable] (caller zeroes it
  * once; tma_ppo_adam_step re-zeroes it) and loss statistics into the workspace. */
 int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mb,

@@ -105,7 +105,7 @@ def _hip_grad(pol, bufs, T, N, indices, start, count, hp, perm=None):
     mb = _lib.Minibatch(_lib.ptr(idx), perm[0] if perm else 0, perm[1] if perm else 0, start, count)
     hpar = _lib.PPOHParams(hp["clip_range"], hp["ent_coef"], hp["vf_coef"], 1 if hp["normalize_advantage"] else 0)
     grad = torch.zeros(pol.n_trainable, device=dev)
-    ws = torch.zeros(int(_lib.lib().tma_ppo_workspace_bytes()), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(int(_lib.lib().tma_ppo_workspace_bytes(C.byref(pol.dims))), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), C.byref(mb), C.byref(hpar), _lib.ptr(grad),
                                                  _lib.ptr(ws), _lib.stream_ptr()))
     out = (C.c_double * 8)()
@@ -151,6 +151,34 @@ def test_minibatch_gradient_matches_autograd(D, H, A, cont, B):
     assert abs(-st[2] / n - stats_ref["entropy_loss"]) < 1e-5 and abs(st[3] / n - stats_ref["approx_kl"]) < 1e-5
     assert abs(st[4] / n - stats_ref["clip_fraction"]) < 1e-6
     assert 0.05 < stats_ref["clip_fraction"] < 0.95  # the test exercises both branches of the clipped surrogate
+
+
+@pytest.mark.parametrize("D,A", [(4, 5), (6, 5)])
+def test_large_minibatch_register_accumulating_kernel(D, A):
+    """B >= 16384 with H = 64 takes the persistent register-accumulating kernel + slab reduction (no atomics)."""
+    H, T, N, B = 64, 64, 400, 20000
+    pol, sd = _policy(D, H, A, False)
+    obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(2))
+    idx = perm[100:100 + B]
+    f = lambda x: _flatten_env_major(x, T, N)[idx]  # noqa: E731
+    tr = sb3_ref.RefTrainer(sd)
+    stats_ref, grads_ref = tr.step(f(obs), f(actions), f(old_lp), f(adv), f(ret), **HP)
+    bufs = dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret)
+    grad, st, _ = _hip_grad(pol, bufs, T, N, perm, 100, B, HP)
+    grad2, _, _ = _hip_grad(pol, bufs, T, N, perm, 100, B, HP)
+    assert torch.equal(grad, grad2)  # slab reduction: bitwise reproducible
+    ref = _ref_grad_flat(pol, grads_ref)
+    err, scale = (grad.cpu() - ref).abs().max().item(), ref.abs().max().item()
+    assert err <= 2e-5 * max(scale, 1.0) + 1e-6, (err, scale)
+    assert st[5] == B and abs(st[0] / B - stats_ref["policy_loss"]) < 1e-5 and abs(st[1] / B - stats_ref["value_loss"]) < 1e-4
+    assert abs(-st[2] / B - stats_ref["entropy_loss"]) < 1e-5 and abs(st[4] / B - stats_ref["clip_fraction"]) < 1e-6
+    # the generic (atomic) kernel on the same minibatch split in two halves gives the same gradient
+    hp2 = dict(HP, normalize_advantage=False)
+    g_full, _, _ = _hip_grad(pol, bufs, T, N, perm, 100, B, hp2)
+    g_a, _, _ = _hip_grad(pol, bufs, T, N, perm, 100, B // 2, hp2)
+    g_b, _, _ = _hip_grad(pol, bufs, T, N, perm, 100 + B // 2, B - B // 2, hp2)
+    assert torch.allclose(g_full, 0.5 * (g_a + g_b), rtol=1e-4, atol=1e-6)
 
 
 def test_full_batch_feistel_permutation_is_a_bijection():

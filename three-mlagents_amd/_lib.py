@@ -71,7 +71,7 @@ SIGNATURES = {
     "tma_policy_act": (_i32, [_vp, _pd, _vp, _i64, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "tma_policy_values": (_i32, [_vp, _pd, _vp, _i64, _vp, _vp]),
     "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
-    "tma_ppo_workspace_bytes": (_i64, []),
+    "tma_ppo_workspace_bytes": (_i64, [_pd]),
     "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
     "tma_ppo_adam_step": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),

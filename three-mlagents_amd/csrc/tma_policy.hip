@@ -23,7 +23,9 @@ constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-
 constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
 constexpr int WS_STATS = 4096;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
 constexpr int MAX_GRAD_BLOCKS = 2048;
-constexpr int64_t WS_BYTES = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;
+constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
+constexpr int H64_BLOCKS = 256;
+constexpr int64_t WS_BYTES = WS_SLABS;
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -443,6 +445,228 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// H = 64 specialisation (BASELINE configs[1]): persistent waves keep the WHOLE parameter gradient of both nets in MFMA
+// accumulators (210 VGPRs) while they walk their share of the 16-sample tiles -- dW += X^T.dZ is accumulated through the
+// MFMA C operand, so there is no per-tile gradient traffic at all.  At the end the 4 waves of a block are summed through
+// LDS and the block writes ONE partial-gradient slab with plain stores; slab_reduce_kernel sums the slabs in a fixed order
+// (bitwise reproducible, no float atomics: the per-tile atomics of the generic kernel serialise on a 37 KB buffer).
+// Requirements: H == 64, D <= 16, Discrete head (A <= 16).
+// ------------------------------------------------------------------------------------------
+struct NetAcc {
+    f32x4 w1[1][4];
+    f32x4 w2[4][4];
+    f32x4 w3[4][1];
+    float b1[4], b2[4], b3[1];
+};
+
+__device__ __forceinline__ void zero_acc(NetAcc &a) {
+    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a.w1[0][j] = z;
+        a.w3[j][0] = z;
+        a.b1[j] = 0.0f;
+        a.b2[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a.w2[i][j] = z;
+    }
+    a.b3[0] = 0.0f;
+}
+
+template <int KT, int NT>
+__device__ __forceinline__ void bwd_weight_acc(const float *xin, int ldx, int K, const float *dz, int ldz, int N, f32x4 (&accW)[KT][NT],
+                                               float (&accb)[NT], int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    float bf[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = nt * 16 + r16;
+#pragma unroll
+        for (int s = 0; s < 4; s++) bf[nt][s] = col < N ? dz[(4 * s + g) * ldz + col] : 0.0f;
+        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const int krow = kt * 16 + r16;
+        float a[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[s] = krow < K ? xin[(4 * s + g) * ldx + krow] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
+    }
+}
+
+// wave -> LDS staging of one [K][N] segment (+ its bias), then block sum -> slab
+template <int KT, int NT>
+__device__ __forceinline__ void flush_segment(float *stage_all, int wave, int wpb, int K, int N, const f32x4 (&accW)[KT][NT], float (&accb)[NT],
+                                              float *slab_w, float *slab_b, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int seg = K * N + N;
+    float *stage = stage_all + wave * seg;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = kt * 16 + g * 4 + r, n = nt * 16 + r16;
+                if (k < K && n < N) stage[k * N + n] = accW[kt][nt][r];
+            }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        float v = accb[nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int n = nt * 16 + r16;
+        if (g == 0 && n < N) stage[K * N + n] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < seg; e += blockDim.x) {
+        float sum = stage_all[e];
+        for (int w = 1; w < wpb; w++) sum += stage_all[w * seg + e];
+        if (e < K * N) slab_w[e] = sum;
+        else slab_b[e - K * N] = sum;
+    }
+    __syncthreads();
+}
+
+// One launch, 2 x n_slabs blocks: even blocks carry the POLICY net, odd blocks the VALUE net (the two MLPs share nothing,
+// SB3 net_arch=dict(pi=..., vf=...)), so a wave holds only ~105 accumulator registers and two blocks fit per CU.
+template <bool IS_PI>
+__device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                              const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
+                                              double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int H = 64;
+    const int D = L.D, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2, ld = H + 2, ld3 = 34;
+    const int per_wave = 16 * (ldx + 4 * ld + ld3) + 16 * 8;
+    float *X = smem + (int64_t)wave * per_wave;
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2 + 16 * ld, *dzB = dzA + 16 * ld, *dz3 = dzB + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
+    float *meta = reinterpret_cast<float *>(row_off + 16);
+    const float invB = 1.0f / (float)mb.count;
+    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
+    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
+    const int NOUT = IS_PI ? A : 1;
+    NetAcc acc;
+    zero_acc(acc);
+    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
+    const int64_t n_tiles = (mb.count + 15) >> 4;
+    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += (int64_t)n_blocks_net * wpb) {
+        if (lane < 16) {
+            const int64_t j = (tile << 4) + lane;
+            int64_t off = -1;
+            meta[lane * 4 + 0] = meta[lane * 4 + 1] = meta[lane * 4 + 2] = meta[lane * 4 + 3] = 0.0f;
+            if (j < mb.count) {
+                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                if constexpr (IS_PI) {
+                    meta[lane * 4 + 0] = rb.log_probs[off];
+                    meta[lane * 4 + 1] = rb.advantages[off];
+                    meta[lane * 4 + 3] = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+                } else {
+                    meta[lane * 4 + 2] = rb.returns[off];
+                }
+            }
+            row_off[lane] = off;
+        }
+        load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
+        dense_tanh(X, ldx, D, Q.W1t, Q.b1, H, h1, ld, lane);
+        dense_tanh(h1, ld, H, Q.W2t, Q.b2, H, h2, ld, lane);
+        f32x4 out[1];
+        dense_head<1>(h2, ld, H, Q.W3t, Q.b3, NOUT, out, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = g * 4 + r;
+            const bool valid = row_off[row] >= 0;
+            if constexpr (IS_PI) {
+                const bool colok = r16 < A;
+                const float x = colok ? out[0][r] : -INFINITY;
+                const float m = gmax16(x);
+                const float e = colok ? expf(x - m) : 0.0f;
+                const float s = gsum16(e);
+                const float lse = m + logf(s);
+                const float lp = colok ? x - lse : 0.0f;
+                const float p = e / s;
+                const int act = __float_as_int(meta[row * 4 + 3]);
+                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                const float ent = -gsum16(p * lp);
+                const float old = meta[row * 4 + 0];
+                const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+                const float ratio = expf(lpa - old);
+                const float pl1 = advn * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+                const float pl2 = advn * rc;
+                const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+                float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
+                dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
+                dz3[row * ld3 + r16] = colok ? dl : 0.0f;
+                if (valid && r16 == 0) {
+                    st_a += (double)(-fminf(pl1, pl2));
+                    st_ent += (double)ent;
+                    st_kl += (double)((ratio - 1.0f) - (lpa - old));
+                    st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+                    st_n += 1.0;
+                }
+            } else {
+                const float diff = out[0][r] - meta[row * 4 + 2];
+                dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                if (valid && r16 == 0) st_a += (double)(diff * diff);
+            }
+        }
+        bwd_weight_acc<4, 1>(h2, ld, H, dz3, ld3, NOUT, acc.w3, acc.b3, lane);
+        dense_bwd_input(dz3, ld3, NOUT, Q.W3, H, h2, ld, dzA, ld, lane);
+        bwd_weight_acc<4, 4>(h1, ld, H, dzA, ld, H, acc.w2, acc.b2, lane);
+        dense_bwd_input(dzA, ld, H, Q.W2, H, h1, ld, dzB, ld, lane);
+        bwd_weight_acc<1, 4>(X, ldx, D, dzB, ld, H, acc.w1, acc.b1, lane);
+    }
+    __syncthreads();
+    flush_segment<1, 4>(smem, wave, wpb, D, H, acc.w1, acc.b1, slab + (IS_PI ? L.pW1t : L.vW1t), slab + (IS_PI ? L.pb1 : L.vb1), lane);
+    flush_segment<4, 4>(smem, wave, wpb, H, H, acc.w2, acc.b2, slab + (IS_PI ? L.pW2t : L.vW2t), slab + (IS_PI ? L.pb2 : L.vb2), lane);
+    flush_segment<4, 1>(smem, wave, wpb, H, NOUT, acc.w3, acc.b3, slab + (IS_PI ? L.pW3t : L.vW3t), slab + (IS_PI ? L.pb3 : L.vb3), lane);
+    double st[5] = {st_a, st_ent, st_kl, st_clip, st_n};
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0)
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < wpb; w++) s += red[w * 5 + threadIdx.x];
+        // slot layout {policy_loss, value_sq_err, entropy, approx_kl, clipped, n}
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += s;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                              const float *__restrict__ ws_adv, float *__restrict__ slabs,
+                                                              double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    float *slab = slabs + (int64_t)pair * L.P;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if ((blockIdx.x & 1) == 0) grad_h64_body<true>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    else grad_h64_body<false>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+}
+
+// grad[e] += sum over blocks of slab[b][e]  (fixed order -> bitwise reproducible)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int P, float *__restrict__ grad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P) return;
+    float s = 0.0f;
+    for (int b = 0; b < n_slabs; b++) s += slabs[(int64_t)b * P + e];
+    grad[e] += s;
+}
+
 // ------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam
 // ------------------------------------------------------------------------------------------
@@ -501,6 +725,12 @@ static int fwd_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
     return wpb * (16 * (ldx + 2 * ld) + 32) * 4;
 }
+static int grad_h64_smem_bytes(const PLayout &L, int wpb) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    const int tile = wpb * (16 * (ldx + 4 * ld + 34) + 16 * 8) * 4;
+    const int flush = wpb * (L.H * L.H + L.H) * 4;
+    return tile > flush ? tile : flush;
+}
 static int grad_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
     return wpb * (16 * (ldx + 6 * ld + 34) + 16 * 8) * 4;
@@ -538,7 +768,11 @@ using namespace tma;
 
 extern "C" {
 
-int64_t tma_ppo_workspace_bytes(void) { return WS_BYTES; }
+int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
+    if (!d || check_dims(d)) return WS_BYTES;
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    return WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4;
+}
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
     int rc = check_dims(d);
@@ -621,6 +855,20 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         TMA_LAUNCH_CHECK();
     }
     const int64_t tiles = ceil_div(mbi->count, 16);
+    if (L.H == 64 && L.D <= 16 && !L.cont && tiles >= 1024) {
+        // register-accumulating persistent kernel + deterministic slab reduction
+        const int wpb4 = 4, smem4 = grad_h64_smem_bytes(L, wpb4);
+        int64_t blocks4 = ceil_div(tiles, wpb4);
+        if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
+        float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
+        auto k = ppo_grad_h64_kernel;
+        if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
+        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+        TMA_LAUNCH_CHECK();
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     int wpb = tiles >= 1024 ? 4 : 1;
     while (wpb > 1 && grad_smem_bytes(L, wpb) > 150 * 1024) wpb >>= 1;
     const int smem = grad_smem_bytes(L, wpb);

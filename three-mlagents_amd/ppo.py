@@ -208,7 +208,7 @@ class PPO:
         self.grad = torch.zeros(P, dtype=f32, device=dev)
         self.exp_avg = torch.zeros(P, dtype=f32, device=dev)
         self.exp_avg_sq = torch.zeros(P, dtype=f32, device=dev)
-        self.workspace = torch.zeros(int(_lib.lib().tma_ppo_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.workspace = torch.zeros(int(_lib.lib().tma_ppo_workspace_bytes(C.byref(self.policy.dims))), dtype=torch.uint8, device=dev)
         b = self.buf
         self._rb = _lib.RolloutBuffers(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["rewards"]), _lib.ptr(b["values"]),
                                        _lib.ptr(b["log_probs"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]), _lib.ptr(b["terminal_obs"]),
