@@ -74,6 +74,9 @@ int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tap
                  float *obs_out, float *rew_out, uint8_t *term_out, uint8_t *trunc_out, float *term_obs_out,
                  double *ep_ret_out, int32_t *ep_len_out, void *stream);
 int tma_env_steps_until_refill(tma_env *h, int *out);
+/* engine options; "refill_small_window" = 1 shortens the register-resident MT19937 window so tests exercise the
+ * general in-memory generator that takes over when rejection sampling needs more outputs */
+int tma_env_set_option(tma_env *h, const char *key, int64_t value);
 /* re-draw the reset states consumed since the last refill (exact numpy MT19937 legacy stream) */
 int tma_env_refill(tma_env *h, void *stream);
 /* flat float64 state [num_envs][state_dim] in the oracle's layout (state injection for parity tests;

@@ -141,6 +141,25 @@ def test_against_oracle_many_envs(task, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("task", ["gridworld", "push"])
+def test_refill_fallback_generator_is_exact(task):
+    """With the register-resident MT19937 window shortened, most seeds need the general in-memory generator: the
+    trajectories must still equal the oracle's bit for bit (exercises the rejection-sampling overflow path)."""
+    n, T, depth = 600, 96, 8
+    eng = _engine(task, n, seed=5, ring_depth=depth)
+    eng.set_option("refill_small_window", 1)
+    ref = orc.OracleVecEnv(task, n, seed=5)
+    assert np.array_equal(eng.reset().cpu().numpy(), ref.reset())
+    tape = orc.action_tape(17, n, T, orc.num_actions(task))
+    for t0 in range(0, T, depth):
+        o = eng.step(None, n_steps=depth, tape_seed=17, tape_t0=t0)
+        for s in range(depth):
+            r = ref.step(tape[t0 + s])
+            assert np.array_equal(o["obs"][s].cpu().numpy(), r["obs"]) and np.array_equal(o["rew"][s].cpu().numpy(), r["rew32"]), (task, t0 + s)
+    assert np.array_equal(eng.get_state().cpu().numpy(), ref.get_state())
+    eng.close()
+
+
 def test_sharding_equals_one_big_env():
     """env_offset sharding: two shards of 512 reproduce envs [0,512) and [512,1024) of one 1024-env engine."""
     T, tape = 64, 5

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tma_env_step": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tma_env_steps_until_refill": (_i32, [_vp, C.POINTER(_i32)]),
     "tma_env_refill": (_i32, [_vp, _vp]),
+    "tma_env_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "tma_env_get_state": (_i32, [_vp, _vp, _vp]),
     "tma_env_set_state": (_i32, [_vp, _vp, _vp]),
     "tma_env_episode_index": (_i32, [_vp, _vp, _vp]),

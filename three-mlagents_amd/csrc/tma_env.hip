@@ -166,57 +166,168 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// seed kernel: mode 0 = VecEnv.reset (episode 0 -> state, episodes 1..D -> ring),
-//              mode 1 = refill (episodes consumed since the last refill -> ring).
-// One thread per env (grid-stride over G threads); MT19937 state in lane-interleaved global scratch.
+// Reset-ring production.  A work item is one (env, episode) pair whose reset record must be drawn with the exact numpy
+// legacy stream of seed s(env, episode).  mode 0 = VecEnv.reset: items are dense (env i, episodes 0..D; episode 0 goes
+// straight into the state).  mode 1 = refill: items are the episodes consumed since the last refill, found through a
+// two-level exclusive scan (per 256-env block, then over blocks) so that every lane of the seeding kernel gets exactly
+// one item regardless of how unevenly episodes ended.
 // ------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(256) void seed_kernel(EnvView v, uint32_t *mt_scratch, int64_t G, int mode, float *obs_out) {
-    __shared__ uint8_t lds_js[36 * 256];
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    MT mt{mt_scratch + tid, G, 0};
-    for (int64_t i = tid; i < v.N; i += G) {
-        const uint32_t gi = v.env_offset + (uint32_t)i;
-        if constexpr (T::USES_MT) {
-            uint32_t lo, hi;
-            if (mode == 0) {
-                lo = 0;
-                hi = (uint32_t)v.D;
-                v.cur_ep[i] = 0;
-                v.ep_ret[i] = 0.0;
-            } else {
-                lo = v.filled_hi[i];
-                hi = v.cur_ep[i] + (uint32_t)v.D;
-            }
-            for (uint32_t e = lo; e <= hi && e >= lo; e++) {
-                uint32_t rec[T::RW > 0 ? T::RW : 1];
-                mt.seed(episode_seed(v.seed_base, gi, e));
-                // adapter.reset(seed): env_ctor() resets once, then env.reset() -- the second draw is the visible one
-                T::draw(mt, lds_js + threadIdx.x, (int)blockDim.x, rec);
-                T::draw(mt, lds_js + threadIdx.x, (int)blockDim.x, rec);
-                if (mode == 0 && e == 0) {
-                    typename T::S s;
-                    T::from_rec(rec, s);
-                    T::pack(v.st, v.N, i, s);
-                    if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
-                } else {
-                    uint32_t *slot = v.ring + ((int64_t)(e % (uint32_t)v.D) * T::RW) * v.N + i;
+struct RefillView {
+    uint32_t *first_ep;   // [N] first episode index each env must (re)fill
+    uint32_t *env_off;    // [N] exclusive prefix of the per-env item counts inside the env's 256-block
+    uint32_t *block_sum;  // [nb]
+    uint32_t *block_off;  // [nb] exclusive prefix of block_sum
+    uint32_t *total;      // [0] = number of items of this refill, [1] = fallback count
+    uint32_t *fb_env, *fb_ep;
+    int nb, fb_cap;
+};
+
+__global__ __launch_bounds__(256) void refill_count_kernel(EnvView v, RefillView rv) {
+    __shared__ uint32_t wsum[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = 0;
+    if (i < v.N) {
+        const uint32_t fh = v.filled_hi[i], nh = v.cur_ep[i] + (uint32_t)v.D + 1u;
+        c = nh - fh;
+        rv.first_ep[i] = fh;
+        v.filled_hi[i] = nh;
+    }
+    uint32_t inc = c;  // inclusive scan inside the wave
 #pragma unroll
-                    for (int w = 0; w < T::RW; w++) slot[(int64_t)w * v.N] = rec[w];
-                }
-            }
-            v.filled_hi[i] = hi + 1;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if ((threadIdx.x & 63) >= d) inc += up;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < v.N) rv.env_off[i] = base + inc - c;
+    if (threadIdx.x == 255) rv.block_sum[blockIdx.x] = base + inc;
+}
+
+__global__ __launch_bounds__(1024) void refill_scan_kernel(RefillView rv) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < rv.nb; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const uint32_t c = b < rv.nb ? rv.block_sum[b] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if ((threadIdx.x & 63) >= d) inc += up;
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = carry;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        if (b < rv.nb) rv.block_off[b] = base + inc - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rv.total[0] = carry;
+}
+
+template <class T>
+__device__ __forceinline__ void commit_record(EnvView &v, int64_t i, uint32_t e, const uint32_t *rec, int mode, float *obs_out) {
+    if (mode == 0 && e == 0) {
+        typename T::S s;
+        T::from_rec(rec, s);
+        T::pack(v.st, v.N, i, s);
+        v.cur_ep[i] = 0;
+        v.ep_ret[i] = 0.0;
+        v.filled_hi[i] = (uint32_t)v.D + 1u;
+        if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
+    } else {
+        uint32_t *slot = v.ring + ((int64_t)(e % (uint32_t)v.D) * T::RW) * v.N + i;
+#pragma unroll
+        for (int w = 0; w < T::RW; w++) slot[(int64_t)w * v.N] = rec[w];
+    }
+}
+
+// upper_bound(a[0..n), x) - 1 : index of the last element <= x
+__device__ __forceinline__ int last_le(const uint32_t *a, int n, uint32_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo - 1;
+}
+
+template <class T, int W>
+__global__ __launch_bounds__(256) void refill_fast_kernel(EnvView v, RefillView rv, int mode, int64_t total_dense, float *obs_out) {
+    const int64_t total = mode == 0 ? total_dense : (int64_t)rv.total[0];
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        int64_t i;
+        uint32_t e;
+        if (mode == 0) {
+            i = t / (v.D + 1);
+            e = (uint32_t)(t - i * (v.D + 1));
         } else {
-            if (mode == 0) {
-                typename T::S s;
-                T::reset_inline(episode_seed(v.seed_base, gi, 0), s);
-                T::pack(v.st, v.N, i, s);
-                v.cur_ep[i] = 0;
-                v.ep_ret[i] = 0.0;
-                if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
+            const int b = last_le(rv.block_off, rv.nb, (uint32_t)t);
+            const uint32_t local = (uint32_t)t - rv.block_off[b];
+            const int64_t i0 = (int64_t)b * 256;
+            const int nloc = (int)((v.N - i0) < 256 ? (v.N - i0) : 256);
+            const int j = last_le(rv.env_off + i0, nloc, local);
+            i = i0 + j;
+            e = rv.first_ep[i] + (local - rv.env_off[i]);
+        }
+        const uint32_t seed = episode_seed(v.seed_base, v.env_offset + (uint32_t)i, e);
+        typename T::Fast c;
+        if (mt_stream<W>(seed, c)) {
+            uint32_t rec[T::RW > 0 ? T::RW : 1];
+            c.finish(rec);
+            commit_record<T>(v, i, e, rec, mode, obs_out);
+        } else {  // more than W outputs needed (rejection sampling): exact general generator takes over
+            const uint32_t k = atomicAdd(&rv.total[1], 1u);
+            if (k < (uint32_t)rv.fb_cap) {
+                rv.fb_env[k] = (uint32_t)i;
+                rv.fb_ep[k] = e;
             }
         }
     }
+}
+
+// general path: full MT19937 state in lane-interleaved global scratch (any number of draws)
+template <class T>
+__global__ __launch_bounds__(256) void refill_fallback_kernel(EnvView v, RefillView rv, uint32_t *mt_scratch, int mode, float *obs_out) {
+    __shared__ uint8_t lds_js[36 * 256];
+    const int64_t G = (int64_t)gridDim.x * 256;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t n = rv.total[1];
+    if (n > (uint32_t)rv.fb_cap) n = (uint32_t)rv.fb_cap;
+    MT mt{mt_scratch + tid, G, 0};
+    for (int64_t k = tid; k < (int64_t)n; k += G) {
+        const int64_t i = rv.fb_env[k];
+        const uint32_t e = rv.fb_ep[k];
+        uint32_t rec[T::RW > 0 ? T::RW : 1];
+        mt.seed(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, e));
+        // adapter.reset(seed): env_ctor() resets once, then env.reset() -- the second draw is the visible one
+        T::draw(mt, lds_js + threadIdx.x, 256, rec);
+        T::draw(mt, lds_js + threadIdx.x, 256, rec);
+        commit_record<T>(v, i, e, rec, mode, obs_out);
+    }
+}
+
+// tasks whose reset needs no MT19937 (Basic, Crawler-shape): VecEnv.reset only
+template <class T>
+__global__ __launch_bounds__(256) void reset_inline_kernel(EnvView v, float *obs_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.N) return;
+    typename T::S s;
+    T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, 0), s);
+    T::pack(v.st, v.N, i, s);
+    v.cur_ep[i] = 0;
+    v.ep_ret[i] = 0.0;
+    if (obs_out) emit_obs<T>(s, obs_out + i * T::OBS);
 }
 
 template <class T>
@@ -264,13 +375,17 @@ static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_
 
 using namespace tma;
 
+constexpr int FB_BLOCKS = 16;      // fallback kernel grid (16 x 256 threads, 2.5 KB of MT19937 scratch each)
+constexpr int FB_CAP = 1 << 20;    // fallback item capacity per refill
+
 struct tma_env {
     int task, device;
     EnvView v;
+    RefillView rv;
     uint32_t *mt_scratch;
-    int64_t G;  // threads of the seed kernel grid
     int steps_since_refill;
     bool is_reset;
+    bool small_window;  // test hook: use the short fast-path window so the fallback generator is exercised
 };
 
 template <class F>
@@ -285,13 +400,42 @@ static int dispatch_task(int task, F &&f) {
     return fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
 }
 
+template <class T, int W>
+static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, float *obs_out, hipStream_t s) {
+    refill_fast_kernel<T, W><<<dim3(blocks), dim3(256), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out);
+}
+
 static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
     return dispatch_task(h->task, [&](auto t) {
         using T = decltype(t);
-        if (mode == 1 && !T::USES_MT) return (int)TMA_OK;
-        seed_kernel<T><<<dim3((unsigned)(h->G / 256)), dim3(256), 0, s>>>(h->v, h->mt_scratch, h->G, mode, obs_out);
-        TMA_LAUNCH_CHECK();
-        return (int)TMA_OK;
+        if constexpr (!T::USES_MT) {
+            if (mode == 0) {
+                reset_inline_kernel<T><<<dim3((unsigned)ceil_div(h->v.N, 256)), dim3(256), 0, s>>>(h->v, obs_out);
+                TMA_LAUNCH_CHECK();
+            }
+            return (int)TMA_OK;
+        } else {
+            TMA_HIP(hipMemsetAsync(h->rv.total, 0, sizeof(uint32_t) * 2, s));
+            int64_t total_dense = 0, blocks;
+            if (mode == 0) {
+                total_dense = h->v.N * (int64_t)(h->v.D + 1);
+                blocks = ceil_div(total_dense, 256);
+            } else {
+                refill_count_kernel<<<dim3((unsigned)h->rv.nb), dim3(256), 0, s>>>(h->v, h->rv);
+                TMA_LAUNCH_CHECK();
+                refill_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(h->rv);
+                TMA_LAUNCH_CHECK();
+                blocks = 2 * (int64_t)h->rv.nb;  // about D / mean-episode-length items per env; the kernel grid-strides past that
+            }
+            if (blocks > 16384) blocks = 16384;
+            if (blocks < 1) blocks = 1;
+            if (h->small_window) launch_fast<T, T::Fast::W_SMALL>(h, mode, total_dense, (unsigned)blocks, obs_out, s);
+            else launch_fast<T, T::Fast::W>(h, mode, total_dense, (unsigned)blocks, obs_out, s);
+            TMA_LAUNCH_CHECK();
+            refill_fallback_kernel<T><<<dim3(FB_BLOCKS), dim3(256), 0, s>>>(h->v, h->rv, h->mt_scratch, mode, obs_out);
+            TMA_LAUNCH_CHECK();
+            return (int)TMA_OK;
+        }
     });
 }
 
@@ -361,11 +505,19 @@ int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, u
     TMA_HIP(hipMemset(v.filled_hi, 0, sizeof(uint32_t) * n));
     TMA_HIP(hipMemset(v.ep_ret, 0, sizeof(double) * n));
     TMA_HIP(hipMemset(v.stats, 0, sizeof(double) * n_stat));
-    // seed-kernel grid: one thread per env up to 128K threads (2.5 KB of MT19937 scratch each)
-    int64_t G = ceil_div(num_envs, 256) * 256;
-    if (G > 131072) G = 131072;
-    h->G = G;
-    if (m.uses_mt) TMA_HIP(hipMalloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)G));
+    if (m.uses_mt) {
+        RefillView &rv = h->rv;
+        rv.nb = (int)ceil_div(num_envs, 256);
+        rv.fb_cap = FB_CAP;
+        TMA_HIP(hipMalloc(&rv.first_ep, sizeof(uint32_t) * n));
+        TMA_HIP(hipMalloc(&rv.env_off, sizeof(uint32_t) * n));
+        TMA_HIP(hipMalloc(&rv.block_sum, sizeof(uint32_t) * rv.nb));
+        TMA_HIP(hipMalloc(&rv.block_off, sizeof(uint32_t) * rv.nb));
+        TMA_HIP(hipMalloc(&rv.total, sizeof(uint32_t) * 2));
+        TMA_HIP(hipMalloc(&rv.fb_env, sizeof(uint32_t) * FB_CAP));
+        TMA_HIP(hipMalloc(&rv.fb_ep, sizeof(uint32_t) * FB_CAP));
+        TMA_HIP(hipMalloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)FB_BLOCKS * 256));
+    }
     *out = h;
     return TMA_OK;
 }
@@ -380,8 +532,24 @@ int tma_env_destroy(tma_env *h) {
     (void)hipFree(h->v.ep_ret);
     (void)hipFree(h->v.stats);
     (void)hipFree(h->mt_scratch);
+    (void)hipFree(h->rv.first_ep);
+    (void)hipFree(h->rv.env_off);
+    (void)hipFree(h->rv.block_sum);
+    (void)hipFree(h->rv.block_off);
+    (void)hipFree(h->rv.total);
+    (void)hipFree(h->rv.fb_env);
+    (void)hipFree(h->rv.fb_ep);
     delete h;
     return TMA_OK;
+}
+
+int tma_env_set_option(tma_env *h, const char *key, int64_t value) {
+    if (!h || !key) return fail(TMA_ERR_INVALID, "null argument");
+    if (strcmp(key, "refill_small_window") == 0) {
+        h->small_window = value != 0;
+        return TMA_OK;
+    }
+    return fail(TMA_ERR_INVALID, "unknown option '%s'", key);
 }
 
 int tma_env_seed(tma_env *h, uint32_t seed_base) {

@@ -95,6 +95,47 @@ struct ShuffleTrace {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------
+// Register-resident fast path for the first W (< 227) outputs after np.random.seed(s).
+// Output k of a fresh MT19937 state depends only on init words k, k+1 and k+397, and init_genrand is a serial chain, so:
+// keep words 0..W in registers (static indices, fully unrolled), run the chain through word 396 without storing, then for
+// i = 397.. generate word i, combine it with words k and k+1 (k = i - 397), temper, and hand the output straight to the
+// task's consumer (a small state machine that replays the legacy shuffle / choice / randint / uniform draws).
+// No memory traffic at all; if a consumer has not finished after W outputs (rejection sampling is unbounded) the caller
+// falls back to the general in-memory generator (struct MT), so the result is exact for every seed.
+// ------------------------------------------------------------------------------------------
+template <int W, class C>
+__device__ __forceinline__ bool mt_stream(uint32_t seed, C &c) {
+    static_assert(W >= 1 && W <= 226, "fast path covers the outputs that need no regenerated word");
+    uint32_t r[W + 1];
+    uint32_t x = seed;
+    r[0] = x;
+#pragma unroll
+    for (int i = 1; i <= W; i++) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+        r[i] = x;
+    }
+#pragma unroll 4
+    for (int i = W + 1; i < 397; i++) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(397 + k);
+        const uint32_t y = (r[k] & 0x80000000u) | (r[k + 1] & 0x7fffffffu);
+        uint32_t v = x ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        c.feed(v);
+    }
+    return c.done();
+}
+
+__device__ __forceinline__ uint32_t interval_mask(uint32_t m) {
+    return m >= 32 ? 63u : m >= 16 ? 31u : m >= 8 ? 15u : m >= 4 ? 7u : m >= 2 ? 3u : 1u;
+}
+
 // ==========================================================================================
 // Basic -- backend/mlagents/envs.py:17-27 (constants, one-hot), :48-58 (reset), :60-81 (step)
 // ==========================================================================================
@@ -180,6 +221,44 @@ struct GridTask {
         S s{a / 5, a % 5, g / 5, g % 5, r / 5, r % 5, (int)gt, 0};
         rec[0] = to_word(s);
     }
+
+    // consumer of the two resets an adapter.reset(seed) performs: 24 shuffle draws + choice, twice; the second one counts
+    struct Fast {
+        static constexpr int W = 128, W_SMALL = 58;
+        int a = 0;
+        uint64_t lo = 0, hi = 0;
+        uint32_t gt = 0;
+        __device__ __forceinline__ bool done() const { return a >= 50; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (a >= 50) return;
+            const int q = a < 25 ? a : a - 25;
+            const uint32_t m = q < 24 ? (uint32_t)(24 - q) : 1u;
+            const uint32_t u = v & interval_mask(m);
+            if (u <= m) {
+                if (a >= 25) {
+                    if (q < 12) lo |= (uint64_t)u << (5 * q);
+                    else if (q < 24) hi |= (uint64_t)u << (5 * (q - 12));
+                    else gt = u;
+                }
+                a++;
+            }
+        }
+        __device__ __forceinline__ int final_at(int p) const {
+            int c = p;
+#pragma unroll
+            for (int i = 1; i <= 24; i++) {
+                const int q = 24 - i;
+                const int j = (int)((q < 12 ? (lo >> (5 * q)) : (hi >> (5 * (q - 12)))) & 31u);
+                c = (c == i) ? j : ((c == j) ? i : c);
+            }
+            return c;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const {
+            const int a0 = final_at(0), g0 = final_at(1), r0 = final_at(2);
+            S s{a0 / 5, a0 % 5, g0 / 5, g0 % 5, r0 / 5, r0 % 5, (int)gt, 0};
+            rec[0] = to_word(s);
+        }
+    };
     __device__ static int steps(const S &s) { return s.steps; }
     __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
         int dx = (a == 4) - (a == 3), dy = (a == 1) - (a == 2);
@@ -246,6 +325,47 @@ struct PushTask {
         S s{a / 6, a % 6, b / 6, b % 6, (int)gx, 0};
         rec[0] = to_word(s);
     }
+
+    // two resets of 35 shuffle draws + randint(0, 6); the second one counts
+    struct Fast {
+        static constexpr int W = 176, W_SMALL = 84;
+        int a = 0;
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        uint32_t gx = 0;
+        __device__ __forceinline__ bool done() const { return a >= 72; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (a >= 72) return;
+            const int q = a < 36 ? a : a - 36;
+            const uint32_t m = q < 35 ? (uint32_t)(35 - q) : 5u;
+            const uint32_t u = v & interval_mask(m);
+            if (u <= m) {
+                if (a >= 36) {
+                    if (q < 10) w0 |= (uint64_t)u << (6 * q);
+                    else if (q < 20) w1 |= (uint64_t)u << (6 * (q - 10));
+                    else if (q < 30) w2 |= (uint64_t)u << (6 * (q - 20));
+                    else if (q < 35) w3 |= (uint64_t)u << (6 * (q - 30));
+                    else gx = u;
+                }
+                a++;
+            }
+        }
+        __device__ __forceinline__ int final_at(int p) const {
+            int c = p;
+#pragma unroll
+            for (int i = 1; i <= 35; i++) {
+                const int q = 35 - i;
+                const uint64_t w = q < 10 ? w0 : q < 20 ? w1 : q < 30 ? w2 : w3;
+                const int j = (int)((w >> (6 * (q % 10))) & 63u);
+                c = (c == i) ? j : ((c == j) ? i : c);
+            }
+            return c;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const {
+            const int a0 = final_at(0), b0 = final_at(1);
+            S s{a0 / 6, a0 % 6, b0 / 6, b0 % 6, (int)gx, 0};
+            rec[0] = to_word(s);
+        }
+    };
     __device__ static int steps(const S &s) { return s.steps; }
     __device__ static int iabs(int v) { return v < 0 ? -v : v; }
     __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
@@ -354,6 +474,39 @@ struct BallTask {
         rec[4] = __float_as_uint((float)mt.uniform(-1.0, 1.0));
         rec[5] = __float_as_uint((float)mt.uniform(-1.0, 1.0));
     }
+
+    // two resets of 6 uniform doubles (12 outputs each); the second one counts
+    struct Fast {
+        static constexpr int W = 24, W_SMALL = 24;
+        int k = 0;
+        uint32_t ah = 0;
+        uint32_t rec6[6] = {0, 0, 0, 0, 0, 0};
+        __device__ __forceinline__ bool done() const { return k >= 24; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (k >= 12) {
+                if ((k & 1) == 0) {
+                    ah = v >> 5;
+                } else {
+                    const double d = ((double)ah * 67108864.0 + (double)(v >> 6)) / 9007199254740992.0;
+                    const int idx = (k - 12) >> 1;
+                    const double half = MAX_TILT * 0.5;
+                    const double lo = idx < 2 ? -half : (idx < 4 ? -1.5 : -1.0);
+                    const double hi = idx < 2 ? half : (idx < 4 ? 1.5 : 1.0);
+                    const double scale = hi - lo;
+                    const double pr = scale * d;
+                    const uint32_t bits = __float_as_uint((float)(lo + pr));
+#pragma unroll
+                    for (int j = 0; j < 6; j++)
+                        if (j == idx) rec6[j] = bits;
+                }
+            }
+            k++;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const {
+#pragma unroll
+            for (int j = 0; j < 6; j++) rec[j] = rec6[j];
+        }
+    };
     __device__ static int steps(const S &s) { return s.steps; }
     __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
         double del[2];

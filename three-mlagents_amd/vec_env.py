@@ -94,6 +94,9 @@ class HipEnvEngine:
         return b
 
     # -- engine calls ---------------------------------------------------------------------
+    def set_option(self, key: str, value: int) -> None:
+        _lib.check(_lib.lib().tma_env_set_option(self._h, key.encode(), int(value)))
+
     def seed(self, seed: int):
         self.seed_base = int(seed) & 0xFFFFFFFF
         _lib.check(_lib.lib().tma_env_seed(self._h, self.seed_base))
