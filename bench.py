@@ -60,17 +60,20 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def timed_kernel_us(fn, reps, stream_sync):
-    """Average duration of one launch, HIP events recorded on the launch stream around each launch."""
+def timed_kernel_us(fn, reps, stream_sync, group=1):
+    """Duration of one launch from HIP events recorded on the launch stream.  group > 1 brackets `group` back-to-back
+    launches with one event pair (a per-launch event pair costs more than a ~5 us kernel); returns (mean, median) per launch."""
     import torch
 
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    n_groups = max(1, reps // group)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_groups)]
     for a, b in evs:
         a.record()
-        fn()
+        for _ in range(group):
+            fn()
         b.record()
     stream_sync()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    ts = sorted(a.elapsed_time(b) * 1e3 / group for a, b in evs)
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
@@ -178,6 +181,7 @@ def main():
     t0 = time.perf_counter()
     t_roll = 0.0
     for _ in range(args.steps):
+        torch.cuda.synchronize()  # attribute the asynchronous tail of the previous update to the update, not to this rollout
         r0 = time.perf_counter()
         model.collect_rollouts()
         torch.cuda.synchronize()
@@ -226,8 +230,10 @@ def main():
                 raise RuntimeError("refill bookkeeping broke")
             eng.step(acts, outputs=outs, want_episode=False)
 
-        reps = 4 * eng.ring_depth - 8
-        avg_us, med_us = timed_kernel_us(step_once, reps, sync)  # includes the refill launch once per ring_depth steps
+        # groups of 8 back-to-back launches; the median group never contains the once-per-ring_depth refill launches
+        while eng.steps_until_refill() != eng.ring_depth:
+            step_once()
+        avg_us, med_us = timed_kernel_us(step_once, 4 * eng.ring_depth, sync, group=8)
         # exclude launches that also carried a refill: use the median for the pure step kernel
         log(f"step kernel: avg {avg_us:.2f} us, median {med_us:.2f} us")
         lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
@@ -281,7 +287,7 @@ def main():
         log(f"grad kernel median {g_med:.1f} us")
         model.grad.zero_()
         tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
-        out["roofline_update"] = {"kernel": "tma::adv_stats_kernel + tma::ppo_grad_kernel (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",
+        out["roofline_update"] = {"kernel": "adv stats + tma::ppo_grad_h64_kernel + slab_reduce (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",
                                   "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                   "launch_us": g_med, "samples": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb, "traffic": None}
         if not args.no_cpu_baseline:

@@ -21,7 +21,8 @@ namespace tma {
 constexpr int WS_ADV = 0;             // float[2]: minibatch advantage mean, std
 constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-squares partials
 constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
-constexpr int WS_STATS = 4096;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
+constexpr int WS_ADV_PART = 4096;     // byte offset of double[128][2] advantage (sum, sumsq) partials
+constexpr int WS_STATS = 8192;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
 constexpr int MAX_GRAD_BLOCKS = 2048;
 constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
 constexpr int H64_BLOCKS = 256;
@@ -230,10 +231,14 @@ __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j,
     return t * N + i;
 }
 
-__global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, float *ws_adv) {
-    __shared__ double s1[16], s2[16];
+// pass 1: up to ADV_BLOCKS blocks, each sums a contiguous slice of the (permuted) minibatch -> (sum, sum of squares) partials
+constexpr int ADV_BLOCKS = 128;
+__global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, double *partials) {
+    __shared__ double s1[4], s2[4];
+    const int64_t per = (mb.count + gridDim.x - 1) / gridDim.x;
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < mb.count) ? j0 + per : mb.count;
     double a = 0.0, b = 0.0;
-    for (int64_t j = threadIdx.x; j < mb.count; j += blockDim.x) {
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
         const double x = (double)adv[sample_offset(mb, mb.start + j, T, N)];
         a += x;
         b += x * x;
@@ -245,11 +250,21 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict
     if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = a, s2[threadIdx.x >> 6] = b;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sa = 0.0, sb = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) sa += s1[w], sb += s2[w];
-        const double n = (double)mb.count;
-        const double mean = sa / n;
-        double var = n > 1.0 ? (sb - n * mean * mean) / (n - 1.0) : 0.0;
+        partials[2 * blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        partials[2 * blockIdx.x + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    }
+}
+// pass 2: one wave folds the partials in a fixed order -> mean, unbiased std (SB3: advantages.std() + 1e-8)
+__global__ void adv_final_kernel(const double *partials, int n_part, int64_t count, float *ws_adv) {
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < n_part; k += 64) a += partials[2 * k], b += partials[2 * k + 1];
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)count, mean = a / n;
+        double var = n > 1.0 ? (b - n * mean * mean) / (n - 1.0) : 0.0;
         if (var < 0.0) var = 0.0;
         ws_adv[0] = (float)mean;
         ws_adv[1] = (float)sqrt(var);
@@ -658,13 +673,29 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_h64_kernel(const float *__res
     else grad_h64_body<false>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
 }
 
-// grad[e] += sum over blocks of slab[b][e]  (fixed order -> bitwise reproducible)
+// grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
+// fixed order -> bitwise reproducible, and enough independent loads in flight to run at L2 speed.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int P, float *__restrict__ grad) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int per = (n_slabs + 3) >> 2;
+    const int b0 = q * per, b1 = (b0 + per < n_slabs) ? b0 + per : n_slabs;
     float s = 0.0f;
-    for (int b = 0; b < n_slabs; b++) s += slabs[(int64_t)b * P + e];
-    grad[e] += s;
+    if (e < P) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = slabs[(int64_t)(b + u) * P + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += t[u];
+        }
+        for (; b < b1; b++) s += slabs[(int64_t)b * P + e];
+    }
+    part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && e < P) grad[e] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -851,7 +882,12 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     float *ws_adv = reinterpret_cast<float *>(ws + WS_ADV);
     double *slots = reinterpret_cast<double *>(ws + WS_STATS);
     if (hpar.normalize_advantage) {
-        adv_stats_kernel<<<dim3(1), dim3(1024), 0, s>>>(rb->advantages, M, rb->T, rb->N, ws_adv);
+        double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
+        int nbk = (int)ceil_div(mbi->count, 1024);
+        if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
+        adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part);
+        TMA_LAUNCH_CHECK();
+        adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, mbi->count, ws_adv);
         TMA_LAUNCH_CHECK();
     }
     const int64_t tiles = ceil_div(mbi->count, 16);
@@ -865,7 +901,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
         k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
