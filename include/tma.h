@@ -114,6 +114,10 @@ int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream);
  * values f32[n], log_prob f32[n].  Sampling uses the counter-based stream (rng_seed, env_offset + row, rng_step). */
 int tma_policy_act(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
                    uint32_t env_offset, int deterministic, void *actions_out, float *values_out, float *logp_out, void *stream);
+/* tma_policy_act for step t plus tma_policy_bootstrap for step t-1 in one launch (prev_* may be NULL) */
+int tma_policy_act_bootstrap(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
+                             uint32_t env_offset, void *actions_out, float *values_out, float *logp_out, const float *prev_terminal_obs,
+                             const uint8_t *prev_truncated, double gamma, float *prev_rewards_inout, void *stream);
 /* ActorCriticPolicy.predict_values */
 int tma_policy_values(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, float *values_out, void *stream);
 /* collect_rollouts timeout bootstrap: rewards[i] += gamma * V(terminal_obs[i]) where truncated[i] */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "tma_policy_param_offsets": (_i32, [_pd, C.POINTER(_i32)]),
     "tma_policy_sync": (_i32, [_vp, _pd, _vp]),
     "tma_policy_act": (_i32, [_vp, _pd, _vp, _i64, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
+    "tma_policy_act_bootstrap": (_i32, [_vp, _pd, _vp, _i64, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp]),
     "tma_policy_values": (_i32, [_vp, _pd, _vp, _i64, _vp, _vp]),
     "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
     "tma_ppo_workspace_bytes": (_i64, [_pd]),

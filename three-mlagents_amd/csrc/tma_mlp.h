@@ -27,8 +27,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 struct PLayout {
     int D, H, A, cont;
     int pW1t, pb1, pW2t, pb2, pW3t, pb3, vW1t, vb1, vW2t, vb2, vW3t, vb3, log_std, P;
-    int pW2, pW3, vW2, vW3, total;
+    int pW2, pW3, vW2, vW3;
+    int img_pi, img_vf;  // LDS-image regions (H == 64 fast path), IMG_FLOATS each; -1 when the shape has no fast path
+    int total;
 };
+
+// ---- H = 64 LDS weight image of ONE net (floats).  Matrices are stored so that the four B operands a lane needs for one
+// k-step (output columns 16j + (lane&15), j = 0..3) are one aligned float4: element [k][r16][j].  ds_read_b128 of that
+// layout is bank-conflict-free (each 16-lane group of the instruction covers 256 contiguous bytes).
+constexpr int IMG_W1 = 0;                   // [16 k][16 r16][4 j]   layer-1 forward   (rows k >= D are zero)
+constexpr int IMG_W2F = IMG_W1 + 1024;      // [64 k][16][4]         layer-2 forward
+constexpr int IMG_W3F = IMG_W2F + 4096;     // [64 k][16 cols]       head forward      (cols >= n_out are zero)
+constexpr int IMG_W3B = IMG_W3F + 1024;     // [16 n][16][4]         head input-gradient: W3[n][k]   (rows n >= n_out zero)
+constexpr int IMG_W2B = IMG_W3B + 1024;     // [64 n][16][4]         layer-2 input-gradient: W2[n][k]
+constexpr int IMG_B1 = IMG_W2B + 4096;      // [64]
+constexpr int IMG_B2 = IMG_B1 + 64;         // [64]
+constexpr int IMG_B3 = IMG_B2 + 64;         // [16]
+constexpr int IMG_FLOATS = IMG_B3 + 16 + 16;  // padded to a multiple of 4 floats (11440)
+constexpr int IMG_FWD_FLOATS = IMG_W3B;       // forward-only kernels stage [0, IMG_W3B) + the biases
 
 __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont) {
     PLayout L;
@@ -52,6 +68,10 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont) {
     L.pW3 = o, o += A * H;
     L.vW2 = o, o += H * H;
     L.vW3 = o, o += H;
+    o = (o + 3) & ~3;  // 16-byte aligned image regions (staged with float4 copies)
+    const bool fast = (H == 64) && (D <= 16) && !cont && (A <= 16);
+    L.img_pi = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
+    L.img_vf = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
     L.total = o;
     return L;
 }
@@ -169,6 +189,82 @@ __device__ __forceinline__ void dense_bwd_weight(const float *xin, int ldx, int 
             }
         }
     }
+}
+
+// ---- H = 64 layers with the weights staged in LDS (image layout above) ----
+// out[16][64] = tanh(in[16][4*KS] . W + b)
+template <int KS_CT>  // KS_CT > 0: compile-time k-step count (fully unrolled); 0: runtime count `KS` (layer 1, 1..4 steps)
+__device__ __forceinline__ void dense64_tanh_lds(const float *in, int ldi, int KS, const float *Wimg, const float *b, float *out, int ldo, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float bias = b[16 * j + r16];
+        acc[j] = f32x4{bias, bias, bias, bias};
+    }
+#pragma unroll
+    for (int ks = 0; ks < (KS_CT > 0 ? KS_CT : KS); ks++) {
+        const int k = 4 * ks + g;
+        const float a = in[r16 * ldi + k];
+        const float4 w = *reinterpret_cast<const float4 *>(Wimg + k * 64 + r16 * 4);
+        acc[0] = mfma16(a, w.x, acc[0]);
+        acc[1] = mfma16(a, w.y, acc[1]);
+        acc[2] = mfma16(a, w.z, acc[2]);
+        acc[3] = mfma16(a, w.w, acc[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + 16 * j + r16] = tanhf(acc[j][r]);
+}
+
+// acc (C layout, column lane&15) = in[16][64] . W3f + b3
+__device__ __forceinline__ f32x4 dense64_head_lds(const float *in, int ldi, const float *W3f, const float *b3, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const float bias = b3[r16];
+    f32x4 acc = f32x4{bias, bias, bias, bias};
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) {
+        const int k = 4 * ks + g;
+        acc = mfma16(in[r16 * ldi + k], W3f[k * 16 + r16], acc);
+    }
+    return acc;
+}
+
+// dzout[16][64] = (dzin[16][4*NS] . Wb) * (1 - hprev^2)
+template <int NS>
+__device__ __forceinline__ void dense64_bwd_input_lds(const float *dzin, int ldz, const float *Wb, const float *hprev, int ldh, float *dzout,
+                                                      int ldo, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) {
+        const int n = 4 * ns + g;
+        const float a = dzin[r16 * ldz + n];
+        const float4 w = *reinterpret_cast<const float4 *>(Wb + n * 64 + r16 * 4);
+        acc[0] = mfma16(a, w.x, acc[0]);
+        acc[1] = mfma16(a, w.y, acc[1]);
+        acc[2] = mfma16(a, w.z, acc[2]);
+        acc[3] = mfma16(a, w.w, acc[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = g * 4 + r, col = 16 * j + r16;
+            const float h = hprev[row * ldh + col];
+            const float d1 = 1.0f - h * h;
+            dzout[row * ldo + col] = acc[j][r] * d1;
+        }
+}
+
+// cooperative float4 copy global -> LDS (n_floats % 4 == 0, both 16-byte aligned)
+__device__ __forceinline__ void stage_copy(const float *__restrict__ src, float *dst, int n_floats) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int e = threadIdx.x; e < (n_floats >> 2); e += blockDim.x) d4[e] = s4[e];
 }
 
 // reductions inside one 16-lane group (lanes sharing lane>>4): xor masks 1,2,4,8 never leave the group

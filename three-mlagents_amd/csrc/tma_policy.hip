@@ -38,10 +38,48 @@ __device__ __forceinline__ Net vf_net(const float *p, const PLayout &L) {
     return Net{p + L.vW1t, p + L.vb1, p + L.vW2t, p + L.vb2, p + L.vW3t, p + L.vb3, p + L.vW2, p + L.vW3};
 }
 
+__device__ __forceinline__ void build_image_elem(float *params, const PLayout &L, int img, int e, int W1t, int b1, int W2t, int b2, int W3t, int b3,
+                                                 int n_out) {
+    const int D = L.D, H = 64;
+    float v = 0.0f;
+    if (e < IMG_W2F) {  // [k][r16][j] <- W1t[k][16j + r16]
+        const int x = e - IMG_W1, k = x >> 6, r16 = (x >> 2) & 15, j = x & 3;
+        v = k < D ? params[W1t + k * H + 16 * j + r16] : 0.0f;
+    } else if (e < IMG_W3F) {
+        const int x = e - IMG_W2F, k = x >> 6, r16 = (x >> 2) & 15, j = x & 3;
+        v = params[W2t + k * H + 16 * j + r16];
+    } else if (e < IMG_W3B) {  // [k][col]
+        const int x = e - IMG_W3F, k = x >> 4, col = x & 15;
+        v = col < n_out ? params[W3t + k * n_out + col] : 0.0f;
+    } else if (e < IMG_W2B) {  // [n][r16][j] <- W3[n][k = 16j + r16] = W3t[k][n]
+        const int x = e - IMG_W3B, n = x >> 6, r16 = (x >> 2) & 15, j = x & 3;
+        v = n < n_out ? params[W3t + (16 * j + r16) * n_out + n] : 0.0f;
+    } else if (e < IMG_B1) {   // [n][r16][j] <- W2[n][k] = W2t[k][n]
+        const int x = e - IMG_W2B, n = x >> 6, r16 = (x >> 2) & 15, j = x & 3;
+        v = params[W2t + (16 * j + r16) * H + n];
+    } else if (e < IMG_B2) {
+        v = params[b1 + (e - IMG_B1)];
+    } else if (e < IMG_B3) {
+        v = params[b2 + (e - IMG_B2)];
+    } else {
+        const int c = e - IMG_B3;
+        v = c < n_out ? params[b3 + c] : 0.0f;
+    }
+    params[img + e] = v;
+}
+
+// refreshes everything derived from the trainable region: [out][in] copies and (H == 64 fast path) the LDS images
 __global__ void sync_transposed_kernel(float *params, PLayout L) {
     const int H = L.H, A = L.A;
-    const int total = 2 * H * H + A * H + H;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int n_copy = 2 * H * H + A * H + H;
+    const int n_img = L.img_pi >= 0 ? 2 * IMG_FLOATS : 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_copy + n_img; e += gridDim.x * blockDim.x) {
+        if (e >= n_copy) {
+            const int x = e - n_copy;
+            if (x < IMG_FLOATS) build_image_elem(params, L, L.img_pi, x, L.pW1t, L.pb1, L.pW2t, L.pb2, L.pW3t, L.pb3, A);
+            else build_image_elem(params, L, L.img_vf, x - IMG_FLOATS, L.vW1t, L.vb1, L.vW2t, L.vb2, L.vW3t, L.vb3, 1);
+            continue;
+        }
         int x = e;
         if (x < H * H) {  // pW2[n][k] = pW2t[k][n]
             const int n = x / H, k = x % H;
@@ -67,11 +105,12 @@ __global__ void sync_transposed_kernel(float *params, PLayout L) {
 
 // stage a [16][D] tile of rows (gathered through row_off[]) into LDS, zero rows that are out of range
 __device__ __forceinline__ void load_obs_tile(const float *__restrict__ src, const int64_t *row_off_lds, int D, float *X, int ldx, int lane) {
-    const int total = 16 * D;
+    const int Dp = (D + 3) & ~3;  // columns D..Dp-1 are the zero padding of the last k-step
+    const int total = 16 * Dp;
     for (int e = lane; e < total; e += 64) {
-        const int row = e / D, c = e - row * D;
+        const int row = e / Dp, c = e - row * Dp;
         const int64_t off = row_off_lds[row];
-        X[row * ldx + c] = off >= 0 ? src[off * D + c] : 0.0f;
+        X[row * ldx + c] = (off >= 0 && c < D) ? src[off * D + c] : 0.0f;
     }
 }
 
@@ -560,16 +599,20 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     constexpr int H = 64;
     const int D = L.D, A = L.A;
     const int ldx = ((D + 3) & ~3) + 2, ld = H + 2, ld3 = 34;
-    const int per_wave = 16 * (ldx + 4 * ld + ld3) + 16 * 8;
-    float *X = smem + (int64_t)wave * per_wave;
-    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2 + 16 * ld, *dzB = dzA + 16 * ld, *dz3 = dzB + 16 * ld;
+    const int per_wave = 16 * (ldx + 2 * ld + ld3) + 16 * 8;
+    float *wimg = smem;  // this net's weight image, staged once per block
+    float *X = smem + IMG_FLOATS + (int64_t)wave * per_wave;
+    // the input-gradient tiles overwrite the activations they are derived from, element for element (dz2 over h2, dz1 over h1)
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2, *dzB = h1, *dz3 = h2 + 16 * ld;
     int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
     float *meta = reinterpret_cast<float *>(row_off + 16);
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
     const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
-    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     const int NOUT = IS_PI ? A : 1;
+    const int KS1 = (D + 3) >> 2;
+    stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
+    __syncthreads();
     NetAcc acc;
     zero_acc(acc);
     double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
@@ -592,10 +635,10 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
             row_off[lane] = off;
         }
         load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
-        dense_tanh(X, ldx, D, Q.W1t, Q.b1, H, h1, ld, lane);
-        dense_tanh(h1, ld, H, Q.W2t, Q.b2, H, h2, ld, lane);
+        dense64_tanh_lds<0>(X, ldx, KS1, wimg + IMG_W1, wimg + IMG_B1, h1, ld, lane);
+        dense64_tanh_lds<16>(h1, ld, 16, wimg + IMG_W2F, wimg + IMG_B2, h2, ld, lane);
         f32x4 out[1];
-        dense_head<1>(h2, ld, H, Q.W3t, Q.b3, NOUT, out, lane);
+        out[0] = dense64_head_lds(h2, ld, wimg + IMG_W3F, wimg + IMG_B3, lane);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = g * 4 + r;
@@ -636,9 +679,9 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
             }
         }
         bwd_weight_acc<4, 1>(h2, ld, H, dz3, ld3, NOUT, acc.w3, acc.b3, lane);
-        dense_bwd_input(dz3, ld3, NOUT, Q.W3, H, h2, ld, dzA, ld, lane);
+        dense64_bwd_input_lds<4>(dz3, ld3, wimg + IMG_W3B, h2, ld, dzA, ld, lane);
         bwd_weight_acc<4, 4>(h1, ld, H, dzA, ld, H, acc.w2, acc.b2, lane);
-        dense_bwd_input(dzA, ld, H, Q.W2, H, h1, ld, dzB, ld, lane);
+        dense64_bwd_input_lds<16>(dzA, ld, wimg + IMG_W2B, h1, ld, dzB, ld, lane);
         bwd_weight_acc<1, 4>(X, ldx, D, dzB, ld, H, acc.w1, acc.b1, lane);
     }
     __syncthreads();
@@ -662,7 +705,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     }
 }
 
-__global__ __launch_bounds__(256, 1) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+__global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                               const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                               double *__restrict__ stat_slots) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -758,7 +801,7 @@ static int fwd_smem_bytes(const PLayout &L, int wpb) {
 }
 static int grad_h64_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    const int tile = wpb * (16 * (ldx + 4 * ld + 34) + 16 * 8) * 4;
+    const int tile = (IMG_FLOATS + wpb * (16 * (ldx + 2 * ld + 34) + 16 * 8)) * 4;
     const int flush = wpb * (L.H * L.H + L.H) * 4;
     return tile > flush ? tile : flush;
 }
@@ -767,11 +810,154 @@ static int grad_smem_bytes(const PLayout &L, int wpb) {
     return wpb * (16 * (ldx + 6 * ld + 34) + 16 * 8) * 4;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// H = 64 forward fast path: both nets' forward weight images staged in LDS once per block (float4 copies of the images
+// tma_policy_sync maintains), B operands by ds_read_b128.  MODE 0 also folds the timeout bootstrap of the PREVIOUS vector
+// step (rewards_prev[i] += gamma * V(terminal_obs_prev[i]) where truncated_prev[i]) into the same launch.
+// ------------------------------------------------------------------------------------------
+constexpr int FWD_IMG = IMG_FWD_FLOATS + 160;  // forward matrices + the three biases
+
+__device__ __forceinline__ void stage_fwd_image(const float *img, float *dst) {
+    stage_copy(img, dst, IMG_FWD_FLOATS);
+    stage_copy(img + IMG_B1, dst + IMG_FWD_FLOATS, 160);
+}
+
+__device__ __forceinline__ f32x4 value_tile_lds(const float *vimg, const float *X, int ldx, int KS1, float *h1, float *h2, int ld, int lane) {
+    dense64_tanh_lds<0>(X, ldx, KS1, vimg + IMG_W1, vimg + IMG_FWD_FLOATS, h1, ld, lane);
+    dense64_tanh_lds<16>(h1, ld, 16, vimg + IMG_W2F, vimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
+    return dense64_head_lds(h2, ld, vimg + IMG_W3F, vimg + IMG_FWD_FLOATS + 128, lane);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void policy_fwd_h64_kernel(const float *__restrict__ params, PLayout L, const float *__restrict__ obs, int64_t n,
+                                                             uint32_t rng_seed, uint32_t rng_step, uint32_t env_offset, int deterministic,
+                                                             int32_t *__restrict__ actions_out, float *__restrict__ values_out,
+                                                             float *__restrict__ logp_out, const float *__restrict__ boot_obs,
+                                                             const uint8_t *__restrict__ boot_trunc, float gamma, float *__restrict__ boot_rewards) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
+    float *vimg = smem, *pimg = smem + FWD_IMG;
+    const int img_floats = (MODE == 0) ? 2 * FWD_IMG : FWD_IMG;
+    const int per_wave = 16 * (ldx + 2 * ld) + 32;
+    float *X = smem + img_floats + (int64_t)wave * per_wave;
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(h2 + 16 * ld);
+    stage_fwd_image(params + L.img_vf, vimg);
+    if constexpr (MODE == 0) stage_fwd_image(params + L.img_pi, pimg);
+    __syncthreads();
+    const int64_t n_tiles = (n + 15) >> 4;
+    if constexpr (MODE != 2) {
+        for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
+            const int64_t row0 = tile << 4;
+            if (lane < 16) row_off[lane] = (row0 + lane < n) ? row0 + lane : -1;
+            load_obs_tile(obs, row_off, D, X, ldx, lane);
+            const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
+            if constexpr (MODE == 1) {
+                if (r16 == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + g * 4 + r;
+                        if (row < n) values_out[row] = vacc[r];
+                    }
+            } else {
+                dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, h1, ld, lane);
+                dense64_tanh_lds<16>(h1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
+                const f32x4 acc = dense64_head_lds(h2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + g * 4 + r;
+                    const bool colok = r16 < A;
+                    const float x = colok ? acc[r] : -INFINITY;
+                    const float m = gmax16(x);
+                    const float e = colok ? expf(x - m) : 0.0f;
+                    const float s = gsum16(e);
+                    const float lse = m + logf(s);
+                    const float lp = x - lse;
+                    int act;
+                    if (deterministic) {
+                        float mn = (colok && x == m) ? (float)r16 : 99.0f;
+                        mn = fminf(mn, __shfl_xor(mn, 1, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 2, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 4, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                        act = (int)mn;
+                    } else {
+                        float c = e / s;
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) {
+                            const float up = __shfl_up(c, d, 16);
+                            if (r16 >= d) c += up;
+                        }
+                        const float u = uniform01(mix32(rng_seed, env_offset + (uint32_t)row, rng_step));
+                        const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                        act = min((int)cnt, A - 1);
+                    }
+                    const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                    const float vrow = __shfl(vacc[r], lane & 48, 64);
+                    if (r16 == r && row < n) {
+                        actions_out[row] = act;
+                        logp_out[row] = lpa;
+                        values_out[row] = vrow;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE != 1) {
+        if (boot_trunc != nullptr) {
+            for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
+                const int64_t row0 = tile << 4;
+                const int64_t rr = row0 + r16;
+                const bool tflag = (rr < n) && boot_trunc[rr] != 0;
+                if (__ballot(tflag) == 0ull) continue;
+                if (lane < 16) row_off[lane] = (row0 + lane < n) ? row0 + lane : -1;
+                load_obs_tile(boot_obs, row_off, D, X, ldx, lane);
+                const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
+                if (r16 == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + g * 4 + r;
+                        if (row < n && boot_trunc[row]) {
+                            const float gv = gamma * vacc[r];
+                            boot_rewards[row] = boot_rewards[row] + gv;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_fwd_h64(const float *params, const PLayout &L, const float *obs, int64_t n, uint32_t seed, uint32_t step, uint32_t env_offset,
+                          int deterministic, void *actions, float *values, float *logp, const float *boot_obs, const uint8_t *boot_trunc, float gamma,
+                          float *boot_rewards, hipStream_t s) {
+    const int64_t tiles = ceil_div(n, 16);
+    const int wpb = tiles >= 512 ? 4 : (tiles >= 64 ? 2 : 1);
+    const int ldx = ((L.D + 3) & ~3) + 2;
+    const int smem = (((MODE == 0) ? 2 : 1) * FWD_IMG + wpb * (16 * (ldx + 2 * 66) + 32)) * 4;
+    int64_t blocks = ceil_div(tiles, wpb);
+    if (blocks > 2048) blocks = 2048;
+    auto k = policy_fwd_h64_kernel<MODE>;
+    if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, static_cast<int32_t *>(actions), values,
+                                                           logp, boot_obs, boot_trunc, gamma, boot_rewards);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
 template <int MODE>
 static int launch_fwd(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t seed, uint32_t step, uint32_t env_offset,
                       int deterministic, void *actions, float *values, float *logp, const uint8_t *trunc, float gamma, float *rewards,
                       hipStream_t s) {
     const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    if (L.img_pi >= 0) {
+        if constexpr (MODE == 2) return launch_fwd_h64<2>(params, L, nullptr, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, obs, trunc, gamma, rewards, s);
+        else return launch_fwd_h64<MODE>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, nullptr, nullptr, 0.0f, nullptr, s);
+    }
     const int64_t tiles = ceil_div(n, 16);
     int wpb = tiles >= 1024 ? 4 : 1;  // small batches: one wave per block so every CU gets work
     while (wpb > 1 && fwd_smem_bytes(L, wpb) > 64 * 1024) wpb >>= 1;
@@ -829,7 +1015,7 @@ int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream) {
     if (rc) return rc;
     if (!params) return fail(TMA_ERR_INVALID, "params is null");
     const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
-    const int total = 2 * L.H * L.H + L.A * L.H + L.H;
+    const int total = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
     sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(params, L);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
@@ -843,6 +1029,26 @@ int tma_policy_act(const float *params, const tma_policy_dims *d, const float *o
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act: n must be >= 1");
     return launch_fwd<0>(params, d, obs, n, rng_seed, rng_step, env_offset, deterministic, actions_out, values_out, logp_out, nullptr, 0.0f, nullptr,
                          (hipStream_t)stream);
+}
+
+int tma_policy_act_bootstrap(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
+                             uint32_t env_offset, void *actions_out, float *values_out, float *logp_out, const float *prev_terminal_obs,
+                             const uint8_t *prev_truncated, double gamma, float *prev_rewards_inout, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !obs || !actions_out || !values_out || !logp_out) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: null buffer");
+    if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: n must be >= 1");
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const bool boot = prev_terminal_obs && prev_truncated && prev_rewards_inout;
+    if (L.img_pi >= 0)  // one launch: bootstrap of the previous step folded into this step's forward
+        return launch_fwd_h64<0>(params, L, obs, n, rng_seed, rng_step, env_offset, 0, actions_out, values_out, logp_out, boot ? prev_terminal_obs : nullptr,
+                                 boot ? prev_truncated : nullptr, (float)gamma, boot ? prev_rewards_inout : nullptr, (hipStream_t)stream);
+    if (boot) {
+        rc = launch_fwd<2>(params, d, prev_terminal_obs, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, prev_truncated, (float)gamma, prev_rewards_inout,
+                           (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_fwd<0>(params, d, obs, n, rng_seed, rng_step, env_offset, 0, actions_out, values_out, logp_out, nullptr, 0.0f, nullptr, (hipStream_t)stream);
 }
 
 int tma_policy_values(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, float *values_out, void *stream) {
@@ -893,7 +1099,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     const int64_t tiles = ceil_div(mbi->count, 16);
     if (L.H == 64 && L.D <= 16 && !L.cont && tiles >= 1024) {
         // register-accumulating persistent kernel + deterministic slab reduction
-        const int wpb4 = 4, smem4 = grad_h64_smem_bytes(L, wpb4);
+        const int wpb4 = 8, smem4 = grad_h64_smem_bytes(L, wpb4);
         int64_t blocks4 = ceil_div(tiles, wpb4);
         if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
@@ -944,7 +1150,7 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
     adam_kernel<<<dim3(nb), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L.P, (float)grad_scale, partials, nb, (float)max_grad_norm,
                                                (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
     TMA_LAUNCH_CHECK();
-    const int total = 2 * L.H * L.H + L.A * L.H + L.H;
+    const int total = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
     sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s>>>(params, L);
     TMA_LAUNCH_CHECK();
     return TMA_OK;

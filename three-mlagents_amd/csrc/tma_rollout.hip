@@ -2,7 +2,7 @@
 // round-trip per vector step.  Per step t it enqueues, on one HIP stream:
 //   policy_act(obs[t]) -> actions[t], values[t], log_probs[t]
 //   env step(actions[t]) -> obs[t+1], rewards[t], terminated[t], truncated[t], terminal_obs   (+ reset-ring refill when due)
-//   timeout bootstrap: rewards[t] += gamma * V(terminal_obs) where truncated[t]
+//   timeout bootstrap: rewards[t] += gamma * V(terminal_obs) where truncated[t]   (folded into step t+1's policy launch)
 // and, after the last step, last_values = V(obs[T]).  Reference call path: model.learn() at
 // /root/reference/backend/mlagents/training.py:166-170 -> SB3 collect_rollouts (SURVEY.md §3.1 hot loop A, App. C.6).
 #include "tma_common.h"
@@ -22,14 +22,19 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
         const float *obs_t = b->obs + (int64_t)t * N * D;
         float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
         void *act_t = static_cast<char *>(b->actions) + (int64_t)t * N * A * act_elem;
-        int rc = tma_policy_act(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, 0, act_t, b->values + (int64_t)t * N,
-                                b->log_probs + (int64_t)t * N, stream);
+        // policy forward of step t; the timeout bootstrap of step t-1 (terminal_obs still holds step t-1's) rides in the same launch
+        int rc = tma_policy_act_bootstrap(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, act_t, b->values + (int64_t)t * N,
+                                          b->log_probs + (int64_t)t * N, t > 0 ? b->terminal_obs : nullptr,
+                                          t > 0 ? b->truncated + (int64_t)(t - 1) * N : nullptr, gamma,
+                                          t > 0 ? b->rewards + (int64_t)(t - 1) * N : nullptr, stream);
         if (rc) return rc;
         rc = tma_env_step(env, act_t, d->continuous ? TMA_ACT_F32 : TMA_ACT_I32, 0, 0, 1, obs_next, b->rewards + (int64_t)t * N,
                           b->terminated + (int64_t)t * N, b->truncated + (int64_t)t * N, b->terminal_obs, nullptr, nullptr, stream);
         if (rc) return rc;
-        rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, N, gamma, b->rewards + (int64_t)t * N, stream);
-        if (rc) return rc;
+        if (t == T - 1) {  // last step of the rollout: nothing follows to carry its bootstrap
+            rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, N, gamma, b->rewards + (int64_t)t * N, stream);
+            if (rc) return rc;
+        }
     }
     if (compute_last_values && t_end == T) {
         if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
