@@ -273,18 +273,20 @@ def test_gae_flags_equals_sb3_layout():
     assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref)
 
 
-def test_native_rollout_equals_stepwise_composition():
-    """tma_rollout_collect == policy.act -> env.step -> bootstrap, step by step (bit-identical: same kernels, same RNG counters)."""
+@pytest.mark.parametrize("task,hidden", [("gridworld", 64), ("push", 64), ("ball3d", 64), ("basic", 64), ("gridworld", 128)])
+def test_native_rollout_equals_stepwise_composition(task, hidden):
+    """tma_rollout_collect (fused multi-step kernel for H=64 on gridworld/push/ball3d, per-step launches otherwise)
+    == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same RNG counters)."""
     from three_mlagents_amd import _lib
     from three_mlagents_amd.ppo import PPO
     from three_mlagents_amd.vec_env import HipVecEnv
 
-    N, T = 200, 48
-    env = HipVecEnv("gridworld", N, seed=3, ring_depth=16)
-    model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [64, 64]})
+    N, T = 200, {"ball3d": 230, "gridworld": 130}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
+    env = HipVecEnv(task, N, seed=3, ring_depth=16)
+    model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
     assert model.collect_rollouts()
     b = {k: v.clone() for k, v in model.buf.items()}
-    env2 = HipVecEnv("gridworld", N, seed=3, ring_depth=16)
+    env2 = HipVecEnv(task, N, seed=3, ring_depth=16)
     eng = env2.engine
     obs = eng.reset()
     assert torch.equal(obs, b["obs"][0])
@@ -299,6 +301,8 @@ def test_native_rollout_equals_stepwise_composition():
         obs = out["obs"][0].clone()
         assert torch.equal(obs, b["obs"][t + 1])
     assert torch.equal(model.policy.predict_values(obs), b["last_values"])
+    if task in ("gridworld", "ball3d"):
+        assert int(b["truncated"].sum()) > 0  # the timeout-bootstrap branch was exercised
     # GAE of the rollout vs the oracle on the same planes
     done = (b["terminated"] | b["truncated"]).float().cpu().numpy()
     es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])

@@ -9,7 +9,7 @@
 // backend/mlagents/training.py:71-89; LegacySingleAgentGymAdapter backend/mlagents/envs.py:87-159;
 // task dynamics backend/mlagents/envs.py:30-84, backend/examples/gridworld.py:33-95,
 // backend/examples/ball3d.py:41-113, backend/examples/push.py:27-125.
-#include "tma_tasks.h"
+#include "tma_internal.h"
 
 #include <cstring>
 #include <new>
@@ -20,39 +20,6 @@ namespace tma {
 char *err_buf() {
     static thread_local char buf[512] = {0};
     return buf;
-}
-
-struct EnvView {
-    int64_t N;
-    int D;  // ring depth
-    uint32_t seed_base, env_offset;
-    uint32_t *st, *ring, *cur_ep, *filled_hi;
-    double *ep_ret, *stats;
-};
-
-template <int OBS>
-__device__ __forceinline__ void store_obs(float *dst, const float *o) {
-    if constexpr (OBS == 4) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    } else if constexpr (OBS % 2 == 0) {
-#pragma unroll
-        for (int k = 0; k < OBS; k += 2) *reinterpret_cast<float2 *>(dst + k) = make_float2(o[k], o[k + 1]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < OBS; k++) dst[k] = o[k];
-    }
-}
-
-// obs of state s -> dst row (wide obs are written straight from the task, narrow ones staged in registers)
-template <class T>
-__device__ __forceinline__ void emit_obs(const typename T::S &s, float *dst) {
-    if constexpr (T::OBS > 32) {
-        T::obs(s, dst);
-    } else {
-        float o[T::OBS];
-        T::obs(s, o);
-        store_obs<T::OBS>(dst, o);
-    }
 }
 
 enum { ACT_I32 = 0, ACT_I64 = 1, ACT_F32 = 2, ACT_TAPE = 3 };
@@ -172,16 +139,6 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
 // two-level exclusive scan (per 256-env block, then over blocks) so that every lane of the seeding kernel gets exactly
 // one item regardless of how unevenly episodes ended.
 // ------------------------------------------------------------------------------------------
-struct RefillView {
-    uint32_t *first_ep;   // [N] first episode index each env must (re)fill
-    uint32_t *env_off;    // [N] exclusive prefix of the per-env item counts inside the env's 256-block
-    uint32_t *block_sum;  // [nb]
-    uint32_t *block_off;  // [nb] exclusive prefix of block_sum
-    uint32_t *total;      // [0] = number of items of this refill, [1] = fallback count
-    uint32_t *fb_env, *fb_ep;
-    int nb, fb_cap;
-};
-
 __global__ __launch_bounds__(256) void refill_count_kernel(EnvView v, RefillView rv) {
     __shared__ uint32_t wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -375,31 +332,6 @@ static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_
 
 using namespace tma;
 
-constexpr int FB_BLOCKS = 16;      // fallback kernel grid (16 x 256 threads, 2.5 KB of MT19937 scratch each)
-constexpr int FB_CAP = 1 << 20;    // fallback item capacity per refill
-
-struct tma_env {
-    int task, device;
-    EnvView v;
-    RefillView rv;
-    uint32_t *mt_scratch;
-    int steps_since_refill;
-    bool is_reset;
-    bool small_window;  // test hook: use the short fast-path window so the fallback generator is exercised
-};
-
-template <class F>
-static int dispatch_task(int task, F &&f) {
-    switch (task) {
-    case TMA_TASK_BASIC: return f(BasicTask{});
-    case TMA_TASK_GRIDWORLD: return f(GridTask{});
-    case TMA_TASK_BALL3D: return f(BallTask{});
-    case TMA_TASK_PUSH: return f(PushTask{});
-    case TMA_TASK_CRAWLER: return f(CrawlerTask{});
-    }
-    return fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
-}
-
 template <class T, int W>
 static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, float *obs_out, hipStream_t s) {
     refill_fast_kernel<T, W><<<dim3(blocks), dim3(256), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out);
@@ -444,6 +376,14 @@ static void launch_step(tma_env *h, const void *actions, uint32_t tape_seed, uin
                         uint8_t *tr, float *tobs, double *epr, int32_t *epl, hipStream_t s) {
     const unsigned blocks = (unsigned)ceil_div(h->v.N, 256);
     step_kernel<T, MODE><<<dim3(blocks), dim3(256), 0, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl);
+}
+
+// internal (not exported): bookkeeping after a kernel outside this file advanced the envs by n_steps
+int tma_env_internal_after_steps(tma_env *h, int n_steps, void *stream) {
+    if (!kMeta[h->task].uses_mt) return TMA_OK;
+    h->steps_since_refill += n_steps;
+    if (h->steps_since_refill >= h->v.D) return tma_env_refill(h, stream);
+    return TMA_OK;
 }
 
 extern "C" {

@@ -1,0 +1,79 @@
+// tma_internal.h -- definitions shared by the translation units of libtma_hip.so (not part of the C ABI).
+#pragma once
+#include "tma_tasks.h"
+
+namespace tma {
+
+struct EnvView {
+    int64_t N;
+    int D;  // ring depth
+    uint32_t seed_base, env_offset;
+    uint32_t *st, *ring, *cur_ep, *filled_hi;
+    double *ep_ret, *stats;
+};
+
+template <int OBS>
+__device__ __forceinline__ void store_obs(float *dst, const float *o) {
+    if constexpr (OBS == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (OBS % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < OBS; k += 2) *reinterpret_cast<float2 *>(dst + k) = make_float2(o[k], o[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < OBS; k++) dst[k] = o[k];
+    }
+}
+
+// obs of state s -> dst row (wide obs are written straight from the task, narrow ones staged in registers)
+template <class T>
+__device__ __forceinline__ void emit_obs(const typename T::S &s, float *dst) {
+    if constexpr (T::OBS > 32) {
+        T::obs(s, dst);
+    } else {
+        float o[T::OBS];
+        T::obs(s, o);
+        store_obs<T::OBS>(dst, o);
+    }
+}
+
+struct RefillView {
+    uint32_t *first_ep;   // [N] first episode index each env must (re)fill
+    uint32_t *env_off;    // [N] exclusive prefix of the per-env item counts inside the env's 256-block
+    uint32_t *block_sum;  // [nb]
+    uint32_t *block_off;  // [nb] exclusive prefix of block_sum
+    uint32_t *total;      // [0] = number of items of this refill, [1] = fallback count
+    uint32_t *fb_env, *fb_ep;
+    int nb, fb_cap;
+};
+
+}  // namespace tma
+
+constexpr int FB_BLOCKS = 16;      // fallback kernel grid (16 x 256 threads, 2.5 KB of MT19937 scratch each)
+constexpr int FB_CAP = 1 << 20;    // fallback item capacity per refill
+
+struct tma_env {
+    int task, device;
+    tma::EnvView v;
+    tma::RefillView rv;
+    uint32_t *mt_scratch;
+    int steps_since_refill;
+    bool is_reset;
+    bool small_window;  // test hook: use the short fast-path window so the fallback generator is exercised
+};
+
+template <class F>
+static int dispatch_task(int task, F &&f) {
+    switch (task) {
+    case TMA_TASK_BASIC: return f(tma::BasicTask{});
+    case TMA_TASK_GRIDWORLD: return f(tma::GridTask{});
+    case TMA_TASK_BALL3D: return f(tma::BallTask{});
+    case TMA_TASK_PUSH: return f(tma::PushTask{});
+    case TMA_TASK_CRAWLER: return f(tma::CrawlerTask{});
+    }
+    return tma::fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
+}
+
+
+// bookkeeping after a kernel outside tma_env.hip advanced the envs by n_steps (triggers the reset-ring refill when due)
+int tma_env_internal_after_steps(tma_env *h, int n_steps, void *stream);

@@ -267,6 +267,32 @@ __device__ __forceinline__ void stage_copy(const float *__restrict__ src, float 
     for (int e = threadIdx.x; e < (n_floats >> 2); e += blockDim.x) d4[e] = s4[e];
 }
 
+// stage a [16][D] tile of rows (gathered through row_off[]) into LDS, zero rows that are out of range
+__device__ __forceinline__ void load_obs_tile(const float *__restrict__ src, const int64_t *row_off_lds, int D, float *X, int ldx, int lane) {
+    const int Dp = (D + 3) & ~3;  // columns D..Dp-1 are the zero padding of the last k-step
+    const int total = 16 * Dp;
+    for (int e = lane; e < total; e += 64) {
+        const int row = e / Dp, c = e - row * Dp;
+        const int64_t off = row_off_lds[row];
+        X[row * ldx + c] = (off >= 0 && c < D) ? src[off * D + c] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+constexpr int FWD_IMG = IMG_FWD_FLOATS + 160;  // forward matrices + the three biases
+
+__device__ __forceinline__ void stage_fwd_image(const float *img, float *dst) {
+    stage_copy(img, dst, IMG_FWD_FLOATS);
+    stage_copy(img + IMG_B1, dst + IMG_FWD_FLOATS, 160);
+}
+
+__device__ __forceinline__ f32x4 value_tile_lds(const float *vimg, const float *X, int ldx, int KS1, float *h1, float *h2, int ld, int lane) {
+    dense64_tanh_lds<0>(X, ldx, KS1, vimg + IMG_W1, vimg + IMG_FWD_FLOATS, h1, ld, lane);
+    dense64_tanh_lds<16>(h1, ld, 16, vimg + IMG_W2F, vimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
+    return dense64_head_lds(h2, ld, vimg + IMG_W3F, vimg + IMG_FWD_FLOATS + 128, lane);
+}
+
 // reductions inside one 16-lane group (lanes sharing lane>>4): xor masks 1,2,4,8 never leave the group
 __device__ __forceinline__ float gsum16(float v) {
     v += __shfl_xor(v, 1, 64);

@@ -103,19 +103,6 @@ __global__ void sync_transposed_kernel(float *params, PLayout L) {
     }
 }
 
-// stage a [16][D] tile of rows (gathered through row_off[]) into LDS, zero rows that are out of range
-__device__ __forceinline__ void load_obs_tile(const float *__restrict__ src, const int64_t *row_off_lds, int D, float *X, int ldx, int lane) {
-    const int Dp = (D + 3) & ~3;  // columns D..Dp-1 are the zero padding of the last k-step
-    const int total = 16 * Dp;
-    for (int e = lane; e < total; e += 64) {
-        const int row = e / Dp, c = e - row * Dp;
-        const int64_t off = row_off_lds[row];
-        X[row * ldx + c] = (off >= 0 && c < D) ? src[off * D + c] : 0.0f;
-    }
-}
-
-__device__ __forceinline__ float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
-
 // ------------------------------------------------------------------------------------------
 // policy_act: obs[n][D] -> sampled (or deterministic) actions, values, log-probs.  One wave per 16 rows.
 // MODE: 0 act (actions+values+logp), 1 values only, 2 timeout bootstrap (rewards[i] += gamma * V(term_obs[i]) where trunc[i])
@@ -816,19 +803,6 @@ static int grad_smem_bytes(const PLayout &L, int wpb) {
 // tma_policy_sync maintains), B operands by ds_read_b128.  MODE 0 also folds the timeout bootstrap of the PREVIOUS vector
 // step (rewards_prev[i] += gamma * V(terminal_obs_prev[i]) where truncated_prev[i]) into the same launch.
 // ------------------------------------------------------------------------------------------
-constexpr int FWD_IMG = IMG_FWD_FLOATS + 160;  // forward matrices + the three biases
-
-__device__ __forceinline__ void stage_fwd_image(const float *img, float *dst) {
-    stage_copy(img, dst, IMG_FWD_FLOATS);
-    stage_copy(img + IMG_B1, dst + IMG_FWD_FLOATS, 160);
-}
-
-__device__ __forceinline__ f32x4 value_tile_lds(const float *vimg, const float *X, int ldx, int KS1, float *h1, float *h2, int ld, int lane) {
-    dense64_tanh_lds<0>(X, ldx, KS1, vimg + IMG_W1, vimg + IMG_FWD_FLOATS, h1, ld, lane);
-    dense64_tanh_lds<16>(h1, ld, 16, vimg + IMG_W2F, vimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
-    return dense64_head_lds(h2, ld, vimg + IMG_W3F, vimg + IMG_FWD_FLOATS + 128, lane);
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void policy_fwd_h64_kernel(const float *__restrict__ params, PLayout L, const float *__restrict__ obs, int64_t n,
                                                              uint32_t rng_seed, uint32_t rng_step, uint32_t env_offset, int deterministic,

@@ -5,7 +5,183 @@
 //   timeout bootstrap: rewards[t] += gamma * V(terminal_obs) where truncated[t]   (folded into step t+1's policy launch)
 // and, after the last step, last_values = V(obs[T]).  Reference call path: model.learn() at
 // /root/reference/backend/mlagents/training.py:166-170 -> SB3 collect_rollouts (SURVEY.md §3.1 hot loop A, App. C.6).
-#include "tma_common.h"
+#include "tma_internal.h"
+#include "tma_mlp.h"
+
+
+namespace tma {
+
+// ------------------------------------------------------------------------------------------
+// Fused rollout chunk (H = 64 policies on GridWorld / Push / Ball3D): ONE launch advances every env by n_steps vector steps.
+// A wavefront owns a tile of 16 envs for the whole chunk: the two forward weight images are staged in LDS once, the tile's
+// observations live in LDS between steps, the 16 env states live in the registers of 16 "owner" lanes (lane = 16*g + r owns
+// tile row 4*g + r, exactly where the policy epilogue leaves that row's action / log-prob / value), and per step the wave runs
+// value net -> policy net -> categorical sample -> env step (+ auto-reset from the ring, Monitor sums) -> obs into LDS and
+// into rollout-buffer slot t+1 -> (only if some env of the tile hit its time limit) value net on the terminal observations
+// for the timeout bootstrap.  No kernel boundary, no HBM round trip of the observation between policy and env.
+// ------------------------------------------------------------------------------------------
+struct ChunkPtrs {
+    float *obs;
+    int32_t *actions;
+    float *rewards, *values, *log_probs;
+    uint8_t *terminated, *truncated;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
+                                                                uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int D = T::OBS;
+    const int A = L.A;
+    constexpr int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
+    float *vimg = smem, *pimg = smem + FWD_IMG;
+    constexpr int per_wave = 16 * (2 * ldx + 2 * ld) + 32;
+    float *X = smem + 2 * FWD_IMG + (int64_t)wave * per_wave;
+    float *XT = X + 16 * ldx, *h1 = XT + 16 * ldx, *h2 = h1 + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(h2 + 16 * ld);
+    stage_fwd_image(params + L.img_vf, vimg);
+    stage_fwd_image(params + L.img_pi, pimg);
+    __syncthreads();
+    const int64_t N = v.N;
+    const int64_t tile = (int64_t)blockIdx.x * wpb + wave;
+    if (tile * 16 >= N) return;
+    const int64_t row0 = tile << 4;
+    const int my_row = g * 4 + r16;  // meaningful for owner lanes (r16 < 4)
+    const int64_t i = row0 + my_row;
+    const bool active = (r16 < 4) && (i < N);
+    const uint32_t gi = v.env_offset + (uint32_t)i;
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    if (active) {
+        T::unpack(v.st, N, i, s);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    if (lane < 16) row_off[lane] = (row0 + lane < N) ? (int64_t)t0 * N + row0 + lane : -1;
+    load_obs_tile(b.obs, row_off, D, X, ldx, lane);
+    for (int e = lane; e < 16 * ldx; e += 64) XT[e] = 0.0f;
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
+        dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, h1, ld, lane);
+        dense64_tanh_lds<16>(h1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
+        const f32x4 acc = dense64_head_lds(h2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
+        int my_act = 0;
+        float my_lp = 0.0f, my_v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t row = row0 + g * 4 + r;
+            const bool colok = r16 < A;
+            const float x = colok ? acc[r] : -INFINITY;
+            const float m = gmax16(x);
+            const float e = colok ? expf(x - m) : 0.0f;
+            const float sum = gsum16(e);
+            const float lse = m + logf(sum);
+            const float lp = x - lse;
+            float c = e / sum;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const float up = __shfl_up(c, d, 16);
+                if (r16 >= d) c += up;
+            }
+            const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+            const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+            const int act = min((int)cnt, A - 1);
+            const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+            const float vrow = __shfl(vacc[r], lane & 48, 64);
+            if (r16 == r) my_act = act, my_lp = lpa, my_v = vrow;
+        }
+        bool tr_flag = false;
+        float rew32 = 0.0f;
+        int64_t off = 0;
+        if (active) {
+            off = (int64_t)t * N + i;
+            b.actions[off] = my_act;
+            b.values[off] = my_v;
+            b.log_probs[off] = my_lp;
+            double r;
+            bool done;
+            T::step(s, my_act, nullptr, r, done);
+            const int steps = T::steps(s);
+            const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+            const bool te = done && !hit, tr = hit;
+            er += r;
+            rew32 = (float)r;
+            b.terminated[off] = (uint8_t)te;
+            b.truncated[off] = (uint8_t)tr;
+            float o[D];
+            if (te || tr) {
+                if (tr) {
+                    T::obs(s, o);
+#pragma unroll
+                    for (int c = 0; c < D; c++) XT[my_row * ldx + c] = o[c];
+                }
+                sret += er, slen += (double)steps, scnt += 1.0;
+                er = 0.0;
+                ce += 1;
+                uint32_t rec[T::RW];
+                const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
+#pragma unroll
+                for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * N];
+                T::from_rec(rec, s);
+            }
+            T::obs(s, o);
+            store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
+#pragma unroll
+            for (int c = 0; c < D; c++) X[my_row * ldx + c] = o[c];
+            b.rewards[off] = rew32;
+            tr_flag = tr;
+        }
+        if (__ballot(tr_flag) != 0ull) {  // timeout bootstrap: rewards += gamma * V(terminal_obs) where truncated
+            const f32x4 vt = value_tile_lds(vimg, XT, ldx, KS1, h1, h2, ld, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float vr = __shfl(vt[r], lane & 48, 64);
+                if (r16 == r && tr_flag) {
+                    const float gv = gamma * vr;
+                    b.rewards[off] = rew32 + gv;
+                }
+            }
+        }
+    }
+    if (active) {
+        T::pack(v.st, N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sret += __shfl_down(sret, o, 64);
+        slen += __shfl_down(slen, o, 64);
+        scnt += __shfl_down(scnt, o, 64);
+    }
+    if (lane == 0 && scnt > 0.0) {  // Monitor aggregate: the 16 tiles of a 256-env slot add with f64 atomics (few per launch)
+        double *slot = v.stats + (row0 >> 8) * 3;
+        atomicAdd(slot + 0, sret);
+        atomicAdd(slot + 1, slen);
+        atomicAdd(slot + 2, scnt);
+    }
+}
+
+template <class T>
+static int launch_chunk(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed, uint32_t rng_step0,
+                        float gamma, hipStream_t s) {
+    const int64_t tiles = ceil_div(env->v.N, 16);
+    const int wpb = tiles >= 1024 ? 4 : 1;  // BASELINE shape (256 tiles): one wave per block so all 256 CUs take part
+    constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
+    const int smem = (2 * FWD_IMG + wpb * (16 * (2 * ldx + 2 * 66) + 32)) * 4;
+    auto k = rollout_chunk_h64_kernel<T>;
+    if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    k<<<dim3((unsigned)ceil_div(tiles, wpb)), dim3(64 * wpb), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+}  // namespace tma
 
 extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin,
                                    int t_end, int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma,
@@ -16,6 +192,34 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
         return fail(TMA_ERR_INVALID, "tma_rollout_collect: rollout buffers has a null plane");
     if (t_begin < 0 || t_end > T || t_begin > t_end) return fail(TMA_ERR_INVALID, "bad step range [%d, %d) for T=%d", t_begin, t_end, T);
     const int64_t N = b->N;
+    if (N != env->v.N) return fail(TMA_ERR_INVALID, "rollout buffers are for %lld envs, the env handle has %lld", (long long)N, (long long)env->v.N);
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const bool fused = L.img_pi >= 0 && env->is_reset &&
+                       (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D) &&
+                       d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
+    if (fused) {
+        TMA_HIP(hipSetDevice(env->device));
+        ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
+        int t = t_begin;
+        while (t < t_end) {
+            int left = 0;
+            int rc = tma_env_steps_until_refill(env, &left);
+            if (rc) return rc;
+            const int n = left < (t_end - t) ? left : (t_end - t);
+            if (env->task == TMA_TASK_GRIDWORLD) rc = launch_chunk<GridTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_PUSH) rc = launch_chunk<PushTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            else rc = launch_chunk<BallTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            if (rc) return rc;
+            rc = tma_env_internal_after_steps(env, n, stream);
+            if (rc) return rc;
+            t += n;
+        }
+        if (compute_last_values && t_end == T) {
+            if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
+            return tma_policy_values(params, d, b->obs + (int64_t)T * N * d->obs_dim, N, b->last_values, stream);
+        }
+        return TMA_OK;
+    }
     const int D = d->obs_dim, A = d->continuous ? d->act_dim : 1;
     const size_t act_elem = d->continuous ? sizeof(float) : sizeof(int32_t);
     for (int t = t_begin; t < t_end; t++) {
