@@ -579,8 +579,9 @@ __device__ __forceinline__ void flush_segment(float *stage_all, int wave, int wp
 // SB3 net_arch=dict(pi=..., vf=...)), so a wave holds only ~105 accumulator registers and two blocks fit per CU.
 template <bool IS_PI>
 __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
-                                              const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
+                                              const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+    __shared__ float adv_ms[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     constexpr int H = 64;
@@ -594,12 +595,27 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
     float *meta = reinterpret_cast<float *>(row_off + 16);
     const float invB = 1.0f / (float)mb.count;
-    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
-    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
     const int NOUT = IS_PI ? A : 1;
     const int KS1 = (D + 3) >> 2;
     stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
+    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {  // fold the minibatch advantage partials (same order as adv_final_kernel)
+        double a = 0.0, bsum = 0.0;
+        for (int k = threadIdx.x; k < n_part; k += 64) a += adv_part[2 * k], bsum += adv_part[2 * k + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            bsum += __shfl_down(bsum, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            const double n = (double)mb.count, mean = a / n;
+            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            adv_ms[0] = (float)mean;
+            adv_ms[1] = (float)sqrt(var);
+        }
+    }
     __syncthreads();
+    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
+    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
     NetAcc acc;
     zero_acc(acc);
     double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
@@ -693,14 +709,14 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
 }
 
 __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
-                                                              const float *__restrict__ ws_adv, float *__restrict__ slabs,
+                                                              const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
                                                               double *__restrict__ stat_slots) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_h64_body<true>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
-    else grad_h64_body<false>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_h64_body<true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    else grad_h64_body<false>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
@@ -767,6 +783,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params, f
         v[e] = vv;
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
         params[e] = params[e] - lr_step * (mm / denom);  // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
+
+// small policies (P <= 32768): clip_grad_norm_ + Adam in ONE single-block launch (the norm needs no second kernel)
+__global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                                         PLayout L, float scale, float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt,
+                                                         float eps, double *norm_out) {
+    __shared__ double red[16];
+    __shared__ float coef_s;
+    const int P = L.P;
+    double sq = 0.0;
+    for (int e = threadIdx.x; e < P; e += 1024) {
+        const float gv = grad[e] * scale;
+        sq += (double)gv * (double)gv;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; w++) tot += red[w];
+        const float total_norm = (float)sqrt(tot);
+        float coef = max_norm / (total_norm + 1e-6f);
+        coef = coef > 1.0f ? 1.0f : coef;
+        if (max_norm <= 0.0f) coef = 1.0f;
+        coef_s = coef;
+        norm_out[0] = (double)total_norm;
+        norm_out[1] = (double)coef;
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    for (int e = threadIdx.x; e < P; e += 1024) {
+        const float gv = (grad[e] * scale) * coef;
+        grad[e] = 0.0f;
+        float mm = m[e], vv = v[e];
+        mm = mm + (gv - mm) * (1.0f - beta1);
+        vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+        m[e] = mm;
+        v[e] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        params[e] = params[e] - lr_step * (mm / denom);
     }
 }
 
@@ -1061,17 +1119,20 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     char *ws = static_cast<char *>(workspace);
     float *ws_adv = reinterpret_cast<float *>(ws + WS_ADV);
     double *slots = reinterpret_cast<double *>(ws + WS_STATS);
+    const int64_t tiles = ceil_div(mbi->count, 16);
+    const bool h64 = L.img_pi >= 0 && tiles >= 1024;
+    double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
+    int nbk = (int)ceil_div(mbi->count, 1024);
+    if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
     if (hpar.normalize_advantage) {
-        double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
-        int nbk = (int)ceil_div(mbi->count, 1024);
-        if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
         adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part);
         TMA_LAUNCH_CHECK();
-        adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, mbi->count, ws_adv);
-        TMA_LAUNCH_CHECK();
+        if (!h64) {  // the H = 64 kernel folds the partials itself
+            adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, mbi->count, ws_adv);
+            TMA_LAUNCH_CHECK();
+        }
     }
-    const int64_t tiles = ceil_div(mbi->count, 16);
-    if (L.H == 64 && L.D <= 16 && !L.cont && tiles >= 1024) {
+    if (h64) {
         // register-accumulating persistent kernel + deterministic slab reduction
         const int wpb4 = 8, smem4 = grad_h64_smem_bytes(L, wpb4);
         int64_t blocks4 = ceil_div(tiles, wpb4);
@@ -1079,7 +1140,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         auto k = ppo_grad_h64_kernel;
         if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
-        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, adv_part, nbk, slabs, slots);
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
         TMA_LAUNCH_CHECK();
@@ -1115,12 +1176,21 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
     char *ws = static_cast<char *>(workspace);
     double *partials = reinterpret_cast<double *>(ws + WS_NORM_PART);
     double *norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
+    if (L.P <= 32768) {
+        opt_small_kernel<<<dim3(1), dim3(1024), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, (float)grad_scale, (float)max_grad_norm, (float)step_size,
+                                                        (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
+        TMA_LAUNCH_CHECK();
+        const int tot = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
+        sync_transposed_kernel<<<dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s>>>(params, L);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     int nb = (int)ceil_div(L.P, 1024);
     if (nb > 256) nb = 256;
     grad_sumsq_kernel<<<dim3(nb), dim3(256), 0, s>>>(grad, L.P, (float)grad_scale, partials);
     TMA_LAUNCH_CHECK();
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
     adam_kernel<<<dim3(nb), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L.P, (float)grad_scale, partials, nb, (float)max_grad_norm,
                                                (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
     TMA_LAUNCH_CHECK();
