@@ -22,6 +22,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units (5 instructions instead of ocml's ~40).
+// Absolute error <= ~2e-7 over the whole range (saturates cleanly to +-1); the parity tolerance is 1e-5.
+__device__ __forceinline__ float tma_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x) = 2^(2x log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 // Flat parameter buffer (floats).  [0, P) is the trainable region in [in][out] ("t") layout; [P, total) holds the
 // [out][in] copies of the matrices whose input gradient is needed (layer 2 and the heads).
 struct PLayout {
@@ -102,7 +109,7 @@ __device__ __forceinline__ void dense_tanh(const float *in, int ldi, int K, cons
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + n0 + 16 * j + r16] = tanhf(acc[j][r]);
+            for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + n0 + 16 * j + r16] = tma_tanh(acc[j][r]);
     }
 }
 
@@ -215,7 +222,7 @@ __device__ __forceinline__ void dense64_tanh_lds(const float *in, int ldi, int K
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + 16 * j + r16] = tanhf(acc[j][r]);
+        for (int r = 0; r < 4; r++) out[(g * 4 + r) * ldo + 16 * j + r16] = tma_tanh(acc[j][r]);
 }
 
 // acc (C layout, column lane&15) = in[16][64] . W3f + b3

@@ -25,7 +25,7 @@ constexpr int WS_ADV_PART = 4096;     // byte offset of double[128][2] advantage
 constexpr int WS_STATS = 8192;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
 constexpr int MAX_GRAD_BLOCKS = 2048;
 constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
-constexpr int H64_BLOCKS = 256;
+constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
 constexpr int64_t WS_BYTES = WS_SLABS;
 
 struct Net {
@@ -519,21 +519,23 @@ __device__ __forceinline__ void zero_acc(NetAcc &a) {
 template <int KT, int NT>
 __device__ __forceinline__ void bwd_weight_acc(const float *xin, int ldx, int K, const float *dz, int ldz, int N, f32x4 (&accW)[KT][NT],
                                                float (&accb)[NT], int lane) {
+    (void)K, (void)N;
     const int r16 = lane & 15, g = lane >> 4;
     float bf[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int col = nt * 16 + r16;
 #pragma unroll
-        for (int s = 0; s < 4; s++) bf[nt][s] = col < N ? dz[(4 * s + g) * ldz + col] : 0.0f;
+        for (int s = 0; s < 4; s++) bf[nt][s] = dz[(4 * s + g) * ldz + col];  // dz tiles are written with zeros in columns >= N
         accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
     }
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
         const int krow = kt * 16 + r16;
         float a[4];
+        // rows krow >= K read whatever follows in LDS: they only feed accumulator rows k >= K, which flush_segment never stores
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = krow < K ? xin[(4 * s + g) * ldx + krow] : 0.0f;
+        for (int s = 0; s < 4; s++) a[s] = xin[(4 * s + g) * ldx + krow];
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -577,7 +579,7 @@ __device__ __forceinline__ void flush_segment(float *stage_all, int wave, int wp
 
 // One launch, 2 x n_slabs blocks: even blocks carry the POLICY net, odd blocks the VALUE net (the two MLPs share nothing,
 // SB3 net_arch=dict(pi=..., vf=...)), so a wave holds only ~105 accumulator registers and two blocks fit per CU.
-template <bool IS_PI>
+template <bool IS_PI, int DT>  // DT > 0: compile-time observation width (folds the LDS addressing), 0: runtime L.D
 __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                               const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
@@ -585,8 +587,9 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     constexpr int H = 64;
-    const int D = L.D, A = L.A;
-    const int ldx = ((D + 3) & ~3) + 2, ld = H + 2, ld3 = 34;
+    const int D = DT > 0 ? DT : L.D, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2;
+    constexpr int ld = H + 2, ld3 = 34;
     const int per_wave = 16 * (ldx + 2 * ld + ld3) + 16 * 8;
     float *wimg = smem;  // this net's weight image, staged once per block
     float *X = smem + IMG_FLOATS + (int64_t)wave * per_wave;
@@ -708,6 +711,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                               const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
                                                               double *__restrict__ stat_slots) {
@@ -715,8 +719,8 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_h64_body<true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
-    else grad_h64_body<false>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
@@ -1138,9 +1142,13 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int64_t blocks4 = ceil_div(tiles, wpb4);
         if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        auto k = ppo_grad_h64_kernel;
-        if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
-        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, adv_part, nbk, slabs, slots);
+        auto launch = [&](auto k) -> int {
+            if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
+            k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, adv_part, nbk, slabs, slots);
+            return TMA_OK;
+        };
+        int lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
+        if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
         TMA_LAUNCH_CHECK();
