@@ -231,7 +231,7 @@ def main():
             eng.step(acts, outputs=outs, want_episode=False)
 
         # groups of 8 back-to-back launches; the median group never contains the once-per-ring_depth refill launches
-        while eng.steps_until_refill() != eng.ring_depth:
+        while eng.steps_until_refill() < eng.ring_depth:  # (tasks without an MT19937 reset never need a refill)
             step_once()
         avg_us, med_us = timed_kernel_us(step_once, 4 * eng.ring_depth, sync, group=8)
         # exclude launches that also carried a refill: use the median for the pure step kernel
@@ -246,9 +246,11 @@ def main():
         }
         # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
         try:
+            if world > 1:
+                raise RuntimeError("skipped in multi-GPU runs (measured at N=1)")
             from three_mlagents_amd.vec_env import HipEnvEngine
 
-            Nb = 1 << 22
+            Nb = (1 << 22) if D <= 32 else (1 << 18)  # wide observations: fewer envs, still far beyond the L2/MALL capacity
             big = HipEnvEngine(args.task, Nb, seed=args.seed, ring_depth=8)
             big.reset()
             bo = {k: v for k, v in big._out(1).items() if k in ("obs", "rew", "term", "trunc")}
@@ -290,7 +292,7 @@ def main():
         out["roofline_update"] = {"kernel": "adv stats + tma::ppo_grad_h64_kernel + slab_reduce (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",
                                   "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                   "launch_us": g_med, "samples": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb, "traffic": None}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as exc:  # noqa: BLE001
