@@ -312,27 +312,32 @@ struct HParams {
     int normalize_advantage;
 };
 
-template <bool CONT>
-__global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
-                                                       const float *__restrict__ ws_adv, float *__restrict__ grad, double *__restrict__ stat_slots) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// Even blocks carry the POLICY net, odd blocks the VALUE net (they share nothing).  The input-gradient tiles overwrite the
+// activations they derive from (dz2 over h2, dz1 over h1), so a wave needs X + 2 activation tiles of LDS and four waves fit.
+template <bool CONT, bool IS_PI>
+__device__ __forceinline__ void grad_generic_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                                  const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ grad,
+                                                  double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int D = L.D, H = L.H, A = L.A;
     const int ldx = ((D + 3) & ~3) + 2, ld = H + 2, ld3 = 34;
-    const int per_wave = 16 * (ldx + 6 * ld + ld3) + 16 * 8;
+    const int per_wave = 16 * (ldx + 2 * ld + ld3) + 16 * 8;
     float *X = smem + (int64_t)wave * per_wave;
-    float *h1p = X + 16 * ldx, *h2p = h1p + 16 * ld, *h1v = h2p + 16 * ld, *h2v = h1v + 16 * ld;
-    float *dzA = h2v + 16 * ld, *dzB = dzA + 16 * ld, *dz3 = dzB + 16 * ld;
-    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);  // 16 x int64 = 32 floats
-    float *meta = reinterpret_cast<float *>(row_off + 16);           // [16][4]: old_logp, adv, ret, action(bits)
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2, *dzB = h1, *dz3 = h2 + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
+    float *meta = reinterpret_cast<float *>(row_off + 16);
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
     const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
-    const Net P = pi_net(params, L), V = vf_net(params, L);
-    double st_pl = 0.0, st_vl = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
+    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
+    const int NOUT = IS_PI ? A : 1;
+    float *gW1 = grad + (IS_PI ? L.pW1t : L.vW1t), *gb1 = grad + (IS_PI ? L.pb1 : L.vb1);
+    float *gW2 = grad + (IS_PI ? L.pW2t : L.vW2t), *gb2 = grad + (IS_PI ? L.pb2 : L.vb2);
+    float *gW3 = grad + (IS_PI ? L.pW3t : L.vW3t), *gb3 = grad + (IS_PI ? L.pb3 : L.vb3);
+    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
     const int64_t n_tiles = (mb.count + 15) >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
+    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += (int64_t)n_blocks_net * wpb) {
         if (lane < 16) {
             const int64_t j = (tile << 4) + lane;
             int64_t off = -1;
@@ -347,17 +352,22 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
             row_off[lane] = off;
         }
         load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
-        // ---- forward ----
-        dense_tanh(X, ldx, D, P.W1t, P.b1, H, h1p, ld, lane);
-        dense_tanh(h1p, ld, H, P.W2t, P.b2, H, h2p, ld, lane);
-        dense_tanh(X, ldx, D, V.W1t, V.b1, H, h1v, ld, lane);
-        dense_tanh(h1v, ld, H, V.W2t, V.b2, H, h2v, ld, lane);
-        f32x4 vacc[1];
-        dense_head<1>(h2v, ld, H, V.W3t, V.b3, 1, vacc, lane);
-        float dlsd[2] = {0.0f, 0.0f};  // continuous: per-column log_std gradient partials
-        if constexpr (!CONT) {
+        dense_tanh(X, ldx, D, Q.W1t, Q.b1, H, h1, ld, lane);
+        dense_tanh(h1, ld, H, Q.W2t, Q.b2, H, h2, ld, lane);
+        if constexpr (!IS_PI) {
+            f32x4 vacc[1];
+            dense_head<1>(h2, ld, H, Q.W3t, Q.b3, 1, vacc, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = g * 4 + r;
+                const bool valid = row_off[row] >= 0;
+                const float diff = vacc[0][r] - meta[row * 4 + 2];
+                dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                if (valid && r16 == 0) st_a += (double)(diff * diff);
+            }
+        } else if constexpr (!CONT) {
             f32x4 acc[1];
-            dense_head<1>(h2p, ld, H, P.W3t, P.b3, A, acc, lane);
+            dense_head<1>(h2, ld, H, Q.W3t, Q.b3, A, acc, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = g * 4 + r;
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
                 dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
                 dz3[row * ld3 + r16] = colok ? dl : 0.0f;
                 if (valid && r16 == 0) {
-                    st_pl += (double)(-fminf(pl1, pl2));
+                    st_a += (double)(-fminf(pl1, pl2));
                     st_ent += (double)ent;
                     st_kl += (double)((ratio - 1.0f) - (lpa - old));
                     st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
@@ -393,8 +403,9 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
             }
         } else {
             f32x4 acc[2];
-            dense_head<2>(h2p, ld, H, P.W3t, P.b3, A, acc, lane);
+            dense_head<2>(h2, ld, H, Q.W3t, Q.b3, A, acc, lane);
             const float *lsp = params + L.log_std;
+            float dlsd[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = g * 4 + r;
@@ -430,16 +441,15 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
                     if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
                 }
                 if (valid && r16 == 0) {
-                    st_pl += (double)(-fminf(pl1, pl2));
+                    st_a += (double)(-fminf(pl1, pl2));
                     st_ent += (double)ent;
                     st_kl += (double)((ratio - 1.0f) - (lpa - old));
                     st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
                     st_n += 1.0;
                 }
             }
-            // log_std gradient: sum the 4 row-groups (lanes sharing lane&15), one atomic per column
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < 2; j++) {  // log_std gradient: fold the 4 row groups, one atomic per column
                 float v = dlsd[j];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
@@ -447,45 +457,38 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
                 if (g == 0 && col < A) atomicAdd(grad + L.log_std + col, v);
             }
         }
-        // ---- backward: policy net ----
-        dense_bwd_weight(h2p, ld, H, dz3, ld3, A, grad + L.pW3t, grad + L.pb3, lane);
-        dense_bwd_input(dz3, ld3, A, P.W3, H, h2p, ld, dzA, ld, lane);
-        dense_bwd_weight(h1p, ld, H, dzA, ld, H, grad + L.pW2t, grad + L.pb2, lane);
-        dense_bwd_input(dzA, ld, H, P.W2, H, h1p, ld, dzB, ld, lane);
-        dense_bwd_weight(X, ldx, D, dzB, ld, H, grad + L.pW1t, grad + L.pb1, lane);
-        // ---- value loss + backward: value net ----
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = g * 4 + r;
-            const bool valid = row_off[row] >= 0;
-            const float v = vacc[0][r], ret = meta[row * 4 + 2];
-            const float diff = v - ret;
-            dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
-            if (valid && r16 == 0) st_vl += (double)(diff * diff);
-        }
-        dense_bwd_weight(h2v, ld, H, dz3, ld3, 1, grad + L.vW3t, grad + L.vb3, lane);
-        dense_bwd_input(dz3, ld3, 1, V.W3, H, h2v, ld, dzA, ld, lane);
-        dense_bwd_weight(h1v, ld, H, dzA, ld, H, grad + L.vW2t, grad + L.vb2, lane);
-        dense_bwd_input(dzA, ld, H, V.W2, H, h1v, ld, dzB, ld, lane);
-        dense_bwd_weight(X, ldx, D, dzB, ld, H, grad + L.vW1t, grad + L.vb1, lane);
+        dense_bwd_weight(h2, ld, H, dz3, ld3, NOUT, gW3, gb3, lane);
+        dense_bwd_input(dz3, ld3, NOUT, Q.W3, H, h2, ld, dzA, ld, lane);
+        dense_bwd_weight(h1, ld, H, dzA, ld, H, gW2, gb2, lane);
+        dense_bwd_input(dzA, ld, H, Q.W2, H, h1, ld, dzB, ld, lane);
+        dense_bwd_weight(X, ldx, D, dzB, ld, H, gW1, gb1, lane);
     }
-    // loss statistics: wave shuffle reduction -> LDS -> this block's slot (plain RMW, summed on the host when logged)
-    double st[6] = {st_pl, st_vl, st_ent, st_kl, st_clip, st_n};
+    double st[5] = {st_a, st_ent, st_kl, st_clip, st_n};
 #pragma unroll
-    for (int q = 0; q < 6; q++)
+    for (int q = 0; q < 5; q++)
         for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
     __syncthreads();
     double *red = reinterpret_cast<double *>(smem);
     if (lane == 0)
-        for (int q = 0; q < 6; q++) red[wave * 6 + q] = st[q];
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 5) {
         double s = 0.0;
-        for (int w = 0; w < wpb; w++) s += red[w * 6 + threadIdx.x];
-        stat_slots[(int64_t)blockIdx.x * 8 + threadIdx.x] += s;
+        for (int w = 0; w < wpb; w++) s += red[w * 5 + threadIdx.x];
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += s;
     }
 }
 
+template <bool CONT>
+__global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                       const float *__restrict__ ws_adv, float *__restrict__ grad, double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if ((blockIdx.x & 1) == 0) grad_generic_body<CONT, true>(params, L, rb, mb, hp, ws_adv, grad, slot, smem, n_pairs, pair);
+    else grad_generic_body<CONT, false>(params, L, rb, mb, hp, ws_adv, grad, slot, smem, n_pairs, pair);
+}
 
 // ------------------------------------------------------------------------------------------
 // H = 64 specialisation (BASELINE configs[1]): persistent waves keep the WHOLE parameter gradient of both nets in MFMA
@@ -856,7 +859,7 @@ static int grad_h64_smem_bytes(const PLayout &L, int wpb) {
 }
 static int grad_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return wpb * (16 * (ldx + 6 * ld + 34) + 16 * 8) * 4;
+    return wpb * (16 * (ldx + 2 * ld + 34) + 16 * 8) * 4;
 }
 
 
@@ -1154,20 +1157,20 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
-    int wpb = tiles >= 1024 ? 4 : 1;
-    while (wpb > 1 && grad_smem_bytes(L, wpb) > 150 * 1024) wpb >>= 1;
+    int wpb = tiles >= 512 ? 4 : 1;
+    while (wpb > 1 && grad_smem_bytes(L, wpb) > 156 * 1024) wpb--;
     const int smem = grad_smem_bytes(L, wpb);
     if (smem > 160 * 1024) return fail(TMA_ERR_INVALID, "policy too wide for the LDS-resident tile (needs %d bytes)", smem);
     int64_t blocks = ceil_div(tiles, wpb);
-    if (blocks > MAX_GRAD_BLOCKS) blocks = MAX_GRAD_BLOCKS;
+    if (blocks > MAX_GRAD_BLOCKS / 2) blocks = MAX_GRAD_BLOCKS / 2;
     if (d->continuous) {
         auto k = ppo_grad_kernel<true>;
         if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
+        k<<<dim3((unsigned)(2 * blocks)), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
     } else {
         auto k = ppo_grad_kernel<false>;
         if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)blocks), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
+        k<<<dim3((unsigned)(2 * blocks)), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
     }
     TMA_LAUNCH_CHECK();
     return TMA_OK;
