@@ -220,29 +220,53 @@ def main():
         sync = lambda: torch.cuda.current_stream(dev).synchronize()  # noqa: E731
         b = model.buf
         L = _lib.lib()
-        # batched step kernel exactly as the rollout launches it (1 vector step, policy actions, terminal obs captured)
+        lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
+        flops_fwd, flops_fb = mlp_flops_per_sample(D, args.hidden, A)
+        # ---- dominant kernel of the timed region: the PPO minibatch forward+backward (MFMA-bound) ----
+        mb = _lib.Minibatch(None, 1, 0, 0, min(batch, total))
+
+        def grad_once():
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(model._rollout_view), C.byref(mb),
+                                                C.byref(model._hp), _lib.ptr(model.grad), _lib.ptr(model.workspace), model._stream()))
+
+        for _ in range(3):
+            grad_once()
+        g_avg, g_med = timed_kernel_us(grad_once, 40, sync, group=4)
+        model.grad.zero_()
+        log(f"minibatch gradient launch group: median {g_med:.1f} us")
+        tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
+        fast = args.hidden == 64 and D <= 16 and not model.policy.continuous and mb.count >= 16384
+        out["roofline"] = {
+            "kernel": ("tma::ppo_grad_h64_kernel (+ adv_partial_kernel + slab_reduce_kernel of the same tma_ppo_minibatch_grad call)" if fast else
+                       "tma::ppo_grad_kernel (+ adv_partial/adv_final of the same tma_ppo_minibatch_grad call)"),
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "launch_us": g_med, "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
+            "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
+        }
+        pmc_path = os.path.join(ROOT, "profiles", "r01_grad_kernel_pmc.json")
+        if fast and args.task == "gridworld" and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            out["roofline"]["traffic"] = pmc.get("traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/r01_grad_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+        # ---- batched env step kernel (the kernel north_star names), launched exactly as VecEnv.step does ----
         acts = b["actions"][0].contiguous()
         outs = dict(obs=torch.empty((1, N, D), device=dev), rew=torch.empty((1, N), device=dev), term=torch.empty((1, N), dtype=torch.uint8, device=dev),
                     trunc=torch.empty((1, N), dtype=torch.uint8, device=dev), term_obs=torch.empty((1, N, D), device=dev))
 
         def step_once():
-            if eng.steps_until_refill() == 0:
-                raise RuntimeError("refill bookkeeping broke")
             eng.step(acts, outputs=outs, want_episode=False)
 
-        # groups of 8 back-to-back launches; the median group never contains the once-per-ring_depth refill launches
         while eng.steps_until_refill() < eng.ring_depth:  # (tasks without an MT19937 reset never need a refill)
             step_once()
         avg_us, med_us = timed_kernel_us(step_once, 4 * eng.ring_depth, sync, group=8)
-        # exclude launches that also carried a refill: use the median for the pure step kernel
-        log(f"step kernel: avg {avg_us:.2f} us, median {med_us:.2f} us")
-        lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
+        log(f"step kernel at {N} envs: median {med_us:.2f} us per launch")
         step_gbps = N * lay / (med_us * 1e-6) / 1e9
-        out["roofline"] = {
-            "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs)", "bound": "hbm", "achieved": step_gbps, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_env_step": lay, "launch_us": med_us,
+        out["roofline_step_kernel"] = {
+            "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs, back-to-back launches)", "bound": "hbm", "achieved": step_gbps,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_env_step": lay, "launch_us": med_us,
             "survey_formula_bytes_per_env_step": sv, "survey_formula_GBps": N * sv / (med_us * 1e-6) / 1e9,
-            "note": "4096 envs move 0.24 MB per launch: the launch is latency-bound, not HBM-bound (SURVEY.md §7.3-4); see roofline_saturated",
+            "note": f"{N} envs move {N * lay / 1e6:.2f} MB per launch: launch-latency-bound, not HBM-bound (SURVEY.md 7.3-4); the training rollout uses the "
+                    "fused multi-step kernel instead; see roofline_step_kernel_saturated for the HBM-bound regime",
         }
         # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
         try:
@@ -262,36 +286,23 @@ def main():
 
             for _ in range(8):
                 big_step()
-            log("saturated engine ready")
             _, med_big = timed_kernel_us(big_step, 40, sync)
             log(f"saturated step kernel median {med_big:.1f} us")
             bytes_big = lay - 4  # tape: no action read
             gb = Nb * bytes_big / (med_big * 1e-6) / 1e9
-            out["roofline_saturated"] = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm",
-                                         "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS, "launch_us": med_big,
-                                         "bytes_per_env_step": bytes_big, "env_steps_per_s_kernel_only": Nb / (med_big * 1e-6),
-                                         "survey_formula_GBps": Nb * (sv - 4) / (med_big * 1e-6) / 1e9}
+            sat = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm", "achieved": gb,
+                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS, "launch_us": med_big, "bytes_per_env_step": bytes_big,
+                   "env_steps_per_s_kernel_only": Nb / (med_big * 1e-6), "survey_formula_GBps": Nb * (sv - 4) / (med_big * 1e-6) / 1e9, "traffic": None}
+            pmc_path = os.path.join(ROOT, "profiles", "r01_step_kernel_pmc.json")
+            if args.task == "gridworld" and os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                sat["traffic"] = pmc.get("traffic_bytes_per_launch")
+                sat["traffic_source"] = "profiles/r01_step_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+            out["roofline_step_kernel_saturated"] = sat
             big.close()
             del big, bo
         except Exception as exc:  # noqa: BLE001
-            out["roofline_saturated"] = {"error": str(exc)}
-        # PPO minibatch forward+backward kernel (the kernel that dominates wall time of the iteration)
-        mb = _lib.Minibatch(None, 1, 0, 0, min(batch, total))
-        flops_fwd, flops_fb = mlp_flops_per_sample(D, args.hidden, A)
-
-        def grad_once():
-            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(model._rollout_view), C.byref(mb),
-                                                C.byref(model._hp), _lib.ptr(model.grad), _lib.ptr(model.workspace), model._stream()))
-
-        for _ in range(2):
-            grad_once()
-        g_avg, g_med = timed_kernel_us(grad_once, 10, sync)
-        log(f"grad kernel median {g_med:.1f} us")
-        model.grad.zero_()
-        tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
-        out["roofline_update"] = {"kernel": "adv stats + tma::ppo_grad_h64_kernel + slab_reduce (one minibatch: gather, fwd, loss, bwd)", "bound": "mfma",
-                                  "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                                  "launch_us": g_med, "samples": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb, "traffic": None}
+            out["roofline_step_kernel_saturated"] = {"error": str(exc)}
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
