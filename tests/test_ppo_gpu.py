@@ -85,7 +85,14 @@ def _rollout(pol, sd, D, A, cont, T, N, seed=0):
         act_flat = actions.reshape(T * N)
     with torch.no_grad():
         _, lp, _ = sb3_ref.evaluate_actions(sd, flat, act_flat)
-    old_lp = (lp + 0.25 * torch.randn(T * N, generator=g)).reshape(T, N)  # ratios spread around 1 -> both clip branches
+    old_lp = lp + 0.25 * torch.randn(T * N, generator=g)  # ratios spread around 1 -> both clip branches
+    # keep every sample clear of the clip boundary: min(r*A, clip(r)*A) switches branch there, so a last-ulp difference in
+    # exp(logp - old) between two correct f32 implementations flips one sample's whole gradient (seen at |logp| ~ 60)
+    for _ in range(3):
+        ratio = torch.exp(lp.double() - old_lp.double())
+        near = ((ratio - 1.0).abs() - 0.2).abs() < 5e-3
+        old_lp = torch.where(near, old_lp + 0.03, old_lp)
+    old_lp = old_lp.reshape(T, N)
     adv = torch.randn(T, N, generator=g)
     ret = torch.randn(T, N, generator=g)
     return obs, actions, old_lp, adv, ret
@@ -179,6 +186,29 @@ def test_large_minibatch_register_accumulating_kernel(D, A):
     g_a, _, _ = _hip_grad(pol, bufs, T, N, perm, 100, B // 2, hp2)
     g_b, _, _ = _hip_grad(pol, bufs, T, N, perm, 100 + B // 2, B - B // 2, hp2)
     assert torch.allclose(g_full, 0.5 * (g_a + g_b), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,H,A,cont", [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 256, 3, False)])
+def test_wide_policy_column_parallel_kernel(D, H, A, cont):
+    """B >= 32768 with H in {128, 256} takes the column-parallel register-accumulating kernel (slab reduction, no atomics
+    except none at all for D <= 32)."""
+    T, N, B = 64, 600, 33000
+    pol, sd = _policy(D, H, A, cont)
+    obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, cont, T, N)
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(2))
+    idx = perm[50:50 + B]
+    f = lambda x: _flatten_env_major(x, T, N)[idx]  # noqa: E731
+    tr = sb3_ref.RefTrainer(sd)
+    stats_ref, grads_ref = tr.step(f(obs), f(actions), f(old_lp), f(adv), f(ret), **HP)
+    bufs = dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret)
+    grad, st, _ = _hip_grad(pol, bufs, T, N, perm, 50, B, HP)
+    grad2, _, _ = _hip_grad(pol, bufs, T, N, perm, 50, B, HP)
+    assert torch.equal(grad, grad2)  # deterministic
+    ref = _ref_grad_flat(pol, grads_ref)
+    err, scale = (grad.cpu() - ref).abs().max().item(), ref.abs().max().item()
+    assert err <= 2e-5 * max(scale, 1.0) + 1e-6, (err, scale)
+    assert st[5] == B and abs(st[0] / B - stats_ref["policy_loss"]) < 1e-5 and abs(st[1] / B - stats_ref["value_loss"]) < 1e-4
+    assert abs(-st[2] / B - stats_ref["entropy_loss"]) < 1e-4 and abs(st[4] / B - stats_ref["clip_fraction"]) < 1e-6
 
 
 def test_full_batch_feistel_permutation_is_a_bijection():

@@ -14,6 +14,7 @@
 #include "tma_mlp.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace tma {
@@ -726,6 +727,464 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
     else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Wide policies (H = 128 / 256: the reference's default net_arch is 256x256, training.py:363-365): column-parallel blocks.
+// A block of 8 waves walks row groups of M = 32 samples for ONE net; wave w owns output columns [w*H/8, (w+1)*H/8) of both
+// hidden layers, so its slice of every weight gradient (dW2: H x H/8 = 128 registers at H = 256) stays in MFMA accumulators
+// for the whole launch, every weight fragment fetched from L2 is used for both 16-row tiles, and each block ends by storing
+// ITS slab of the gradient with plain stores (no atomics; slab_reduce_kernel folds the blocks in a fixed order).
+// Activations of the row group live in block-shared LDS; __syncthreads separates the layers.
+// ------------------------------------------------------------------------------------------
+struct LossStats {
+    double a = 0.0, ent = 0.0, kl = 0.0, clip = 0.0, n = 0.0;
+};
+
+// clipped-surrogate + entropy gradient wrt the head outputs of one 16-row tile (C layout), written to dz3[16][ld3]
+template <bool CONT>
+__device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
+                                                 const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
+                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = g * 4 + r;
+        const int64_t off = row_off[row];
+        const bool valid = off >= 0;
+        const float old = meta[row * 4 + 0];
+        const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+        float lpa, ent;
+        float d[2] = {0.0f, 0.0f}, sd[2] = {1.0f, 1.0f}, p = 0.0f, lp = 0.0f;
+        int act = 0;
+        if constexpr (!CONT) {
+            const bool colok = r16 < A;
+            const float x = colok ? acc[0][r] : -INFINITY;
+            const float m = gmax16(x);
+            const float e = colok ? expf(x - m) : 0.0f;
+            const float s = gsum16(e);
+            const float lse = m + logf(s);
+            lp = colok ? x - lse : 0.0f;
+            p = e / s;
+            act = __float_as_int(meta[row * 4 + 3]);
+            lpa = gsum16((r16 == act) ? lp : 0.0f);
+            ent = -gsum16(p * lp);
+        } else {
+            float lpsum = 0.0f, entsum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = 16 * j + r16;
+                if (col < A) {
+                    const float lsd = log_std[col];
+                    sd[j] = expf(lsd);
+                    const float a = valid ? static_cast<const float *>(actions)[off * A + col] : 0.0f;
+                    d[j] = a - acc[j][r];
+                    lpsum += -(d[j] * d[j]) / (2.0f * (sd[j] * sd[j])) - lsd - 0.9189385332046727f;
+                    entsum += 1.4189385332046727f + lsd;
+                }
+            }
+            lpa = gsum16(lpsum);
+            ent = gsum16(entsum);
+        }
+        const float ratio = expf(lpa - old);
+        const float pl1 = advn * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+        const float pl2 = advn * rc;
+        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+        if constexpr (!CONT) {
+            float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
+            dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
+            dz3[row * ld3 + r16] = (r16 < A) ? dl : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = 16 * j + r16;
+                const float var = sd[j] * sd[j];
+                dz3[row * ld3 + col] = (col < A) ? g_lp * (d[j] / var) : 0.0f;
+                if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
+            }
+        }
+        if (valid && r16 == 0) {
+            st.a += (double)(-fminf(pl1, pl2));
+            st.ent += (double)ent;
+            st.kl += (double)((ratio - 1.0f) - (lpa - old));
+            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+            st.n += 1.0;
+        }
+    }
+}
+
+template <bool CONT, bool IS_PI, int NTW>
+__device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                               const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
+                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+    constexpr int M = 32, H = 128 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, A = L.A;
+    const int NOUT = IS_PI ? A : 1;
+    const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2, KT1 = (D + 15) >> 4;
+    const bool acc_w1 = KT1 <= 2;  // D <= 32: dW1 slice in registers too; wider observations use float atomics for layer 1
+    float *X = smem, *h1 = X + M * ldx, *h2 = h1 + M * ld, *dz3 = h2 + M * ld;
+    float *meta = dz3 + M * ld3;
+    int64_t *row_off = reinterpret_cast<int64_t *>(meta + M * 4);
+    float *scratch = reinterpret_cast<float *>(row_off + M);  // 64 floats
+    const int n_base = wave * 16 * NTW;
+    const float invB = 1.0f / (float)mb.count;
+    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
+    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
+    const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 aW2[KT2][NTW], aW1[2][NTW], aW3[NTW][NT3];
+    float ab1[NTW], ab2[NTW], ab3[NT3], dlsd[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        ab1[j] = ab2[j] = 0.0f;
+        aW1[0][j] = aW1[1][j] = z4;
+#pragma unroll
+        for (int i = 0; i < KT2; i++) aW2[i][j] = z4;
+#pragma unroll
+        for (int q = 0; q < NT3; q++) aW3[j][q] = z4;
+    }
+#pragma unroll
+    for (int q = 0; q < NT3; q++) ab3[q] = 0.0f;
+    LossStats st;
+    const int64_t n_groups = (mb.count + M - 1) / M;
+    for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
+        // ---- P0: gather sample metadata and the observation rows ----
+        if (threadIdx.x < M) {
+            const int64_t j = grp * M + threadIdx.x;
+            int64_t off = -1;
+            float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+            if (j < mb.count) {
+                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
+                if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+            }
+            meta[threadIdx.x * 4 + 0] = m0, meta[threadIdx.x * 4 + 1] = m1, meta[threadIdx.x * 4 + 2] = m2, meta[threadIdx.x * 4 + 3] = m3;
+            row_off[threadIdx.x] = off;
+        }
+        __syncthreads();
+        {
+            const int Dp = (D + 3) & ~3, tot = M * Dp;
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                const int row = e / Dp, c = e - row * Dp;
+                const int64_t off = row_off[row];
+                X[row * ldx + c] = (off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- P1: layer 1 forward, this wave's columns, both row tiles ----
+        {
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const float bias = Q.b1[n_base + 16 * j + r16];
+                acc[j][0] = acc[j][1] = f32x4{bias, bias, bias, bias};
+            }
+            for (int ks = 0; ks < KS1; ks++) {
+                const int k = 4 * ks + g;
+                const bool ok = k < D;
+                const float a0 = X[r16 * ldx + k], a1 = X[(16 + r16) * ldx + k];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const float w = ok ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
+                    acc[j][0] = mfma16(a0, w, acc[j][0]);
+                    acc[j][1] = mfma16(a1, w, acc[j][1]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h1[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
+        }
+        __syncthreads();
+        // ---- P2: layer 2 forward ----
+        {
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const float bias = Q.b2[n_base + 16 * j + r16];
+                acc[j][0] = acc[j][1] = f32x4{bias, bias, bias, bias};
+            }
+#pragma unroll 2
+            for (int ks = 0; ks < H / 4; ks++) {
+                const int k = 4 * ks + g;
+                const float a0 = h1[r16 * ld + k], a1 = h1[(16 + r16) * ld + k];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const float w = Q.W2t[(int64_t)k * H + n_base + 16 * j + r16];
+                    acc[j][0] = mfma16(a0, w, acc[j][0]);
+                    acc[j][1] = mfma16(a1, w, acc[j][1]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h2[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
+        }
+        __syncthreads();
+        // ---- P3: head + loss: wave mt (0, 1) takes row tile mt ----
+        if (wave < 2) {
+            const int mt = wave;
+            const float *hh = h2 + mt * 16 * ld;
+            f32x4 out[NT3];
+            dense_head<NT3>(hh, ld, H, Q.W3t, Q.b3, NOUT, out, lane);
+            float *dzt = dz3 + mt * 16 * ld3;
+            if constexpr (IS_PI) {
+                policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
+                                       lane);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = g * 4 + r;
+                    const bool valid = row_off[mt * 16 + row] >= 0;
+                    const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
+                    dzt[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                    if (valid && r16 == 0) st.a += (double)(diff * diff);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P4: head weight gradient (this wave's k rows), head bias, and dz2 = (dz3 . W3) * (1 - h2^2) in place ----
+        {
+#pragma unroll
+            for (int q = 0; q < NT3; q++) {
+                const int col = 16 * q + r16;
+                float bf[8];
+#pragma unroll
+                for (int sidx = 0; sidx < 8; sidx++) bf[sidx] = dz3[(4 * sidx + g) * ld3 + col];
+                if (wave == 0) {
+                    float c = 0.0f;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) c += bf[sidx];
+                    ab3[q] += c;
+                }
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    const int krow = n_base + 16 * i + r16;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) aW3[i][q] = mfma16(h2[(4 * sidx + g) * ld + krow], bf[sidx], aW3[i][q]);
+                }
+            }
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = z4;
+            const int NS = (NOUT + 3) >> 2;
+            for (int ns = 0; ns < NS; ns++) {
+                const int n = 4 * ns + g;
+                const bool ok = n < NOUT;
+                const float a0 = dz3[r16 * ld3 + n], a1 = dz3[(16 + r16) * ld3 + n];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const float w = ok ? Q.W3[(int64_t)n * H + n_base + 16 * j + r16] : 0.0f;
+                    acc[j][0] = mfma16(a0, w, acc[j][0]);
+                    acc[j][1] = mfma16(a1, w, acc[j][1]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float *pp = h2 + (mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16;
+                        const float h = *pp;
+                        *pp = acc[j][mt][r] * (1.0f - h * h);
+                    }
+        }
+        __syncthreads();
+        // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dz1 = (dz2 . W2) * (1 - h1^2) kept in registers until every wave is done with h1 ----
+        f32x4 dz1[NTW][2];
+        {
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const int col = n_base + 16 * j + r16;
+                float bf[8];
+                float c = 0.0f;
+#pragma unroll
+                for (int sidx = 0; sidx < 8; sidx++) {
+                    bf[sidx] = h2[(4 * sidx + g) * ld + col];
+                    c += bf[sidx];
+                }
+                ab2[j] += c;
+#pragma unroll
+                for (int kt = 0; kt < KT2; kt++) {
+                    const int krow = kt * 16 + r16;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) aW2[kt][j] = mfma16(h1[(4 * sidx + g) * ld + krow], bf[sidx], aW2[kt][j]);
+                    if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 128 LDS reads (register budget)
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++) dz1[j][0] = dz1[j][1] = z4;
+#pragma unroll 2
+            for (int ns = 0; ns < H / 4; ns++) {
+                const int n = 4 * ns + g;
+                const float a0 = h2[r16 * ld + n], a1 = h2[(16 + r16) * ld + n];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const float w = Q.W2[(int64_t)n * H + n_base + 16 * j + r16];
+                    dz1[j][0] = mfma16(a0, w, dz1[j][0]);
+                    dz1[j][1] = mfma16(a1, w, dz1[j][1]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NTW; j++)
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float *pp = h1 + (mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16;
+                    const float h = *pp;
+                    *pp = dz1[j][mt][r] * (1.0f - h * h);
+                }
+        // ---- P6: dW1 slice += X^T . dz1[:, slice] (each wave reads back only the columns it just wrote) ----
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+            const int col = n_base + 16 * j + r16;
+            float bf[8];
+            float c = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                bf[sidx] = h1[(4 * sidx + g) * ld + col];
+                c += bf[sidx];
+            }
+            ab1[j] += c;
+            if (acc_w1) {
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++) {
+                    if (kt < KT1) {
+                        const int krow = kt * 16 + r16;
+#pragma unroll
+                        for (int sidx = 0; sidx < 8; sidx++) {
+                            const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
+                            aW1[kt][j] = mfma16(a, bf[sidx], aW1[kt][j]);
+                        }
+                    }
+                }
+            } else {
+                float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t);
+                for (int kt = 0; kt < KT1; kt++) {
+                    f32x4 t = z4;
+                    const int krow = kt * 16 + r16;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) {
+                        const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
+                        t = mfma16(a, bf[sidx], t);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int k = kt * 16 + g * 4 + r;
+                        if (k < D) gW1[(int64_t)k * H + col] += t[r];  // this wave is the only writer of these slab columns
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
+    float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
+    float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);
+    float *gW3 = slab + (IS_PI ? L.pW3t : L.vW3t), *gb3 = slab + (IS_PI ? L.pb3 : L.vb3);
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const int col = n_base + 16 * j + r16;
+#pragma unroll
+        for (int kt = 0; kt < KT2; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+        if (acc_w1) {
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = kt * 16 + g * 4 + r;
+                    if (k < D) gW1[(int64_t)k * H + col] = aW1[kt][j][r];
+                }
+        }
+        float v1 = ab1[j], v2 = ab2[j];
+        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+        v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
+        if (g == 0) gb1[col] = v1, gb2[col] = v2;
+#pragma unroll
+        for (int q = 0; q < NT3; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
+                if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
+            }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < NT3; q++) {
+            float v = ab3[q];
+            v += __shfl_xor(v, 16, 64), v += __shfl_xor(v, 32, 64);
+            const int n = 16 * q + r16;
+            if (g == 0 && n < NOUT) gb3[n] = v;
+        }
+    }
+    if constexpr (IS_PI && CONT) {  // log_std gradient: the two head waves hold one row tile each
+        float v0 = dlsd[0], v1 = dlsd[1];
+        v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
+        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+        if (wave == 1 && g == 0) scratch[r16] = v0, scratch[16 + r16] = v1;
+        __syncthreads();
+        if (wave == 0 && g == 0) {
+            if (r16 < A) slab[L.log_std + r16] = v0 + scratch[r16];
+            if (16 + r16 < A) slab[L.log_std + 16 + r16] = v1 + scratch[16 + r16];
+        }
+    }
+    // loss statistics of the head waves -> this pair's slot
+    double sv[5] = {st.a, st.ent, st.kl, st.clip, st.n};
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        for (int o = 32; o > 0; o >>= 1) sv[q] += __shfl_down(sv[q], o, 64);
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0 && wave < 2)
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = sv[q];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const double ssum = red[threadIdx.x] + red[5 + threadIdx.x];
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += ssum;
+    }
+}
+
+template <bool CONT, int NTW>
+__global__ __launch_bounds__(512, 2) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                               const float *__restrict__ ws_adv, float *__restrict__ slabs,
+                                                               double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    float *slab = slabs + (int64_t)pair * L.P;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    else grad_wide_body<CONT, false, NTW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+}
+
+// zero the layer-1 weight columns of every slab when they are accumulated in place (observations wider than 32)
+__global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
+    const int per = L.D * L.H;
+    const int64_t tot = (int64_t)n_slabs * 2 * per;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / (2 * per);
+        const int x = (int)(e - b * 2 * per);
+        slabs[b * L.P + (x < per ? L.pW1t + x : L.vW1t + (x - per))] = 0.0f;
+    }
+}
+
+static int grad_wide_smem_bytes(const PLayout &L) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64) * 4;
+}
+
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
 // fixed order -> bitwise reproducible, and enough independent loads in flight to run at L2 speed.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int P, float *__restrict__ grad) {
@@ -1154,6 +1613,31 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
+    static const bool force_wide = getenv("TMA_FORCE_WIDE") != nullptr;  // test hook: take the column-parallel kernel at any batch size
+    if ((L.H == 128 || L.H == 256) && (tiles >= 2048 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
+        // column-parallel register-accumulating kernel + deterministic slab reduction
+        const int smemw = grad_wide_smem_bytes(L);
+        int64_t pairs = ceil_div(ceil_div(mbi->count, 32), 4);
+        if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
+        float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
+        if (L.D > 32) {
+            slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
+            TMA_LAUNCH_CHECK();
+        }
+        auto launch = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
+            k<<<dim3((unsigned)(2 * pairs)), dim3(512), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+            return TMA_OK;
+        };
+        int lrc;
+        if (L.H == 256) lrc = d->continuous ? launch(ppo_grad_wide_kernel<true, 2>) : launch(ppo_grad_wide_kernel<false, 2>);
+        else lrc = d->continuous ? launch(ppo_grad_wide_kernel<true, 1>) : launch(ppo_grad_wide_kernel<false, 1>);
+        if (lrc) return lrc;
+        TMA_LAUNCH_CHECK();
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
