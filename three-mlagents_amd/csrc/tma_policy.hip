@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace tma {
@@ -730,8 +731,9 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
 
 // ------------------------------------------------------------------------------------------
 // Wide policies (H = 128 / 256: the reference's default net_arch is 256x256, training.py:363-365): column-parallel blocks.
-// A block of 8 waves walks row groups of M = 32 samples for ONE net; wave w owns output columns [w*H/8, (w+1)*H/8) of both
-// hidden layers, so its slice of every weight gradient (dW2: H x H/8 = 128 registers at H = 256) stays in MFMA accumulators
+// A block of 4 waves (one per SIMD, so each wave has the full 512-register budget: 256 accumulator + 256 working registers)
+// walks row groups of M = 32 samples for ONE net; wave w owns output columns [w*H/4, (w+1)*H/4) of both hidden layers, so its
+// slice of every weight gradient (dW2: H x H/4 = 256 registers at H = 256) stays in MFMA accumulators
 // for the whole launch, every weight fragment fetched from L2 is used for both 16-row tiles, and each block ends by storing
 // ITS slab of the gradient with plain stores (no atomics; slab_reduce_kernel folds the blocks in a fixed order).
 // Activations of the row group live in block-shared LDS; __syncthreads separates the layers.
@@ -813,17 +815,18 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
     }
 }
 
-template <bool CONT, bool IS_PI, int NTW>
+template <bool CONT, bool IS_PI, int NTW, int KT1C>  // KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32, 0: layer-1 gradient accumulated in the slab)
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
-    constexpr int M = 32, H = 128 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
+    constexpr int M = 32, H = 64 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2, KT1 = (D + 15) >> 4;
-    const bool acc_w1 = KT1 <= 2;  // D <= 32: dW1 slice in registers too; wider observations use float atomics for layer 1
+    constexpr bool acc_w1 = KT1C > 0;
+    constexpr int KT1A = KT1C > 0 ? KT1C : 1;
     float *X = smem, *h1 = X + M * ldx, *h2 = h1 + M * ld, *dz3 = h2 + M * ld;
     float *meta = dz3 + M * ld3;
     int64_t *row_off = reinterpret_cast<int64_t *>(meta + M * 4);
@@ -834,12 +837,13 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
     const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 aW2[KT2][NTW], aW1[2][NTW], aW3[NTW][NT3];
+    f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
     float ab1[NTW], ab2[NTW], ab3[NT3], dlsd[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
         ab1[j] = ab2[j] = 0.0f;
-        aW1[0][j] = aW1[1][j] = z4;
+#pragma unroll
+        for (int i = 0; i < KT1A; i++) aW1[i][j] = z4;
 #pragma unroll
         for (int i = 0; i < KT2; i++) aW2[i][j] = z4;
 #pragma unroll
@@ -900,31 +904,24 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     for (int r = 0; r < 4; r++) h1[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
         }
         __syncthreads();
-        // ---- P2: layer 2 forward ----
-        {
-            f32x4 acc[NTW][2];
+        // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live) ----
 #pragma unroll
-            for (int j = 0; j < NTW; j++) {
-                const float bias = Q.b2[n_base + 16 * j + r16];
-                acc[j][0] = acc[j][1] = f32x4{bias, bias, bias, bias};
-            }
-#pragma unroll 2
+        for (int j = 0; j < NTW; j++) {
+            const float bias = Q.b2[n_base + 16 * j + r16];
+            f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
+            const float *wcol = Q.W2t + n_base + 16 * j + r16;
+#pragma unroll 8
             for (int ks = 0; ks < H / 4; ks++) {
                 const int k = 4 * ks + g;
-                const float a0 = h1[r16 * ld + k], a1 = h1[(16 + r16) * ld + k];
-#pragma unroll
-                for (int j = 0; j < NTW; j++) {
-                    const float w = Q.W2t[(int64_t)k * H + n_base + 16 * j + r16];
-                    acc[j][0] = mfma16(a0, w, acc[j][0]);
-                    acc[j][1] = mfma16(a1, w, acc[j][1]);
-                }
+                const float w = wcol[(int64_t)k * H];
+                c0 = mfma16(h1[r16 * ld + k], w, c0);
+                c1 = mfma16(h1[(16 + r16) * ld + k], w, c1);
             }
 #pragma unroll
-            for (int j = 0; j < NTW; j++)
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) h2[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
+            for (int r = 0; r < 4; r++) {
+                h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
+                h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+            }
         }
         __syncthreads();
         // ---- P3: head + loss: wave mt (0, 1) takes row tile mt ----
@@ -1000,37 +997,41 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dz1 = (dz2 . W2) * (1 - h1^2) kept in registers until every wave is done with h1 ----
         f32x4 dz1[NTW][2];
         {
+            float bf[NTW][8];
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 const int col = n_base + 16 * j + r16;
-                float bf[8];
                 float c = 0.0f;
 #pragma unroll
                 for (int sidx = 0; sidx < 8; sidx++) {
-                    bf[sidx] = h2[(4 * sidx + g) * ld + col];
-                    c += bf[sidx];
+                    bf[j][sidx] = h2[(4 * sidx + g) * ld + col];
+                    c += bf[j][sidx];
                 }
                 ab2[j] += c;
-#pragma unroll
-                for (int kt = 0; kt < KT2; kt++) {
-                    const int krow = kt * 16 + r16;
-#pragma unroll
-                    for (int sidx = 0; sidx < 8; sidx++) aW2[kt][j] = mfma16(h1[(4 * sidx + g) * ld + krow], bf[sidx], aW2[kt][j]);
-                    if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 128 LDS reads (register budget)
-                }
             }
 #pragma unroll
-            for (int j = 0; j < NTW; j++) dz1[j][0] = dz1[j][1] = z4;
-#pragma unroll 2
-            for (int ns = 0; ns < H / 4; ns++) {
-                const int n = 4 * ns + g;
-                const float a0 = h2[r16 * ld + n], a1 = h2[(16 + r16) * ld + n];
+            for (int kt = 0; kt < KT2; kt++) {  // one A fragment (8 LDS reads) feeds all NTW column tiles
+                float av[8];
 #pragma unroll
-                for (int j = 0; j < NTW; j++) {
-                    const float w = Q.W2[(int64_t)n * H + n_base + 16 * j + r16];
-                    dz1[j][0] = mfma16(a0, w, dz1[j][0]);
-                    dz1[j][1] = mfma16(a1, w, dz1[j][1]);
+                for (int sidx = 0; sidx < 8; sidx++) av[sidx] = h1[(4 * sidx + g) * ld + kt * 16 + r16];
+#pragma unroll
+                for (int sidx = 0; sidx < 8; sidx++)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma16(av[sidx], bf[j][sidx], aW2[kt][j]);
+                __builtin_amdgcn_sched_barrier(0);  // do not let the scheduler hoist later tiles' reads over this one (register budget)
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                f32x4 c0 = z4, c1 = z4;
+                const float *wcol = Q.W2 + n_base + 16 * j + r16;
+#pragma unroll 8
+                for (int ns = 0; ns < H / 4; ns++) {
+                    const int n = 4 * ns + g;
+                    const float w = wcol[(int64_t)n * H];
+                    c0 = mfma16(h2[r16 * ld + n], w, c0);
+                    c1 = mfma16(h2[(16 + r16) * ld + n], w, c1);
                 }
+                dz1[j][0] = c0, dz1[j][1] = c1;
             }
         }
         __syncthreads();
@@ -1056,16 +1057,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 c += bf[sidx];
             }
             ab1[j] += c;
-            if (acc_w1) {
+            if constexpr (acc_w1) {
 #pragma unroll
-                for (int kt = 0; kt < 2; kt++) {
-                    if (kt < KT1) {
-                        const int krow = kt * 16 + r16;
+                for (int kt = 0; kt < KT1A; kt++) {
+                    const int krow = kt * 16 + r16;
 #pragma unroll
-                        for (int sidx = 0; sidx < 8; sidx++) {
-                            const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
-                            aW1[kt][j] = mfma16(a, bf[sidx], aW1[kt][j]);
-                        }
+                    for (int sidx = 0; sidx < 8; sidx++) {
+                        const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
+                        aW1[kt][j] = mfma16(a, bf[sidx], aW1[kt][j]);
                     }
                 }
             } else {
@@ -1099,9 +1098,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         for (int kt = 0; kt < KT2; kt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
-        if (acc_w1) {
+        if constexpr (acc_w1) {
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++)
+            for (int kt = 0; kt < KT1A; kt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int k = kt * 16 + g * 4 + r;
@@ -1157,16 +1156,16 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     }
 }
 
-template <bool CONT, int NTW>
-__global__ __launch_bounds__(512, 2) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+template <bool CONT, int NTW, int KT1C>
+__global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                double *__restrict__ stat_slots) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
-    else grad_wide_body<CONT, false, NTW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    else grad_wide_body<CONT, false, NTW, KT1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
 }
 
 // zero the layer-1 weight columns of every slab when they are accumulated in place (observations wider than 32)
@@ -1617,24 +1616,28 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         return TMA_OK;
     }
     static const bool force_wide = getenv("TMA_FORCE_WIDE") != nullptr;  // test hook: take the column-parallel kernel at any batch size
-    if ((L.H == 128 || L.H == 256) && (tiles >= 2048 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
+    if ((L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 2048 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
         // column-parallel register-accumulating kernel + deterministic slab reduction
         const int smemw = grad_wide_smem_bytes(L);
         int64_t pairs = ceil_div(ceil_div(mbi->count, 32), 4);
         if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        if (L.D > 32) {
+        if (L.D > 32) {  // layer-1 gradient accumulates in place in the slab
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
             TMA_LAUNCH_CHECK();
         }
         auto launch = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(2 * pairs)), dim3(512), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+            k<<<dim3((unsigned)(2 * pairs)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
             return TMA_OK;
         };
-        int lrc;
-        if (L.H == 256) lrc = d->continuous ? launch(ppo_grad_wide_kernel<true, 2>) : launch(ppo_grad_wide_kernel<false, 2>);
-        else lrc = d->continuous ? launch(ppo_grad_wide_kernel<true, 1>) : launch(ppo_grad_wide_kernel<false, 1>);
+        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : 0);
+        auto pick = [&](auto ntw) -> int {
+            constexpr int NTWc = decltype(ntw)::value;
+            if (d->continuous) return kt1 == 1 ? launch(ppo_grad_wide_kernel<true, NTWc, 1>) : (kt1 == 2 ? launch(ppo_grad_wide_kernel<true, NTWc, 2>) : launch(ppo_grad_wide_kernel<true, NTWc, 0>));
+            return kt1 == 1 ? launch(ppo_grad_wide_kernel<false, NTWc, 1>) : (kt1 == 2 ? launch(ppo_grad_wide_kernel<false, NTWc, 2>) : launch(ppo_grad_wide_kernel<false, NTWc, 0>));
+        };
+        int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad);
