@@ -110,6 +110,8 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     meta = json.loads((tmp_path / "runs" / "basic" / "t1" / "metadata.json").read_text())
     assert meta["run_id"] == "t1" and len(meta["episode_rewards"]) == 4 and meta["task"]["id"] == "basic"
     assert os.path.exists(tmp_path / "runs" / "basic" / "t1" / "eval" / "evaluations.npz")
+    prog = (tmp_path / "runs" / "basic" / "t1" / "tb" / "progress.csv").read_text().splitlines()
+    assert "rollout/ep_rew_mean" in prog[0] and "train/approx_kl" in prog[0] and len(prog) >= 2
     cli.main(["evaluate", "basic", "basic_policy_t1.zip", "--episodes", "3"])
     ev = json.loads(capsys.readouterr().out)
     assert ev["episodes"] == 3 and len(ev["episode_lengths"]) == 3

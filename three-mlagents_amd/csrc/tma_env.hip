@@ -27,22 +27,40 @@ enum { ACT_I32 = 0, ACT_I64 = 1, ACT_F32 = 2, ACT_TAPE = 3 };
 // ------------------------------------------------------------------------------------------
 // step kernel: n_steps vector steps with the state held in registers.
 // ------------------------------------------------------------------------------------------
+// Tasks whose observation row is not a power-of-two number of bytes (Basic 21 floats, Crawler 172) stage the block's
+// observations in LDS ([threads][OBS|1], odd stride = conflict-free) and store them with fully coalesced rows; a per-lane
+// store of such rows would touch 64 different cache lines per instruction (measured 20x slower on Basic).
+template <class T>
+struct ObsStaging {
+    static constexpr bool USE_LDS = T::OBS > 8;
+    static constexpr int OBSP = T::OBS | 1;
+    static constexpr int THREADS = T::OBS > 32 ? 64 : 256;
+};
+
 template <class T, int ACTMODE>
 __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__restrict__ actions, uint32_t tape_seed, uint32_t tape_t0,
                                                    int n_steps, float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                    uint8_t *__restrict__ term_out, uint8_t *__restrict__ trunc_out,
                                                    float *__restrict__ term_obs_out, double *__restrict__ ep_ret_out,
                                                    int32_t *__restrict__ ep_len_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float obs_tile[];
+    using OS = ObsStaging<T>;
+    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t i = blk0 + threadIdx.x;
+    const bool active = i < v.N;
     double sret = 0.0, slen = 0.0, scnt = 0.0;
-    if (i < v.N) {
-        typename T::S s;
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    const uint32_t gi = v.env_offset + (uint32_t)i;
+    if (active) {
         T::unpack(v.st, v.N, i, s);
-        double er = v.ep_ret[i];
-        uint32_t ce = v.cur_ep[i];
-        const uint32_t gi = v.env_offset + (uint32_t)i;
-        for (int k = 0; k < n_steps; k++) {
-            const int64_t off = (int64_t)k * v.N + i;
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int k = 0; k < n_steps; k++) {
+        const int64_t off = (int64_t)k * v.N + i;
+        if (active) {
             int a = 0;
             float fa[T::ADIM];
             if constexpr (T::NACT > 0) {
@@ -103,14 +121,27 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
                 if (ep_ret_out) ep_ret_out[off] = 0.0;
                 if (ep_len_out) ep_len_out[off] = 0;
             }
-            emit_obs<T>(s, obs_out + off * T::OBS);
+            if constexpr (OS::USE_LDS) T::obs(s, obs_tile + threadIdx.x * OS::OBSP);
+            else emit_obs<T>(s, obs_out + off * T::OBS);
         }
+        if constexpr (OS::USE_LDS) {  // block-cooperative, fully coalesced store of the block's observation rows
+            __syncthreads();
+            const int64_t rows = (v.N - blk0) < (int64_t)blockDim.x ? (v.N - blk0) : (int64_t)blockDim.x;
+            float *dst = obs_out + ((int64_t)k * v.N + blk0) * T::OBS;
+            for (int e = threadIdx.x; e < (int)rows * T::OBS; e += blockDim.x) {
+                const int row = e / T::OBS, c = e - row * T::OBS;
+                dst[e] = obs_tile[row * OS::OBSP + c];
+            }
+            __syncthreads();
+        }
+    }
+    if (active) {
         T::pack(v.st, v.N, i, s);
         v.ep_ret[i] = er;
         v.cur_ep[i] = ce;
     }
-    // Monitor aggregate: wavefront shuffle reduction, then one plain read-modify-write per block into the block's own
-    // slot (no atomics: same-address atomics serialise at ~12 ns each, MI355X_MICROARCH "fanin"); the host sums the slots.
+    // Monitor aggregate: wavefront shuffle reduction, then one update per block of the 256-env slot it belongs to (plain
+    // read-modify-write when the block IS the slot, f64 atomics when four 64-thread blocks share it); the host sums the slots.
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         sret += __shfl_down(sret, o, 64);
@@ -118,16 +149,19 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
         scnt += __shfl_down(scnt, o, 64);
     }
     __shared__ double red[3][4];
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) red[0][wave] = sret, red[1][wave] = slen, red[2][wave] = scnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        double c = 0.0, a0 = 0.0, a1 = 0.0;
+        for (int w = 0; w < nw; w++) a0 += red[0][w], a1 += red[1][w], c += red[2][w];
         if (c > 0.0) {
-            double *slot = v.stats + (int64_t)blockIdx.x * 3;
-            slot[0] += red[0][0] + red[0][1] + red[0][2] + red[0][3];
-            slot[1] += red[1][0] + red[1][1] + red[1][2] + red[1][3];
-            slot[2] += c;
+            double *slot = v.stats + (blk0 >> 8) * 3;
+            if (blockDim.x == 256) {
+                slot[0] += a0, slot[1] += a1, slot[2] += c;
+            } else {
+                atomicAdd(slot + 0, a0), atomicAdd(slot + 1, a1), atomicAdd(slot + 2, c);
+            }
         }
     }
 }
@@ -374,8 +408,10 @@ static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
 template <class T, int MODE>
 static void launch_step(tma_env *h, const void *actions, uint32_t tape_seed, uint32_t t0, int n_steps, float *obs, float *rew, uint8_t *te,
                         uint8_t *tr, float *tobs, double *epr, int32_t *epl, hipStream_t s) {
-    const unsigned blocks = (unsigned)ceil_div(h->v.N, 256);
-    step_kernel<T, MODE><<<dim3(blocks), dim3(256), 0, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl);
+    using OS = ObsStaging<T>;
+    const unsigned blocks = (unsigned)ceil_div(h->v.N, OS::THREADS);
+    const size_t smem = OS::USE_LDS ? sizeof(float) * OS::THREADS * OS::OBSP : 0;
+    step_kernel<T, MODE><<<dim3(blocks), dim3(OS::THREADS), smem, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl);
 }
 
 // internal (not exported): bookkeeping after a kernel outside this file advanced the envs by n_steps

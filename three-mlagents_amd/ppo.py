@@ -313,10 +313,24 @@ class PPO:
                               "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
                               "rollout/episodes": cnt, "train/n_updates": self._n_updates})
                 self.logger_values = stats
+                self._write_progress(stats)
                 if self.verbose >= 1 and self.rank == 0:
                     print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
         cb.on_training_end()
         return self
+
+    def _write_progress(self, stats: dict) -> None:
+        """Scalar log per iteration (the keys SB3's logger writes: rollout/*, train/*, time/*) as CSV under tensorboard_log."""
+        if not self.tensorboard_log or self.rank != 0:
+            return
+        os.makedirs(self.tensorboard_log, exist_ok=True)
+        path = os.path.join(self.tensorboard_log, "progress.csv")
+        keys = sorted(stats)
+        new = not os.path.exists(path)
+        with open(path, "a", encoding="utf-8") as f:
+            if new:
+                f.write(",".join(keys) + "\n")
+            f.write(",".join(repr(float(stats[k])) for k in keys) + "\n")
 
     # -- inference ------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
