@@ -628,24 +628,56 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     zero_acc(acc);
     double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
     const int64_t n_tiles = (mb.count + 15) >> 4;
-    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += (int64_t)n_blocks_net * wpb) {
-        if (lane < 16) {
-            const int64_t j = (tile << 4) + lane;
-            int64_t off = -1;
-            meta[lane * 4 + 0] = meta[lane * 4 + 1] = meta[lane * 4 + 2] = meta[lane * 4 + 3] = 0.0f;
+    // The gather of a tile (permutation index, 3-4 scalars and the observation row per sample: dependent global loads) is
+    // issued one tile AHEAD into registers and committed to LDS at the top of the next iteration, so its latency hides
+    // under the current tile's MFMA work instead of stalling every tile (compile-time D only).
+    constexpr int DP_CT = (DT + 3) & ~3;
+    constexpr int NV = DT > 0 ? DP_CT / 4 : 1;  // observation values per lane: 16 rows x DP_CT floats / 64 lanes
+    int64_t pf_off = -1;
+    float pf_m0 = 0.0f, pf_m1 = 0.0f, pf_m2 = 0.0f, pf_m3 = 0.0f, pf_x[NV];
+    auto fetch = [&](int64_t tl) {
+        pf_off = -1, pf_m0 = pf_m1 = pf_m2 = pf_m3 = 0.0f;
+        if (lane < 16 && tl < n_tiles) {
+            const int64_t j = (tl << 4) + lane;
             if (j < mb.count) {
-                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                pf_off = sample_offset(mb, mb.start + j, rb.T, rb.N);
                 if constexpr (IS_PI) {
-                    meta[lane * 4 + 0] = rb.log_probs[off];
-                    meta[lane * 4 + 1] = rb.advantages[off];
-                    meta[lane * 4 + 3] = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+                    pf_m0 = rb.log_probs[pf_off];
+                    pf_m1 = rb.advantages[pf_off];
+                    pf_m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[pf_off]);
                 } else {
-                    meta[lane * 4 + 2] = rb.returns[off];
+                    pf_m2 = rb.returns[pf_off];
                 }
             }
-            row_off[lane] = off;
         }
-        load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
+        if constexpr (DT > 0) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) {
+                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
+                const int64_t orow = __shfl(pf_off, row, 64);
+                pf_x[q] = (orow >= 0 && c < DT) ? rb.obs[orow * DT + c] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&]() {
+        if (lane < 16) {
+            meta[lane * 4 + 0] = pf_m0, meta[lane * 4 + 1] = pf_m1, meta[lane * 4 + 2] = pf_m2, meta[lane * 4 + 3] = pf_m3;
+            row_off[lane] = pf_off;
+        }
+        if constexpr (DT > 0) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) {
+                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
+                X[row * ldx + c] = pf_x[q];
+            }
+        }
+    };
+    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
+    fetch((int64_t)block_net * wpb + wave);
+    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
+        commit();
+        if constexpr (DT == 0) load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
+        fetch(tile + tile_stride);
         dense64_tanh_lds<0>(X, ldx, KS1, wimg + IMG_W1, wimg + IMG_B1, h1, ld, lane);
         dense64_tanh_lds<16>(h1, ld, 16, wimg + IMG_W2F, wimg + IMG_B2, h2, ld, lane);
         f32x4 out[1];
