@@ -258,8 +258,27 @@ def main():
 
         while eng.steps_until_refill() < eng.ring_depth:  # (tasks without an MT19937 reset never need a refill)
             step_once()
-        avg_us, med_us = timed_kernel_us(step_once, 4 * eng.ring_depth, sync, group=8)
-        log(f"step kernel at {N} envs: median {med_us:.2f} us per launch")
+        reps = max(1, min(eng.ring_depth, 64) - 1)  # stays inside one refill window: only step kernels between the two events
+        adt = _lib.ACT_F32 if model.policy.continuous else _lib.ACT_I32
+
+        def step_burst():
+            _lib.check(L.tma_env_step_repeat(eng._h, _lib.ptr(acts), adt, reps, _lib.ptr(outs["obs"]), _lib.ptr(outs["rew"]), _lib.ptr(outs["term"]),
+                                             _lib.ptr(outs["trunc"]), _lib.ptr(outs["term_obs"]), model._stream()))
+            step_once()  # closes the refill window (this launch and the refill are outside the timed burst)
+
+        bursts = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.tma_env_step_repeat(eng._h, _lib.ptr(acts), adt, reps, _lib.ptr(outs["obs"]), _lib.ptr(outs["rew"]), _lib.ptr(outs["term"]),
+                                             _lib.ptr(outs["trunc"]), _lib.ptr(outs["term_obs"]), model._stream()))
+            e1.record()
+            step_once()
+            sync()
+            bursts.append(e0.elapsed_time(e1) * 1e3 / reps)
+        bursts.sort()
+        med_us = bursts[len(bursts) // 2]
+        log(f"step kernel at {N} envs: median {med_us:.2f} us per launch ({reps} native back-to-back launches per burst)")
         step_gbps = N * lay / (med_us * 1e-6) / 1e9
         out["roofline_step_kernel"] = {
             "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs, back-to-back launches)", "bound": "hbm", "achieved": step_gbps,

@@ -73,6 +73,10 @@ int tma_env_reset(tma_env *h, float *obs_out, void *stream);
 int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tape_seed, uint32_t tape_t0, int n_steps,
                  float *obs_out, float *rew_out, uint8_t *term_out, uint8_t *trunc_out, float *term_obs_out,
                  double *ep_ret_out, int32_t *ep_len_out, void *stream);
+/* `reps` consecutive single-step launches with the same action buffer and output planes, issued from native code with no
+ * host-language round trip in between (launch-latency measurements; semantics = calling tma_env_step `reps` times) */
+int tma_env_step_repeat(tma_env *h, const void *actions, int action_dtype, int reps, float *obs_out, float *rew_out, uint8_t *term_out,
+                        uint8_t *trunc_out, float *term_obs_out, void *stream);
 int tma_env_steps_until_refill(tma_env *h, int *out);
 /* engine options; "refill_small_window" = 1 shortens the register-resident MT19937 window so tests exercise the
  * general in-memory generator that takes over when rejection sampling needs more outputs */

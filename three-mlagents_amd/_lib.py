@@ -57,6 +57,7 @@ SIGNATURES = {
     "tma_env_seed": (_i32, [_vp, _u32]),
     "tma_env_reset": (_i32, [_vp, _vp, _vp]),
     "tma_env_step": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tma_env_step_repeat": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tma_env_steps_until_refill": (_i32, [_vp, C.POINTER(_i32)]),
     "tma_env_refill": (_i32, [_vp, _vp]),
     "tma_env_set_option": (_i32, [_vp, C.c_char_p, _i64]),

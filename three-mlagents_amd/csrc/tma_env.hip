@@ -607,6 +607,16 @@ int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tap
     return TMA_OK;
 }
 
+int tma_env_step_repeat(tma_env *h, const void *actions, int action_dtype, int reps, float *obs_out, float *rew_out, uint8_t *term_out,
+                        uint8_t *trunc_out, float *term_obs_out, void *stream) {
+    if (reps < 1) return fail(TMA_ERR_INVALID, "reps must be >= 1");
+    for (int r = 0; r < reps; r++) {
+        int rc = tma_env_step(h, actions, action_dtype, 0, 0, 1, obs_out, rew_out, term_out, trunc_out, term_obs_out, nullptr, nullptr, stream);
+        if (rc) return rc;
+    }
+    return TMA_OK;
+}
+
 int tma_env_get_state(tma_env *h, double *state_out, void *stream) {
     if (!h || !state_out) return fail(TMA_ERR_INVALID, "null argument");
     TMA_HIP(hipSetDevice(h->device));
