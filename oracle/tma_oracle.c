@@ -109,20 +109,20 @@ void orc_mt_uniform(uint32_t seed, double lo, double hi, double *out, int n) {
 #define CRAWLER_STATE (2 * CRAWLER_NJ + CRAWLER_NJ + 8 + 1) /* q, qd, prev action, root(8), steps */
 
 int orc_obs_dim(int task) {
-    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS};
+    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS, 4};
     return d[task];
 }
 int orc_num_actions(int task) {
-    static const int d[] = {3, 5, 5, 5, 0};
+    static const int d[] = {3, 5, 5, 5, 0, 4};
     return d[task];
 }
 int orc_act_dim(int task) { return task == ORC_CRAWLER ? CRAWLER_NJ : 1; }
 int orc_state_dim(int task) {
-    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE};
+    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE, 4};
     return d[task];
 }
 int orc_max_episode_steps(int task) {
-    static const int d[] = {50, 100, 200, 120, 1000};
+    static const int d[] = {50, 100, 200, 120, 1000, 150};
     return d[task];
 }
 
@@ -350,6 +350,53 @@ static void ball_step(double *st, int a, float *obs, double *reward, int *done) 
     ball_obs(st, obs);
 }
 
+
+/* =========================================================================================
+ * WallJump -- backend/examples/walljump.py:14-20,33-98.   state = [agent_x, in_air, wall_height, steps]
+ * ======================================================================================= */
+static void wj_obs(const double *st, float *obs) { /* walljump.py:48-53 */
+    obs[0] = (float)((19.0 - st[0]) / 19.0);
+    obs[1] = (float)((10.0 - st[0]) / 19.0);
+    obs[2] = (float)st[2];
+    obs[3] = st[1] == 0 ? 1.0f : 0.0f;
+}
+static void wj_reset(orc_mt *rng, double *st) { /* walljump.py:40-45 */
+    st[0] = 0;
+    st[1] = 0;
+    st[2] = orc_mt_double(rng) < 0.7 ? 1 : 0; /* int(np.random.rand() < 0.7) */
+    st[3] = 0;
+}
+static void wj_step(double *st, int a, float *obs, double *reward, int *done) { /* walljump.py:56-98 */
+    static const int DX[4] = {0, 1, -1, 1};
+    int x = (int)st[0], in_air = (int)st[1], wall = (int)st[2];
+    double r = -0.01;
+    int d = 0, just_jumped = 0;
+    if (a == 3 && in_air == 0) {
+        in_air = 3;
+        just_jumped = 1;
+    }
+    int px = clipi(x + DX[a], 0, 19);
+    int crossing = (x < 10 && 10 <= px) || (px < 10 && 10 <= x);
+    if (crossing && wall == 1 && in_air == 0) {
+        px = x;
+        r = r - 0.02;
+    }
+    if (just_jumped && !crossing && abs(10 - x) > 1) r = r - 0.03;
+    x = px;
+    if (in_air > 0) in_air -= 1;
+    if (x == 19) {
+        r = 1.0;
+        d = 1;
+    }
+    st[0] = x;
+    st[1] = in_air;
+    st[3] += 1;
+    if (st[3] >= 150) d = 1;
+    *reward = r;
+    *done = d;
+    wj_obs(st, obs);
+}
+
 /* =========================================================================================
  * Crawler-shape (BUILD-DEFINED, parity unpinned): 172-dim obs / 20-dim Box(-1,1) action chain
  * of damped, spring-coupled joints driving a planar root.  Stands in for the reference's
@@ -509,6 +556,7 @@ static void task_obs(int task, const double *st, float *obs) {
     case ORC_BALL3D: ball_obs(st, obs); break;
     case ORC_PUSH: push_obs(st, obs); break;
     case ORC_CRAWLER: crawler_obs(st, obs); break;
+    case ORC_WALLJUMP: wj_obs(st, obs); break;
     }
 }
 
@@ -534,6 +582,11 @@ void orc_reset_from_seed(int task, uint32_t seed, double *st, float *obs) {
         push_reset(&rng, st);
         break;
     case ORC_CRAWLER: crawler_reset_hash(seed, st); break;
+    case ORC_WALLJUMP:
+        orc_mt_seed(&rng, seed);
+        wj_reset(&rng, st);
+        wj_reset(&rng, st);
+        break;
     }
     if (obs) task_obs(task, st, obs);
 }
@@ -547,6 +600,7 @@ void orc_legacy_step(int task, double *st, const void *action, float *obs, doubl
     case ORC_BALL3D: ball_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_PUSH: push_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_CRAWLER: crawler_step(st, (const float *)action, obs, reward, done); break;
+    case ORC_WALLJUMP: wj_step(st, *(const int32_t *)action, obs, reward, done); break;
     }
 }
 
@@ -611,7 +665,7 @@ void orc_vec_step(orc_vec *v, const void *actions, float *obs_out, float *rew32_
         const void *act = task == ORC_CRAWLER ? (const void *)((const float *)actions + (size_t)i * v->A)
                                               : (const void *)((const int32_t *)actions + i);
         orc_legacy_step(task, st, act, obs, &r, &done);
-        int steps = (int)st[task == ORC_CRAWLER ? 3 * CRAWLER_NJ + 8 : (task == ORC_BASIC ? 1 : (task == ORC_PUSH ? 5 : (task == ORC_GRIDWORLD ? 7 : 6)))];
+        int steps = (int)st[task == ORC_CRAWLER ? 3 * CRAWLER_NJ + 8 : (task == ORC_BASIC ? 1 : (task == ORC_PUSH ? 5 : (task == ORC_GRIDWORLD ? 7 : (task == ORC_WALLJUMP ? 3 : 6))))];
         if (task == ORC_BASIC) { /* envs.py:76 */
             terminated = done;
             truncated = (steps >= max_steps) && !terminated;

@@ -9,7 +9,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-TASKS = ["basic", "gridworld", "push", "ball3d"]
+TASKS = ["basic", "gridworld", "push", "ball3d", "walljump"]
 FLOAT_TOL = 1e-5  # north_star: float tasks within 1e-5
 
 
@@ -76,7 +76,7 @@ def test_golden_transitions_state_injection(golden, task):
     g = golden(task)
     tin, tout, tobs = g["tr_in"], g["tr_out"], g["tr_obs"]
     n = len(tin)
-    sdim = {"basic": 2, "gridworld": 8, "push": 6, "ball3d": 8}[task]
+    sdim = {"basic": 2, "gridworld": 8, "push": 6, "ball3d": 8, "walljump": 4}[task]
     eng = _engine(task, n, seed=1, ring_depth=2)
     eng.reset()
     eng.set_state(tin[:, :sdim].astype(np.float64))
@@ -91,7 +91,7 @@ def test_golden_transitions_state_injection(golden, task):
         legacy_done = tout[:, 8].astype(bool)
     else:
         assert np.array_equal(obs, tobs)
-        rcol = {"basic": 2, "gridworld": 3, "push": 5}[task]
+        rcol = {"basic": 2, "gridworld": 3, "push": 5, "walljump": 4}[task]
         assert np.array_equal(o["rew"][0].cpu().numpy(), tout[:, rcol].astype(np.float32))
         legacy_done = (tout[:, rcol + 1] + (tout[:, rcol + 2] if task == "basic" else 0)).astype(bool)
     assert np.array_equal(done, legacy_done)
@@ -136,7 +136,7 @@ def test_against_oracle_many_envs(task, mode):
     st = eng.get_state().cpu().numpy()
     inexact += _cmp(task, "state", st, ref.get_state(), "final")
     print(f"[{task}/{mode}] not bit-identical to oracle: {inexact}")
-    if task in ("basic", "gridworld", "push"):
+    if task in ("basic", "gridworld", "push", "walljump"):
         assert inexact == 0
     eng.close()
 

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle as orc
 
-TASKS = ["basic", "gridworld", "push", "ball3d"]
+TASKS = ["basic", "gridworld", "push", "ball3d", "walljump"]
 
 
 def test_known_answer_basic_reference_unit_test():
@@ -59,6 +59,9 @@ def test_single_transitions(golden, task):
         elif task == "push":
             st, obs, r, done = orc.legacy_step(task, row_in[:6].astype(np.float64), int(row_in[6]))
             assert [st[0], st[1], st[2], st[3], st[5], r, float(done)] == list(row_out)
+        elif task == "walljump":
+            st, obs, r, done = orc.legacy_step(task, row_in[:4].astype(np.float64), int(row_in[4]))
+            assert [st[0], st[1], st[2], st[3], r, float(done)] == list(row_out)
         else:
             st, obs, r, done = orc.legacy_step(task, row_in[:8], int(row_in[8]))
             got = [*st[:7], r, float(done)]

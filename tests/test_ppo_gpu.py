@@ -303,7 +303,7 @@ def test_gae_flags_equals_sb3_layout():
     assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref)
 
 
-@pytest.mark.parametrize("task,hidden", [("gridworld", 64), ("push", 64), ("ball3d", 64), ("basic", 64), ("gridworld", 128)])
+@pytest.mark.parametrize("task,hidden", [("gridworld", 64), ("push", 64), ("ball3d", 64), ("walljump", 64), ("basic", 64), ("gridworld", 128)])
 def test_native_rollout_equals_stepwise_composition(task, hidden):
     """tma_rollout_collect (fused multi-step kernel for H=64 on gridworld/push/ball3d, per-step launches otherwise)
     == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same RNG counters)."""
@@ -311,7 +311,7 @@ def test_native_rollout_equals_stepwise_composition(task, hidden):
     from three_mlagents_amd.ppo import PPO
     from three_mlagents_amd.vec_env import HipVecEnv
 
-    N, T = 200, {"ball3d": 230, "gridworld": 130}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
+    N, T = 200, {"ball3d": 230, "gridworld": 130, "walljump": 170}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
     env = HipVecEnv(task, N, seed=3, ring_depth=16)
     model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
     assert model.collect_rollouts()
@@ -331,7 +331,7 @@ def test_native_rollout_equals_stepwise_composition(task, hidden):
         obs = out["obs"][0].clone()
         assert torch.equal(obs, b["obs"][t + 1])
     assert torch.equal(model.policy.predict_values(obs), b["last_values"])
-    if task in ("gridworld", "ball3d"):
+    if task in ("gridworld", "ball3d", "walljump"):
         assert int(b["truncated"].sum()) > 0  # the timeout-bootstrap branch was exercised
     # GAE of the rollout vs the oracle on the same planes
     done = (b["terminated"] | b["truncated"]).float().cpu().numpy()

@@ -12,7 +12,7 @@ def test_trainable_tasks_have_factories():  # test_mlagents.py:25-30
     assert len(trainable) >= 5
     for task in trainable:
         assert task.trainable and task.card()["trainable"] is True
-    assert {t.id for t in trainable} == {"basic", "gridworld", "ball3d", "push", "ant"}
+    assert {t.id for t in trainable} == {"basic", "gridworld", "ball3d", "push", "ant", "walljump"}
     assert len(list_task_cards()) == 19 and "env_factory" not in list_task_cards()[0]
 
 
@@ -22,7 +22,7 @@ def test_alias_resolution():  # test_mlagents.py:47-49
     with pytest.raises(KeyError):
         get_task("not-a-task")  # registry.py:359-362
     with pytest.raises(ValueError):
-        make_env("walljump")  # registry.py:368-369: registered but not trainable here
+        make_env("bicycle")  # registry.py:368-369: registered but not trainable here
 
 
 def test_predict_requires_model_file():  # test_mlagents.py:105-108
@@ -72,7 +72,7 @@ def test_cli_grammar():  # cli.py:14-41
 def test_spaces_match_reference_declarations():  # envs.py:38-44,166-199
     from three_mlagents_amd.spaces import task_spaces
 
-    for name, (d, n) in {"basic": (21, 3), "gridworld": (4, 5), "ball3d": (6, 5), "push": (4, 5)}.items():
+    for name, (d, n) in {"basic": (21, 3), "gridworld": (4, 5), "ball3d": (6, 5), "push": (4, 5), "walljump": (4, 4)}.items():
         obs_space, act_space = task_spaces(name)
         assert obs_space.shape == (d,) and obs_space.dtype == np.float32 and act_space.n == n
         assert act_space.contains(act_space.sample()) and not act_space.contains(n)

@@ -70,6 +70,7 @@ static int dispatch_task(int task, F &&f) {
     case TMA_TASK_BALL3D: return f(tma::BallTask{});
     case TMA_TASK_PUSH: return f(tma::PushTask{});
     case TMA_TASK_CRAWLER: return f(tma::CrawlerTask{});
+    case TMA_TASK_WALLJUMP: return f(tma::WallJumpTask{});
     }
     return tma::fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
 }

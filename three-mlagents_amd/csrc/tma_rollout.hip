@@ -195,7 +195,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     if (N != env->v.N) return fail(TMA_ERR_INVALID, "rollout buffers are for %lld envs, the env handle has %lld", (long long)N, (long long)env->v.N);
     const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
     const bool fused = L.img_pi >= 0 && env->is_reset &&
-                       (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D) &&
+                       (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D || env->task == TMA_TASK_WALLJUMP) &&
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
     if (fused) {
         TMA_HIP(hipSetDevice(env->device));
@@ -208,6 +208,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
             const int n = left < (t_end - t) ? left : (t_end - t);
             if (env->task == TMA_TASK_GRIDWORLD) rc = launch_chunk<GridTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             else if (env->task == TMA_TASK_PUSH) rc = launch_chunk<PushTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_WALLJUMP) rc = launch_chunk<WallJumpTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             else rc = launch_chunk<BallTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             if (rc) return rc;
             rc = tma_env_internal_after_steps(env, n, stream);

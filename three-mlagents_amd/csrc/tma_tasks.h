@@ -561,6 +561,79 @@ struct BallTask {
     }
 };
 
+
+// ==========================================================================================
+// WallJump -- backend/examples/walljump.py:14-20 (constants), :40-45 (reset), :48-53 (obs), :56-98 (step);
+// adapter: backend/mlagents/envs.py:202-211 (Discrete(4), Box(-1,1,(4,)), 150-step limit).  SURVEY.md §8f rank N3.
+// ==========================================================================================
+struct WallJumpTask {
+    static constexpr int ID = TMA_TASK_WALLJUMP, OBS = 4, NACT = 4, ADIM = 1, MAXSTEPS = 150, SW = 1, RW = 1, SDIM = 4;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    struct S {
+        int x, in_air, wall, steps;
+    };
+    __device__ static void from_word(uint32_t w, S &s) {
+        s.x = w & 31;
+        s.in_air = (w >> 5) & 3;
+        s.wall = (w >> 7) & 1;
+        s.steps = (w >> 8) & 255;
+    }
+    __device__ static uint32_t to_word(const S &s) { return (uint32_t)s.x | ((uint32_t)s.in_air << 5) | ((uint32_t)s.wall << 7) | ((uint32_t)s.steps << 8); }
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) { from_word(st[i], s); }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) { st[i] = to_word(s); }
+    __device__ static void from_rec(const uint32_t *rec, S &s) { s = S{0, 0, (int)(rec[0] & 1u), 0}; }
+    __device__ static void draw(MT &mt, uint8_t *, int, uint32_t *rec) { rec[0] = mt.dbl() < 0.7 ? 1u : 0u; }  // int(np.random.rand() < 0.7)
+    // two resets of one rk_double (2 outputs each); the second one counts
+    struct Fast {
+        static constexpr int W = 4, W_SMALL = 4;
+        int k = 0;
+        uint32_t ah = 0, wall = 0;
+        __device__ __forceinline__ bool done() const { return k >= 4; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (k == 2) ah = v >> 5;
+            if (k == 3) wall = (((double)ah * 67108864.0 + (double)(v >> 6)) / 9007199254740992.0) < 0.7 ? 1u : 0u;
+            k++;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const { rec[0] = wall; }
+    };
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        double rew = -0.01;
+        bool d = false, just_jumped = false;
+        if (a == 3 && s.in_air == 0) {
+            s.in_air = 3;
+            just_jumped = true;
+        }
+        const int dx = (a == 1 || a == 3) ? 1 : (a == 2 ? -1 : 0);
+        int px = clampi(s.x + dx, 0, 19);
+        const bool crossing = (s.x < 10 && 10 <= px) || (px < 10 && 10 <= s.x);
+        if (crossing && s.wall == 1 && s.in_air == 0) {
+            px = s.x;
+            rew = rew - 0.02;
+        }
+        const int dw = 10 - s.x;
+        if (just_jumped && !crossing && (dw < 0 ? -dw : dw) > 1) rew = rew - 0.03;
+        s.x = px;
+        if (s.in_air > 0) s.in_air -= 1;
+        if (s.x == 19) {
+            rew = 1.0;
+            d = true;
+        }
+        s.steps += 1;
+        if (s.steps >= 150) d = true;
+        r = rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        o[0] = (float)((double)(19 - s.x) / 19.0);
+        o[1] = (float)((double)(10 - s.x) / 19.0);
+        o[2] = (float)s.wall;
+        o[3] = s.in_air == 0 ? 1.0f : 0.0f;
+    }
+    __device__ static void to_flat(const S &s, double *f) { f[0] = s.x, f[1] = s.in_air, f[2] = s.wall, f[3] = s.steps; }
+    __device__ static void from_flat(const double *f, S &s) { s = S{(int)f[0], (int)f[1], (int)f[2], (int)f[3]}; }
+};
+
 // ==========================================================================================
 // Crawler-shape (BUILD-DEFINED, parity unpinned against the reference: the reference's "ant" task is
 // gym.make("Ant-v5") over MuJoCo, backend/mlagents/envs.py:274-277, backend/examples/crawler.py:31-85).

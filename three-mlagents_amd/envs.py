@@ -114,5 +114,9 @@ def make_push_env() -> HipSingleEnv:
     return HipSingleEnv("push")
 
 
+def make_walljump_env() -> HipSingleEnv:
+    return HipSingleEnv("walljump")
+
+
 def make_ant_env() -> HipSingleEnv:
     return HipSingleEnv("crawler")

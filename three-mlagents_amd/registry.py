@@ -1,7 +1,8 @@
 """Task registry with the reference's surface: `TaskSpec`, `TASKS`, `list_tasks`, `list_task_cards`, `get_task`, `make_env`
 (/root/reference/backend/mlagents/registry.py:18-49,52-337,340-370).
 
-The five north-star tasks (basic, gridworld, ball3d, push, ant/crawler) get an `env_factory` backed by the HIP engine; the
+The five north-star tasks (basic, gridworld, ball3d, push, ant/crawler) plus walljump get an `env_factory`
+backed by the HIP engine; the
 other registry ids are kept as catalogue entries so `list`/alias resolution behave the same, but they are not trainable
 here (their dynamics are outside the hot-path scope).
 """
@@ -66,6 +67,9 @@ TASKS: dict[str, TaskSpec] = {
     "push": TaskSpec("push", "Push Block", "navigation", "gymnasium", "benchmark", "dqn", "push_policy", 200_000, eval_episodes=100, n_envs=1,
                      reward_threshold=0.65, tags=("object-manipulation", "sparse-reward", "planning"),
                      publication_role="single-agent manipulation transfer task", env_factory=envs.make_push_env),
+    "walljump": TaskSpec("walljump", "Wall Jump", "navigation", "gymnasium", "benchmark", "dqn", "walljump_policy", 150_000, eval_episodes=100,
+                         n_envs=1, reward_threshold=0.7, tags=("conditional-skill", "exploration", "procedural-wall"),
+                         publication_role="conditional-control benchmark", env_factory=envs.make_walljump_env),
     "ant": TaskSpec("ant", "Crawler (synthetic 172/20 articulated chain)", "continuous-control", "gymnasium", "benchmark", "ppo", "ant_policy",
                     3_000_000, eval_episodes=20, n_envs=8, tags=("locomotion", "articulated"), action="continuous",
                     publication_role="locomotion throughput/scaling shape",
@@ -76,7 +80,6 @@ TASKS: dict[str, TaskSpec] = {
 
 # remaining registry ids: (title, family, interface, tier, algorithm, prefix, timesteps, eval_episodes, n_envs, observation, action)
 _CATALOGUE = {
-    "walljump": ("Wall Jump", "navigation", "gymnasium", "benchmark", "dqn", "walljump_policy", 150_000, 100, 1, "vector", "discrete"),
     "brickbreak": ("Brick Break", "arcade", "gymnasium", "benchmark", "ppo", "brickbreak_policy", 500_000, 50, 8, "vector", "discrete"),
     "bicycle": ("Bicycle", "continuous-control", "gymnasium", "benchmark", "ppo", "bicycle_policy", 500_000, 50, 8, "vector", "discrete"),
     "glider": ("Glider", "aerospace", "gymnasium", "frontier", "ppo", "glider_policy", 1_000_000, 50, 8, "vector", "discrete"),

@@ -91,6 +91,8 @@ def task_spaces(task_name: str):
         return Box(-1.0, 1.0, shape=(4,), dtype=np.float32), Discrete(5)
     if task_name == "push":
         return Box(-1.0, 1.0, shape=(4,), dtype=np.float32), Discrete(5)
+    if task_name == "walljump":  # envs.py:202-211
+        return Box(-1.0, 1.0, shape=(4,), dtype=np.float32), Discrete(4)
     if task_name == "crawler":
         return Box(-np.inf, np.inf, shape=(172,), dtype=np.float32), Box(-1.0, 1.0, shape=(20,), dtype=np.float32)
     raise KeyError(task_name)

@@ -9,6 +9,7 @@ What is imported, unmodified, from the reference:
   backend/examples/gridworld.py   (GridWorldEnv)
   backend/examples/ball3d.py      (Ball3DEnv)
   backend/examples/push.py        (PushEnv)
+  backend/examples/walljump.py    (WallJumpEnv)
 `gymnasium` is not installed here, so a ~20-line stand-in (Env with a no-op reset, Box/Discrete
 holders) is placed in sys.modules first; it carries no arithmetic.
 
@@ -113,6 +114,8 @@ def get_state(task: str, env) -> np.ndarray:
         )
     if task == "push":
         return np.array([*e.agent_pos, *e.box_pos, e.goal_pos[0], e.steps], dtype=np.float64)
+    if task == "walljump":
+        return np.array([e.agent_x, e.in_air, e.wall_height, e.steps], dtype=np.float64)
     if task == "ball3d":
         first = 1.0 if e.rot.dtype == np.float32 else 0.0
         return np.array([*e.rot, *e.pos, *e.vel, e.steps, first], dtype=np.float64)
@@ -258,6 +261,24 @@ def ball3d_transitions(mod, rng):
     return dict(tr_in=np.array(rows_in, np.float64), tr_out=np.array(rows_out, np.float64), tr_obs=np.stack(obs_out))
 
 
+def walljump_transitions(mod, rng):
+    from examples.walljump import WallJumpEnv
+
+    e = WallJumpEnv()
+    rows_in, rows_out, obs_out = [], [], []
+    for x in range(20):
+        for in_air in range(4):
+            for wall in (0, 1):
+                for act in range(4):
+                    steps = int(rng.choice([0, 1, 148, 149]))
+                    e.agent_x, e.in_air, e.wall_height, e.steps = x, in_air, wall, steps
+                    o, rew, done = e.step(act)
+                    rows_in.append([x, in_air, wall, steps, act])
+                    rows_out.append([e.agent_x, e.in_air, e.wall_height, e.steps, float(rew), float(done)])
+                    obs_out.append(o)
+    return dict(tr_in=np.array(rows_in, np.int32), tr_out=np.array(rows_out, np.float64), tr_obs=np.stack(obs_out))
+
+
 def basic_transitions(mod):
     env = mod.make_basic_env()
     rows_in, rows_out, obs_out = [], [], []
@@ -313,6 +334,7 @@ def main():
         "gridworld": (16, 700, 1, 12),
         "push": (16, 900, 1, 13),
         "ball3d": (16, 900, 1, 14),
+        "walljump": (16, 700, 1, 15),
     }
     for task, (n, T, base, tape) in cfg.items():
         d = vec_rollout(mod, task, n, T, base, tape)
@@ -326,6 +348,8 @@ def main():
             d.update(push_transitions(mod, rng))
         elif task == "ball3d":
             d.update(ball3d_transitions(mod, rng))
+        elif task == "walljump":
+            d.update(walljump_transitions(mod, rng))
         else:
             d.update(basic_transitions(mod))
         path = os.path.join(OUT, f"{task}.npz")
