@@ -118,3 +118,31 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     from three_mlagents_amd.training import predict_action
 
     assert predict_action("basic", np.eye(21, dtype=np.float32)[10], "basic_policy_t1.zip") in (0, 1, 2)
+
+
+def test_load_zip_with_sb3_schema(tmp_path):
+    """A zip laid out the way stable-baselines3 writes it: SB3's own `data` keys, policy.pth with SB3's state_dict
+    names -- the policy shape is recovered from the tensors and `predict` works."""
+    import io
+    import zipfile
+
+    import torch
+
+    from oracle import sb3_ref
+    from three_mlagents_amd.ppo import PPO
+
+    sd = sb3_ref.init_policy(4, 64, 5, False, seed=7)
+    path = tmp_path / "gridworld_policy_sb3like.zip"
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("data", json.dumps({"policy_class": {":type:": "<class 'abc.ABCMeta'>", ":serialized:": "gAWV..."}, "n_envs": 8,
+                                        "learning_rate": {":type:": "<class 'function'>", ":serialized:": "gAWV..."}, "gamma": 0.99, "n_steps": 1024}))
+        bio = io.BytesIO()
+        torch.save(sd, bio)
+        z.writestr("policy.pth", bio.getvalue())
+        z.writestr("policy.optimizer.pth", b"not-a-pickle")
+        z.writestr("_stable_baselines3_version", "2.9.0")
+    model = PPO.load(str(path))
+    obs = torch.randn(9, 4, generator=torch.Generator().manual_seed(0))
+    act, _ = model.predict(obs.numpy(), deterministic=True)
+    logits, _ = sb3_ref.forward(sd, obs)
+    assert np.array_equal(act, logits.argmax(dim=1).numpy()) and model.n_steps == 1024 and model.learning_rate == 3e-4

@@ -393,12 +393,30 @@ class PPO:
         with zipfile.ZipFile(path) as z:
             data = json.loads(z.read("data").decode())
             sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
-            opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=False)
-        model = cls(data.get("policy_class", "MlpPolicy"), None, learning_rate=data["learning_rate"], n_steps=data["n_steps"],
-                    batch_size=data["batch_size"], n_epochs=data["n_epochs"], gamma=data["gamma"], gae_lambda=data["gae_lambda"],
-                    clip_range=data["clip_range"], normalize_advantage=data["normalize_advantage"], ent_coef=data["ent_coef"],
-                    vf_coef=data["vf_coef"], max_grad_norm=data["max_grad_norm"], policy_kwargs=data.get("policy_kwargs"), seed=data.get("seed"),
-                    _init_setup_model=False)
+            try:
+                opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=False)
+            except Exception:  # noqa: BLE001 - a zip written by stable-baselines3 itself (optimizer pickles need SB3)
+                opt = {}
+        # zips written by stable-baselines3 carry their own `data` schema: recover the policy shape from the state_dict,
+        # whose keys/shapes are SB3's (mlp_extractor.policy_net.{0,2}, mlp_extractor.value_net.{0,2}, action_net, value_net, log_std)
+        w1, wa = sd["mlp_extractor.policy_net.0.weight"], sd["action_net.weight"]
+        data.setdefault("obs_dim", int(w1.shape[1]))
+        data.setdefault("hidden", int(w1.shape[0]))
+        data.setdefault("act_dim", int(wa.shape[0]))
+        data.setdefault("continuous", "log_std" in sd)
+        if sd["mlp_extractor.policy_net.2.weight"].shape != (data["hidden"], data["hidden"]) or sd["mlp_extractor.value_net.0.weight"].shape != w1.shape:
+            raise ValueError("unsupported net_arch in policy zip: the engine needs two equal hidden layers for pi and vf")
+
+        def _num(key, default):
+            v = data.get(key, default)
+            return default if isinstance(v, dict) or v is None else v  # SB3 stores schedules as pickled objects
+
+        model = cls(data.get("policy_class", "MlpPolicy") if isinstance(data.get("policy_class"), str) else "MlpPolicy", None,
+                    learning_rate=_num("learning_rate", 3e-4), n_steps=_num("n_steps", 2048), batch_size=_num("batch_size", 64),
+                    n_epochs=_num("n_epochs", 10), gamma=_num("gamma", 0.99), gae_lambda=_num("gae_lambda", 0.95), clip_range=_num("clip_range", 0.2),
+                    normalize_advantage=_num("normalize_advantage", True), ent_coef=_num("ent_coef", 0.0), vf_coef=_num("vf_coef", 0.5),
+                    max_grad_norm=_num("max_grad_norm", 0.5),
+                    policy_kwargs={"net_arch": [data["hidden"], data["hidden"]]}, seed=_num("seed", 0), _init_setup_model=False)
         model.num_timesteps, model._n_updates, model._adam_step = data.get("num_timesteps", 0), data.get("_n_updates", 0), data.get("_adam_step", 0)
         if env is not None:
             model.env = env
