@@ -340,14 +340,14 @@ def test_native_rollout_equals_stepwise_composition(task, hidden):
     assert np.array_equal(b["advantages"].cpu().numpy(), adv_ref) and np.array_equal(b["returns"].cpu().numpy(), ret_ref)
 
 
-@pytest.mark.parametrize("task,n_envs,iters,thresh", [("basic", 256, 30, 0.5)])
+@pytest.mark.parametrize("task,n_envs,iters,thresh", [("basic", 256, 30, 0.5), ("gridworld", 4096, 50, 0.6)])
 def test_ppo_learns(task, n_envs, iters, thresh):
     from three_mlagents_amd.evaluation import evaluate_policy
     from three_mlagents_amd.ppo import PPO
     from three_mlagents_amd.vec_env import HipVecEnv
 
     env = HipVecEnv(task, n_envs, seed=1)
-    model = PPO("MlpPolicy", env, n_steps=64, batch_size=2048, n_epochs=4, ent_coef=0.01, seed=1, policy_kwargs={"net_arch": [64, 64]})
+    model = PPO("MlpPolicy", env, n_steps=64, batch_size=max(2048, n_envs * 8), n_epochs=4, ent_coef=0.01, seed=1, policy_kwargs={"net_arch": [64, 64]})
     eval_env = HipVecEnv(task, 16, seed=10_001)
     before, _ = evaluate_policy(model, eval_env, n_eval_episodes=32, deterministic=True)
     model.learn(n_envs * 64 * iters)
@@ -358,7 +358,7 @@ def test_ppo_learns(task, n_envs, iters, thresh):
     import tempfile, os
 
     with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "basic_policy_test")
+        path = os.path.join(d, f"{task}_policy_test")
         model.save(path)
         loaded = PPO.load(path)
         obs = eval_env.reset()

@@ -293,6 +293,8 @@ class PPO:
         cb = as_callback(callback)
         if reset_num_timesteps:
             self.num_timesteps = 0
+        else:  # SB3 _setup_learn: "make sure training timesteps are ahead of the internal counter"
+            total_timesteps = int(total_timesteps) + self.num_timesteps
         self._total_timesteps = int(total_timesteps)
         cb.init_callback(self)
         cb.on_training_start(locals(), globals())
