@@ -1478,6 +1478,194 @@ static int launch_fwd_h64(const float *params, const PLayout &L, const float *ob
     return TMA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Wide-policy forward (H = 128 / 192 / 256): the column-parallel layout of ppo_grad_wide_kernel without the backward pass.
+// A block of 4 waves carries a row group of 32 samples through both nets; wave w computes hidden columns [w*H/4, (w+1)*H/4),
+// every weight fragment read from L2 serves both 16-row tiles, waves 0/1 finish the heads (sampling / log-prob / value).
+// One wave per tile (policy_fwd_kernel) needs ~3700 dependent MFMAs with L2 loads per tile at H = 256: ~300 us per launch.
+// ------------------------------------------------------------------------------------------
+template <bool CONT, int MODE, int NTW>
+__global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__restrict__ params, PLayout L, const float *__restrict__ obs, int64_t n,
+                                                              uint32_t rng_seed, uint32_t rng_step, uint32_t env_offset, int deterministic,
+                                                              void *__restrict__ actions_out, float *__restrict__ values_out,
+                                                              float *__restrict__ logp_out, const uint8_t *__restrict__ trunc, float gamma,
+                                                              float *__restrict__ rewards) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int M = 32, H = 64 * NTW, ld = H + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2;
+    float *X = smem, *h1 = X + M * ldx, *h2 = h1 + M * ld;
+    const int n_base = wave * 16 * NTW;
+    const int64_t n_groups = (n + M - 1) / M;
+    auto hidden = [&](const Net &Q) {  // X -> h1 -> h2 for this wave's columns, both row tiles
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+            const float bias = Q.b1[n_base + 16 * j + r16];
+            f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
+            for (int ks = 0; ks < KS1; ks++) {
+                const int k = 4 * ks + g;
+                const float w = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
+                c0 = mfma16(X[r16 * ldx + k], w, c0);
+                c1 = mfma16(X[(16 + r16) * ldx + k], w, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                h1[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
+                h1[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+            const float bias = Q.b2[n_base + 16 * j + r16];
+            f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
+            const float *wcol = Q.W2t + n_base + 16 * j + r16;
+#pragma unroll 8
+            for (int ks = 0; ks < H / 4; ks++) {
+                const int k = 4 * ks + g;
+                const float w = wcol[(int64_t)k * H];
+                c0 = mfma16(h1[r16 * ld + k], w, c0);
+                c1 = mfma16(h1[(16 + r16) * ld + k], w, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
+                h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+            }
+        }
+        __syncthreads();
+    };
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t row0 = grp * M;
+        if constexpr (MODE == 2) {  // skip row groups without a truncated env (block-uniform vote)
+            const int64_t rr = row0 + threadIdx.x;
+            const int any = __syncthreads_or((threadIdx.x < M && rr < n && trunc[rr] != 0) ? 1 : 0);
+            if (!any) continue;
+        }
+        {
+            const int Dp = (D + 3) & ~3, tot = M * Dp;
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                const int row = e / Dp, c = e - row * Dp;
+                X[row * ldx + c] = (row0 + row < n && c < D) ? obs[(row0 + row) * D + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const Net V = vf_net(params, L);
+        hidden(V);
+        f32x4 vacc[1] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        const int mt = wave & 1;
+        if (wave < 2) dense_head<1>(h2 + mt * 16 * ld, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        if constexpr (MODE == 1) {
+            if (wave < 2 && r16 == 0)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + mt * 16 + g * 4 + r;
+                    if (row < n) values_out[row] = vacc[0][r];
+                }
+        } else if constexpr (MODE == 2) {
+            if (wave < 2 && r16 == 0)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + mt * 16 + g * 4 + r;
+                    if (row < n && trunc[row]) {
+                        const float gv = gamma * vacc[0][r];
+                        rewards[row] = rewards[row] + gv;
+                    }
+                }
+        } else {
+            __syncthreads();  // every wave is done reading h2 of the value net before the policy net overwrites h1/h2
+            const Net P = pi_net(params, L);
+            hidden(P);
+            if (wave < 2) {
+                const float *hh = h2 + mt * 16 * ld;
+                if constexpr (!CONT) {
+                    f32x4 acc[1];
+                    dense_head<1>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + mt * 16 + g * 4 + r;
+                        const bool colok = r16 < A;
+                        const float x = colok ? acc[0][r] : -INFINITY;
+                        const float m = gmax16(x);
+                        const float e = colok ? expf(x - m) : 0.0f;
+                        const float sm = gsum16(e);
+                        const float lse = m + logf(sm);
+                        const float lp = x - lse;
+                        int act;
+                        if (deterministic) {
+                            float mn = (colok && x == m) ? (float)r16 : 99.0f;
+                            mn = fminf(mn, __shfl_xor(mn, 1, 64));
+                            mn = fminf(mn, __shfl_xor(mn, 2, 64));
+                            mn = fminf(mn, __shfl_xor(mn, 4, 64));
+                            mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                            act = (int)mn;
+                        } else {
+                            float c = e / sm;
+#pragma unroll
+                            for (int d = 1; d < 16; d <<= 1) {
+                                const float up = __shfl_up(c, d, 16);
+                                if (r16 >= d) c += up;
+                            }
+                            const float u = uniform01(mix32(rng_seed, env_offset + (uint32_t)row, rng_step));
+                            const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                            act = min((int)cnt, A - 1);
+                        }
+                        const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                        const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                        if (r16 == r && row < n) {
+                            static_cast<int32_t *>(actions_out)[row] = act;
+                            logp_out[row] = lpa;
+                            values_out[row] = vrow;
+                        }
+                    }
+                } else {
+                    f32x4 acc[2];
+                    dense_head<2>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
+                    const float *ls = params + L.log_std;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + mt * 16 + g * 4 + r;
+                        const uint32_t gi = env_offset + (uint32_t)row;
+                        float lpsum = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int col = 16 * j + r16;
+                            if (col < A) {
+                                const float mu = acc[j][r], lsd = ls[col], sd = expf(lsd);
+                                float a = mu;
+                                if (!deterministic) {
+                                    const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rng_step)), 5.9604645e-08f);
+                                    const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rng_step));
+                                    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+                                    a = mu + sd * z;
+                                }
+                                const float d = a - mu;
+                                lpsum += -(d * d) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                                if (row < n) static_cast<float *>(actions_out)[row * A + col] = a;
+                            }
+                        }
+                        lpsum = gsum16(lpsum);
+                        const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                        if (r16 == r && row < n) {
+                            logp_out[row] = lpsum;
+                            values_out[row] = vrow;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the next row group overwrites X / h1 / h2
+    }
+}
+
+static int fwd_wide_smem_bytes(const PLayout &L) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    return 32 * (ldx + 2 * ld) * 4;
+}
+
 template <int MODE>
 static int launch_fwd(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t seed, uint32_t step, uint32_t env_offset,
                       int deterministic, void *actions, float *values, float *logp, const uint8_t *trunc, float gamma, float *rewards,
@@ -1486,6 +1674,23 @@ static int launch_fwd(const float *params, const tma_policy_dims *d, const float
     if (L.img_pi >= 0) {
         if constexpr (MODE == 2) return launch_fwd_h64<2>(params, L, nullptr, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, obs, trunc, gamma, rewards, s);
         else return launch_fwd_h64<MODE>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, nullptr, nullptr, 0.0f, nullptr, s);
+    }
+    if ((L.H == 128 || L.H == 192 || L.H == 256) && fwd_wide_smem_bytes(L) <= 160 * 1024) {
+        const int smemw = fwd_wide_smem_bytes(L);
+        int64_t groups = ceil_div(n, 32);
+        if (groups > 4096) groups = 4096;
+        auto launchw = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
+            k<<<dim3((unsigned)groups), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, trunc, gamma,
+                                                                rewards);
+            return TMA_OK;
+        };
+        int wrc;
+        if (d->continuous) wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<true, MODE, 4>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<true, MODE, 3>) : launchw(policy_fwd_wide_kernel<true, MODE, 2>));
+        else wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<false, MODE, 4>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<false, MODE, 3>) : launchw(policy_fwd_wide_kernel<false, MODE, 2>));
+        if (wrc) return wrc;
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
     }
     const int64_t tiles = ceil_div(n, 16);
     int wpb = tiles >= 1024 ? 4 : 1;  // small batches: one wave per block so every CU gets work
