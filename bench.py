@@ -201,7 +201,7 @@ def main():
         "metric": "env_steps_per_sec", "value": env_steps / el, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{args.task} (5x5 GridWorld), {N} envs/GPU, full PPO iterations: n_steps={T}, MLP pi/vf {args.hidden}x{args.hidden} tanh, "
+            "workload": f"{args.task}, {N} envs/GPU, full PPO iterations: n_steps={T}, MLP pi/vf {args.hidden}x{args.hidden} tanh, "
                         f"n_epochs={args.n_epochs}, batch_size={batch} ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
                         f"gae_lambda=0.95, clip=0.2, ent=0.01, vf=0.5, max_grad_norm=0.5",
             "envs_per_gpu": N, "n_steps": T, "batch_size": batch, "n_epochs": args.n_epochs, "hidden": args.hidden,

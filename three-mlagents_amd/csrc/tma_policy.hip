@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
     const int n_base = wave * 16 * NTW;
     const int64_t n_groups = (n + M - 1) / M;
     auto hidden = [&](const Net &Q) {  // X -> h1 -> h2 for this wave's columns, both row tiles
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b1[n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
@@ -1518,17 +1518,19 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b2[n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
             const float *wcol = Q.W2t + n_base + 16 * j + r16;
-#pragma unroll 8
+            float wv[H / 4];  // the whole weight column slice of this tile is fetched first: one L2 latency per tile, not per k-step
+#pragma unroll
+            for (int ks = 0; ks < H / 4; ks++) wv[ks] = wcol[(int64_t)(4 * ks + g) * H];
+#pragma unroll
             for (int ks = 0; ks < H / 4; ks++) {
                 const int k = 4 * ks + g;
-                const float w = wcol[(int64_t)k * H];
-                c0 = mfma16(h1[r16 * ld + k], w, c0);
-                c1 = mfma16(h1[(16 + r16) * ld + k], w, c1);
+                c0 = mfma16(h1[r16 * ld + k], wv[ks], c0);
+                c1 = mfma16(h1[(16 + r16) * ld + k], wv[ks], c1);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -1822,7 +1824,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     float *ws_adv = reinterpret_cast<float *>(ws + WS_ADV);
     double *slots = reinterpret_cast<double *>(ws + WS_STATS);
     const int64_t tiles = ceil_div(mbi->count, 16);
-    const bool h64 = L.img_pi >= 0 && tiles >= 1024;
+    const bool h64 = L.img_pi >= 0 && tiles >= 16;  // >= 256 samples: persistent LDS-image kernel; smaller batches: generic kernel
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
@@ -1853,10 +1855,10 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         return TMA_OK;
     }
     static const bool force_wide = getenv("TMA_FORCE_WIDE") != nullptr;  // test hook: take the column-parallel kernel at any batch size
-    if ((L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 2048 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
+    if ((L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 8 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
         // column-parallel register-accumulating kernel + deterministic slab reduction
         const int smemw = grad_wide_smem_bytes(L);
-        int64_t pairs = ceil_div(ceil_div(mbi->count, 32), 4);
+        int64_t pairs = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
         if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         if (L.D > 32) {  // layer-1 gradient accumulates in place in the slab
