@@ -31,6 +31,7 @@ LAYOUT_BYTES = {"gridworld": 4 + 4 + 4 + 8 + 8 + 4 + 4 + 16 + 4 + 2, "push": 58,
 SURVEY_BYTES = {"gridworld": 90, "push": 74, "basic": 110, "ball3d": 114}
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense peak (~2.5 PF)
 
 
 def mlp_flops_per_sample(D, H, A):
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--n-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=0, help="0 -> 32 minibatches per epoch (the reference's default schedule: 8 envs x 1024 / 256)")
+    ap.add_argument("--mfma-dtype", default="f32", choices=["f32", "bf16"],
+                    help="MFMA operand type of the hidden-layer GEMMs (bf16: hidden 128/192/256 only; BASELINE.json configs[2])")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -165,7 +168,7 @@ def main():
     env = make_vector_env(args.task, n_envs=N, seed=args.seed, device=dev, env_offset=rank * N)
     model = PPO("MlpPolicy", env, learning_rate=3e-4, n_steps=T, batch_size=batch, n_epochs=args.n_epochs, gamma=0.99, gae_lambda=0.95,
                 clip_range=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, seed=args.seed,
-                policy_kwargs={"net_arch": {"pi": [args.hidden] * 2, "vf": [args.hidden] * 2}})
+                policy_kwargs={"net_arch": {"pi": [args.hidden] * 2, "vf": [args.hidden] * 2}, "mfma_dtype": args.mfma_dtype})
     D, A = model.policy.obs_dim, model.policy.act_dim
 
     def iteration():
@@ -199,7 +202,7 @@ def main():
 
     out = {
         "metric": "env_steps_per_sec", "value": env_steps / el, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma_dtype, "data": "synthetic",
         "config": {
             "workload": f"{args.task}, {N} envs/GPU, full PPO iterations: n_steps={T}, MLP pi/vf {args.hidden}x{args.hidden} tanh, "
                         f"n_epochs={args.n_epochs}, batch_size={batch} ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
@@ -236,12 +239,16 @@ def main():
         log(f"minibatch gradient launch group: median {g_med:.1f} us")
         tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
         fast = args.hidden == 64 and D <= 16 and not model.policy.continuous and mb.count >= 16384
+        bf = args.mfma_dtype == "bf16"
+        wide = args.hidden in (128, 192, 256)
+        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
+        kname = ("tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
         out["roofline"] = {
-            "kernel": ("tma::ppo_grad_h64_kernel (+ adv_partial_kernel + slab_reduce_kernel of the same tma_ppo_minibatch_grad call)" if fast else
-                       "tma::ppo_grad_kernel (+ adv_partial/adv_final of the same tma_ppo_minibatch_grad call)"),
-            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "kernel": kname + " (+ adv_partial / slab_reduce kernels of the same tma_ppo_minibatch_grad call)",
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
             "launch_us": g_med, "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
-            "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
+            "note": ("bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
+                     "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
         }
         pmc_path = os.path.join(ROOT, "profiles", "r01_grad_kernel_pmc.json")
         if fast and args.task == "gridworld" and os.path.exists(pmc_path):

@@ -106,6 +106,9 @@ typedef struct {
     int hidden;     /* H: two tanh layers of width H for both the policy and the value net (multiple of 64) */
     int act_dim;    /* Discrete(n): n (2..16); Box: action dimension (1..32) */
     int continuous; /* 0: Categorical head; 1: DiagGaussian head with a state-independent log_std */
+    int mfma_dtype; /* 0: f32 MFMA everywhere (parity mode, every hidden width); 1: bf16 MFMA operands with f32 master
+                       weights and f32 accumulation for the hidden-layer and head GEMMs (hidden = 128 / 192 / 256 only:
+                       BASELINE.json configs[2] "PPO MLP(256,256) bf16").  Rollout and update use the same forward code. */
 } tma_policy_dims;
 
 /* parameter buffer = n_total floats: [0, n_trainable) trainable, [in][out] layout, order

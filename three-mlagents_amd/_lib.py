@@ -20,7 +20,7 @@ _vp, _i32, _i64, _u32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_do
 
 
 class PolicyDims(C.Structure):
-    _fields_ = [("obs_dim", _i32), ("hidden", _i32), ("act_dim", _i32), ("continuous", _i32)]
+    _fields_ = [("obs_dim", _i32), ("hidden", _i32), ("act_dim", _i32), ("continuous", _i32), ("mfma_dtype", _i32)]
 
 
 class Rollout(C.Structure):

@@ -36,8 +36,34 @@ struct PLayout {
     int pW1t, pb1, pW2t, pb2, pW3t, pb3, vW1t, vb1, vW2t, vb2, vW3t, vb3, log_std, P;
     int pW2, pW3, vW2, vW3;
     int img_pi, img_vf;  // LDS-image regions (H == 64 fast path), IMG_FLOATS each; -1 when the shape has no fast path
+    int bf16;            // 1: the hidden-layer GEMMs run on the bf16 MFMA (f32 master weights, f32 accumulate) -- tma_wide_bf16.h
+    int bf_pi, bf_vf;    // float offsets of the bf16 fragment-major weight images of the two nets; -1 in f32 mode
     int total;
 };
+
+// ---- bf16 weight images of ONE net (offsets in bf16 elements from the image base).  Every image is "fragment-major": the
+// eight bf16 one lane feeds to v_mfma_f32_16x16x32_bf16 as its B operand for (output tile, k-step) are contiguous, and the
+// 64 lanes of the wave follow each other, so one B fragment is a single fully coalesced 1 KiB load.
+struct BfNet {
+    int fW1;   // [H/16 n-tiles][Kp1/32 k-steps][64 lanes][8]: W1[k = 32ks + 8(l>>4) + j][n = 16nt + (l&15)], rows k >= D zero
+    int fW2;   // [H/16][H/32][64][8]:                         W2[k][n] likewise                          (layer-2 forward)
+    int bW2;   // [H/16 k'-tiles][H/32 n-steps][64][8]:        W2[k' = 16kt + (l&15)][n = 32ns + 8(l>>4) + j]   (dh1 = dz2 . W2^T)
+    int fW3;   // [NT3 a-tiles][H/32][64][8]:                  W3[k][a = 16at + (l&15)], columns a >= n_out zero  (head forward)
+    int bW3;   // [H/16 k'-tiles][64][8]:                      W3[k' = 16kt + (l&15)][a = 8(l>>4) + j]           (dh2 = dz3 . W3^T)
+    int size;  // bf16 elements, multiple of 8
+};
+__host__ __device__ inline BfNet bf_net_layout(int D, int H, int n_out) {
+    const int Kp1 = (D + 31) & ~31, NT3 = n_out > 16 ? 2 : 1;
+    BfNet B;
+    int o = 0;
+    B.fW1 = o, o += H * Kp1;
+    B.fW2 = o, o += H * H;
+    B.bW2 = o, o += H * H;
+    B.fW3 = o, o += NT3 * 16 * H;
+    B.bW3 = o, o += H * 32;
+    B.size = o;
+    return B;
+}
 
 // ---- H = 64 LDS weight image of ONE net (floats).  Matrices are stored so that the four B operands a lane needs for one
 // k-step (output columns 16j + (lane&15), j = 0..3) are one aligned float4: element [k][r16][j].  ds_read_b128 of that
@@ -53,7 +79,7 @@ constexpr int IMG_B3 = IMG_B2 + 64;         // [16]
 constexpr int IMG_FLOATS = IMG_B3 + 16 + 16;  // padded to a multiple of 4 floats (11440)
 constexpr int IMG_FWD_FLOATS = IMG_W3B;       // forward-only kernels stage [0, IMG_W3B) + the biases
 
-__host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont) {
+__host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, int bf16 = 0) {
     PLayout L;
     L.D = D, L.H = H, L.A = A, L.cont = cont;
     int o = 0;
@@ -79,6 +105,12 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont) {
     const bool fast = (H == 64) && (D <= 16) && !cont && (A <= 16);
     L.img_pi = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
     L.img_vf = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
+    L.bf16 = bf16 ? 1 : 0;
+    L.bf_pi = L.bf_vf = -1;
+    if (L.bf16) {
+        L.bf_pi = o, o += bf_net_layout(D, H, A).size / 2;
+        L.bf_vf = o, o += bf_net_layout(D, H, 1).size / 2;
+    }
     L.total = o;
     return L;
 }

@@ -312,6 +312,7 @@ struct Rollout {
 struct HParams {
     float clip_range, ent_coef, vf_coef;
     int normalize_advantage;
+    int debug;  // TMA_BF_DEBUG (profiling aid, default 0): bit mask of phases the bf16 wide kernel skips -- timing attribution only
 };
 
 // Even blocks carry the POLICY net, odd blocks the VALUE net (they share nothing).  The input-gradient tiles overwrite the
@@ -1200,6 +1201,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__re
     else grad_wide_body<CONT, false, NTW, KT1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
 }
 
+#include "tma_wide_bf16.h"
+
 // zero the layer-1 weight columns of every slab when they are accumulated in place (observations wider than 32)
 __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
     const int per = L.D * L.H;
@@ -1325,6 +1328,20 @@ __global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ par
     }
 }
 
+static inline PLayout layout_of(const tma_policy_dims *d) { return make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous, d->mfma_dtype); }
+
+// everything derived from the trainable region: [out][in] copies, H == 64 LDS images, bf16 fragment images
+static int launch_sync(float *params, const PLayout &L, hipStream_t s) {
+    const int total = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
+    sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s>>>(params, L);
+    TMA_LAUNCH_CHECK();
+    if (L.bf16) {
+        build_bf16_images_kernel<<<dim3(256), dim3(256), 0, s>>>(params, L);
+        TMA_LAUNCH_CHECK();
+    }
+    return TMA_OK;
+}
+
 static int check_dims(const tma_policy_dims *d) {
     if (!d) return fail(TMA_ERR_INVALID, "policy dims is null");
     if (d->obs_dim < 1 || d->obs_dim > 4096) return fail(TMA_ERR_INVALID, "obs_dim out of range: %d", d->obs_dim);
@@ -1334,6 +1351,13 @@ static int check_dims(const tma_policy_dims *d) {
         if (d->act_dim < 1 || d->act_dim > 32) return fail(TMA_ERR_INVALID, "Box action dim must be in [1, 32] (got %d)", d->act_dim);
     } else if (d->act_dim < 2 || d->act_dim > 16)
         return fail(TMA_ERR_INVALID, "Discrete action count must be in [2, 16] (got %d)", d->act_dim);
+    if (d->mfma_dtype != 0 && d->mfma_dtype != 1) return fail(TMA_ERR_INVALID, "mfma_dtype must be 0 (f32) or 1 (bf16), got %d", d->mfma_dtype);
+    if (d->mfma_dtype == 1) {
+        if (d->hidden != 128 && d->hidden != 192 && d->hidden != 256)
+            return fail(TMA_ERR_INVALID, "the bf16 MFMA path covers hidden widths 128 / 192 / 256 (got %d)", d->hidden);
+        if (grad_wide_bf_smem_bytes(d->obs_dim, d->hidden, 2) > 160 * 1024)
+            return fail(TMA_ERR_INVALID, "obs_dim %d too wide for the bf16 LDS tile", d->obs_dim);
+    }
     return TMA_OK;
 }
 
@@ -1485,7 +1509,7 @@ static int launch_fwd_h64(const float *params, const PLayout &L, const float *ob
 // every weight fragment read from L2 serves both 16-row tiles, waves 0/1 finish the heads (sampling / log-prob / value).
 // One wave per tile (policy_fwd_kernel) needs ~3700 dependent MFMAs with L2 loads per tile at H = 256: ~300 us per launch.
 // ------------------------------------------------------------------------------------------
-template <bool CONT, int MODE, int NTW>
+template <bool CONT, int MODE, int NTW, bool BF>
 __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__restrict__ params, PLayout L, const float *__restrict__ obs, int64_t n,
                                                               uint32_t rng_seed, uint32_t rng_step, uint32_t env_offset, int deterministic,
                                                               void *__restrict__ actions_out, float *__restrict__ values_out,
@@ -1493,14 +1517,25 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                                                               float *__restrict__ rewards) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int M = 32, H = 64 * NTW, ld = H + 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int D = L.D, A = L.A;
     const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2;
     float *X = smem, *h1 = X + M * ldx, *h2 = h1 + M * ld;
+    // bf16 mode (tma_wide_bf16.h): the same LDS bytes hold bf16 A images; the forward code is shared with the update kernel
+    const int Kp1 = (D + 31) & ~31, ldxb = Kp1 + 16, lda = H + 16;
+    bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *A1 = Xa + M * ldxb, *A2 = A1 + M * lda;
     const int n_base = wave * 16 * NTW;
     const int64_t n_groups = (n + M - 1) / M;
-    auto hidden = [&](const Net &Q) {  // X -> h1 -> h2 for this wave's columns, both row tiles
+    auto hidden = [&](const Net &Q, bool is_pi) {  // X -> h1 -> h2 for this wave's columns, both row tiles
+        if constexpr (BF) {
+            const BfNetPtr W = bf_net_ptr(params, L, is_pi);
+            bf_hidden_layer<NTW, 2, false>(Xa, ldxb, Kp1 >> 5, W.fW1, Q.b1, A1, lda, nullptr, n_base, lane);
+            __syncthreads();
+            bf_hidden_layer<NTW, 2, false>(A1, lda, H / 32, W.fW2, Q.b2, A2, lda, nullptr, n_base, lane);
+            __syncthreads();
+            return;
+        }
 #pragma unroll 1
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b1[n_base + 16 * j + r16];
@@ -1547,7 +1582,12 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
             const int any = __syncthreads_or((threadIdx.x < M && rr < n && trunc[rr] != 0) ? 1 : 0);
             if (!any) continue;
         }
-        {
+        if constexpr (BF) {
+            for (int e = threadIdx.x; e < M * Kp1; e += blockDim.x) {
+                const int row = e / Kp1, c = e - row * Kp1;
+                Xa[row * ldxb + c] = (bf16_t)((row0 + row < n && c < D) ? obs[(row0 + row) * D + c] : 0.0f);
+            }
+        } else {
             const int Dp = (D + 3) & ~3, tot = M * Dp;
             for (int e = threadIdx.x; e < tot; e += blockDim.x) {
                 const int row = e / Dp, c = e - row * Dp;
@@ -1556,10 +1596,13 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
         }
         __syncthreads();
         const Net V = vf_net(params, L);
-        hidden(V);
+        hidden(V, false);
         f32x4 vacc[1] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
         const int mt = wave & 1;
-        if (wave < 2) dense_head<1>(h2 + mt * 16 * ld, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        if (wave < 2) {
+            if constexpr (BF) bf_head<1>(A2, lda, 16 * mt, H / 32, bf_net_ptr(params, L, false).fW3, V.b3, 1, vacc, lane);
+            else dense_head<1>(h2 + mt * 16 * ld, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        }
         if constexpr (MODE == 1) {
             if (wave < 2 && r16 == 0)
 #pragma unroll
@@ -1580,12 +1623,13 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
         } else {
             __syncthreads();  // every wave is done reading h2 of the value net before the policy net overwrites h1/h2
             const Net P = pi_net(params, L);
-            hidden(P);
+            hidden(P, true);
             if (wave < 2) {
                 const float *hh = h2 + mt * 16 * ld;
                 if constexpr (!CONT) {
                     f32x4 acc[1];
-                    dense_head<1>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
+                    if constexpr (BF) bf_head<1>(A2, lda, 16 * mt, H / 32, bf_net_ptr(params, L, true).fW3, P.b3, A, acc, lane);
+                    else dense_head<1>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int64_t row = row0 + mt * 16 + g * 4 + r;
@@ -1625,7 +1669,8 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                     }
                 } else {
                     f32x4 acc[2];
-                    dense_head<2>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
+                    if constexpr (BF) bf_head<2>(A2, lda, 16 * mt, H / 32, bf_net_ptr(params, L, true).fW3, P.b3, A, acc, lane);
+                    else dense_head<2>(hh, ld, H, P.W3t, P.b3, A, acc, lane);
                     const float *ls = params + L.log_std;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -1672,10 +1717,27 @@ template <int MODE>
 static int launch_fwd(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t seed, uint32_t step, uint32_t env_offset,
                       int deterministic, void *actions, float *values, float *logp, const uint8_t *trunc, float gamma, float *rewards,
                       hipStream_t s) {
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     if (L.img_pi >= 0) {
         if constexpr (MODE == 2) return launch_fwd_h64<2>(params, L, nullptr, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, obs, trunc, gamma, rewards, s);
         else return launch_fwd_h64<MODE>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, nullptr, nullptr, 0.0f, nullptr, s);
+    }
+    if (L.bf16) {
+        const int smemw = fwd_wide_bf_smem_bytes(L.D, L.H);
+        int64_t groups = ceil_div(n, 32);
+        if (groups > 4096) groups = 4096;
+        auto launchw = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
+            k<<<dim3((unsigned)groups), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, trunc, gamma,
+                                                                rewards);
+            return TMA_OK;
+        };
+        int wrc;
+        if (d->continuous) wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<true, MODE, 4, true>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<true, MODE, 3, true>) : launchw(policy_fwd_wide_kernel<true, MODE, 2, true>));
+        else wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<false, MODE, 4, true>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<false, MODE, 3, true>) : launchw(policy_fwd_wide_kernel<false, MODE, 2, true>));
+        if (wrc) return wrc;
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
     }
     if ((L.H == 128 || L.H == 192 || L.H == 256) && fwd_wide_smem_bytes(L) <= 160 * 1024) {
         const int smemw = fwd_wide_smem_bytes(L);
@@ -1688,8 +1750,8 @@ static int launch_fwd(const float *params, const tma_policy_dims *d, const float
             return TMA_OK;
         };
         int wrc;
-        if (d->continuous) wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<true, MODE, 4>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<true, MODE, 3>) : launchw(policy_fwd_wide_kernel<true, MODE, 2>));
-        else wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<false, MODE, 4>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<false, MODE, 3>) : launchw(policy_fwd_wide_kernel<false, MODE, 2>));
+        if (d->continuous) wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<true, MODE, 4, false>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<true, MODE, 3, false>) : launchw(policy_fwd_wide_kernel<true, MODE, 2, false>));
+        else wrc = L.H == 256 ? launchw(policy_fwd_wide_kernel<false, MODE, 4, false>) : (L.H == 192 ? launchw(policy_fwd_wide_kernel<false, MODE, 3, false>) : launchw(policy_fwd_wide_kernel<false, MODE, 2, false>));
         if (wrc) return wrc;
         TMA_LAUNCH_CHECK();
         return TMA_OK;
@@ -1723,14 +1785,14 @@ extern "C" {
 
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     return WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4;
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
     int rc = check_dims(d);
     if (rc) return rc;
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     if (n_trainable) *n_trainable = L.P;
     if (n_total) *n_total = L.total;
     return TMA_OK;
@@ -1740,7 +1802,7 @@ int tma_policy_param_offsets(const tma_policy_dims *d, int32_t *out13) {
     int rc = check_dims(d);
     if (rc) return rc;
     if (!out13) return fail(TMA_ERR_INVALID, "out13 is null");
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     const int o[13] = {L.pW1t, L.pb1, L.pW2t, L.pb2, L.pW3t, L.pb3, L.vW1t, L.vb1, L.vW2t, L.vb2, L.vW3t, L.vb3, L.log_std};
     for (int i = 0; i < 13; i++) out13[i] = o[i];
     return TMA_OK;
@@ -1750,11 +1812,8 @@ int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream) {
     int rc = check_dims(d);
     if (rc) return rc;
     if (!params) return fail(TMA_ERR_INVALID, "params is null");
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
-    const int total = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
-    sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(params, L);
-    TMA_LAUNCH_CHECK();
-    return TMA_OK;
+    const PLayout L = layout_of(d);
+    return launch_sync(params, L, (hipStream_t)stream);
 }
 
 int tma_policy_act(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
@@ -1774,7 +1833,7 @@ int tma_policy_act_bootstrap(const float *params, const tma_policy_dims *d, cons
     if (rc) return rc;
     if (!params || !obs || !actions_out || !values_out || !logp_out) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: null buffer");
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: n must be >= 1");
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     const bool boot = prev_terminal_obs && prev_truncated && prev_rewards_inout;
     if (L.img_pi >= 0)  // one launch: bootstrap of the previous step folded into this step's forward
         return launch_fwd_h64<0>(params, L, obs, n, rng_seed, rng_step, env_offset, 0, actions_out, values_out, logp_out, boot ? prev_terminal_obs : nullptr,
@@ -1816,10 +1875,11 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     if (mbi->count < 1 || mbi->start < 0 || mbi->start + mbi->count > total)
         return fail(TMA_ERR_INVALID, "minibatch [%lld, +%lld) outside the %lld-sample rollout", (long long)mbi->start, (long long)mbi->count, (long long)total);
     hipStream_t s = (hipStream_t)stream;
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
     Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total};
-    HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, (hp->normalize_advantage && mbi->count > 1) ? 1 : 0};
+    static const int bf_debug = getenv("TMA_BF_DEBUG") ? atoi(getenv("TMA_BF_DEBUG")) : 0;
+    HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, (hp->normalize_advantage && mbi->count > 1) ? 1 : 0, bf_debug};
     char *ws = static_cast<char *>(workspace);
     float *ws_adv = reinterpret_cast<float *>(ws + WS_ADV);
     double *slots = reinterpret_cast<double *>(ws + WS_STATS);
@@ -1851,6 +1911,49 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
+    if (L.bf16) {
+        const int MTc = 2;
+        const int smemw = grad_wide_bf_smem_bytes(L.D, L.H, MTc);
+        int64_t pairs = ceil_div(mbi->count, 16 * MTc);
+        if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
+        float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
+        if (L.D > 32) {
+            slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
+            TMA_LAUNCH_CHECK();
+        }
+        auto launch = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
+            k<<<dim3((unsigned)(2 * pairs)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+            return TMA_OK;
+        };
+        // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2); 161..192 (Crawler's 172) -> (0, 6); else runtime width
+        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
+        auto pick = [&](auto ntw) -> int {
+            constexpr int NTWc = decltype(ntw)::value;
+            if (d->continuous) {
+                switch (variant) {
+                    case 0: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 1, 1>);
+                    case 1: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 2, 1>);
+                    case 2: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 2>);
+                    case 3: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 6>);
+                    default: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 0>);
+                }
+            }
+            switch (variant) {
+                case 0: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 1, 1>);
+                case 1: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 2, 1>);
+                case 2: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 2>);
+                case 3: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 6>);
+                default: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 0>);
+            }
+        };
+        int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+        if (lrc) return lrc;
+        TMA_LAUNCH_CHECK();
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -1909,7 +2012,7 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
     if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step: null buffer");
     if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
     hipStream_t s = (hipStream_t)stream;
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = layout_of(d);
     char *ws = static_cast<char *>(workspace);
     double *partials = reinterpret_cast<double *>(ws + WS_NORM_PART);
     double *norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
@@ -1919,10 +2022,7 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
         opt_small_kernel<<<dim3(1), dim3(1024), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, (float)grad_scale, (float)max_grad_norm, (float)step_size,
                                                         (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
         TMA_LAUNCH_CHECK();
-        const int tot = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
-        sync_transposed_kernel<<<dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s>>>(params, L);
-        TMA_LAUNCH_CHECK();
-        return TMA_OK;
+        return launch_sync(params, L, s);
     }
     int nb = (int)ceil_div(L.P, 1024);
     if (nb > 256) nb = 256;
@@ -1931,10 +2031,7 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
     adam_kernel<<<dim3(nb), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L.P, (float)grad_scale, partials, nb, (float)max_grad_norm,
                                                (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
     TMA_LAUNCH_CHECK();
-    const int total = 2 * L.H * L.H + L.A * L.H + L.H + (L.img_pi >= 0 ? 2 * IMG_FLOATS : 0);
-    sync_transposed_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s>>>(params, L);
-    TMA_LAUNCH_CHECK();
-    return TMA_OK;
+    return launch_sync(params, L, s);
 }
 
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {

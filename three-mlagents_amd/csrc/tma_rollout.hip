@@ -193,7 +193,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     if (t_begin < 0 || t_end > T || t_begin > t_end) return fail(TMA_ERR_INVALID, "bad step range [%d, %d) for T=%d", t_begin, t_end, T);
     const int64_t N = b->N;
     if (N != env->v.N) return fail(TMA_ERR_INVALID, "rollout buffers are for %lld envs, the env handle has %lld", (long long)N, (long long)env->v.N);
-    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous);
+    const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous, d->mfma_dtype);
     const bool fused = L.img_pi >= 0 && env->is_reset &&
                        (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D || env->task == TMA_TASK_WALLJUMP) &&
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);

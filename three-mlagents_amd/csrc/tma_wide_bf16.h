@@ -1,0 +1,756 @@
+// tma_wide_bf16.h -- bf16-MFMA variant of the column-parallel wide-policy kernels (hidden = 128 / 192 / 256).
+//
+// Included by tma_policy.hip inside namespace tma, after Net / Rollout / Minibatch / HParams / policy_loss_tile.
+//
+// Why a second data path: BASELINE.json configs[2] names "PPO MLP(256,256) bf16".  With f32 MFMA operands the 256-wide
+// update re-streams 0.5 MB of f32 weights from L2 for every 32-sample row group and issues 4 flops/lane/cycle; with
+// v_mfma_f32_16x16x32_bf16 (8 bf16 per lane per operand, f32 accumulate) the same GEMMs need 1/8 of the MFMA issue slots
+// and half the weight bytes.  Master weights, Adam state, biases, the loss and every gradient ACCUMULATOR stay f32; only the
+// MFMA operands (activations, weights, back-propagated deltas) are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32), which is what torch.autocast(bfloat16) does to the same SB3 MlpPolicy (third-party; constructed at
+// /root/reference/backend/mlagents/training.py:150 with the net_arch of training.py:363-365).
+//
+// Data layout
+//   * weights: "fragment-major" bf16 images (BfNet in tma_mlp.h) rebuilt by build_bf16_images_kernel after every Adam
+//     step: one B fragment = one coalesced 1 KiB load, no LDS staging, no transposes at run time.
+//   * activations of a row group of M = 16*MT samples live in LDS twice:
+//       A image  [M][K + 16] bf16   row-major, row stride == 32 B mod 64 B  -> conflict-free ds_read_b128 A fragments
+//       T image  [K][M]      bf16   transposed, 16-byte chunks XOR-swizzled -> conflict-free ds_read_b128 fragments for
+//                                   the weight-gradient GEMMs (reduction over the samples) and 8-byte C-layout access.
+//   * a block = 4 waves (one per SIMD, 512 registers each); wave w owns output columns [w*H/4, (w+1)*H/4) of both hidden
+//     layers and keeps its slice of dW2 / dW1 / dW3 in MFMA accumulators for the whole launch (as the f32 kernel does).
+#pragma once
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// B fragment `idx` of a fragment-major image.  The load is made through an explicit global (address space 1) pointer: a
+// pointer that went through the LICM-defeating asm in the gradient kernel is "generic" to the compiler, and a flat_load
+// counts on lgkmcnt as well as vmcnt -- every LDS wait would then also wait for the weight prefetch in flight.
+typedef const bf16x8 __attribute__((address_space(1))) *bf_gptr;
+// value the optimiser must treat as new (not loop-invariant) but provably wave-uniform: SGPR addressing survives
+__device__ __forceinline__ const bf16_t *launder_uniform(const bf16_t *p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const bf16_t *>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int launder_uniform(int x) {
+    asm volatile("" : "+s"(x));
+    return __builtin_amdgcn_readfirstlane(x);
+}
+__device__ __forceinline__ bf16x8 bf_frag(const bf16_t *__restrict__ img, int idx, int lane) {
+    // uniform (SGPR) fragment base + one 32-bit per-lane offset: the saddr form of global_load, no 64-bit VGPR address per fragment
+    return reinterpret_cast<bf_gptr>(reinterpret_cast<uintptr_t>(img + (int64_t)idx * 512))[(uint32_t)lane];
+}
+
+// ---- T image addressing: row `r` holds M bf16 (M/8 chunks of 16 bytes); chunk c is stored at position c ^ t_swz<MT>(r).
+// MT = 2 (64-byte rows): swz = (-(r >> 2)) & 3;  MT = 4 (128-byte rows): swz = 2 * ((r >> 1) & 3).  With either, the four
+// 16-lane groups of a ds_read_b128 whose lanes read (row = r0 + (l&15), chunk = c0 + (l>>4)) cover 64 distinct banks.
+template <int MT>
+__device__ __forceinline__ int t_swz(int r) {
+    if constexpr (MT == 2) return (-(r >> 2)) & 3;
+    else return 2 * ((r >> 1) & 3);
+}
+template <int MT>
+__device__ __forceinline__ int t_off(int r, int m) {  // element offset of T[r][m]
+    return r * (16 * MT) + 8 * ((m >> 3) ^ t_swz<MT>(r)) + (m & 7);
+}
+// fragment for an MFMA whose reduction runs over samples 32*kk .. 32*kk+31: lane reads T[row][32kk + 8g .. +7]
+template <int MT>
+__device__ __forceinline__ bf16x8 t_frag(const bf16_t *T, int row, int kk, int g) {
+    return *reinterpret_cast<const bf16x8 *>(T + row * (16 * MT) + 8 * ((4 * kk + g) ^ t_swz<MT>(row)));
+}
+// C-layout access: the 4 samples m = 16mt + 4g .. +3 of column n
+template <int MT>
+__device__ __forceinline__ bf16x4 *t_quad(bf16_t *T, int n, int mt, int g) {
+    return reinterpret_cast<bf16x4 *>(T + t_off<MT>(n, 16 * mt + 4 * g));
+}
+__device__ __forceinline__ bf16x8 a_frag(const bf16_t *A, int ld, int row, int ks, int g) {
+    return *reinterpret_cast<const bf16x8 *>(A + row * ld + 32 * ks + 8 * g);
+}
+
+// rebuilds the fragment-major bf16 images of both nets from the f32 master weights ([in][out] flat layout)
+__global__ void build_bf16_images_kernel(float *params, PLayout L) {
+    const int D = L.D, H = L.H;
+    const int Kp1 = (D + 31) & ~31, KS1 = Kp1 / 32, KS2 = H / 32;
+    for (int net = 0; net < 2; net++) {
+        const int n_out = net == 0 ? L.A : 1;
+        const BfNet B = bf_net_layout(D, H, n_out);
+        bf16_t *img = reinterpret_cast<bf16_t *>(params + (net == 0 ? L.bf_pi : L.bf_vf));
+        const float *W1 = params + (net == 0 ? L.pW1t : L.vW1t), *W2 = params + (net == 0 ? L.pW2t : L.vW2t), *W3 = params + (net == 0 ? L.pW3t : L.vW3t);
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B.size; e += gridDim.x * blockDim.x) {
+            float v;
+            if (e < B.fW2) {
+                const int x = e - B.fW1, j = x & 7, l = (x >> 3) & 63, rest = x >> 9, ks = rest % KS1, nt = rest / KS1;
+                const int k = 32 * ks + 8 * (l >> 4) + j, n = 16 * nt + (l & 15);
+                v = k < D ? W1[k * H + n] : 0.0f;
+            } else if (e < B.bW2) {
+                const int x = e - B.fW2, j = x & 7, l = (x >> 3) & 63, rest = x >> 9, ks = rest % KS2, nt = rest / KS2;
+                v = W2[(32 * ks + 8 * (l >> 4) + j) * H + 16 * nt + (l & 15)];
+            } else if (e < B.fW3) {
+                const int x = e - B.bW2, j = x & 7, l = (x >> 3) & 63, rest = x >> 9, ns = rest % KS2, kt = rest / KS2;
+                v = W2[(16 * kt + (l & 15)) * H + 32 * ns + 8 * (l >> 4) + j];
+            } else if (e < B.bW3) {
+                const int x = e - B.fW3, j = x & 7, l = (x >> 3) & 63, rest = x >> 9, ks = rest % KS2, at = rest / KS2;
+                const int k = 32 * ks + 8 * (l >> 4) + j, a = 16 * at + (l & 15);
+                v = a < n_out ? W3[k * n_out + a] : 0.0f;
+            } else {
+                const int x = e - B.bW3, j = x & 7, l = (x >> 3) & 63, kt = x >> 9;
+                const int a = 8 * (l >> 4) + j;
+                v = a < n_out ? W3[(16 * kt + (l & 15)) * n_out + a] : 0.0f;
+            }
+            img[e] = (bf16_t)v;
+        }
+    }
+}
+
+// One hidden layer for this wave's NTW column tiles and all MT row tiles of the group:
+//   Aout[m][n] (and Tout[n][m]) = bf16(tanh(Ain[m][:] . W[:, n] + b[n])).   Ain: A image with KS k-steps of 32.
+template <int NTW, int MT, bool STORE_T>
+__device__ __forceinline__ void bf_hidden_layer(const bf16_t *Ain, int ldin, int KS, const bf16_t *__restrict__ Wimg, const float *__restrict__ bias,
+                                                bf16_t *Aout, int ldo, bf16_t *Tout, int n_base, int lane) {
+    const int r16 = lane & 15, g = lane >> 4, nt0 = n_base >> 4;
+    f32x4 acc[NTW][MT];
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const float b = bias[n_base + 16 * j + r16];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[j][mt] = f32x4{b, b, b, b};
+    }
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ks++) {
+        bf16x8 w[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; j++) w[j] = bf_frag(Wimg, (nt0 + j) * KS + ks, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const bf16x8 a = a_frag(Ain, ldin, 16 * mt + r16, ks, g);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][mt] = mfma_bf(a, w[j], acc[j][mt]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const int n = n_base + 16 * j + r16;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            bf16x4 q;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
+                Aout[(16 * mt + 4 * g + r) * ldo + n] = q[r];
+            }
+            if constexpr (STORE_T) *t_quad<MT>(Tout, n, mt, g) = q;
+        }
+    }
+}
+
+// head of one 16-row tile: acc[q] (C layout, column 16q + (lane&15)) = A2[tile rows][:] . W3 + b3.
+// Summation order = the gradient kernel's split-K head (four partial sums over k-steps ks = w, w + 4, ..., added to the bias
+// in wave order), so the log-probabilities of the rollout and of the first update epoch agree bit for bit.
+template <int NT3>
+__device__ __forceinline__ void bf_head(const bf16_t *A2, int ld, int row0, int KS2, const bf16_t *__restrict__ W3img, const float *__restrict__ b3,
+                                        int n_out, f32x4 (&acc)[NT3], int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 part[4][NT3];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int q = 0; q < NT3; q++) part[w][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int ks = w + 4 * i;
+            if (ks < KS2) {
+                const bf16x8 a = a_frag(A2, ld, row0 + r16, ks, g);
+#pragma unroll
+                for (int q = 0; q < NT3; q++) part[w][q] = mfma_bf(a, bf_frag(W3img, q * KS2 + ks, lane), part[w][q]);
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < NT3; q++) {
+        const int col = 16 * q + r16;
+        const float b = col < n_out ? b3[col] : 0.0f;
+        acc[q] = f32x4{b, b, b, b};
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc[q] += part[w][q];
+    }
+}
+
+struct BfNetPtr {
+    const bf16_t *fW1, *fW2, *bW2, *fW3, *bW3;
+};
+__device__ __forceinline__ BfNetPtr bf_net_ptr(const float *params, const PLayout &L, bool is_pi) {
+    const BfNet B = bf_net_layout(L.D, L.H, is_pi ? L.A : 1);
+    const bf16_t *img = reinterpret_cast<const bf16_t *>(params + (is_pi ? L.bf_pi : L.bf_vf));
+    return BfNetPtr{img + B.fW1, img + B.fW2, img + B.bW2, img + B.fW3, img + B.bW3};
+}
+
+// LDS bytes of the gradient kernel for a row group of M = 16*MT samples
+__host__ __device__ inline int grad_wide_bf_smem_bytes(int D, int H, int MT) {
+    const int M = 16 * MT, Kp1 = (D + 31) & ~31;
+    const int bf = M * (Kp1 + 16) + Kp1 * M + 2 * M * (H + 16) + 2 * H * M + M * 48 + 32 * M;
+    // + f32: dz3, meta, scratch, head partial sums [4 waves][MT][2][64][4], biases [2H + 32]; f64: stats [MT][4][5]; i64: row offsets x2
+    return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + MT * 4 * 5 * 8 + 2 * M * 8;
+}
+__host__ __device__ inline int fwd_wide_bf_smem_bytes(int D, int H) {
+    const int Kp1 = (D + 31) & ~31;
+    return (32 * (Kp1 + 16) + 2 * 32 * (H + 16)) * 2;
+}
+
+// Gradient of one minibatch for ONE net, persistent over row groups of M = 16*MT samples.
+//
+// Latency plan (one wave per SIMD, so nothing but this wave's own loads in flight hides the L2 round trip):
+//   * the two H x H weight streams of a group (layer-2 forward fragments, then layer-2 input-gradient fragments) are the
+//     same for every group, so they run through a register ring of R = 4*NTW fragments: the slot a fragment is consumed
+//     from is reloaded at once with the fragment R positions further down the (cyclic) stream -- four k-steps of lookahead
+//     that carry across phases, barriers and groups;
+//   * group-invariant small operands stay in registers for the whole launch (layer-1 fragments when D <= 32, the head's
+//     input-gradient fragments); the head's forward fragments are fetched behind the layer-2 epilogue;
+//   * the NEXT group's sample metadata and observation rows are gathered into registers while this group computes and
+//     committed to LDS at the top of the next iteration (KS1C > 0: compile-time observation width).
+// KT1C: 16-row k-tiles of dW1 kept in registers (0: accumulated in the slab);  KS1C: compile-time layer-1 k-steps (0: runtime).
+template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C>
+__device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                                  const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
+                                                  double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net) {
+    constexpr int M = 16 * MT, MK = MT / 2, H = 64 * NTW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
+    constexpr int R = 4 * NTW, SL = 2 * KS2 * NTW;
+    constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
+    constexpr int NX = PF ? 2 * MT * KS1C : 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
+    const int r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, A = L.A;
+    const int NOUT = IS_PI ? A : 1;
+    const int Kp1 = KS1C > 0 ? 32 * KS1C : ((D + 31) & ~31), KS1 = Kp1 >> 5, KT1 = Kp1 >> 4, ldx = Kp1 + 16;
+    constexpr bool acc_w1 = KT1C > 0;
+    constexpr int KT1A = KT1C > 0 ? KT1C : 1;
+    bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *Xt = Xa + M * ldx, *A1 = Xt + Kp1 * M, *A2 = A1 + M * lda;
+    bf16_t *T1 = A2 + M * lda, *T2 = T1 + H * M, *Z3a = T2 + H * M, *Z3t = Z3a + M * ldz;
+    float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M), *meta = dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
+    float *hpart = scratch + 128;              // [4 waves][MT][2][64 lanes][4]: split-K partial head outputs
+    float *bias = hpart + 4 * MT * 2 * 256;    // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
+    double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [MT][4][5] loss statistics (lanes r16 == 0 of the head waves)
+    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + MT * 4 * 5), *row_off_next = row_off + M;
+    const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
+    const float invB = 1.0f / (float)mb.count;
+    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
+    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
+    BfNetPtr W = bf_net_ptr(params, L, IS_PI);
+    const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
+    float ab1[NTW], ab2[NTW], ab3 = 0.0f, dlsd[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        ab1[j] = ab2[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KT1A; i++) aW1[i][j] = z4;
+#pragma unroll
+        for (int i = 0; i < KT2; i++) aW2[i][j] = z4;
+#pragma unroll
+        for (int q = 0; q < NT3; q++) aW3[j][q] = z4;
+    }
+    for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
+        bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
+    if (threadIdx.x < MT * 4 * 5) stat_lds[threadIdx.x] = 0.0;
+    // ---- weight operands: ring over the two H x H streams, resident small fragments ----
+    int nt0l = nt0;  // laundered copy (see the asm in the group loop): keeps the fragment address arithmetic scalar and inside the loop
+    auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
+        if (s < SL / 2) return bf_frag(W.fW2, (nt0l + s % NTW) * KS2 + s / NTW, lane);
+        const int t = s - SL / 2;
+        return bf_frag(W.bW2, (nt0l + t % NTW) * KS2 + t / NTW, lane);
+    };
+    bf16x8 ring[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) ring[s] = sload(s);
+    // ---- prefetch registers for the next group's samples ----
+    float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
+    int64_t poff = -1;
+    auto fetch_meta = [&](int64_t grp) {
+        if (threadIdx.x < M) {
+            const int64_t j = grp * M + threadIdx.x;
+            poff = -1, pm0 = pm1 = pm2 = pm3 = 0.0f;
+            if (j < mb.count) {
+                poff = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
+                if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
+            }
+            row_off_next[threadIdx.x] = poff;
+        }
+    };
+    auto fetch_obs = [&]() {  // rows named by row_off_next (visible after a barrier)
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int e = threadIdx.x + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const int64_t off = row_off_next[row];
+                px[i] = (off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f;
+            }
+        }
+    };
+    const int64_t n_groups = (mb.count + M - 1) / M;
+    if (block_net < n_groups) {
+        fetch_meta(block_net);
+        __syncthreads();
+        fetch_obs();
+    }
+    for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
+        // The weight images do not change during the launch, so every fragment load below is loop-invariant and LICM would
+        // hoist all of them out of the group loop -- i.e. try to keep ~1 KiB per lane of weights "in registers" and spill
+        // them to scratch.  Laundering the (uniform) image pointers once per iteration keeps the loads where they are written.
+        // (The wave's tile index is laundered too: otherwise the invariant per-fragment offsets are hoisted as 64-bit VGPR pairs.)
+        W.fW1 = launder_uniform(W.fW1), W.fW2 = launder_uniform(W.fW2), W.bW2 = launder_uniform(W.bW2), W.fW3 = launder_uniform(W.fW3);
+        W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l);
+        // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
+        bf16x8 w1r[NTW];  // layer-1 fragments of this wave: issued now, consumed after the commit and its barrier
+        if constexpr (KS1C == 1) {
+#pragma unroll
+            for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0l + j, lane);
+        }
+        if (threadIdx.x < M) {
+            meta[threadIdx.x * 4 + 0] = pm0, meta[threadIdx.x * 4 + 1] = pm1, meta[threadIdx.x * 4 + 2] = pm2, meta[threadIdx.x * 4 + 3] = pm3;
+            row_off[threadIdx.x] = poff;
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int e = threadIdx.x + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const bf16_t v = (bf16_t)px[i];
+                Xa[row * ldx + c] = v;
+                Xt[t_off<MT>(c, row)] = v;
+            }
+        } else {
+            __syncthreads();
+            for (int e = threadIdx.x; e < M * Kp1; e += blockDim.x) {
+                const int row = e / Kp1, c = e - row * Kp1;
+                const int64_t off = row_off[row];
+                const bf16_t v = (bf16_t)((off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f);
+                Xa[row * ldx + c] = v;
+                Xt[t_off<MT>(c, row)] = v;
+            }
+        }
+        __syncthreads();
+#ifdef TMA_BF_PHASE_DEBUG
+        const int dbg = hp.debug;  // timing attribution builds only: skipping phases perturbs register allocation
+#else
+        constexpr int dbg = 0;
+#endif
+        const bool has_next = grp + n_blocks_net < n_groups && !(dbg & 1);  // block-uniform
+        if (has_next) fetch_meta(grp + n_blocks_net);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P1: layer 1 forward ----
+        if (!(dbg & 64)) {
+            f32x4 acc[NTW][MT];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const float b = bias[n_base + 16 * j + r16];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[j][mt] = f32x4{b, b, b, b};
+            }
+            if constexpr (KS1C == 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const bf16x8 a = a_frag(Xa, ldx, 16 * mt + r16, 0, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) acc[j][mt] = mfma_bf(a, w1r[j], acc[j][mt]);
+                }
+            } else {
+#pragma unroll 2
+                for (int ks = 0; ks < KS1; ks++) {
+                    bf16x8 w[NTW];
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) w[j] = bf_frag(W.fW1, (nt0l + j) * KS1 + ks, lane);
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const bf16x8 a = a_frag(Xa, ldx, 16 * mt + r16, ks, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) acc[j][mt] = mfma_bf(a, w[j], acc[j][mt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const int n = n_base + 16 * j + r16;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
+                        A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    }
+                    *t_quad<MT>(T1, n, mt, g) = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (has_next) fetch_obs();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P2: layer 2 forward through the weight ring ----
+        constexpr int HK = (KS2 + 3) / 4;  // head k-steps per wave (split-K over the four waves: ks = wave, wave + 4, ...)
+        bf16x8 w3f[HK * NT3];
+        if (!(dbg & 32)) {
+            f32x4 acc[NTW][MT];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const float b = bias[H + n_base + 16 * j + r16];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[j][mt] = f32x4{b, b, b, b};
+            }
+            bf16x8 a[2][MT];  // A fragments one k-step ahead (the scheduler is fenced per k-step: the pipeline below is explicit)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                if (ks + 1 < KS2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) a[(ks + 1) & 1][mt] = a_frag(A1, lda, 16 * mt + r16, ks + 1, g);
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const int s = ks * NTW + j;
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[ks & 1][mt], ring[s % R], acc[j][mt]);
+                    ring[s % R] = sload((s + R) % SL);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the epilogue and the barrier
+#pragma unroll
+                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (wave + 4 * i < KS2 ? wave + 4 * i : 0), lane);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const int n = n_base + 16 * j + r16;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
+                        A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    }
+                    *t_quad<MT>(T2, n, mt, g) = q;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P3a: split-K head: every wave multiplies its k-steps of h2 for all row tiles, partial sums through LDS ----
+        bf16x8 w3b[NTW];  // head input-gradient fragments for P4, in flight behind the head
+#pragma unroll
+        for (int j = 0; j < NTW; j++) w3b[j] = bf_frag(W.bW3, nt0l + j, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                f32x4 part[NT3];
+#pragma unroll
+                for (int q = 0; q < NT3; q++) part[q] = z4;
+#pragma unroll
+                for (int i = 0; i < HK; i++) {
+                    const int ks = wave + 4 * i;
+                    if (ks < KS2) {
+                        const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                        for (int q = 0; q < NT3; q++) part[q] = mfma_bf(a, w3f[i * NT3 + q], part[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * MT + mt) * 2 + q) * 64 + lane) * 4) = part[q];
+            }
+        }
+        __syncthreads();
+        // ---- P3b: loss on row tile `wave`; dz3 as bf16 in both layouts ----
+        if (wave < MT && !(dbg & 4)) {
+            const int mt = wave;
+            f32x4 out[NT3];
+#pragma unroll
+            for (int q = 0; q < NT3; q++) {
+                const float b = bias[2 * H + 16 * q + r16];
+                out[q] = f32x4{b, b, b, b};
+#pragma unroll
+                for (int w = 0; w < 4; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * MT + mt) * 2 + q) * 64 + lane) * 4);
+            }
+            LossStats st;
+            float *dzt = dz3 + mt * 16 * ld3;
+            if constexpr (IS_PI) {
+                policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
+                                       lane);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = g * 4 + r;
+                    const bool valid = row_off[mt * 16 + row] >= 0;
+                    const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
+                    dzt[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                    if (valid && r16 == 0) st.a += (double)(diff * diff);
+                }
+            }
+            if (r16 == 0) {  // only these lanes carry statistics (policy_loss_tile / the value branch accumulate under r16 == 0)
+                double *sl = stat_lds + (mt * 4 + g) * 5;
+                sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
+            }
+            {  // Z3a[m][a]: lane = (row, 8-column chunk)
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int a = 8 * g + j;
+                    v[j] = (bf16_t)(a < 16 * NT3 ? dzt[r16 * ld3 + a] : 0.0f);
+                }
+                *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
+            }
+            {  // Z3t[a][m]: lane = (a, 8-sample half of the tile); the f32 column sum feeds the head bias gradient
+                const int a = lane & 31, half = lane >> 5;
+                bf16x8 v;
+                float c = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float x = a < 16 * NT3 ? dzt[(8 * half + j) * ld3 + a] : 0.0f;
+                    c += x;
+                    v[j] = (bf16_t)x;
+                }
+                ab3 += c;
+                *reinterpret_cast<bf16x8 *>(Z3t + t_off<MT>(a, 16 * mt + 8 * half)) = v;
+            }
+        }
+        __syncthreads();
+        // ---- P4: head weight gradient (this wave's k rows); dz2 = (dz3 . W3^T) * (1 - h2^2) in place in A2 / T2 ----
+        if (!(dbg & 16)) {
+#pragma unroll
+            for (int kk = 0; kk < MK; kk++) {
+                bf16x8 zb[NT3];
+#pragma unroll
+                for (int q = 0; q < NT3; q++) zb[q] = t_frag<MT>(Z3t, 16 * q + r16, kk, g);
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    const bf16x8 a = t_frag<MT>(T2, n_base + 16 * i + r16, kk, g);
+#pragma unroll
+                    for (int q = 0; q < NT3; q++) aW3[i][q] = mfma_bf(a, zb[q], aW3[i][q]);
+                }
+            }
+            bf16x8 za[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) za[mt] = *reinterpret_cast<const bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                const int n = n_base + 16 * j + r16;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const f32x4 dh = mfma_bf(za[mt], w3b[j], z4);
+                    bf16x4 *tq = t_quad<MT>(T2, n, mt, g);
+                    const bf16x4 h4 = *tq;
+                    bf16x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float h = (float)h4[r];
+                        const float dz = dh[r] * (1.0f - h * h);
+                        ab2[j] += dz;
+                        q[r] = (bf16_t)dz;
+                        A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    }
+                    *tq = q;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dh1 = dz2 . W2^T for this wave's columns (weight ring) ----
+        f32x4 dh1[NTW][MT];
+#pragma unroll
+        for (int j = 0; j < NTW; j++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) dh1[j][mt] = z4;
+        if (!(dbg & 2)) {
+            bf16x8 zb[NTW][MK];
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T2, n_base + 16 * j + r16, kk, g);
+            bf16x8 ta[4][MK];  // T1 fragments three k-tiles ahead
+#pragma unroll
+            for (int kt = 0; kt < 3; kt++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) ta[kt][kk] = t_frag<MT>(T1, 16 * kt + r16, kk, g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < KT2; kt++) {
+                if (kt + 3 < KT2) {
+#pragma unroll
+                    for (int kk = 0; kk < MK; kk++) ta[(kt + 3) & 3][kk] = t_frag<MT>(T1, 16 * (kt + 3) + r16, kk, g);
+                }
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma_bf(ta[kt & 3][kk], zb[j][kk], aW2[kt][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) dh1[j][mt] = z4;
+            bf16x8 a[2][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
+#pragma unroll
+            for (int ns = 0; ns < KS2; ns++) {
+                if (ns + 1 < KS2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) a[(ns + 1) & 1][mt] = a_frag(A2, lda, 16 * mt + r16, ns + 1, g);
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    const int s = SL / 2 + ns * NTW + j;
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) dh1[j][mt] = mfma_bf(a[ns & 1][mt], ring[s % R], dh1[j][mt]);
+                    ring[s % R] = sload((s + R) % SL);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // every wave is done with T1 (all rows) and A2
+        // ---- P6: dz1 = dh1 * (1 - h1^2) in place in T1 (own rows);  dW1 slice += X^T . dz1[:, slice] ----
+        if (!(dbg & 8))
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+            const int n = n_base + 16 * j + r16;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                bf16x4 *tq = t_quad<MT>(T1, n, mt, g);
+                const bf16x4 h4 = *tq;
+                bf16x4 q;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float h = (float)h4[r];
+                    const float dz = dh1[j][mt][r] * (1.0f - h * h);
+                    ab1[j] += dz;
+                    q[r] = (bf16_t)dz;
+                }
+                *tq = q;
+            }
+        }
+        {
+            bf16x8 zb[NTW][MK];
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T1, n_base + 16 * j + r16, kk, g);
+            if constexpr (acc_w1) {
+#pragma unroll
+                for (int kt = 0; kt < KT1A; kt++)
+#pragma unroll
+                    for (int kk = 0; kk < MK; kk++) {
+                        const bf16x8 a = t_frag<MT>(Xt, 16 * kt + r16, kk, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) aW1[kt][j] = mfma_bf(a, zb[j][kk], aW1[kt][j]);
+                    }
+            } else {
+                float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t);
+                for (int kt = 0; kt < KT1; kt++) {
+                    f32x4 t[NTW];
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) t[j] = z4;
+#pragma unroll
+                    for (int kk = 0; kk < MK; kk++) {
+                        const bf16x8 a = t_frag<MT>(Xt, 16 * kt + r16, kk, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) t[j] = mfma_bf(a, zb[j][kk], t[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int k = kt * 16 + g * 4 + r;
+                            if (k < D) gW1[(int64_t)k * H + n_base + 16 * j + r16] += t[j][r];  // this wave is the only writer of these slab columns
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
+    float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
+    float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);
+    float *gW3 = slab + (IS_PI ? L.pW3t : L.vW3t), *gb3 = slab + (IS_PI ? L.pb3 : L.vb3);
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const int col = n_base + 16 * j + r16;
+#pragma unroll
+        for (int kt = 0; kt < KT2; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+        if constexpr (acc_w1) {
+#pragma unroll
+            for (int kt = 0; kt < KT1A; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = kt * 16 + g * 4 + r;
+                    if (k < D) gW1[(int64_t)k * H + col] = aW1[kt][j][r];
+                }
+        }
+        float v1 = ab1[j], v2 = ab2[j];
+        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+        v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
+        if (g == 0) gb1[col] = v1, gb2[col] = v2;
+#pragma unroll
+        for (int q = 0; q < NT3; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
+                if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
+            }
+    }
+    // head bias gradient / log_std gradient / loss statistics: partial sums of the MT head waves folded through LDS
+    __syncthreads();
+    {
+        float v = ab3;
+        v += __shfl_xor(v, 32, 64);  // lanes a and a + 32 hold the two halves of a tile's column sum
+        float v0 = dlsd[0], v1 = dlsd[1];
+        v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
+        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+        if (wave < MT) {
+            if (lane < 32) scratch[wave * 32 + lane] = v;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 32) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < MT; w++) s += scratch[w * 32 + lane];
+            if (lane < NOUT) gb3[lane] = s;
+        }
+        __syncthreads();
+        if constexpr (IS_PI && CONT) {
+            if (wave < MT && g == 0) scratch[wave * 32 + r16] = v0, scratch[wave * 32 + 16 + r16] = v1;
+            __syncthreads();
+            if (wave == 0 && lane < 32) {
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < MT; w++) s += scratch[w * 32 + lane];
+                if (lane < A) slab[L.log_std + lane] = s;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double ssum = 0.0;
+        for (int w = 0; w < MT * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += ssum;
+    }
+}
+
+template <bool CONT, int NTW, int MT, int KT1C, int KS1C>
+__global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                                  const float *__restrict__ ws_adv, float *__restrict__ slabs,
+                                                                  double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bf[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    float *slab = slabs + (int64_t)pair * L.P;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if ((blockIdx.x & 1) == 0) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, n_pairs, pair);
+    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, n_pairs, pair);
+}

@@ -57,8 +57,11 @@ def _hidden_from_net_arch(net_arch) -> int:
 class HipActorCriticPolicy:
     """Parameters of SB3's ActorCriticPolicy(MlpPolicy) in one flat HBM buffer + the forward kernels."""
 
-    def __init__(self, obs_dim: int, act_dim: int, continuous: bool, hidden: int, device, seed: int = 0):
-        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0)
+    def __init__(self, obs_dim: int, act_dim: int, continuous: bool, hidden: int, device, seed: int = 0, mfma_dtype: str = "f32"):
+        if mfma_dtype not in ("f32", "bf16"):
+            raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', got {mfma_dtype!r}")
+        self.mfma_dtype = mfma_dtype
+        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0, 1 if mfma_dtype == "bf16" else 0)
         self.obs_dim, self.act_dim, self.continuous, self.hidden = int(obs_dim), int(act_dim), bool(continuous), int(hidden)
         self.device = torch.device(device)
         nt, ntot = C.c_int64(0), C.c_int64(0)
@@ -191,7 +194,9 @@ class PPO:
         H = _hidden_from_net_arch(self.policy_kwargs.get("net_arch"))
         cont = eng.num_actions == 0
         A = eng.act_dim if cont else eng.num_actions
-        self.policy = HipActorCriticPolicy(eng.obs_dim, A, cont, H, self.device, seed=self.seed)
+        # policy_kwargs["mfma_dtype"] = "bf16" (engine extension; BASELINE.json configs[2]): bf16 MFMA operands for 128..256-wide nets
+        self.policy = HipActorCriticPolicy(eng.obs_dim, A, cont, H, self.device, seed=self.seed,
+                                           mfma_dtype=self.policy_kwargs.get("mfma_dtype", "f32"))
         env.seed(self.seed)  # BaseAlgorithm.set_random_seed -> env.seed(seed): env i gets seed + i
         T, N, D, dev = self.n_steps, self.n_envs, eng.obs_dim, self.device
         f32 = torch.float32
@@ -409,6 +414,9 @@ class PPO:
         if sd["mlp_extractor.policy_net.2.weight"].shape != (data["hidden"], data["hidden"]) or sd["mlp_extractor.value_net.0.weight"].shape != w1.shape:
             raise ValueError("unsupported net_arch in policy zip: the engine needs two equal hidden layers for pi and vf")
 
+        pk = data.get("policy_kwargs")
+        mfma = pk.get("mfma_dtype", "f32") if isinstance(pk, dict) else "f32"
+
         def _num(key, default):
             v = data.get(key, default)
             return default if isinstance(v, dict) or v is None else v  # SB3 stores schedules as pickled objects
@@ -418,7 +426,7 @@ class PPO:
                     n_epochs=_num("n_epochs", 10), gamma=_num("gamma", 0.99), gae_lambda=_num("gae_lambda", 0.95), clip_range=_num("clip_range", 0.2),
                     normalize_advantage=_num("normalize_advantage", True), ent_coef=_num("ent_coef", 0.0), vf_coef=_num("vf_coef", 0.5),
                     max_grad_norm=_num("max_grad_norm", 0.5),
-                    policy_kwargs={"net_arch": [data["hidden"], data["hidden"]]}, seed=_num("seed", 0), _init_setup_model=False)
+                    policy_kwargs={"net_arch": [data["hidden"], data["hidden"]], "mfma_dtype": mfma}, seed=_num("seed", 0), _init_setup_model=False)
         model.num_timesteps, model._n_updates, model._adam_step = data.get("num_timesteps", 0), data.get("_n_updates", 0), data.get("_adam_step", 0)
         if env is not None:
             model.env = env
@@ -433,7 +441,7 @@ class PPO:
 
             dev = _require_gpu(None if device == "auto" else device)
             model.device = dev
-            model.policy = HipActorCriticPolicy(data["obs_dim"], data["act_dim"], data["continuous"], data["hidden"], dev, seed=0)
+            model.policy = HipActorCriticPolicy(data["obs_dim"], data["act_dim"], data["continuous"], data["hidden"], dev, seed=0, mfma_dtype=mfma)
             model.policy.load_state_dict(sd)
         return model
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time one tma_ppo_minibatch_grad launch group and one tma_policy_act launch (HIP events) for a task / width / MFMA dtype.
+usage: time_grad.py [task hidden dtype batch]..."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from three_mlagents_amd import _lib
+from three_mlagents_amd.ppo import PPO
+from three_mlagents_amd.training import make_vector_env
+
+
+def med_us(fn, reps=30, group=4):
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(group):
+            fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 / group for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+args = sys.argv[1:] or ["ball3d", "256", "bf16", "131072"]
+for i in range(0, len(args), 4):
+    task, H, dt, B = args[i], int(args[i + 1]), args[i + 2], int(args[i + 3])
+    env = make_vector_env(task, n_envs=4096, seed=1)
+    m = PPO("MlpPolicy", env, n_steps=max(32, B // 4096), batch_size=B, n_epochs=1, seed=1, policy_kwargs={"net_arch": [H, H], "mfma_dtype": dt})
+    m.collect_rollouts()
+    mb = _lib.Minibatch(None, 1, 0, 0, B)
+    L = _lib.lib()
+
+    def grad():
+        _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(m.policy.params), C.byref(m.policy.dims), C.byref(m._rollout_view), C.byref(mb), C.byref(m._hp),
+                                            _lib.ptr(m.grad), _lib.ptr(m.workspace), m._stream()))
+
+    obs = m.buf["obs"][0]
+
+    def act():
+        m.policy.act(obs, rng_seed=1, rng_step=0)
+
+    for _ in range(3):
+        grad(), act()
+    print(f"{task} H={H} {dt} B={B}: grad {med_us(grad):.1f} us   act(4096) {med_us(act):.1f} us", flush=True)
