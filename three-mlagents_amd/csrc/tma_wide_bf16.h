@@ -223,8 +223,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     constexpr int R = 4 * NTW, SL = 2 * KS2 * NTW;
     constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
     constexpr int NX = PF ? 2 * MT * KS1C : 1;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
-    const int r16 = lane & 15, g = lane >> 4;
+    const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
+    // Every lane-derived LDS / global address in the group loop is loop-invariant; hoisted, there are far more of them than
+    // registers and they come back as scratch reloads -- each one an s_waitcnt vmcnt(0) that drains the weight prefetch.
+    // TMA_RELANE at the head of a phase re-derives lane / r16 / g from an opaque copy, so the addresses of that phase are
+    // computed there (a few VALU instructions) and die with it.
+    int lane = lane0, r16 = lane0 & 15, g = lane0 >> 4;
+#define TMA_RELANE()                       \
+    do {                                   \
+        lane = lane0;                      \
+        asm volatile("" : "+v"(lane));     \
+        r16 = lane & 15, g = lane >> 4;    \
+    } while (0)
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int Kp1 = KS1C > 0 ? 32 * KS1C : ((D + 31) & ~31), KS1 = Kp1 >> 5, KT1 = Kp1 >> 4, ldx = Kp1 + 16;
@@ -272,16 +282,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // ---- prefetch registers for the next group's samples ----
     float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
+    const int mrow = wave * (M / 4) + lane0;  // sample row whose metadata this lane gathers (lanes < M/4 of every wave: the Feistel
+    const bool mlane = lane0 < M / 4;         // permutation arithmetic is spread over the four waves instead of skewing wave 0)
     auto fetch_meta = [&](int64_t grp) {
-        if (threadIdx.x < M) {
-            const int64_t j = grp * M + threadIdx.x;
+        if (mlane) {
+            const int64_t j = grp * M + mrow;
             poff = -1, pm0 = pm1 = pm2 = pm3 = 0.0f;
             if (j < mb.count) {
                 poff = sample_offset(mb, mb.start + j, rb.T, rb.N);
                 pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
                 if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
             }
-            row_off_next[threadIdx.x] = poff;
+            row_off_next[mrow] = poff;
         }
     };
     auto fetch_obs = [&]() {  // rows named by row_off_next (visible after a barrier)
@@ -307,15 +319,16 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         // (The wave's tile index is laundered too: otherwise the invariant per-fragment offsets are hoisted as 64-bit VGPR pairs.)
         W.fW1 = launder_uniform(W.fW1), W.fW2 = launder_uniform(W.fW2), W.bW2 = launder_uniform(W.bW2), W.fW3 = launder_uniform(W.fW3);
         W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l);
+        TMA_RELANE();
         // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
         bf16x8 w1r[NTW];  // layer-1 fragments of this wave: issued now, consumed after the commit and its barrier
         if constexpr (KS1C == 1) {
 #pragma unroll
             for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0l + j, lane);
         }
-        if (threadIdx.x < M) {
-            meta[threadIdx.x * 4 + 0] = pm0, meta[threadIdx.x * 4 + 1] = pm1, meta[threadIdx.x * 4 + 2] = pm2, meta[threadIdx.x * 4 + 3] = pm3;
-            row_off[threadIdx.x] = poff;
+        if (mlane) {
+            meta[mrow * 4 + 0] = pm0, meta[mrow * 4 + 1] = pm1, meta[mrow * 4 + 2] = pm2, meta[mrow * 4 + 3] = pm3;
+            row_off[mrow] = poff;
         }
         if constexpr (PF) {
 #pragma unroll
@@ -342,8 +355,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         constexpr int dbg = 0;
 #endif
         const bool has_next = grp + n_blocks_net < n_groups && !(dbg & 1);  // block-uniform
-        if (has_next) fetch_meta(grp + n_blocks_net);
-        __builtin_amdgcn_sched_barrier(0);
+        TMA_RELANE();
         // ---- P1: layer 1 forward ----
         if (!(dbg & 64)) {
             f32x4 acc[NTW][MT];
@@ -390,8 +402,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
-        if (has_next) fetch_obs();
-        __builtin_amdgcn_sched_barrier(0);
+        TMA_RELANE();
         // ---- P2: layer 2 forward through the weight ring ----
         constexpr int HK = (KS2 + 3) / 4;  // head k-steps per wave (split-K over the four waves: ks = wave, wave + 4, ...)
         bf16x8 w3f[HK * NT3];
@@ -425,6 +436,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the epilogue and the barrier
 #pragma unroll
                 for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (wave + 4 * i < KS2 ? wave + 4 * i : 0), lane);
+            // Next group's sample gathers (HBM-latency loads) go out HERE and at the top of P3: vmcnt retires in order, so the
+            // first wait on a load issued after them also waits for them -- and from here on P3 / P4 / the first half of P5 only
+            // consume fragments that are already in flight.
+            if (has_next) fetch_meta(grp + n_blocks_net);
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 const int n = n_base + 16 * j + r16;
@@ -441,10 +456,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P3a: split-K head: every wave multiplies its k-steps of h2 for all row tiles, partial sums through LDS ----
         bf16x8 w3b[NTW];  // head input-gradient fragments for P4, in flight behind the head
 #pragma unroll
         for (int j = 0; j < NTW; j++) w3b[j] = bf_frag(W.bW3, nt0l + j, lane);
+        if (has_next) fetch_obs();
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 4)) {
 #pragma unroll
@@ -466,6 +483,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P3b: loss on row tile `wave`; dz3 as bf16 in both layouts ----
         if (wave < MT && !(dbg & 4)) {
             const int mt = wave;
@@ -520,6 +538,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P4: head weight gradient (this wave's k rows); dz2 = (dz3 . W3^T) * (1 - h2^2) in place in A2 / T2 ----
         if (!(dbg & 16)) {
 #pragma unroll
@@ -559,6 +578,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dh1 = dz2 . W2^T for this wave's columns (weight ring) ----
         f32x4 dh1[NTW][MT];
 #pragma unroll
@@ -589,10 +609,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma_bf(ta[kt & 3][kk], zb[j][kk], aW2[kt][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int j = 0; j < NTW; j++)
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) dh1[j][mt] = z4;
+            TMA_RELANE();
             bf16x8 a[2][MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
@@ -613,6 +630,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();  // every wave is done with T1 (all rows) and A2
+        TMA_RELANE();
         // ---- P6: dz1 = dh1 * (1 - h1^2) in place in T1 (own rows);  dW1 slice += X^T . dz1[:, slice] ----
         if (!(dbg & 8))
 #pragma unroll
@@ -672,6 +690,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
         __syncthreads();
     }
+#undef TMA_RELANE
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
     float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
     float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);
