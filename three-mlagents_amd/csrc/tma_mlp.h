@@ -332,19 +332,44 @@ __device__ __forceinline__ f32x4 value_tile_lds(const float *vimg, const float *
     return dense64_head_lds(h2, ld, vimg + IMG_W3F, vimg + IMG_FWD_FLOATS + 128, lane);
 }
 
-// reductions inside one 16-lane group (lanes sharing lane>>4): xor masks 1,2,4,8 never leave the group
+// reductions inside one 16-lane group (lanes sharing lane>>4) as DPP row operations -- VALU only, no ds_bpermute round trip
+// through the LDS (what __shfl_xor compiles to: ~100 cycles and an lgkmcnt wait per step, 16 dependent steps per softmax row).
+// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 exchanges; after them every lane of a quad holds the quad's value, so
+// row_half_mirror (lane i <- 7-i) delivers the other quad of the half and row_mirror (i <- 15-i) the other half: the same
+// pairing, hence bit-for-bit the same result, as the xor-1/2/4/8 butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float gsum16(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_row<0xB1>(v);
+    v += dpp_row<0x4E>(v);
+    v += dpp_row<0x141>(v);
+    v += dpp_row<0x140>(v);
     return v;
 }
+__device__ __forceinline__ float gmin16(float v) {
+    v = fminf(v, dpp_row<0xB1>(v));
+    v = fminf(v, dpp_row<0x4E>(v));
+    v = fminf(v, dpp_row<0x141>(v));
+    v = fminf(v, dpp_row<0x140>(v));
+    return v;
+}
+// inclusive prefix sum over the 16 lanes of a group: row_shr:d with bound_ctrl feeds 0 to lanes whose source leaves the row
+__device__ __forceinline__ float gscan16(float c) {
+    c += dpp_row<0x111>(c);
+    c += dpp_row<0x112>(c);
+    c += dpp_row<0x114>(c);
+    c += dpp_row<0x118>(c);
+    return c;
+}
+// value of the group's first lane (lane & 15 == 0), valid in the lanes of the group's first quad (lane & 15 < 4)
+__device__ __forceinline__ float gfirst_quad(float v) { return dpp_row<0x00>(v); }
 __device__ __forceinline__ float gmax16(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64));
-    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, dpp_row<0xB1>(v));
+    v = fmaxf(v, dpp_row<0x4E>(v));
+    v = fmaxf(v, dpp_row<0x141>(v));
+    v = fmaxf(v, dpp_row<0x140>(v));
     return v;
 }
 

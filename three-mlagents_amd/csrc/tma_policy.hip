@@ -29,6 +29,7 @@ constexpr int MAX_GRAD_BLOCKS = 2048;
 constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
 constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
 constexpr int64_t WS_BYTES = WS_SLABS;
+constexpr int64_t OFFS_CAP = 1 << 22;  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -181,25 +182,17 @@ __global__ __launch_bounds__(256) void policy_fwd_kernel(const float *__restrict
                     if (deterministic) {
                         const float cand = (colok && x == m) ? (float)r16 : 99.0f;
                         float mn = cand;
-                        mn = fminf(mn, __shfl_xor(mn, 1, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 2, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 4, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                        mn = gmin16(mn);
                         act = (int)mn;
                     } else {
-                        float c = e / s;
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) {
-                            const float up = __shfl_up(c, d, 16);
-                            if (r16 >= d) c += up;
-                        }
+                        const float c = gscan16(e / s);
                         const uint32_t gi = env_offset + (uint32_t)row;
                         const float u = uniform01(mix32(rng_seed, gi, rng_step));
                         const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
                         act = min((int)cnt, A - 1);
                     }
                     const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                    const float vrow = __shfl(vacc[0][r], lane & 48, 64);  // value sits in column 0 of the group
+                    const float vrow = gfirst_quad(vacc[0][r]);  // value sits in column 0 of the group
                     if (r16 == r && row < n) {
                         static_cast<int32_t *>(actions_out)[row] = act;
                         logp_out[row] = lpa;
@@ -233,7 +226,7 @@ __global__ __launch_bounds__(256) void policy_fwd_kernel(const float *__restrict
                         }
                     }
                     lpsum = gsum16(lpsum);
-                    const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                    const float vrow = gfirst_quad(vacc[0][r]);
                     if (r16 == r && row < n) {
                         logp_out[row] = lpsum;
                         values_out[row] = vrow;
@@ -251,6 +244,8 @@ struct Minibatch {
     const int64_t *indices;  // optional explicit flat (env-major: f = i*T + t) indices
     uint32_t perm_seed, perm_epoch;
     int64_t start, count, total;  // rows [start, start+count) of the permuted buffer of `total` samples
+    const int32_t *offs;          // optional: offs[j] = buffer offset of minibatch row j (written by adv_partial_kernel), saves the
+                                  // permutation arithmetic in the gradient kernel
 };
 
 __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {
@@ -261,13 +256,16 @@ __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j,
 
 // pass 1: up to ADV_BLOCKS blocks, each sums a contiguous slice of the (permuted) minibatch -> (sum, sum of squares) partials
 constexpr int ADV_BLOCKS = 128;
-__global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, double *partials) {
+__global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, double *partials,
+                                                          int32_t *__restrict__ offs_out) {
     __shared__ double s1[4], s2[4];
     const int64_t per = (mb.count + gridDim.x - 1) / gridDim.x;
     const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < mb.count) ? j0 + per : mb.count;
     double a = 0.0, b = 0.0;
     for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
-        const double x = (double)adv[sample_offset(mb, mb.start + j, T, N)];
+        const int64_t off = sample_offset(mb, mb.start + j, T, N);
+        if (offs_out) offs_out[j] = (int32_t)off;
+        const double x = (double)adv[off];
         a += x;
         b += x * x;
     }
@@ -1433,24 +1431,16 @@ __global__ __launch_bounds__(256) void policy_fwd_h64_kernel(const float *__rest
                     int act;
                     if (deterministic) {
                         float mn = (colok && x == m) ? (float)r16 : 99.0f;
-                        mn = fminf(mn, __shfl_xor(mn, 1, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 2, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 4, 64));
-                        mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                        mn = gmin16(mn);
                         act = (int)mn;
                     } else {
-                        float c = e / s;
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) {
-                            const float up = __shfl_up(c, d, 16);
-                            if (r16 >= d) c += up;
-                        }
+                        const float c = gscan16(e / s);
                         const float u = uniform01(mix32(rng_seed, env_offset + (uint32_t)row, rng_step));
                         const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
                         act = min((int)cnt, A - 1);
                     }
                     const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                    const float vrow = __shfl(vacc[r], lane & 48, 64);
+                    const float vrow = gfirst_quad(vacc[r]);
                     if (r16 == r && row < n) {
                         actions_out[row] = act;
                         logp_out[row] = lpa;
@@ -1643,24 +1633,16 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                         int act;
                         if (deterministic) {
                             float mn = (colok && x == m) ? (float)r16 : 99.0f;
-                            mn = fminf(mn, __shfl_xor(mn, 1, 64));
-                            mn = fminf(mn, __shfl_xor(mn, 2, 64));
-                            mn = fminf(mn, __shfl_xor(mn, 4, 64));
-                            mn = fminf(mn, __shfl_xor(mn, 8, 64));
+                            mn = gmin16(mn);
                             act = (int)mn;
                         } else {
-                            float c = e / sm;
-#pragma unroll
-                            for (int d = 1; d < 16; d <<= 1) {
-                                const float up = __shfl_up(c, d, 16);
-                                if (r16 >= d) c += up;
-                            }
+                            const float c = gscan16(e / sm);
                             const float u = uniform01(mix32(rng_seed, env_offset + (uint32_t)row, rng_step));
                             const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
                             act = min((int)cnt, A - 1);
                         }
                         const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                        const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                        const float vrow = gfirst_quad(vacc[0][r]);
                         if (r16 == r && row < n) {
                             static_cast<int32_t *>(actions_out)[row] = act;
                             logp_out[row] = lpa;
@@ -1695,7 +1677,7 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                             }
                         }
                         lpsum = gsum16(lpsum);
-                        const float vrow = __shfl(vacc[0][r], lane & 48, 64);
+                        const float vrow = gfirst_quad(vacc[0][r]);
                         if (r16 == r && row < n) {
                             logp_out[row] = lpsum;
                             values_out[row] = vrow;
@@ -1786,7 +1768,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4;
+    return WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4 + (L.bf16 ? OFFS_CAP * 4 : 0);
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -1877,7 +1859,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     hipStream_t s = (hipStream_t)stream;
     const PLayout L = layout_of(d);
     Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
-    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total};
+    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr};
     static const int bf_debug = getenv("TMA_BF_DEBUG") ? atoi(getenv("TMA_BF_DEBUG")) : 0;
     HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, (hp->normalize_advantage && mbi->count > 1) ? 1 : 0, bf_debug};
     char *ws = static_cast<char *>(workspace);
@@ -1888,9 +1870,13 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
-    if (hpar.normalize_advantage) {
-        adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part);
+    int32_t *offs = (L.bf16 && mbi->count <= OFFS_CAP) ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4) : nullptr;
+    if (hpar.normalize_advantage || offs) {
+        adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part, offs);
         TMA_LAUNCH_CHECK();
+        M.offs = offs;
+    }
+    if (hpar.normalize_advantage) {
         if (!h64) {  // the H = 64 kernel folds the partials itself
             adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, mbi->count, ws_adv);
             TMA_LAUNCH_CHECK();

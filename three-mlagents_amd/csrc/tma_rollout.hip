@@ -82,17 +82,12 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
             const float sum = gsum16(e);
             const float lse = m + logf(sum);
             const float lp = x - lse;
-            float c = e / sum;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const float up = __shfl_up(c, d, 16);
-                if (r16 >= d) c += up;
-            }
+            const float c = gscan16(e / sum);
             const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
             const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
             const int act = min((int)cnt, A - 1);
             const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-            const float vrow = __shfl(vacc[r], lane & 48, 64);
+            const float vrow = gfirst_quad(vacc[r]);
             if (r16 == r) my_act = act, my_lp = lpa, my_v = vrow;
         }
         bool tr_flag = false;
@@ -140,7 +135,7 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
             const f32x4 vt = value_tile_lds(vimg, XT, ldx, KS1, h1, h2, ld, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float vr = __shfl(vt[r], lane & 48, 64);
+                const float vr = gfirst_quad(vt[r]);
                 if (r16 == r && tr_flag) {
                     const float gv = gamma * vr;
                     b.rewards[off] = rew32 + gv;

@@ -44,7 +44,10 @@ __device__ __forceinline__ int launder_uniform(int x) {
 }
 __device__ __forceinline__ bf16x8 bf_frag(const bf16_t *__restrict__ img, int idx, int lane) {
     // uniform (SGPR) fragment base + one 32-bit per-lane offset: the saddr form of global_load, no 64-bit VGPR address per fragment
-    return reinterpret_cast<bf_gptr>(reinterpret_cast<uintptr_t>(img + (int64_t)idx * 512))[(uint32_t)lane];
+    typedef const char __attribute__((address_space(1))) *gbyte_ptr;
+    const gbyte_ptr base = reinterpret_cast<gbyte_ptr>(reinterpret_cast<uintptr_t>(img + (int64_t)idx * 512));
+    const uint32_t voff = (uint32_t)lane * 16u;  // 32-bit per-lane offset + scalar base: global_load ... v, s[base:base+1]
+    return *reinterpret_cast<bf_gptr>(base + voff);
 }
 
 // ---- T image addressing: row `r` holds M bf16 (M/8 chunks of 16 bytes); chunk c is stored at position c ^ t_swz<MT>(r).
@@ -229,6 +232,17 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // TMA_RELANE at the head of a phase re-derives lane / r16 / g from an opaque copy, so the addresses of that phase are
     // computed there (a few VALU instructions) and die with it.
     int lane = lane0, r16 = lane0 & 15, g = lane0 >> 4;
+#ifdef TMA_BF_PHASE_TICKS
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define TMA_TICK(i)                                    \
+    do {                                               \
+        const long long tn = clock64();                \
+        tph[i] += tn - tlast;                          \
+        tlast = tn;                                    \
+    } while (0)
+#else
+#define TMA_TICK(i)
+#endif
 #define TMA_RELANE()                       \
     do {                                   \
         lane = lane0;                      \
@@ -289,7 +303,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             const int64_t j = grp * M + mrow;
             poff = -1, pm0 = pm1 = pm2 = pm3 = 0.0f;
             if (j < mb.count) {
-                poff = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                poff = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
                 if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
             }
@@ -302,7 +316,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int i = 0; i < NX; i++) {
                 const int e = threadIdx.x + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
                 const int64_t off = row_off_next[row];
-                px[i] = (off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f;
+                const bool ok = off >= 0 && c < D;  // branchless: a clamped address is always loadable
+                const float x = rb.obs[ok ? off * D + c : 0];
+                px[i] = ok ? x : 0.0f;
             }
         }
     };
@@ -319,6 +335,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         // (The wave's tile index is laundered too: otherwise the invariant per-fragment offsets are hoisted as 64-bit VGPR pairs.)
         W.fW1 = launder_uniform(W.fW1), W.fW2 = launder_uniform(W.fW2), W.bW2 = launder_uniform(W.bW2), W.fW3 = launder_uniform(W.fW3);
         W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l);
+        TMA_TICK(0);
         TMA_RELANE();
         // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
         bf16x8 w1r[NTW];  // layer-1 fragments of this wave: issued now, consumed after the commit and its barrier
@@ -355,6 +372,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         constexpr int dbg = 0;
 #endif
         const bool has_next = grp + n_blocks_net < n_groups && !(dbg & 1);  // block-uniform
+        TMA_TICK(1);
         TMA_RELANE();
         // ---- P1: layer 1 forward ----
         if (!(dbg & 64)) {
@@ -402,6 +420,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(2);
         TMA_RELANE();
         // ---- P2: layer 2 forward through the weight ring ----
         constexpr int HK = (KS2 + 3) / 4;  // head k-steps per wave (split-K over the four waves: ks = wave, wave + 4, ...)
@@ -456,6 +475,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(3);
         TMA_RELANE();
         // ---- P3a: split-K head: every wave multiplies its k-steps of h2 for all row tiles, partial sums through LDS ----
         bf16x8 w3b[NTW];  // head input-gradient fragments for P4, in flight behind the head
@@ -483,6 +503,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(4);
         TMA_RELANE();
         // ---- P3b: loss on row tile `wave`; dz3 as bf16 in both layouts ----
         if (wave < MT && !(dbg & 4)) {
@@ -538,6 +559,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(5);
         TMA_RELANE();
         // ---- P4: head weight gradient (this wave's k rows); dz2 = (dz3 . W3^T) * (1 - h2^2) in place in A2 / T2 ----
         if (!(dbg & 16)) {
@@ -578,6 +600,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(6);
         TMA_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dh1 = dz2 . W2^T for this wave's columns (weight ring) ----
         f32x4 dh1[NTW][MT];
@@ -630,6 +653,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();  // every wave is done with T1 (all rows) and A2
+        TMA_TICK(7);
         TMA_RELANE();
         // ---- P6: dz1 = dh1 * (1 - h1^2) in place in T1 (own rows);  dW1 slice += X^T . dz1[:, slice] ----
         if (!(dbg & 8))
@@ -690,7 +714,15 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
         __syncthreads();
     }
+#ifdef TMA_BF_PHASE_TICKS
+    TMA_TICK(8);
+    if (threadIdx.x == 0 && block_net == 0 && mb.offs) {  // phase cycle counts of pair 0 -> tail of the offsets cache (debug builds only)
+        long long *dbg_out = reinterpret_cast<long long *>(const_cast<int32_t *>(mb.offs) + (1 << 22) - 64) + (IS_PI ? 0 : 12);
+        for (int i = 0; i < 12; i++) dbg_out[i] = tph[i];
+    }
+#endif
 #undef TMA_RELANE
+#undef TMA_TICK
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
     float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
     float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);

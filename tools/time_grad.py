@@ -44,3 +44,11 @@ for i in range(0, len(args), 4):
     for _ in range(3):
         grad(), act()
     print(f"{task} H={H} {dt} B={B}: grad {med_us(grad):.1f} us   act(4096) {med_us(act):.1f} us", flush=True)
+    if os.environ.get("TMA_PHASE_DUMP") and dt == "bf16":
+        grad(); torch.cuda.synchronize()
+        ws = m.workspace
+        tail = ws[-64 * 4:].cpu().numpy().view("int64")  # last 64 int32 of the offsets cache
+        names = ["tail(prev P6 end)", "P0 commit", "P1", "P2", "P3a", "P3b", "P4", "P5", "P6+after-loop"]
+        for role, o in (("pi", 0), ("vf", 12)):
+            v = tail[o:o + 9]
+            print("   ", role, "cycles:", {n: int(x) for n, x in zip(names, v)}, "sum", int(v.sum()))
