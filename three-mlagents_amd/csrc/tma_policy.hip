@@ -29,6 +29,7 @@ constexpr int MAX_GRAD_BLOCKS = 2048;
 constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
 constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
 constexpr int64_t WS_BYTES = WS_SLABS;
+constexpr int BF_SLABS = 160;  // bf16 wide kernel: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
 constexpr int64_t OFFS_CAP = 1 << 22;  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
 struct Net {
@@ -1219,10 +1220,14 @@ static int grad_wide_smem_bytes(const PLayout &L) {
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
 // fixed order -> bitwise reproducible, and enough independent loads in flight to run at L2 speed.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int P, float *__restrict__ grad) {
+// Parameters in [vf_begin, vf_end) (the value net) are summed over n_slabs_vf slabs, all others over n_slabs (the policy net may
+// run on more blocks than the value net -- the bf16 wide kernel balances the two by their cost per row group).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs_pi, int P, float *__restrict__ grad,
+                                                          int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
+    const int n_slabs = (n_slabs_vf >= 0 && e >= vf_begin && e < vf_end) ? n_slabs_vf : n_slabs_pi;
     const int per = (n_slabs + 3) >> 2;
     const int b0 = q * per, b1 = (b0 + per < n_slabs) ? b0 + per : n_slabs;
     float s = 0.0f;
@@ -1768,7 +1773,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4 + (L.bf16 ? OFFS_CAP * 4 : 0);
+    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + (L.bf16 ? OFFS_CAP * 4 : 0);
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -1870,7 +1875,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
-    int32_t *offs = (L.bf16 && mbi->count <= OFFS_CAP) ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)H64_BLOCKS * L.P * 4) : nullptr;
+    int32_t *offs = (L.bf16 && mbi->count <= OFFS_CAP) ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)BF_SLABS * L.P * 4) : nullptr;
     if (hpar.normalize_advantage || offs) {
         adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part, offs);
         TMA_LAUNCH_CHECK();
@@ -1903,16 +1908,18 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     if (L.bf16) {
         const int MTc = 2;
         const int smemw = grad_wide_bf_smem_bytes(L.D, L.H, MTc);
-        int64_t pairs = ceil_div(mbi->count, 16 * MTc);
-        if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
+        // 256 blocks = one per CU.  A policy-net row group costs ~1.3x a value-net one (loss on the head waves), so the policy net
+        // gets 9/16 of the blocks; with fewer row groups than that, one block per group.
+        const int64_t groups = ceil_div(mbi->count, 16 * MTc);
+        const int n_pi = (int)(groups < 144 ? groups : 144), n_vf = (int)(groups < 112 ? groups : 112);
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         if (L.D > 32) {
-            slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
+            slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, n_pi, L);
             TMA_LAUNCH_CHECK();
         }
         auto launch = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(2 * pairs)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi);
             return TMA_OK;
         };
         // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2); 161..192 (Crawler's 172) -> (0, 6); else runtime width
@@ -1939,7 +1946,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }

@@ -290,9 +290,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         const int t = s - SL / 2;
         return bf_frag(W.bW2, (nt0l + t % NTW) * KS2 + t / NTW, lane);
     };
-    bf16x8 ring[R];
+    bf16x8 ring[R], w1r[NTW];  // w1r: layer-1 fragments (D <= 32), re-issued at the end of P5 for the next group
 #pragma unroll
     for (int s = 0; s < R; s++) ring[s] = sload(s);
+    if constexpr (KS1C == 1) {
+#pragma unroll
+        for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
+    }
     // ---- prefetch registers for the next group's samples ----
     float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
@@ -338,11 +342,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         TMA_TICK(0);
         TMA_RELANE();
         // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
-        bf16x8 w1r[NTW];  // layer-1 fragments of this wave: issued now, consumed after the commit and its barrier
-        if constexpr (KS1C == 1) {
-#pragma unroll
-            for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0l + j, lane);
-        }
         if (mlane) {
             meta[mrow * 4 + 0] = pm0, meta[mrow * 4 + 1] = pm1, meta[mrow * 4 + 2] = pm2, meta[mrow * 4 + 3] = pm3;
             row_off[mrow] = poff;
@@ -426,6 +425,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         constexpr int HK = (KS2 + 3) / 4;  // head k-steps per wave (split-K over the four waves: ks = wave, wave + 4, ...)
         bf16x8 w3f[HK * NT3];
         if (!(dbg & 32)) {
+#pragma unroll
+            for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase
+#pragma unroll
+                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (wave + 4 * i < KS2 ? wave + 4 * i : 0), lane);
             f32x4 acc[NTW][MT];
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
@@ -451,10 +454,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the epilogue and the barrier
-#pragma unroll
-                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (wave + 4 * i < KS2 ? wave + 4 * i : 0), lane);
             // Next group's sample gathers (HBM-latency loads) go out HERE and at the top of P3: vmcnt retires in order, so the
             // first wait on a load issued after them also waits for them -- and from here on P3 / P4 / the first half of P5 only
             // consume fragments that are already in flight.
@@ -651,6 +650,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (KS1C == 1) {  // next group's layer-1 fragments: P6 + P0 of latency cover
+#pragma unroll
+                for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0l + j, lane);
+            }
         }
         __syncthreads();  // every wave is done with T1 (all rows) and A2
         TMA_TICK(7);
@@ -797,11 +800,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 template <bool CONT, int NTW, int MT, int KT1C, int KS1C>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                   const float *__restrict__ ws_adv, float *__restrict__ slabs,
-                                                                  double *__restrict__ stat_slots) {
+                                                                  double *__restrict__ stat_slots, int n_pi) {
     extern __shared__ __attribute__((aligned(16))) char smem_bf[];
-    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
-    float *slab = slabs + (int64_t)pair * L.P;
-    double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, n_pairs, pair);
-    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, n_pairs, pair);
+    // blocks [0, n_pi): policy net, [n_pi, gridDim.x): value net.  Block b of a net owns slab b (its net's parameters only) and
+    // statistics slot b (policy: entries 0, 2.. ; value: entry 1 -- disjoint, so a policy and a value block may share a slot).
+    const bool is_pi = (int)blockIdx.x < n_pi;
+    const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
+    float *slab = slabs + (int64_t)b * L.P;
+    double *slot = stat_slots + (int64_t)b * 8;
+    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
+    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
 }
