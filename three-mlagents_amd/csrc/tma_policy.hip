@@ -852,8 +852,16 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
     constexpr int M = 32, H = 64 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
+    const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (same two measures as tma_wide_bf16.h: the weight pointers are laundered once per row group so LICM cannot hoist the
+    // loop-invariant weight loads out of the group loop and spill them, and lane-derived addresses are re-derived per phase)
+    int lane = lane0, r16 = lane0 & 15, g = lane0 >> 4;
+#define TMA_RELANE()                       \
+    do {                                   \
+        lane = lane0;                      \
+        asm volatile("" : "+v"(lane));     \
+        r16 = lane & 15, g = lane >> 4;    \
+    } while (0)
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2, KT1 = (D + 15) >> 4;
@@ -867,7 +875,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
     const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
-    const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
+    Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
     float ab1[NTW], ab2[NTW], ab3[NT3], dlsd[2] = {0.0f, 0.0f};
@@ -886,6 +894,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     LossStats st;
     const int64_t n_groups = (mb.count + M - 1) / M;
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
+        {
+            const float *pl = params;
+            asm volatile("" : "+s"(pl));
+            Q = IS_PI ? pi_net(pl, L) : vf_net(pl, L);
+        }
+        TMA_RELANE();
         // ---- P0: gather sample metadata and the observation rows ----
         if (threadIdx.x < M) {
             const int64_t j = grp * M + threadIdx.x;
@@ -909,6 +923,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P1: layer 1 forward, this wave's columns, both row tiles ----
         {
             f32x4 acc[NTW][2];
@@ -936,6 +951,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     for (int r = 0; r < 4; r++) h1[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live) ----
 #pragma unroll
         for (int j = 0; j < NTW; j++) {
@@ -956,6 +972,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P3: head + loss: wave mt (0, 1) takes row tile mt ----
         if (wave < 2) {
             const int mt = wave;
@@ -978,6 +995,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P4: head weight gradient (this wave's k rows), head bias, and dz2 = (dz3 . W3) * (1 - h2^2) in place ----
         {
 #pragma unroll
@@ -1026,6 +1044,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     }
         }
         __syncthreads();
+        TMA_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dz1 = (dz2 . W2) * (1 - h1^2) kept in registers until every wave is done with h1 ----
         f32x4 dz1[NTW][2];
         {
@@ -1077,6 +1096,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     const float h = *pp;
                     *pp = dz1[j][mt][r] * (1.0f - h * h);
                 }
+        TMA_RELANE();
         // ---- P6: dW1 slice += X^T . dz1[:, slice] (each wave reads back only the columns it just wrote) ----
 #pragma unroll
         for (int j = 0; j < NTW; j++) {
@@ -1119,6 +1139,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
     }
+#undef TMA_RELANE
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
     float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
     float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);
