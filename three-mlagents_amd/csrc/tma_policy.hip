@@ -345,7 +345,7 @@ __device__ __forceinline__ void grad_generic_body(const float *__restrict__ para
             int64_t off = -1;
             meta[lane * 4 + 0] = meta[lane * 4 + 1] = meta[lane * 4 + 2] = meta[lane * 4 + 3] = 0.0f;
             if (j < mb.count) {
-                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 meta[lane * 4 + 0] = rb.log_probs[off];
                 meta[lane * 4 + 1] = rb.advantages[off];
                 meta[lane * 4 + 2] = rb.returns[off];
@@ -640,7 +640,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
         if (lane < 16 && tl < n_tiles) {
             const int64_t j = (tl << 4) + lane;
             if (j < mb.count) {
-                pf_off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                pf_off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 if constexpr (IS_PI) {
                     pf_m0 = rb.log_probs[pf_off];
                     pf_m1 = rb.advantages[pf_off];
@@ -906,7 +906,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             int64_t off = -1;
             float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
             if (j < mb.count) {
-                off = sample_offset(mb, mb.start + j, rb.T, rb.N);
+                off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
                 if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
             }
@@ -1794,7 +1794,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + (L.bf16 ? OFFS_CAP * 4 : 0);
+    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4;
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -1896,7 +1896,9 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
-    int32_t *offs = (L.bf16 && mbi->count <= OFFS_CAP) ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)BF_SLABS * L.P * 4) : nullptr;
+    // offsets cache: written by the advantage pass, read by every gradient kernel (saves the permutation arithmetic per sample)
+    int32_t *offs = (mbi->count <= OFFS_CAP && (hpar.normalize_advantage || L.bf16))
+                        ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4) : nullptr;
     if (hpar.normalize_advantage || offs) {
         adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part, offs);
         TMA_LAUNCH_CHECK();
