@@ -14,7 +14,7 @@ from test_ppo_gpu import HP, _flatten_env_major, _hip_grad, _ref_grad_flat, _rol
 
 pytestmark = pytest.mark.gpu
 
-BF_CONFIGS = [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 192, 3, False), (40, 256, 7, True)]
+BF_CONFIGS = [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 192, 3, False), (40, 256, 7, True), (100, 128, 4, False)]
 
 
 def _bf(x):

@@ -1936,7 +1936,8 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         const int64_t groups = ceil_div(mbi->count, 16 * MTc);
         const int n_pi = (int)(groups < 144 ? groups : 144), n_vf = (int)(groups < 112 ? groups : 112);
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        if (L.D > 32) {
+        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
+        if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, n_pi, L);
             TMA_LAUNCH_CHECK();
         }
@@ -1945,26 +1946,27 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi);
             return TMA_OK;
         };
-        // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2); 161..192 (Crawler's 172) -> (0, 6); else runtime width
-        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
+        // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2) two passes; 161..192 (Crawler's 172) -> (0, 6) two
+        // passes; else runtime width, one pass with dW1 in the slab
         auto pick = [&](auto ntw) -> int {
             constexpr int NTWc = decltype(ntw)::value;
-            if (d->continuous) {
+            auto both = [&](auto cont) -> int {
+                constexpr bool C = decltype(cont)::value;
                 switch (variant) {
-                    case 0: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 1, 1>);
-                    case 1: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 2, 1>);
-                    case 2: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 2>);
-                    case 3: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 6>);
-                    default: return launch(ppo_grad_wide_bf_kernel<true, NTWc, 2, 0, 0>);
+                    case 0: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 1, 1, 0>);
+                    case 1: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 2, 1, 0>);
+                    case 2: {
+                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 0>);
+                        return rc2 ? rc2 : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 1>);
+                    }
+                    case 3: {
+                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 0>);
+                        return rc2 ? rc2 : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 1>);
+                    }
+                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>);
                 }
-            }
-            switch (variant) {
-                case 0: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 1, 1>);
-                case 1: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 2, 1>);
-                case 2: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 2>);
-                case 3: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 6>);
-                default: return launch(ppo_grad_wide_bf_kernel<false, NTWc, 2, 0, 0>);
-            }
+            };
+            return d->continuous ? both(std::true_type{}) : both(std::false_type{});
         };
         int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;

@@ -218,7 +218,11 @@ __host__ __device__ inline int fwd_wide_bf_smem_bytes(int D, int H) {
 //   * the NEXT group's sample metadata and observation rows are gathered into registers while this group computes and
 //     committed to LDS at the top of the next iteration (KS1C > 0: compile-time observation width).
 // KT1C: 16-row k-tiles of dW1 kept in registers (0: accumulated in the slab);  KS1C: compile-time layer-1 k-steps (0: runtime).
-template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C>
+// PASS: observations wider than 32 leave no registers for dW1 next to dW2's 256 accumulators.  With a compile-time width the
+// minibatch is then walked twice: PASS 0 accumulates everything except dW1, PASS 1 recomputes the forward / backward chain and
+// keeps only dW1 (2*KS1C k-tiles) in registers -- 1.8x the MFMA work instead of a 0.4 MB read-modify-write of the slab per row
+// group.  (Every store of PASS 0's quantities is compiled out of PASS 1, so the MFMAs that feed only them disappear as dead code.)
+template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C, int PASS>
 __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                   const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                   double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net) {
@@ -252,8 +256,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int Kp1 = KS1C > 0 ? 32 * KS1C : ((D + 31) & ~31), KS1 = Kp1 >> 5, KT1 = Kp1 >> 4, ldx = Kp1 + 16;
-    constexpr bool acc_w1 = KT1C > 0;
-    constexpr int KT1A = KT1C > 0 ? KT1C : 1;
+    constexpr bool MAIN = PASS == 0;
+    constexpr bool two_pass = KT1C == 0 && KS1C > 0;
+    static_assert(PASS == 0 || two_pass, "PASS 1 exists only for wide observations of compile-time width");
+    constexpr bool acc_w1 = KT1C > 0 || PASS == 1;              // dW1 in registers
+    constexpr bool rmw_w1 = KT1C == 0 && KS1C == 0;             // dW1 accumulated in the slab (runtime width)
+    constexpr int KT1A = KT1C > 0 ? KT1C : (PASS == 1 ? 2 * KS1C : 1);
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *Xt = Xa + M * ldx, *A1 = Xt + Kp1 * M, *A2 = A1 + M * lda;
     bf16_t *T1 = A2 + M * lda, *T2 = T1 + H * M, *Z3a = T2 + H * M, *Z3t = Z3a + M * ldz;
     float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M), *meta = dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
@@ -530,7 +538,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     if (valid && r16 == 0) st.a += (double)(diff * diff);
                 }
             }
-            if (r16 == 0) {  // only these lanes carry statistics (policy_loss_tile / the value branch accumulate under r16 == 0)
+            if (MAIN && r16 == 0) {  // only these lanes carry statistics (policy_loss_tile / the value branch accumulate under r16 == 0)
                 double *sl = stat_lds + (mt * 4 + g) * 5;
                 sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
             }
@@ -693,7 +701,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                         for (int j = 0; j < NTW; j++) aW1[kt][j] = mfma_bf(a, zb[j][kk], aW1[kt][j]);
                     }
-            } else {
+            } else if constexpr (rmw_w1) {
                 float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t);
                 for (int kt = 0; kt < KT1; kt++) {
                     f32x4 t[NTW];
@@ -733,10 +741,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
         const int col = n_base + 16 * j + r16;
+        if constexpr (MAIN) {
 #pragma unroll
-        for (int kt = 0; kt < KT2; kt++)
+            for (int kt = 0; kt < KT2; kt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+                for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+        }
         if constexpr (acc_w1) {
 #pragma unroll
             for (int kt = 0; kt < KT1A; kt++)
@@ -746,21 +756,23 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     if (k < D) gW1[(int64_t)k * H + col] = aW1[kt][j][r];
                 }
         }
-        float v1 = ab1[j], v2 = ab2[j];
-        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-        v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
-        if (g == 0) gb1[col] = v1, gb2[col] = v2;
+        if constexpr (MAIN) {
+            float v1 = ab1[j], v2 = ab2[j];
+            v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+            v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
+            if (g == 0) gb1[col] = v1, gb2[col] = v2;
 #pragma unroll
-        for (int q = 0; q < NT3; q++)
+            for (int q = 0; q < NT3; q++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
-                if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
-            }
+                for (int r = 0; r < 4; r++) {
+                    const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
+                    if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
+                }
+        }
     }
     // head bias gradient / log_std gradient / loss statistics: partial sums of the MT head waves folded through LDS
     __syncthreads();
-    {
+    if constexpr (MAIN) {
         float v = ab3;
         v += __shfl_xor(v, 32, 64);  // lanes a and a + 32 hold the two halves of a tile's column sum
         float v0 = dlsd[0], v1 = dlsd[1];
@@ -789,7 +801,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
     }
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (MAIN && threadIdx.x < 5) {
         double ssum = 0.0;
         for (int w = 0; w < MT * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
         const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
@@ -797,7 +809,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     }
 }
 
-template <bool CONT, int NTW, int MT, int KT1C, int KS1C>
+template <bool CONT, int NTW, int MT, int KT1C, int KS1C, int PASS>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                   const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                   double *__restrict__ stat_slots, int n_pi) {
@@ -808,6 +820,6 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *_
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
-    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
+    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
+    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
 }
