@@ -8,6 +8,7 @@ behaviour.  What sits underneath is the HIP engine instead of DummyVecEnv + SB3.
 from __future__ import annotations
 
 import json
+import os
 import platform
 import uuid
 from dataclasses import asdict, dataclass
@@ -240,9 +241,13 @@ def _default_model_kwargs(algorithm_name: str, *, train_env, task: TaskSpec, tot
         n_steps = 1024 if task.research_tier == "foundation" else 2048
         if task.observation == "image":
             raise ValueError(f"Task '{task.id}' needs task-specific CNN policy settings.")
+        policy_kwargs: dict[str, Any] = {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}
+        # engine extension (no counterpart in the reference): TMA_MFMA_DTYPE=bf16 runs the 256-wide GEMMs on the bf16 MFMA
+        # (f32 master weights / accumulation; BASELINE.json configs[2]).  Default f32 = the reference's numerics.
+        if os.environ.get("TMA_MFMA_DTYPE", "f32").lower() == "bf16":
+            policy_kwargs["mfma_dtype"] = "bf16"
         return {**common, "learning_rate": 3e-4, "n_steps": n_steps, "batch_size": 256, "n_epochs": 10, "gamma": 0.99, "gae_lambda": 0.95,
-                "clip_range": 0.2, "ent_coef": 0.01, "vf_coef": 0.5, "max_grad_norm": 0.5,
-                "policy_kwargs": {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}}
+                "clip_range": 0.2, "ent_coef": 0.01, "vf_coef": 0.5, "max_grad_norm": 0.5, "policy_kwargs": policy_kwargs}
     return common
 
 

@@ -7,6 +7,10 @@ R=${1:-r01}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench -- python bench.py --gpus 1 --steps 3 --warmup 1 > gpurun_out/${R}_bench.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench.log > gpurun_out/${R}_bench_n1.json
 cp $(ls -t gpurun_out/${R}_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_n1_kernel_stats.csv
+# BASELINE configs[2]: Ball3D, 4096 envs, MLP 256x256 with bf16 MFMA operands -- kernel stats of the exact bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_ball3d_bf16 -- python bench.py --gpus 1 --steps 3 --warmup 1 --task ball3d --hidden 256 --mfma-dtype bf16 --no-cpu-baseline > gpurun_out/${R}_bench_ball3d_bf16.log 2>&1
+grep -E "^\{" gpurun_out/${R}_bench_ball3d_bf16.log > gpurun_out/${R}_bench_ball3d_bf16_n1.json
+cp $(ls -t gpurun_out/${R}_bench_ball3d_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_ball3d_bf16_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_step_$c -- python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2 > gpurun_out/${R}_pmc_step_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_grad_$c -- python tools/prof_grad.py > gpurun_out/${R}_pmc_grad_$c.log 2>&1
