@@ -1591,7 +1591,11 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
         }
         __syncthreads();
     };
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // MODE 0 runs the value net and the policy net of a row group on two different blocks (even / odd blockIdx): 4096 envs are only
+    // 128 row groups, so this fills all 256 CUs and halves the dependent chain of a vector step.
+    constexpr int NR = MODE == 0 ? 2 : 1;
+    const int role = MODE == 0 ? (int)(blockIdx.x & 1) : 0;
+    for (int64_t grp = blockIdx.x / NR; grp < n_groups; grp += gridDim.x / NR) {
         const int64_t row0 = grp * M;
         if constexpr (MODE == 2) {  // skip row groups without a truncated env (block-uniform vote)
             const int64_t rr = row0 + threadIdx.x;
@@ -1612,15 +1616,17 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
         }
         __syncthreads();
         const Net V = vf_net(params, L);
-        hidden(V, false);
         f32x4 vacc[1] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
         const int mt = wave & 1;
-        if (wave < 2) {
-            if constexpr (BF) bf_head<1>(A2, lda, 16 * mt, H / 32, bf_net_ptr(params, L, false).fW3, V.b3, 1, vacc, lane);
-            else dense_head<1>(h2 + mt * 16 * ld, ld, H, V.W3t, V.b3, 1, vacc, lane);
+        if (role == 0) {
+            hidden(V, false);
+            if (wave < 2) {
+                if constexpr (BF) bf_head<1>(A2, lda, 16 * mt, H / 32, bf_net_ptr(params, L, false).fW3, V.b3, 1, vacc, lane);
+                else dense_head<1>(h2 + mt * 16 * ld, ld, H, V.W3t, V.b3, 1, vacc, lane);
+            }
         }
-        if constexpr (MODE == 1) {
-            if (wave < 2 && r16 == 0)
+        if constexpr (MODE == 1 || MODE == 0) {
+            if (role == 0 && wave < 2 && r16 == 0)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int64_t row = row0 + mt * 16 + g * 4 + r;
@@ -1636,8 +1642,8 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                         rewards[row] = rewards[row] + gv;
                     }
                 }
-        } else {
-            __syncthreads();  // every wave is done reading h2 of the value net before the policy net overwrites h1/h2
+        }
+        if constexpr (MODE == 0) if (role == 1) {
             const Net P = pi_net(params, L);
             hidden(P, true);
             if (wave < 2) {
@@ -1668,11 +1674,9 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                             act = min((int)cnt, A - 1);
                         }
                         const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                        const float vrow = gfirst_quad(vacc[0][r]);
                         if (r16 == r && row < n) {
                             static_cast<int32_t *>(actions_out)[row] = act;
                             logp_out[row] = lpa;
-                            values_out[row] = vrow;
                         }
                     }
                 } else {
@@ -1703,11 +1707,7 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                             }
                         }
                         lpsum = gsum16(lpsum);
-                        const float vrow = gfirst_quad(vacc[0][r]);
-                        if (r16 == r && row < n) {
-                            logp_out[row] = lpsum;
-                            values_out[row] = vrow;
-                        }
+                        if (r16 == r && row < n) logp_out[row] = lpsum;
                     }
                 }
             }
@@ -1736,8 +1736,8 @@ static int launch_fwd(const float *params, const tma_policy_dims *d, const float
         if (groups > 4096) groups = 4096;
         auto launchw = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)groups), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, trunc, gamma,
-                                                                rewards);
+            k<<<dim3((unsigned)(MODE == 0 ? 2 * groups : groups)), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions,
+                                                                                           values, logp, trunc, gamma, rewards);
             return TMA_OK;
         };
         int wrc;
@@ -1753,8 +1753,8 @@ static int launch_fwd(const float *params, const tma_policy_dims *d, const float
         if (groups > 4096) groups = 4096;
         auto launchw = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)groups), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions, values, logp, trunc, gamma,
-                                                                rewards);
+            k<<<dim3((unsigned)(MODE == 0 ? 2 * groups : groups)), dim3(256), smemw, s>>>(params, L, obs, n, seed, step, env_offset, deterministic, actions,
+                                                                                           values, logp, trunc, gamma, rewards);
             return TMA_OK;
         };
         int wrc;
