@@ -146,6 +146,9 @@ typedef struct {
                                NULL -> on-device Feistel permutation keyed by (perm_seed, perm_epoch) */
     uint32_t perm_seed, perm_epoch;
     int64_t start, count;   /* this minibatch = permuted rows [start, start + count) */
+    int64_t prepared_batch; /* 0: self-contained call.  > 0: tma_ppo_epoch_prepare ran on this workspace for the same rollout view,
+                               (perm_seed, perm_epoch) and this batch size, start is a multiple of it -- the per-minibatch advantage
+                               pass is skipped and the cached sample offsets / advantage partials are used */
 } tma_minibatch;
 
 typedef struct {
@@ -159,6 +162,11 @@ int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d);
  * once; tma_ppo_adam_step re-zeroes it) and loss statistics into the workspace. */
 int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mb,
                            const tma_ppo_hparams *hp, float *grad, void *workspace, void *stream);
+/* Once per epoch (optional): sample offsets of the whole permutation and the advantage (sum, sum of squares) partials of every
+ * minibatch [k*batch_size, (k+1)*batch_size) in one launch, instead of one small launch in front of every minibatch gradient.
+ * epoch->start / count describe the whole pass (0, T*N).  Needs T*N <= 2^22 and batch_size >= 256, else TMA_ERR_INVALID. */
+int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int64_t batch_size, const tma_policy_dims *d, void *workspace,
+                          void *stream);
 /* clip_grad_norm_(max_grad_norm) + Adam.step() (+ refresh of the [out][in] copies).  grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce(sum)). */
 int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,

@@ -367,3 +367,44 @@ def test_ppo_learns(task, n_envs, iters, thresh):
         assert np.array_equal(a1, a2)
         with pytest.raises(FileNotFoundError):
             PPO.load(os.path.join(d, "missing.zip"))
+
+
+def test_epoch_prepare_equals_per_minibatch_pass():
+    """tma_ppo_epoch_prepare (one launch per epoch) + prepared minibatches give bit-identical gradients and statistics to
+    the self-contained per-minibatch calls, including the ragged last minibatch."""
+    from three_mlagents_amd import _lib
+
+    D, H, A, T, N = 4, 64, 5, 48, 700
+    pol, sd = _policy(D, H, A, False)
+    obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+    dev = torch.device("cuda", 0)
+    d = {k: v.to(dev).contiguous() for k, v in dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret).items()}
+    rv = _lib.Rollout(_lib.ptr(d["obs"]), _lib.ptr(d["actions"]), _lib.ptr(d["old_lp"]), _lib.ptr(d["adv"]), _lib.ptr(d["ret"]), T, N)
+    hpar = _lib.PPOHParams(0.2, 0.01, 0.5, 1)
+    L = _lib.lib()
+    total, batch = T * N, 9000  # 33600 samples -> 3 full minibatches + one of 6600
+    ws = torch.zeros(int(L.tma_ppo_workspace_bytes(C.byref(pol.dims))), dtype=torch.uint8, device=dev)
+
+    def run(prepared):
+        out = []
+        if prepared:
+            ep = _lib.Minibatch(None, 77, 3, 0, total, 0)
+            _lib.check(L.tma_ppo_epoch_prepare(C.byref(rv), C.byref(ep), batch, C.byref(pol.dims), _lib.ptr(ws), _lib.stream_ptr()))
+        for start in range(0, total, batch):
+            mb = _lib.Minibatch(None, 77, 3, start, min(batch, total - start), batch if prepared else 0)
+            grad = torch.zeros(pol.n_trainable, device=dev)
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), C.byref(mb), C.byref(hpar), _lib.ptr(grad),
+                                                _lib.ptr(ws), _lib.stream_ptr()))
+            st = (C.c_double * 8)()
+            _lib.check(L.tma_ppo_pop_stats(_lib.ptr(ws), st, _lib.stream_ptr()))
+            out.append((grad.cpu(), list(st)[:6]))
+        return out
+
+    a, b = run(False), run(True)
+    assert len(a) == 4
+    for (g0, s0), (g1, s1) in zip(a, b):
+        assert torch.equal(g0, g1) and s0 == s1
+    bad = _lib.Minibatch(None, 77, 3, 100, 500, batch)  # start not on the prepared split
+    grad = torch.zeros(pol.n_trainable, device=dev)
+    assert L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), C.byref(bad), C.byref(hpar), _lib.ptr(grad), _lib.ptr(ws),
+                                    _lib.stream_ptr()) != 0

@@ -28,7 +28,7 @@ class Rollout(C.Structure):
 
 
 class Minibatch(C.Structure):
-    _fields_ = [("indices", _vp), ("perm_seed", _u32), ("perm_epoch", _u32), ("start", _i64), ("count", _i64)]
+    _fields_ = [("indices", _vp), ("perm_seed", _u32), ("perm_epoch", _u32), ("start", _i64), ("count", _i64), ("prepared_batch", _i64)]
 
 
 class PPOHParams(C.Structure):
@@ -76,6 +76,7 @@ SIGNATURES = {
     "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
     "tma_ppo_workspace_bytes": (_i64, [_pd]),
     "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
+    "tma_ppo_epoch_prepare": (_i32, [C.POINTER(Rollout), C.POINTER(Minibatch), _i64, _pd, _vp, _vp]),
     "tma_ppo_adam_step": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
     "tma_rollout_collect": (_i32, [_vp, _vp, _pd, C.POINTER(RolloutBuffers), _i32, _i32, _i32, _u32, _u32, _u32, _f64, _i32, _vp]),

@@ -30,7 +30,8 @@ constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // by
 constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
 constexpr int64_t WS_BYTES = WS_SLABS;
 constexpr int BF_SLABS = 160;  // bf16 wide kernel: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
-constexpr int64_t OFFS_CAP = 1 << 22;  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
+constexpr int64_t OFFS_CAP = 1 << 22;
+constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -257,10 +258,22 @@ __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j,
 
 // pass 1: up to ADV_BLOCKS blocks, each sums a contiguous slice of the (permuted) minibatch -> (sum, sum of squares) partials
 constexpr int ADV_BLOCKS = 128;
+// gridDim.y > 1 (tma_ppo_epoch_prepare): blockIdx.y = minibatch k of an epoch split into chunks of `batch` rows; partials and
+// offsets of minibatch k land at partials + 2 * k * gridDim.x and offs_out + k * batch.
 __global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, double *partials,
-                                                          int32_t *__restrict__ offs_out) {
+                                                          int32_t *__restrict__ offs_out, int64_t batch = 0) {
     __shared__ double s1[4], s2[4];
-    const int64_t per = (mb.count + gridDim.x - 1) / gridDim.x;
+    if (gridDim.y > 1 || batch > 0) {
+        const int64_t k = blockIdx.y, s0 = k * batch;
+        const int64_t cnt = (s0 + batch <= mb.count) ? batch : mb.count - s0;
+        mb.start += s0, mb.count = cnt;
+        partials += 2 * k * gridDim.x;
+        if (offs_out) offs_out += s0;
+    }
+    int nb = (int)((mb.count + 1023) / 1024);  // partial blocks this minibatch uses: the same split as a stand-alone launch
+    if (nb > (int)gridDim.x) nb = gridDim.x;
+    if ((int)blockIdx.x >= nb) return;
+    const int64_t per = (mb.count + nb - 1) / nb;
     const int64_t j0 = (int64_t)blockIdx.x * per, j1 = (j0 + per < mb.count) ? j0 + per : mb.count;
     double a = 0.0, b = 0.0;
     for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
@@ -1318,10 +1331,29 @@ __global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ par
     __shared__ double red[16];
     __shared__ float coef_s;
     const int P = L.P;
+    // P <= 10240 (the 64x64 nets: 9350): every thread keeps its <= 10 elements of grad / m / v / params in registers, so all four
+    // streams are in flight together and the second pass needs no global load (one memory round trip instead of two).
+    constexpr int NE = 10;
+    const bool small = P <= NE * 1024;
+    float rg[NE], rm[NE], rv[NE], rp[NE];
     double sq = 0.0;
-    for (int e = threadIdx.x; e < P; e += 1024) {
-        const float gv = grad[e] * scale;
-        sq += (double)gv * (double)gv;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = threadIdx.x + 1024 * i;
+            const bool ok = e < P;
+            rg[i] = ok ? grad[e] * scale : 0.0f;
+            rm[i] = ok ? m[e] : 0.0f;
+            rv[i] = ok ? v[e] : 0.0f;
+            rp[i] = ok ? params[e] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NE; i++) sq += (double)rg[i] * (double)rg[i];
+    } else {
+        for (int e = threadIdx.x; e < P; e += 1024) {
+            const float gv = grad[e] * scale;
+            sq += (double)gv * (double)gv;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
@@ -1339,6 +1371,24 @@ __global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ par
     }
     __syncthreads();
     const float coef = coef_s;
+    if (small) {
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = threadIdx.x + 1024 * i;
+            if (e < P) {
+                const float gv = rg[i] * coef;
+                grad[e] = 0.0f;
+                float mm = rm[i], vv = rv[i];
+                mm = mm + (gv - mm) * (1.0f - beta1);
+                vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+                m[e] = mm;
+                v[e] = vv;
+                const float denom = sqrtf(vv) / bc2_sqrt + eps;
+                params[e] = rp[i] - lr_step * (mm / denom);
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < P; e += 1024) {
         const float gv = (grad[e] * scale) * coef;
         grad[e] = 0.0f;
@@ -1794,7 +1844,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4;
+    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES;
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -1886,6 +1936,10 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     const PLayout L = layout_of(d);
     Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
     Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr};
+    const bool prepared = mbi->prepared_batch > 0;
+    if (prepared && (mbi->prepared_batch < 256 || total > OFFS_CAP || mbi->start % mbi->prepared_batch != 0 || mbi->count > mbi->prepared_batch))
+        return fail(TMA_ERR_INVALID, "minibatch [%lld, +%lld) does not match the prepared epoch split (batch %lld)", (long long)mbi->start,
+                    (long long)mbi->count, (long long)mbi->prepared_batch);
     static const int bf_debug = getenv("TMA_BF_DEBUG") ? atoi(getenv("TMA_BF_DEBUG")) : 0;
     HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, (hp->normalize_advantage && mbi->count > 1) ? 1 : 0, bf_debug};
     char *ws = static_cast<char *>(workspace);
@@ -1896,10 +1950,16 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
+    const int64_t offs_base = WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4;
+    if (prepared) {  // tma_ppo_epoch_prepare left this minibatch's partials and the epoch's offsets in the workspace
+        int stride = (int)ceil_div(mbi->prepared_batch, 1024);
+        if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+        adv_part = reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4) + 2 * (mbi->start / mbi->prepared_batch) * stride;
+        M.offs = reinterpret_cast<int32_t *>(ws + offs_base) + mbi->start;
+    }
     // offsets cache: written by the advantage pass, read by every gradient kernel (saves the permutation arithmetic per sample)
-    int32_t *offs = (mbi->count <= OFFS_CAP && (hpar.normalize_advantage || L.bf16))
-                        ? reinterpret_cast<int32_t *>(ws + WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4) : nullptr;
-    if (hpar.normalize_advantage || offs) {
+    int32_t *offs = (!prepared && mbi->count <= OFFS_CAP && (hpar.normalize_advantage || L.bf16)) ? reinterpret_cast<int32_t *>(ws + offs_base) : nullptr;
+    if (!prepared && (hpar.normalize_advantage || offs)) {
         adv_partial_kernel<<<dim3(nbk), dim3(256), 0, s>>>(rb->advantages, M, rb->T, rb->N, adv_part, offs);
         TMA_LAUNCH_CHECK();
         M.offs = offs;
@@ -2019,6 +2079,30 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         k<<<dim3((unsigned)(2 * blocks)), dim3(64 * wpb), smem, s>>>(params, L, R, M, hpar, ws_adv, grad, slots);
     }
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int64_t batch_size, const tma_policy_dims *d, void *workspace,
+                          void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!rb || !epoch || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_epoch_prepare: null argument");
+    if (!rb->advantages || rb->T < 1 || rb->N < 1) return fail(TMA_ERR_INVALID, "rollout view: advantages / T / N");
+    const int64_t total = (int64_t)rb->T * rb->N;
+    if (total > OFFS_CAP) return fail(TMA_ERR_INVALID, "epoch of %lld samples exceeds the %lld-entry offsets cache", (long long)total, (long long)OFFS_CAP);
+    if (batch_size < 256) return fail(TMA_ERR_INVALID, "tma_ppo_epoch_prepare needs batch_size >= 256 (got %lld)", (long long)batch_size);
+    if (epoch->start != 0 || epoch->count != total) return fail(TMA_ERR_INVALID, "epoch descriptor must cover [0, T*N)");
+    const PLayout L = layout_of(d);
+    char *ws = static_cast<char *>(workspace);
+    const int64_t offs_base = WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4;
+    int stride = (int)ceil_div(batch_size, 1024);
+    if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+    const int64_t n_mb = ceil_div(total, batch_size);
+    if (n_mb > 65535) return fail(TMA_ERR_INVALID, "too many minibatches per epoch (%lld)", (long long)n_mb);
+    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr};
+    adv_partial_kernel<<<dim3(stride, (unsigned)n_mb), dim3(256), 0, (hipStream_t)stream>>>(
+        rb->advantages, M, rb->T, rb->N, reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4), reinterpret_cast<int32_t *>(ws + offs_base), batch_size);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }

@@ -266,10 +266,16 @@ class PPO:
         L = _lib.lib()
         total = self.n_steps * self.n_envs
         scale = 1.0 / self.world_size
+        perm_seed = (self.seed * 2654435761 + 12345) & 0xFFFFFFFF
+        can_prepare = total <= (1 << 22) and self.batch_size >= 256  # limits of tma_ppo_epoch_prepare (include/tma.h)
         for _ in range(self.n_epochs):
+            if can_prepare:  # one launch per epoch: sample offsets of the permutation + advantage partials of every minibatch
+                ep = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, 0, total, 0)
+                _lib.check(L.tma_ppo_epoch_prepare(C.byref(self._rollout_view), C.byref(ep), self.batch_size, C.byref(self.policy.dims),
+                                                   _lib.ptr(self.workspace), self._stream()))
             for start in range(0, total, self.batch_size):
-                mb = _lib.Minibatch(None, (self.seed * 2654435761 + 12345) & 0xFFFFFFFF, self._epoch_counter & 0xFFFFFFFF, start,
-                                    min(self.batch_size, total - start))
+                mb = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, start, min(self.batch_size, total - start),
+                                    self.batch_size if can_prepare else 0)
                 _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
                                                     C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
                 if self.world_size > 1:
