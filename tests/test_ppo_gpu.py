@@ -262,6 +262,11 @@ def test_adam_and_clip_match_torch(D, H, A, cont):
     obs = torch.randn(33, D)
     _, v_ref = sb3_ref.forward({k: t.detach() for k, t in tr.sd.items()}, obs)
     assert torch.allclose(pol.predict_values(obs.cuda()).cpu(), v_ref, rtol=1e-4, atol=1e-5)
+    # ... and every derived region (transposed copies, LDS images, bf16 images) equals what a full tma_policy_sync rebuilds
+    # (the H = 64 optimizer kernel scatters the updated parameters into them itself instead of launching the refresh)
+    after_step = pol.params.clone()
+    _lib.check(_lib.lib().tma_policy_sync(_lib.ptr(pol.params), C.byref(pol.dims), _lib.stream_ptr()))
+    assert torch.equal(after_step, pol.params)
 
 
 def test_timeout_bootstrap():
