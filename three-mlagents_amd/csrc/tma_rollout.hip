@@ -162,6 +162,176 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
     }
 }
 
+// Two-wave variant for the BASELINE shape (4096 envs = 256 tiles = one tile per CU): the dependent chain of a vector step is split
+// over two SIMDs of the CU.  Wave 0 runs the policy net, samples, steps the 16 envs and writes obs / actions / log-probs / flags;
+// wave 1 runs the value net on the same observation tile (and, one step later, the timeout bootstrap of any env that hit its time
+// limit).  Observations and terminal observations are double-buffered in LDS by step parity, so the only synchronisation is one
+// workgroup barrier per step.  Rewards of truncated rows are written by wave 1 (reward + gamma * V(terminal obs)), all others by
+// wave 0 -- the two waves never store to the same address.  Same arithmetic per element as rollout_chunk_h64_kernel.
+template <class T>
+__global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
+                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int D = T::OBS;
+    const int A = L.A;
+    constexpr int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
+    float *vimg = smem, *pimg = smem + FWD_IMG;
+    float *X0 = smem + 2 * FWD_IMG;                    // [2][16][ldx] observation tile, by step parity
+    float *XT0 = X0 + 2 * 16 * ldx;                    // [2][16][ldx] terminal observations of truncated rows
+    float *hp1 = XT0 + 2 * 16 * ldx, *hp2 = hp1 + 16 * ld, *hv1 = hp2 + 16 * ld, *hv2 = hv1 + 16 * ld;
+    float *rw = hv2 + 16 * ld;                         // [2][16] reward of a truncated row (before the bootstrap)
+    int *trf = reinterpret_cast<int *>(rw + 32);       // [2][16] row truncated at this parity's step
+    int *flag = trf + 32;                              // [2] any row truncated
+    int64_t *row_off = reinterpret_cast<int64_t *>(flag + 2 + 2);
+    stage_fwd_image(params + L.img_vf, vimg);
+    stage_fwd_image(params + L.img_pi, pimg);
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x << 4;
+    const int my_row = g * 4 + r16;  // meaningful for owner lanes (r16 < 4)
+    const int64_t i = row0 + my_row;
+    const bool active = (r16 < 4) && (i < N);
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    if (wave == 0 && active) {
+        T::unpack(v.st, N, i, s);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    if (wave == 0) {
+        if (lane < 16) row_off[lane] = (row0 + lane < N) ? (int64_t)t0 * N + row0 + lane : -1;
+        load_obs_tile(b.obs, row_off, D, X0, ldx, lane);
+        for (int e = lane; e < 2 * 16 * ldx; e += 64) XT0[e] = 0.0f;
+        if (lane < 2) flag[lane] = 0;
+    }
+    __syncthreads();
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k, p = k & 1, q = p ^ 1;
+        const float *X = X0 + p * 16 * ldx;
+        float *Xn = X0 + q * 16 * ldx, *XT = XT0 + p * 16 * ldx;
+        if (wave == 1) {
+            const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, hv1, hv2, ld, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float vrow = gfirst_quad(vacc[r]);
+                if (r16 == r && active) b.values[(int64_t)t * N + i] = vrow;
+            }
+            if (k > 0 && flag[q]) {  // timeout bootstrap of step t-1: rewards = reward + gamma * V(terminal_obs) where truncated
+                const f32x4 vt = value_tile_lds(vimg, XT0 + q * 16 * ldx, ldx, KS1, hv1, hv2, ld, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float vr = gfirst_quad(vt[r]);
+                    if (r16 == r && active && trf[q * 16 + my_row]) {
+                        const float gv = gamma * vr;
+                        b.rewards[(int64_t)(t - 1) * N + i] = rw[q * 16 + my_row] + gv;
+                    }
+                }
+            }
+        } else {
+            dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, hp1, ld, lane);
+            dense64_tanh_lds<16>(hp1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, hp2, ld, lane);
+            const f32x4 acc = dense64_head_lds(hp2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
+            int my_act = 0;
+            float my_lp = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t row = row0 + g * 4 + r;
+                const bool colok = r16 < A;
+                const float x = colok ? acc[r] : -INFINITY;
+                const float m = gmax16(x);
+                const float e = colok ? expf(x - m) : 0.0f;
+                const float sum = gsum16(e);
+                const float lse = m + logf(sum);
+                const float lp = x - lse;
+                const float c = gscan16(e / sum);
+                const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                const int act = min((int)cnt, A - 1);
+                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                if (r16 == r) my_act = act, my_lp = lpa;
+            }
+            bool tr_flag = false;
+            if (active) {
+                const int64_t off = (int64_t)t * N + i;
+                b.actions[off] = my_act;
+                b.log_probs[off] = my_lp;
+                double r;
+                bool done;
+                T::step(s, my_act, nullptr, r, done);
+                const int steps = T::steps(s);
+                const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+                const bool te = done && !hit, tr = hit;
+                er += r;
+                const float rew32 = (float)r;
+                b.terminated[off] = (uint8_t)te;
+                b.truncated[off] = (uint8_t)tr;
+                float o[D];
+                if (te || tr) {
+                    if (tr) {
+                        T::obs(s, o);
+#pragma unroll
+                        for (int c = 0; c < D; c++) XT[my_row * ldx + c] = o[c];
+                        rw[p * 16 + my_row] = rew32;
+                    }
+                    sret += er, slen += (double)steps, scnt += 1.0;
+                    er = 0.0;
+                    ce += 1;
+                    uint32_t rec[T::RW];
+                    const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
+#pragma unroll
+                    for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * N];
+                    T::from_rec(rec, s);
+                }
+                T::obs(s, o);
+                store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
+#pragma unroll
+                for (int c = 0; c < D; c++) Xn[my_row * ldx + c] = o[c];
+                if (!tr) b.rewards[off] = rew32;  // truncated rows: wave 1 writes reward + bootstrap after the barrier
+                trf[p * 16 + my_row] = tr ? 1 : 0;
+                tr_flag = tr;
+            }
+            const bool any = __ballot(tr_flag) != 0ull;
+            if (lane == 0) flag[p] = any ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (wave == 1) {  // bootstrap of the chunk's last step
+        const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
+        if (n_steps > 0 && flag[q]) {
+            const f32x4 vt = value_tile_lds(vimg, XT0 + q * 16 * ldx, ldx, KS1, hv1, hv2, ld, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float vr = gfirst_quad(vt[r]);
+                if (r16 == r && active && trf[q * 16 + my_row]) {
+                    const float gv = gamma * vr;
+                    b.rewards[(int64_t)t * N + i] = rw[q * 16 + my_row] + gv;
+                }
+            }
+        }
+        return;
+    }
+    if (active) {
+        T::pack(v.st, N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sret += __shfl_down(sret, o, 64);
+        slen += __shfl_down(slen, o, 64);
+        scnt += __shfl_down(scnt, o, 64);
+    }
+    if (lane == 0 && scnt > 0.0) {
+        double *slot = v.stats + (row0 >> 8) * 3;
+        atomicAdd(slot + 0, sret);
+        atomicAdd(slot + 1, slen);
+        atomicAdd(slot + 2, scnt);
+    }
+}
+
 template <class T>
 static int launch_chunk(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed, uint32_t rng_step0,
                         float gamma, hipStream_t s) {
@@ -169,6 +339,14 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
     const int wpb = tiles >= 1024 ? 4 : 1;  // BASELINE shape (256 tiles): one wave per block so all 256 CUs take part
     constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
     const int smem = (2 * FWD_IMG + wpb * (16 * (2 * ldx + 2 * 66) + 32)) * 4;
+    if (wpb == 1) {  // one tile per CU: split the policy and the value net of a tile over two waves
+        const int smem2 = (2 * FWD_IMG + 4 * 16 * ldx + 4 * 16 * 66 + 32 + 32 + 4 + 32) * 4;
+        auto k2 = rollout_chunk2_h64_kernel<T>;
+        if (smem2 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+        k2<<<dim3((unsigned)tiles), dim3(128), smem2, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     auto k = rollout_chunk_h64_kernel<T>;
     if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     k<<<dim3((unsigned)ceil_div(tiles, wpb)), dim3(64 * wpb), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
