@@ -171,6 +171,12 @@ int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int
  * first (1/world_size after an all-reduce(sum)). */
 int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
                       double beta1, double beta2, double eps, double max_grad_norm, double grad_scale, void *workspace, void *stream);
+/* Same update for the single-GPU case where `grad` is exactly what the LAST tma_ppo_minibatch_grad on this workspace produced
+ * (no all-reduce, no accumulation over several minibatches; last_count = that minibatch's sample count): the gradient norm is taken
+ * from partial sums the gradient reduction already left in the workspace and the derived copies are written by the optimizer kernel
+ * itself (one launch instead of three).  Falls back to tma_ppo_adam_step(grad_scale = 1) for shapes without that fast path. */
+int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
+                            double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int64_t last_count);
 /* out8: sums since the last call of {policy_loss, value_sq_err, entropy, approx_kl, clipped, n_samples}, then the last
  * total grad norm and clip coefficient.  Synchronises `stream`. */
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream);

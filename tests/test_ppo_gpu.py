@@ -413,3 +413,41 @@ def test_epoch_prepare_equals_per_minibatch_pass():
     grad = torch.zeros(pol.n_trainable, device=dev)
     assert L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), C.byref(bad), C.byref(hpar), _lib.ptr(grad), _lib.ptr(ws),
                                     _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("D,A", [(4, 5), (21, 3)])
+def test_adam_step_local_equals_adam_step(D, A):
+    """tma_ppo_adam_step_local (norm from the reduction's partials, derived copies written by the optimizer kernel) against
+    the three-launch tma_ppo_adam_step on the same gradient: same norm / parameters up to the f64 summation order of the norm."""
+    from three_mlagents_amd import _lib
+
+    H, T, N, B = 64, 32, 64, 1024
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    res = []
+    for local in (False, True):
+        pol, sd = _policy(D, H, A, False)
+        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+        m = torch.zeros(pol.n_trainable, device=dev)
+        v = torch.zeros(pol.n_trainable, device=dev)
+        norms = []
+        for step in range(1, 4):
+            grad, st, ws = _hip_grad(pol, dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret), T, N, None, 100 * step, B, HP, perm=(5, step))
+            if local:
+                _lib.check(L.tma_ppo_adam_step_local(_lib.ptr(pol.params), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), C.byref(pol.dims), step, 3e-4, 0.9,
+                                                     0.999, 1e-5, 0.5, _lib.ptr(ws), _lib.stream_ptr(), B))
+            else:
+                _lib.check(L.tma_ppo_adam_step(_lib.ptr(pol.params), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), C.byref(pol.dims), step, 3e-4, 0.9, 0.999,
+                                               1e-5, 0.5, 1.0, _lib.ptr(ws), _lib.stream_ptr()))
+            out = (C.c_double * 8)()
+            _lib.check(L.tma_ppo_pop_stats(_lib.ptr(ws), out, _lib.stream_ptr()))
+            norms.append((out[6], out[7]))
+            assert float(grad.abs().max()) == 0.0
+        after = pol.params.clone()
+        _lib.check(L.tma_policy_sync(_lib.ptr(pol.params), C.byref(pol.dims), _lib.stream_ptr()))
+        assert torch.equal(after, pol.params)  # every derived region is what a full refresh rebuilds
+        res.append((after.cpu(), m.cpu(), v.cpu(), norms))
+    (p0, m0, v0, n0), (p1, m1, v1, n1) = res
+    for (a0, c0), (a1, c1) in zip(n0, n1):
+        assert abs(a0 - a1) <= 1e-6 * max(1.0, a0) and abs(c0 - c1) <= 1e-6
+    assert torch.allclose(p0, p1, rtol=0, atol=1e-7) and torch.allclose(m0, m1, rtol=1e-6, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-6, atol=1e-12)

@@ -1256,8 +1256,10 @@ static int grad_wide_smem_bytes(const PLayout &L) {
 // fixed order -> bitwise reproducible, and enough independent loads in flight to run at L2 speed.
 // Parameters in [vf_begin, vf_end) (the value net) are summed over n_slabs_vf slabs, all others over n_slabs (the policy net may
 // run on more blocks than the value net -- the bf16 wide kernel balances the two by their cost per row group).
+// sq_part (optional): sq_part[blockIdx.x] = sum of squares of this block's 64 finished gradient entries (f64, fixed order) -- lets
+// tma_ppo_adam_step_local skip its own pass over the gradient for the norm.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs_pi, int P, float *__restrict__ grad,
-                                                          int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0) {
+                                                          int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0, double *__restrict__ sq_part = nullptr) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -1278,7 +1280,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     }
     part[q][lane] = s;
     __syncthreads();
-    if (q == 0 && e < P) grad[e] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (q == 0) {
+        float gnew = 0.0f;
+        if (e < P) {
+            gnew = grad[e] + (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+            grad[e] = gnew;
+        }
+        if (sq_part) {
+            double sq = (double)gnew * (double)gnew;
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+            if (lane == 0) sq_part[blockIdx.x] = sq;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1323,6 +1336,81 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params, f
     }
 }
 
+
+// Fast-path layouts (H == 64, LDS images): the derived locations of trainable parameter e -- its [out][in] copy and its slots in
+// the forward / input-gradient images of its net (inverse of build_image_elem).
+__device__ __forceinline__ void scatter_derived_h64(float *params, const PLayout &L, int e, float val) {
+    constexpr int H = 64;
+    const int D = L.D, A = L.A;
+    const bool vf = e >= L.vW1t && e < L.log_std;
+    const int base = vf ? L.vW1t : L.pW1t, img = vf ? L.img_vf : L.img_pi, n_out = vf ? 1 : A;
+    int x = e - base;
+    if (x < D * H) {  // W1t[k][n]
+        const int k = x >> 6, n = x & 63;
+        params[img + IMG_W1 + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        return;
+    }
+    x -= D * H;
+    if (x < H) { params[img + IMG_B1 + x] = val; return; }
+    x -= H;
+    if (x < H * H) {  // W2t[k][n]
+        const int k = x >> 6, n = x & 63;
+        params[(vf ? L.vW2 : L.pW2) + n * H + k] = val;
+        params[img + IMG_W2F + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        params[img + IMG_W2B + n * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * H;
+    if (x < H) { params[img + IMG_B2 + x] = val; return; }
+    x -= H;
+    if (x < H * n_out) {  // W3t[k][a]
+        const int k = x / n_out, a = x - k * n_out;
+        params[(vf ? L.vW3 : L.pW3) + a * H + k] = val;
+        params[img + IMG_W3F + k * 16 + a] = val;
+        params[img + IMG_W3B + a * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * n_out;
+    if (x < n_out) params[img + IMG_B3 + x] = val;
+}
+
+// tma_ppo_adam_step_local, H == 64 fast path: one thread per parameter over ceil(P / 256) blocks.  The norm comes from the
+// sum-of-squares partials slab_reduce_kernel left (every block folds them in the same fixed order), and each thread writes its
+// updated parameter to the flat buffer AND to its derived copies / image slots -- no single-block optimizer, no refresh launch.
+__global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
+                                                               float *__restrict__ v, PLayout L, const double *__restrict__ sq_part, int n_part,
+                                                               float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt, float eps,
+                                                               double *norm_out) {
+    __shared__ double red[4];
+    __shared__ float coef_s;
+    double a = (int)threadIdx.x < n_part ? sq_part[threadIdx.x] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+        const float total_norm = (float)sqrt(tot);
+        float coef = max_norm / (total_norm + 1e-6f);
+        coef = coef > 1.0f ? 1.0f : coef;
+        if (max_norm <= 0.0f) coef = 1.0f;
+        coef_s = coef;
+        if (blockIdx.x == 0) norm_out[0] = (double)total_norm, norm_out[1] = (double)coef;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= L.P) return;
+    const float gv = grad[e] * coef_s;
+    grad[e] = 0.0f;
+    float mm = m[e], vv = v[e];
+    mm = mm + (gv - mm) * (1.0f - beta1);
+    vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    const float pn = params[e] - lr_step * (mm / denom);
+    params[e] = pn;
+    if (e < L.log_std) scatter_derived_h64(params, L, e, pn);
+}
 
 // small policies (P <= 32768): clip_grad_norm_ + Adam in ONE single-block launch (the norm needs no second kernel)
 __global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
@@ -1984,7 +2072,8 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0,
+                                                                                   L.P <= 64 * 256 ? reinterpret_cast<double *>(ws + WS_NORM_PART) : nullptr);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -2134,6 +2223,27 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
                                                (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
     TMA_LAUNCH_CHECK();
     return launch_sync(params, L, s);
+}
+
+int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
+                            double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int64_t last_count) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step_local: null buffer");
+    if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
+    const PLayout L = layout_of(d);
+    // the partials exist only when the last tma_ppo_minibatch_grad took the H == 64 persistent kernel (>= 256 samples)
+    if (!(L.img_pi >= 0 && L.P <= 64 * 256 && last_count >= 256))
+        return tma_ppo_adam_step(params, grad, exp_avg, exp_avg_sq, d, step, lr, beta1, beta2, eps, max_grad_norm, 1.0, workspace, stream);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = static_cast<char *>(workspace);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
+    adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
+        params, grad, exp_avg, exp_avg_sq, L, reinterpret_cast<const double *>(ws + WS_NORM_PART), (int)ceil_div(L.P, 64), (float)max_grad_norm,
+        (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
 }
 
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {

@@ -283,9 +283,14 @@ class PPO:
 
                     tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
                 self._adam_step += 1
-                _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                               C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5, self.max_grad_norm,
-                                               scale, _lib.ptr(self.workspace), self._stream()))
+                if self.world_size == 1:  # grad is exactly the last minibatch's: norm partials + derived copies ride in one launch
+                    _lib.check(L.tma_ppo_adam_step_local(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                                         _lib.ptr(self.exp_avg_sq), C.byref(self.policy.dims), self._adam_step, self.learning_rate,
+                                                         0.9, 0.999, 1e-5, self.max_grad_norm, _lib.ptr(self.workspace), self._stream(), mb.count))
+                else:
+                    _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                                   C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
+                                                   self.max_grad_norm, scale, _lib.ptr(self.workspace), self._stream()))
             self._epoch_counter += 1
         self._n_updates += self.n_epochs
 
