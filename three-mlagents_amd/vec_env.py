@@ -41,9 +41,13 @@ def _require_gpu(device):
 class HipEnvEngine:
     """Thin owner of one `tma_env` handle plus its output tensors."""
 
-    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int = 32):
+    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int | None = None):
         task = TASK_ALIASES.get(task, task)
         self.task_name = task
+        if ring_depth is None:
+            # A refill launch is bound by the serial MT19937 seeding chain of its few thousand lanes, not by their number: a deeper
+            # ring means proportionally fewer refill (and rollout-chunk) launches at the same cost each.  Memory = N * depth records.
+            ring_depth = 128 if num_envs <= 16384 else (64 if num_envs <= 131072 else 32)
         self.task = _lib.task_id(task)  # KeyError for unknown tasks
         L = _lib.lib()
         self.num_envs = int(num_envs)
@@ -174,7 +178,7 @@ class HipEnvEngine:
 class HipVecEnv:
     """SB3 `VecEnv`-shaped view of a HipEnvEngine (drop-in for DummyVecEnv(Monitor(...)))."""
 
-    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int = 32):
+    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int | None = None):
         self.engine = HipEnvEngine(task, num_envs, seed=seed, device=device, env_offset=env_offset, ring_depth=ring_depth)
         self.task_id = self.engine.task_name
         self.num_envs = self.engine.num_envs
@@ -279,7 +283,7 @@ class HipVecEnv:
 class HipVectorEnv:
     """Gymnasium `VectorEnv`-shaped view (reset(seed=) -> (obs, infos); step -> 5-tuple)."""
 
-    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int = 32):
+    def __init__(self, task: str, num_envs: int, *, seed: int = 1, device=None, env_offset: int = 0, ring_depth: int | None = None):
         self._vec = HipVecEnv(task, num_envs, seed=seed, device=device, env_offset=env_offset, ring_depth=ring_depth)
         self.engine = self._vec.engine
         self.num_envs = self._vec.num_envs
