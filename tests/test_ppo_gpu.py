@@ -415,19 +415,25 @@ def test_epoch_prepare_equals_per_minibatch_pass():
                                     _lib.stream_ptr()) != 0
 
 
-@pytest.mark.parametrize("D,A", [(4, 5), (21, 3)])
-def test_adam_step_local_equals_adam_step(D, A):
+@pytest.mark.parametrize("D,H,A,cont,dtype", [(4, 64, 5, False, "f32"), (21, 64, 3, False, "f32"), (6, 256, 5, False, "f32"), (6, 256, 5, False, "bf16"),
+                                                (172, 256, 20, True, "bf16"), (21, 192, 3, False, "bf16"), (40, 128, 7, True, "f32")])
+def test_adam_step_local_equals_adam_step(D, H, A, cont, dtype):
     """tma_ppo_adam_step_local (norm from the reduction's partials, derived copies written by the optimizer kernel) against
     the three-launch tma_ppo_adam_step on the same gradient: same norm / parameters up to the f64 summation order of the norm."""
     from three_mlagents_amd import _lib
 
-    H, T, N, B = 64, 32, 64, 1024
+    T, N, B = 32, 64, 1024
     L = _lib.lib()
     dev = torch.device("cuda", 0)
     res = []
     for local in (False, True):
-        pol, sd = _policy(D, H, A, False)
-        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+        if dtype == "bf16":
+            from test_bf16_gpu import _policies
+
+            pol, sd = _policies(D, H, A, cont)
+        else:
+            pol, sd = _policy(D, H, A, cont)
+        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, cont, T, N)
         m = torch.zeros(pol.n_trainable, device=dev)
         v = torch.zeros(pol.n_trainable, device=dev)
         norms = []

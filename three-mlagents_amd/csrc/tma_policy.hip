@@ -31,7 +31,8 @@ constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 25
 constexpr int64_t WS_BYTES = WS_SLABS;
 constexpr int BF_SLABS = 160;  // bf16 wide kernel: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
 constexpr int64_t OFFS_CAP = 1 << 22;
-constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
+constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch
+constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_kernel for policies beyond the 256 slots at WS_NORM_PART  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -1412,6 +1413,84 @@ __global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict
     if (e < L.log_std) scatter_derived_h64(params, L, e, pn);
 }
 
+// Column-parallel layouts (H = 128 / 192 / 256): derived locations of trainable parameter e -- the [out][in] f32 copies of W2 / W3
+// and, in bf16 mode, its slots in the fragment-major images (inverse of build_bf16_images_kernel).
+__device__ __forceinline__ void scatter_derived_wide(float *params, const PLayout &L, int e, float val) {
+    const int D = L.D, H = L.H;
+    const bool vf = e >= L.vW1t && e < L.log_std;
+    const int base = vf ? L.vW1t : L.pW1t, n_out = vf ? 1 : L.A;
+    bf16_t *img = L.bf16 ? reinterpret_cast<bf16_t *>(params + (vf ? L.bf_vf : L.bf_pi)) : nullptr;
+    const BfNet B = bf_net_layout(D, H, n_out);
+    const int KS2 = H >> 5, KS1 = ((D + 31) & ~31) >> 5;
+    const bf16_t bv = (bf16_t)val;
+    int x = e - base;
+    if (x < D * H) {  // W1t[k][n]
+        const int k = x / H, n = x - k * H;
+        if (img) img[B.fW1 + (((n >> 4) * KS1 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = bv;
+        return;
+    }
+    x -= D * H;
+    if (x < H) return;
+    x -= H;
+    if (x < H * H) {  // W2t[k][n]
+        const int k = x / H, n = x - k * H;
+        params[(vf ? L.vW2 : L.pW2) + n * H + k] = val;
+        if (img) {
+            img[B.fW2 + (((n >> 4) * KS2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = bv;
+            img[B.bW2 + (((k >> 4) * KS2 + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (k & 15)) * 8 + (n & 7)] = bv;
+        }
+        return;
+    }
+    x -= H * H;
+    if (x < H) return;
+    x -= H;
+    if (x < H * n_out) {  // W3t[k][a]
+        const int k = x / n_out, a = x - k * n_out;
+        params[(vf ? L.vW3 : L.pW3) + a * H + k] = val;
+        if (img) {
+            img[B.fW3 + (((a >> 4) * KS2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (a & 15)) * 8 + (k & 7)] = bv;
+            img[B.bW3 + ((k >> 4) * 64 + ((a >> 3) & 3) * 16 + (k & 15)) * 8 + (a & 7)] = bv;
+        }
+    }
+}
+
+// tma_ppo_adam_step_local for the column-parallel layouts: as adam_scatter_h64_kernel, with up to WIDE_SQ_SLOTS norm partials
+__global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
+                                                                float *__restrict__ v, PLayout L, const double *__restrict__ sq_part, int n_part,
+                                                                float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt, float eps,
+                                                                double *norm_out) {
+    __shared__ double red[4];
+    __shared__ float coef_s;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < n_part; b += 256) a += sq_part[b];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+        const float total_norm = (float)sqrt(tot);
+        float coef = max_norm / (total_norm + 1e-6f);
+        coef = coef > 1.0f ? 1.0f : coef;
+        if (max_norm <= 0.0f) coef = 1.0f;
+        coef_s = coef;
+        if (blockIdx.x == 0) norm_out[0] = (double)total_norm, norm_out[1] = (double)coef;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= L.P) return;
+    const float gv = grad[e] * coef_s;
+    grad[e] = 0.0f;
+    float mm = m[e], vv = v[e];
+    mm = mm + (gv - mm) * (1.0f - beta1);
+    vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    const float pn = params[e] - lr_step * (mm / denom);
+    params[e] = pn;
+    if (e < L.log_std) scatter_derived_wide(params, L, e, pn);
+}
+
 // small policies (P <= 32768): clip_grad_norm_ + Adam in ONE single-block launch (the norm needs no second kernel)
 __global__ __launch_bounds__(1024) void opt_small_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
                                                          PLayout L, float scale, float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt,
@@ -1502,6 +1581,14 @@ static int launch_sync(float *params, const PLayout &L, hipStream_t s) {
         TMA_LAUNCH_CHECK();
     }
     return TMA_OK;
+}
+
+// where slab_reduce_kernel leaves its sum-of-squares partials (one per 64 parameters) for tma_ppo_adam_step_local
+static double *sq_partials(char *ws, const PLayout &L) {
+    const int n = (int)ceil_div(L.P, 64);
+    if (n <= 256) return reinterpret_cast<double *>(ws + WS_NORM_PART);
+    if (n > WIDE_SQ_SLOTS) return nullptr;
+    return reinterpret_cast<double *>(ws + WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES);
 }
 
 static int check_dims(const tma_policy_dims *d) {
@@ -1932,7 +2019,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES;
+    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8;
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -2072,8 +2159,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0,
-                                                                                   L.P <= 64 * 256 ? reinterpret_cast<double *>(ws + WS_NORM_PART) : nullptr);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -2120,7 +2206,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -2149,7 +2235,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad, -1, 0, 0, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -2232,16 +2318,26 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
     if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step_local: null buffer");
     if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
     const PLayout L = layout_of(d);
-    // the partials exist only when the last tma_ppo_minibatch_grad took the H == 64 persistent kernel (>= 256 samples)
-    if (!(L.img_pi >= 0 && L.P <= 64 * 256 && last_count >= 256))
+    // the partials exist only when the last tma_ppo_minibatch_grad ended in slab_reduce_kernel: the H == 64 persistent kernel
+    // (>= 256 samples), the bf16 column-parallel kernel (any size) or the f32 column-parallel kernel (>= 128 samples)
+    char *ws = static_cast<char *>(workspace);
+    const bool h64 = L.img_pi >= 0 && last_count >= 256;
+    const bool wide_f32 = !L.bf16 && (L.H == 128 || L.H == 192 || L.H == 256) && last_count >= 128 && grad_wide_smem_bytes(L) <= 160 * 1024 &&
+                          getenv("TMA_FORCE_WIDE") == nullptr;
+    const double *sqp = sq_partials(ws, L);
+    if (!(h64 || L.bf16 || wide_f32) || !sqp || last_count < 1)
         return tma_ppo_adam_step(params, grad, exp_avg, exp_avg_sq, d, step, lr, beta1, beta2, eps, max_grad_norm, 1.0, workspace, stream);
     hipStream_t s = (hipStream_t)stream;
-    char *ws = static_cast<char *>(workspace);
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
-    adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
-        params, grad, exp_avg, exp_avg_sq, L, reinterpret_cast<const double *>(ws + WS_NORM_PART), (int)ceil_div(L.P, 64), (float)max_grad_norm,
-        (float)step_size, (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
+    if (h64)
+        adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
+            params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
+            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
+    else
+        adam_scatter_wide_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
+            params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
+            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }
