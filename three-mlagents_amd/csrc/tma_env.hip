@@ -256,7 +256,7 @@ __device__ __forceinline__ int last_le(const uint32_t *a, int n, uint32_t x) {
 template <class T, int W>
 __global__ __launch_bounds__(256) void refill_fast_kernel(EnvView v, RefillView rv, int mode, int64_t total_dense, float *obs_out) {
     const int64_t total = mode == 0 ? total_dense : (int64_t)rv.total[0];
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t i;
         uint32_t e;
         if (mode == 0) {
@@ -367,8 +367,8 @@ static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_
 using namespace tma;
 
 template <class T, int W>
-static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, float *obs_out, hipStream_t s) {
-    refill_fast_kernel<T, W><<<dim3(blocks), dim3(256), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out);
+static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, unsigned threads, float *obs_out, hipStream_t s) {
+    refill_fast_kernel<T, W><<<dim3(blocks), dim3(threads), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out);
 }
 
 static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
@@ -383,6 +383,7 @@ static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
         } else {
             TMA_HIP(hipMemsetAsync(h->rv.total, 0, sizeof(uint32_t) * 2, s));
             int64_t total_dense = 0, blocks;
+            unsigned threads = 256;
             if (mode == 0) {
                 total_dense = h->v.N * (int64_t)(h->v.D + 1);
                 blocks = ceil_div(total_dense, 256);
@@ -392,11 +393,18 @@ static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
                 refill_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(h->rv);
                 TMA_LAUNCH_CHECK();
                 blocks = 2 * (int64_t)h->rv.nb;  // about D / mean-episode-length items per env; the kernel grid-strides past that
+                if (h->v.N <= 65536) {
+                    // few thousand items, each a serial ~4k-instruction MT19937 seeding chain on ONE lane: single-wave blocks and a
+                    // grid sized for one item per lane put them on every CU instead of on 2 * N / 256 of them (blocks without an
+                    // item leave at once)
+                    threads = 64;
+                    blocks = ceil_div(h->v.N * (int64_t)h->v.D, 256);
+                }
             }
             if (blocks > 16384) blocks = 16384;
             if (blocks < 1) blocks = 1;
-            if (h->small_window) launch_fast<T, T::Fast::W_SMALL>(h, mode, total_dense, (unsigned)blocks, obs_out, s);
-            else launch_fast<T, T::Fast::W>(h, mode, total_dense, (unsigned)blocks, obs_out, s);
+            if (h->small_window) launch_fast<T, T::Fast::W_SMALL>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s);
+            else launch_fast<T, T::Fast::W>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s);
             TMA_LAUNCH_CHECK();
             refill_fallback_kernel<T><<<dim3(FB_BLOCKS), dim3(256), 0, s>>>(h->v, h->rv, h->mt_scratch, mode, obs_out);
             TMA_LAUNCH_CHECK();
