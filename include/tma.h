@@ -191,9 +191,12 @@ typedef struct {
     float *log_probs;      /* [T][N] */
     uint8_t *terminated;   /* [T][N] */
     uint8_t *truncated;    /* [T][N] */
-    float *terminal_obs;   /* [N][D] scratch, rewritten every step */
+    float *terminal_obs;   /* [K][N][D] scratch (K = terminal_obs_slots): slot (t mod K) holds step t's pre-reset observations */
     float *last_values;    /* [N] */
     int64_t N;
+    int terminal_obs_slots; /* K >= 1 (0 is read as 1).  With K > 1 the non-fused path computes the timeout bootstrap
+                               rewards[t] += gamma * V(terminal_obs[t]) of K consecutive steps in ONE launch over K*N rows
+                               instead of one small launch per vector step */
 } tma_rollout_buffers;
 int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin, int t_end,
                         int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma, int compute_last_values,

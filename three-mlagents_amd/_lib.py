@@ -37,7 +37,7 @@ class PPOHParams(C.Structure):
 
 class RolloutBuffers(C.Structure):
     _fields_ = [("obs", _vp), ("actions", _vp), ("rewards", _vp), ("values", _vp), ("log_probs", _vp), ("terminated", _vp),
-                ("truncated", _vp), ("terminal_obs", _vp), ("last_values", _vp), ("N", _i64)]
+                ("truncated", _vp), ("terminal_obs", _vp), ("last_values", _vp), ("N", _i64), ("terminal_obs_slots", _i32)]
 
 
 _pd = C.POINTER(PolicyDims)

@@ -396,22 +396,47 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     }
     const int D = d->obs_dim, A = d->continuous ? d->act_dim : 1;
     const size_t act_elem = d->continuous ? sizeof(float) : sizeof(int32_t);
-    for (int t = t_begin; t < t_end; t++) {
-        const float *obs_t = b->obs + (int64_t)t * N * D;
-        float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
-        void *act_t = static_cast<char *>(b->actions) + (int64_t)t * N * A * act_elem;
-        // policy forward of step t; the timeout bootstrap of step t-1 (terminal_obs still holds step t-1's) rides in the same launch
-        int rc = tma_policy_act_bootstrap(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, act_t, b->values + (int64_t)t * N,
-                                          b->log_probs + (int64_t)t * N, t > 0 ? b->terminal_obs : nullptr,
-                                          t > 0 ? b->truncated + (int64_t)(t - 1) * N : nullptr, gamma,
-                                          t > 0 ? b->rewards + (int64_t)(t - 1) * N : nullptr, stream);
-        if (rc) return rc;
-        rc = tma_env_step(env, act_t, d->continuous ? TMA_ACT_F32 : TMA_ACT_I32, 0, 0, 1, obs_next, b->rewards + (int64_t)t * N,
-                          b->terminated + (int64_t)t * N, b->truncated + (int64_t)t * N, b->terminal_obs, nullptr, nullptr, stream);
-        if (rc) return rc;
-        if (t == T - 1) {  // last step of the rollout: nothing follows to carry its bootstrap
-            rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, N, gamma, b->rewards + (int64_t)t * N, stream);
+    const int K = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
+    if (K == 1) {
+        for (int t = t_begin; t < t_end; t++) {
+            const float *obs_t = b->obs + (int64_t)t * N * D;
+            float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
+            void *act_t = static_cast<char *>(b->actions) + (int64_t)t * N * A * act_elem;
+            // policy forward of step t; the timeout bootstrap of step t-1 (terminal_obs still holds step t-1's) rides in the same launch
+            int rc = tma_policy_act_bootstrap(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, act_t, b->values + (int64_t)t * N,
+                                              b->log_probs + (int64_t)t * N, t > 0 ? b->terminal_obs : nullptr,
+                                              t > 0 ? b->truncated + (int64_t)(t - 1) * N : nullptr, gamma,
+                                              t > 0 ? b->rewards + (int64_t)(t - 1) * N : nullptr, stream);
             if (rc) return rc;
+            rc = tma_env_step(env, act_t, d->continuous ? TMA_ACT_F32 : TMA_ACT_I32, 0, 0, 1, obs_next, b->rewards + (int64_t)t * N,
+                              b->terminated + (int64_t)t * N, b->truncated + (int64_t)t * N, b->terminal_obs, nullptr, nullptr, stream);
+            if (rc) return rc;
+            if (t == T - 1) {  // last step of the rollout: nothing follows to carry its bootstrap
+                rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, N, gamma, b->rewards + (int64_t)t * N, stream);
+                if (rc) return rc;
+            }
+        }
+    } else {
+        // K terminal-observation slots: step t writes slot (t - w0) of its window [w0, w0 + K); the window's bootstraps are one launch
+        // over the K*N rows (terminal_obs, truncated[w0..] and rewards[w0..] are all contiguous in the step index).
+        int w0 = t_begin;
+        for (int t = t_begin; t < t_end; t++) {
+            const float *obs_t = b->obs + (int64_t)t * N * D;
+            float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
+            void *act_t = static_cast<char *>(b->actions) + (int64_t)t * N * A * act_elem;
+            int rc = tma_policy_act(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, 0, act_t, b->values + (int64_t)t * N,
+                                    b->log_probs + (int64_t)t * N, stream);
+            if (rc) return rc;
+            rc = tma_env_step(env, act_t, d->continuous ? TMA_ACT_F32 : TMA_ACT_I32, 0, 0, 1, obs_next, b->rewards + (int64_t)t * N,
+                              b->terminated + (int64_t)t * N, b->truncated + (int64_t)t * N, b->terminal_obs + (int64_t)(t - w0) * N * D, nullptr,
+                              nullptr, stream);
+            if (rc) return rc;
+            if (t - w0 + 1 == K || t == t_end - 1) {
+                rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)w0 * N, (int64_t)(t - w0 + 1) * N, gamma,
+                                          b->rewards + (int64_t)w0 * N, stream);
+                if (rc) return rc;
+                w0 = t + 1;
+            }
         }
     }
     if (compute_last_values && t_end == T) {

@@ -200,12 +200,14 @@ class PPO:
         env.seed(self.seed)  # BaseAlgorithm.set_random_seed -> env.seed(seed): env i gets seed + i
         T, N, D, dev = self.n_steps, self.n_envs, eng.obs_dim, self.device
         f32 = torch.float32
+        # terminal-observation slots: the non-fused rollout path bootstraps this many steps per launch (include/tma.h)
+        self._tobs_slots = max(1, min(16, T, (256 << 20) // max(1, N * D * 4)))
         self.buf = dict(
             obs=torch.zeros((T + 1, N, D), dtype=f32, device=dev),
             actions=torch.zeros((T, N, A), dtype=f32, device=dev) if cont else torch.zeros((T, N), dtype=torch.int32, device=dev),
             rewards=torch.zeros((T, N), dtype=f32, device=dev), values=torch.zeros((T, N), dtype=f32, device=dev),
             log_probs=torch.zeros((T, N), dtype=f32, device=dev), terminated=torch.zeros((T, N), dtype=torch.uint8, device=dev),
-            truncated=torch.zeros((T, N), dtype=torch.uint8, device=dev), terminal_obs=torch.zeros((N, D), dtype=f32, device=dev),
+            truncated=torch.zeros((T, N), dtype=torch.uint8, device=dev), terminal_obs=torch.zeros((self._tobs_slots, N, D), dtype=f32, device=dev),
             last_values=torch.zeros((N,), dtype=f32, device=dev), advantages=torch.zeros((T, N), dtype=f32, device=dev),
             returns=torch.zeros((T, N), dtype=f32, device=dev),
         )
@@ -217,7 +219,7 @@ class PPO:
         b = self.buf
         self._rb = _lib.RolloutBuffers(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["rewards"]), _lib.ptr(b["values"]),
                                        _lib.ptr(b["log_probs"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]), _lib.ptr(b["terminal_obs"]),
-                                       _lib.ptr(b["last_values"]), N)
+                                       _lib.ptr(b["last_values"]), N, self._tobs_slots)
         self._rollout_view = _lib.Rollout(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["log_probs"]), _lib.ptr(b["advantages"]),
                                           _lib.ptr(b["returns"]), T, N)
         self._hp = _lib.PPOHParams(self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0)
