@@ -250,6 +250,11 @@ def main():
             "note": ("bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
                      "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
         }
+        pmc_bf = os.path.join(ROOT, "profiles", "r01_gradbf_kernel_pmc.json")
+        if bf and args.hidden == 256 and args.task == "ball3d" and os.path.exists(pmc_bf):
+            pmc = json.load(open(pmc_bf))
+            out["roofline"]["traffic"] = pmc.get("traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/r01_gradbf_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
         pmc_path = os.path.join(ROOT, "profiles", "r01_grad_kernel_pmc.json")
         if fast and args.task == "gridworld" and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))

@@ -38,6 +38,10 @@ struct PLayout {
     int img_pi, img_vf;  // LDS-image regions (H == 64 fast path), IMG_FLOATS each; -1 when the shape has no fast path
     int bf16;            // 1: the hidden-layer GEMMs run on the bf16 MFMA (f32 master weights, f32 accumulate) -- tma_wide_bf16.h
     int bf_pi, bf_vf;    // float offsets of the bf16 fragment-major weight images of the two nets; -1 in f32 mode
+    int fr_pi, fr_vf;    // f32 mode, H = 128 / 192 / 256: fragment-major f32 images of W2 (forward, then input-gradient), 2*H*H floats per
+                         // net: element i of lane l in fragment (tile t, group q) is the B operand of k-step 4q + i -- forward
+                         // W2[k = 16q + 4i + (l>>4)][n = 16t + (l&15)], input-gradient W2[k' = 16t + (l&15)][n = 16q + 4i + (l>>4)] -- so a
+                         // lane's operands for four consecutive k-steps are one coalesced 16-byte load; -1 otherwise
     int total;
 };
 
@@ -111,8 +115,29 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, in
         L.bf_pi = o, o += bf_net_layout(D, H, A).size / 2;
         L.bf_vf = o, o += bf_net_layout(D, H, 1).size / 2;
     }
+    L.fr_pi = L.fr_vf = -1;
+    if (!L.bf16 && (H == 128 || H == 192 || H == 256)) {
+        L.fr_pi = o, o += 2 * H * H;
+        L.fr_vf = o, o += 2 * H * H;
+    }
     L.total = o;
     return L;
+}
+
+// value the optimiser must treat as new (not loop-invariant) but provably wave-uniform: keeps weight loads of a persistent loop
+// from being hoisted in front of it (and spilled), and keeps their address arithmetic scalar
+__device__ __forceinline__ const float *launder_uniform(const float *p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float *>(((uint64_t)hi << 32) | lo);
+}
+// fragment `idx` (64 lanes x 4 floats) of an f32 fragment-major image: scalar base + 32-bit lane offset, explicit global load
+__device__ __forceinline__ f32x4 frag_f32(const float *img, int idx, int lane) {
+    typedef const char __attribute__((address_space(1))) *gbyte_ptr;
+    typedef const f32x4 __attribute__((address_space(1))) *gvec_ptr;
+    const gbyte_ptr base = reinterpret_cast<gbyte_ptr>(reinterpret_cast<uintptr_t>(img + (int64_t)idx * 256));
+    return *reinterpret_cast<gvec_ptr>(base + (uint32_t)lane * 16u);
 }
 
 // out[16][N] = tanh(in[16][K] . Wt[K][N] + b)   (N % 64 == 0; in/out are wave-private LDS tiles)

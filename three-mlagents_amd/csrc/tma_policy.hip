@@ -74,6 +74,18 @@ __device__ __forceinline__ void build_image_elem(float *params, const PLayout &L
     params[img + e] = v;
 }
 
+// f32 fragment-major images of W2 for the column-parallel f32 kernels (layout: PLayout::fr_pi)
+__global__ void build_f32_frag_images_kernel(float *params, PLayout L) {
+    const int H = L.H, NQ = H >> 4, per = H * H;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * per; e += gridDim.x * blockDim.x) {
+        const int net = e / (2 * per), x = e - net * 2 * per, bwd = x >= per, y = bwd ? x - per : x;
+        const float *W2 = params + (net == 0 ? L.pW2t : L.vW2t);
+        const int i = y & 3, l = (y >> 2) & 63, rest = y >> 8, q = rest % NQ, t = rest / NQ;
+        const int a = 16 * q + 4 * i + (l >> 4), b = 16 * t + (l & 15);  // forward: (k, n) = (a, b); input-gradient: (k', n) = (b, a)
+        params[(net == 0 ? L.fr_pi : L.fr_vf) + x] = bwd ? W2[b * H + a] : W2[a * H + b];
+    }
+}
+
 // refreshes everything derived from the trainable region: [out][in] copies and (H == 64 fast path) the LDS images
 __global__ void sync_transposed_kernel(float *params, PLayout L) {
     const int H = L.H, A = L.A;
@@ -906,12 +918,29 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
     for (int q = 0; q < NT3; q++) ab3[q] = 0.0f;
     LossStats st;
+    // The two H x H weight streams of a row group (layer-2 forward, then layer-2 input-gradient) come from the fragment-major f32
+    // images (PLayout::fr_pi) through a register ring of R fragments: one 16-byte load per lane feeds four k-steps (8 MFMAs), and
+    // the slot a fragment is consumed from is reloaded at once with the fragment R positions further down the cyclic stream --
+    // 2 k cycles of MFMA work of lookahead that carries across phases, barriers and row groups.
+    constexpr int NQ = H / 16, R = 8, SL = 2 * NTW * NQ;
+    static_assert(SL % R == 0, "ring must divide the per-group fragment stream");
+    const float *fr = params + (IS_PI ? L.fr_pi : L.fr_vf);
+    int nt0 = wave * NTW;
+    auto sload = [&](int s) -> f32x4 {  // s in [0, SL): compile-time after unrolling
+        const int half = s >= SL / 2, t = half ? s - SL / 2 : s;
+        return frag_f32(fr + half * H * H, (nt0 + t / NQ) * NQ + t % NQ, lane0);
+    };
+    f32x4 ring[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) ring[s] = sload(s);
     const int64_t n_groups = (mb.count + M - 1) / M;
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
         {
-            const float *pl = params;
-            asm volatile("" : "+s"(pl));
+            const float *pl = launder_uniform(params);
             Q = IS_PI ? pi_net(pl, L) : vf_net(pl, L);
+            fr = pl + (IS_PI ? L.fr_pi : L.fr_vf);
+            asm volatile("" : "+s"(nt0));
+            nt0 = __builtin_amdgcn_readfirstlane(nt0);
         }
         TMA_RELANE();
         // ---- P0: gather sample metadata and the observation rows ----
@@ -966,18 +995,23 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
         TMA_RELANE();
-        // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live) ----
+        // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live), weights through the ring ----
 #pragma unroll
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b2[n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
-            const float *wcol = Q.W2t + n_base + 16 * j + r16;
-#pragma unroll 8
-            for (int ks = 0; ks < H / 4; ks++) {
-                const int k = 4 * ks + g;
-                const float w = wcol[(int64_t)k * H];
-                c0 = mfma16(h1[r16 * ld + k], w, c0);
-                c1 = mfma16(h1[(16 + r16) * ld + k], w, c1);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int s = j * NQ + q;
+                const f32x4 w4 = ring[s % R];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = 16 * q + 4 * i + g;
+                    c0 = mfma16(h1[r16 * ld + k], w4[i], c0);
+                    c1 = mfma16(h1[(16 + r16) * ld + k], w4[i], c1);
+                }
+                ring[s % R] = sload((s + R) % SL);
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -1088,13 +1122,18 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 f32x4 c0 = z4, c1 = z4;
-                const float *wcol = Q.W2 + n_base + 16 * j + r16;
-#pragma unroll 8
-                for (int ns = 0; ns < H / 4; ns++) {
-                    const int n = 4 * ns + g;
-                    const float w = wcol[(int64_t)n * H];
-                    c0 = mfma16(h2[r16 * ld + n], w, c0);
-                    c1 = mfma16(h2[(16 + r16) * ld + n], w, c1);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const int s = SL / 2 + j * NQ + q;
+                    const f32x4 w4 = ring[s % R];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int n = 16 * q + 4 * i + g;
+                        c0 = mfma16(h2[r16 * ld + n], w4[i], c0);
+                        c1 = mfma16(h2[(16 + r16) * ld + n], w4[i], c1);
+                    }
+                    ring[s % R] = sload((s + R) % SL);
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 dz1[j][0] = c0, dz1[j][1] = c1;
             }
@@ -1435,6 +1474,12 @@ __device__ __forceinline__ void scatter_derived_wide(float *params, const PLayou
     if (x < H * H) {  // W2t[k][n]
         const int k = x / H, n = x - k * H;
         params[(vf ? L.vW2 : L.pW2) + n * H + k] = val;
+        if (L.fr_pi >= 0) {  // f32 fragment images: forward slot of (k, n), input-gradient slot of (k' = k, n)
+            float *fr = params + (vf ? L.fr_vf : L.fr_pi);
+            const int NQ = H >> 4;
+            fr[(((n >> 4) * NQ + (k >> 4)) * 64 + (k & 3) * 16 + (n & 15)) * 4 + ((k >> 2) & 3)] = val;
+            fr[H * H + (((k >> 4) * NQ + (n >> 4)) * 64 + (n & 3) * 16 + (k & 15)) * 4 + ((n >> 2) & 3)] = val;
+        }
         if (img) {
             img[B.fW2 + (((n >> 4) * KS2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = bv;
             img[B.bW2 + (((k >> 4) * KS2 + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (k & 15)) * 8 + (n & 7)] = bv;
@@ -1578,6 +1623,10 @@ static int launch_sync(float *params, const PLayout &L, hipStream_t s) {
     TMA_LAUNCH_CHECK();
     if (L.bf16) {
         build_bf16_images_kernel<<<dim3(256), dim3(256), 0, s>>>(params, L);
+        TMA_LAUNCH_CHECK();
+    }
+    if (L.fr_pi >= 0) {
+        build_f32_frag_images_kernel<<<dim3((unsigned)ceil_div(4 * L.H * L.H, 256)), dim3(256), 0, s>>>(params, L);
         TMA_LAUNCH_CHECK();
     }
     return TMA_OK;

@@ -14,6 +14,7 @@ cp $(ls -t gpurun_out/${R}_bench_ball3d_bf16/*/*kernel_stats.csv | head -1) gpur
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_step_$c -- python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2 > gpurun_out/${R}_pmc_step_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_grad_$c -- python tools/prof_grad.py > gpurun_out/${R}_pmc_grad_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_$c -- python tools/prof_grad_bf16.py ball3d 256 bf16 > gpurun_out/${R}_pmc_gradbf_$c.log 2>&1
 done
 python - "$R" <<'PY'
 import csv, glob, json, sys
@@ -23,13 +24,14 @@ def mean_counter(tag, counter, kernel_substr):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
     return sum(vals) / len(vals), len(vals)
 out = {}
-for tag, sub, alg in (("step", "step_kernel<tma::GridTask, 3>", 54 * 4194304), ("grad", "ppo_grad_h64_kernel", None)):
+for tag, sub, alg in (("step", "step_kernel<tma::GridTask, 3>", 54 * 4194304), ("grad", "ppo_grad_h64_kernel", None), ("gradbf", "ppo_grad_wide_bf_kernel", None)):
     fs, n1 = mean_counter(tag, "FETCH_SIZE", sub)
     ws, n2 = mean_counter(tag, "WRITE_SIZE", sub)
     d = {"kernel_match": sub, "dispatches": n1, "FETCH_SIZE_KB_mean": fs, "WRITE_SIZE_KB_mean": ws,
          "traffic_bytes_per_launch": (2 * fs + ws) * 1024,
          "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md §HBM; verified on refill_count_kernel: 8 B/env of dword loads read as exactly 1/2), WRITE_SIZE as is",
-         "command": ("python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2" if tag == "step" else "python tools/prof_grad.py")}
+         "command": ("python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2" if tag == "step" else
+                     "python tools/prof_grad.py" if tag == "grad" else "python tools/prof_grad_bf16.py ball3d 256 bf16")}
     if alg:
         d["algorithmic_bytes_per_launch"] = alg
         d["traffic_over_algorithmic"] = d["traffic_bytes_per_launch"] / alg
