@@ -873,7 +873,10 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
     }
 }
 
-template <bool CONT, bool IS_PI, int NTW, int KT1C>  // KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32, 0: layer-1 gradient accumulated in the slab)
+// KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32), 0: layer-1 gradient accumulated in the slab, -1: dW1 skipped
+// (first of two passes).  PASS 1 = second pass for wide observations of known width: the forward / backward chain is recomputed and
+// ONLY dW1 (KT1C k-tiles) is accumulated and stored -- every other store is compiled out, so the MFMAs feeding only them vanish.
+template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
@@ -891,7 +894,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2, KT1 = (D + 15) >> 4;
-    constexpr bool acc_w1 = KT1C > 0;
+    constexpr bool MAIN = PASS == 0;
+    constexpr bool acc_w1 = KT1C > 0, rmw_w1 = KT1C == 0;
     constexpr int KT1A = KT1C > 0 ? KT1C : 1;
     float *X = smem, *h1 = X + M * ldx, *h2 = h1 + M * ld, *dz3 = h2 + M * ld;
     float *meta = dz3 + M * ld3;
@@ -922,7 +926,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     // images (PLayout::fr_pi) through a register ring of R fragments: one 16-byte load per lane feeds four k-steps (8 MFMAs), and
     // the slot a fragment is consumed from is reloaded at once with the fragment R positions further down the cyclic stream --
     // 2 k cycles of MFMA work of lookahead that carries across phases, barriers and row groups.
-    constexpr int NQ = H / 16, R = 8, SL = 2 * NTW * NQ;
+    constexpr int NQ = H / 16, R = 4, SL = 2 * NTW * NQ;
     static_assert(SL % R == 0, "ring must divide the per-group fragment stream");
     const float *fr = params + (IS_PI ? L.fr_pi : L.fr_vf);
     int nt0 = wave * NTW;
@@ -1172,7 +1176,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                         aW1[kt][j] = mfma16(a, bf[sidx], aW1[kt][j]);
                     }
                 }
-            } else {
+            } else if constexpr (rmw_w1) {
                 float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t);
                 for (int kt = 0; kt < KT1; kt++) {
                     f32x4 t = z4;
@@ -1200,10 +1204,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
         const int col = n_base + 16 * j + r16;
+        if constexpr (MAIN) {
 #pragma unroll
-        for (int kt = 0; kt < KT2; kt++)
+            for (int kt = 0; kt < KT2; kt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+                for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+        }
         if constexpr (acc_w1) {
 #pragma unroll
             for (int kt = 0; kt < KT1A; kt++)
@@ -1213,18 +1219,21 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     if (k < D) gW1[(int64_t)k * H + col] = aW1[kt][j][r];
                 }
         }
-        float v1 = ab1[j], v2 = ab2[j];
-        v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-        v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
-        if (g == 0) gb1[col] = v1, gb2[col] = v2;
+        if constexpr (MAIN) {
+            float v1 = ab1[j], v2 = ab2[j];
+            v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+            v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
+            if (g == 0) gb1[col] = v1, gb2[col] = v2;
 #pragma unroll
-        for (int q = 0; q < NT3; q++)
+            for (int q = 0; q < NT3; q++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
-                if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
-            }
+                for (int r = 0; r < 4; r++) {
+                    const int k = n_base + 16 * j + g * 4 + r, n = 16 * q + r16;
+                    if (n < NOUT) gW3[(int64_t)k * NOUT + n] = aW3[j][q][r];
+                }
+        }
     }
+    if constexpr (!MAIN) return;
     if (wave == 0) {
 #pragma unroll
         for (int q = 0; q < NT3; q++) {
@@ -1262,7 +1271,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     }
 }
 
-template <bool CONT, int NTW, int KT1C>
+template <bool CONT, int NTW, int KT1C, int PASS = 0>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                double *__restrict__ stat_slots) {
@@ -1270,8 +1279,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__re
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
-    else grad_wide_body<CONT, false, NTW, KT1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
 }
 
 #include "tma_wide_bf16.h"
@@ -2266,7 +2275,10 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int64_t pairs = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
         if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        if (L.D > 32) {  // layer-1 gradient accumulates in place in the slab
+        // dW1: D <= 32 in registers; D in 161..176 (Crawler's 172: 11 k-tiles) by a second pass that keeps only dW1 in registers;
+        // any other width accumulates it in place in the slab
+        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : ((L.D > 160 && L.D <= 176) ? 11 : 0));
+        if (kt1 == 0) {
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
             TMA_LAUNCH_CHECK();
         }
@@ -2275,11 +2287,19 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             k<<<dim3((unsigned)(2 * pairs)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
             return TMA_OK;
         };
-        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : 0);
         auto pick = [&](auto ntw) -> int {
             constexpr int NTWc = decltype(ntw)::value;
-            if (d->continuous) return kt1 == 1 ? launch(ppo_grad_wide_kernel<true, NTWc, 1>) : (kt1 == 2 ? launch(ppo_grad_wide_kernel<true, NTWc, 2>) : launch(ppo_grad_wide_kernel<true, NTWc, 0>));
-            return kt1 == 1 ? launch(ppo_grad_wide_kernel<false, NTWc, 1>) : (kt1 == 2 ? launch(ppo_grad_wide_kernel<false, NTWc, 2>) : launch(ppo_grad_wide_kernel<false, NTWc, 0>));
+            auto both = [&](auto cont) -> int {
+                constexpr bool C = decltype(cont)::value;
+                if (kt1 == 1) return launch(ppo_grad_wide_kernel<C, NTWc, 1>);
+                if (kt1 == 2) return launch(ppo_grad_wide_kernel<C, NTWc, 2>);
+                if (kt1 == 11) {
+                    const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0>);
+                    return rc2 ? rc2 : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1>);
+                }
+                return launch(ppo_grad_wide_kernel<C, NTWc, 0>);
+            };
+            return d->continuous ? both(std::true_type{}) : both(std::false_type{});
         };
         int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
         if (lrc) return lrc;
