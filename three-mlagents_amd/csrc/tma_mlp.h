@@ -42,6 +42,7 @@ struct PLayout {
                          // net: element i of lane l in fragment (tile t, group q) is the B operand of k-step 4q + i -- forward
                          // W2[k = 16q + 4i + (l>>4)][n = 16t + (l&15)], input-gradient W2[k' = 16t + (l&15)][n = 16q + 4i + (l>>4)] -- so a
                          // lane's operands for four consecutive k-steps are one coalesced 16-byte load; -1 otherwise
+    int fr1_pi, fr1_vf;  // same fragment layout for W1 (k padded with zero rows to 16 * ceil(D / 16)), present when fr_pi >= 0 and D > 32
     int total;
 };
 
@@ -119,6 +120,11 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, in
     if (!L.bf16 && (H == 128 || H == 192 || H == 256)) {
         L.fr_pi = o, o += 2 * H * H;
         L.fr_vf = o, o += 2 * H * H;
+    }
+    L.fr1_pi = L.fr1_vf = -1;
+    if (L.fr_pi >= 0 && D > 32) {
+        L.fr1_pi = o, o += H * 16 * ((D + 15) / 16);
+        L.fr1_vf = o, o += H * 16 * ((D + 15) / 16);
     }
     L.total = o;
     return L;

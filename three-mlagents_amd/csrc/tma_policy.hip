@@ -84,6 +84,16 @@ __global__ void build_f32_frag_images_kernel(float *params, PLayout L) {
         const int a = 16 * q + 4 * i + (l >> 4), b = 16 * t + (l & 15);  // forward: (k, n) = (a, b); input-gradient: (k', n) = (b, a)
         params[(net == 0 ? L.fr_pi : L.fr_vf) + x] = bwd ? W2[b * H + a] : W2[a * H + b];
     }
+    if (L.fr1_pi >= 0) {
+        const int NQ1 = (L.D + 15) / 16, per1 = H * 16 * NQ1;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * per1; e += gridDim.x * blockDim.x) {
+            const int net = e / per1, y = e - net * per1;
+            const float *W1 = params + (net == 0 ? L.pW1t : L.vW1t);
+            const int i = y & 3, l = (y >> 2) & 63, rest = y >> 8, q = rest % NQ1, t = rest / NQ1;
+            const int k = 16 * q + 4 * i + (l >> 4), n = 16 * t + (l & 15);
+            params[(net == 0 ? L.fr1_pi : L.fr1_vf) + y] = k < L.D ? W1[k * H + n] : 0.0f;
+        }
+    }
 }
 
 // refreshes everything derived from the trainable region: [out][in] copies and (H == 64 fast path) the LDS images
@@ -876,7 +886,8 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
 // KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32), 0: layer-1 gradient accumulated in the slab, -1: dW1 skipped
 // (first of two passes).  PASS 1 = second pass for wide observations of known width: the forward / backward chain is recomputed and
 // ONLY dW1 (KT1C k-tiles) is accumulated and stored -- every other store is compiled out, so the MFMAs feeding only them vanish.
-template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS>
+// NQ1C > 0: layer-1 weights (16 * NQ1C >= D rows) also run through the ring, from the fragment image PLayout::fr1_pi.
+template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
@@ -926,12 +937,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     // images (PLayout::fr_pi) through a register ring of R fragments: one 16-byte load per lane feeds four k-steps (8 MFMAs), and
     // the slot a fragment is consumed from is reloaded at once with the fragment R positions further down the cyclic stream --
     // 2 k cycles of MFMA work of lookahead that carries across phases, barriers and row groups.
-    constexpr int NQ = H / 16, R = 4, SL = 2 * NTW * NQ;
+    constexpr int NQ = H / 16, S1 = NTW * NQ1C, SL = S1 + 2 * NTW * NQ;
+    constexpr int R = SL % 4 == 0 ? 4 : (SL % 5 == 0 ? 5 : 3);  // ring slots are static registers: R must divide the cyclic stream
     static_assert(SL % R == 0, "ring must divide the per-group fragment stream");
-    const float *fr = params + (IS_PI ? L.fr_pi : L.fr_vf);
+    const float *fr = params + (IS_PI ? L.fr_pi : L.fr_vf), *fr1 = params + (IS_PI ? L.fr1_pi : L.fr1_vf);
     int nt0 = wave * NTW;
-    auto sload = [&](int s) -> f32x4 {  // s in [0, SL): compile-time after unrolling
-        const int half = s >= SL / 2, t = half ? s - SL / 2 : s;
+    auto sload = [&](int s) -> f32x4 {  // s in [0, SL): compile-time after unrolling.  Order: [layer 1: q outer, tile inner] [layer-2 forward] [input-gradient]
+        if (s < S1) return frag_f32(fr1, (nt0 + s % NTW) * NQ1C + s / NTW, lane0);
+        const int u = s - S1, half = u >= NTW * NQ, t = half ? u - NTW * NQ : u;
         return frag_f32(fr + half * H * H, (nt0 + t / NQ) * NQ + t % NQ, lane0);
     };
     f32x4 ring[R];
@@ -943,6 +956,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             const float *pl = launder_uniform(params);
             Q = IS_PI ? pi_net(pl, L) : vf_net(pl, L);
             fr = pl + (IS_PI ? L.fr_pi : L.fr_vf);
+            fr1 = pl + (IS_PI ? L.fr1_pi : L.fr1_vf);
             asm volatile("" : "+s"(nt0));
             nt0 = __builtin_amdgcn_readfirstlane(nt0);
         }
@@ -979,6 +993,30 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 const float bias = Q.b1[n_base + 16 * j + r16];
                 acc[j][0] = acc[j][1] = f32x4{bias, bias, bias, bias};
             }
+            if constexpr (NQ1C > 0) {
+#pragma unroll
+                for (int q = 0; q < NQ1C; q++) {
+                    float a0[4], a1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int k = 16 * q + 4 * i + g;
+                        const bool ok = k < D;  // the image's rows >= D are zero, but the LDS columns there are not initialised
+                        a0[i] = ok ? X[r16 * ldx + k] : 0.0f, a1[i] = ok ? X[(16 + r16) * ldx + k] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        const int s = q * NTW + j;
+                        const f32x4 w4 = ring[s % R];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            acc[j][0] = mfma16(a0[i], w4[i], acc[j][0]);
+                            acc[j][1] = mfma16(a1[i], w4[i], acc[j][1]);
+                        }
+                        ring[s % R] = sload((s + R) % SL);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
             for (int ks = 0; ks < KS1; ks++) {
                 const int k = 4 * ks + g;
                 const bool ok = k < D;
@@ -1006,7 +1044,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const int s = j * NQ + q;
+                const int s = S1 + j * NQ + q;
                 const f32x4 w4 = ring[s % R];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -1128,7 +1166,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 f32x4 c0 = z4, c1 = z4;
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const int s = SL / 2 + j * NQ + q;
+                    const int s = S1 + NTW * NQ + j * NQ + q;
                     const f32x4 w4 = ring[s % R];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -1271,7 +1309,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     }
 }
 
-template <bool CONT, int NTW, int KT1C, int PASS = 0>
+template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                double *__restrict__ stat_slots) {
@@ -1279,8 +1317,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__re
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
-    else grad_wide_body<CONT, false, NTW, KT1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
 }
 
 #include "tma_wide_bf16.h"
@@ -1475,6 +1513,8 @@ __device__ __forceinline__ void scatter_derived_wide(float *params, const PLayou
     if (x < D * H) {  // W1t[k][n]
         const int k = x / H, n = x - k * H;
         if (img) img[B.fW1 + (((n >> 4) * KS1 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7)] = bv;
+        if (L.fr1_pi >= 0)
+            params[(vf ? L.fr1_vf : L.fr1_pi) + (((n >> 4) * ((D + 15) / 16) + (k >> 4)) * 64 + (k & 3) * 16 + (n & 15)) * 4 + ((k >> 2) & 3)] = val;
         return;
     }
     x -= D * H;
@@ -2294,8 +2334,8 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
                 if (kt1 == 1) return launch(ppo_grad_wide_kernel<C, NTWc, 1>);
                 if (kt1 == 2) return launch(ppo_grad_wide_kernel<C, NTWc, 2>);
                 if (kt1 == 11) {
-                    const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0>);
-                    return rc2 ? rc2 : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1>);
+                    const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0, 11>);
+                    return rc2 ? rc2 : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1, 11>);
                 }
                 return launch(ppo_grad_wide_kernel<C, NTWc, 0>);
             };
