@@ -308,15 +308,17 @@ def test_gae_flags_equals_sb3_layout():
     assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref)
 
 
-@pytest.mark.parametrize("task,hidden", [("gridworld", 64), ("push", 64), ("ball3d", 64), ("walljump", 64), ("basic", 64), ("gridworld", 128)])
-def test_native_rollout_equals_stepwise_composition(task, hidden):
+@pytest.mark.parametrize("task,hidden,N", [("gridworld", 64, 200), ("push", 64, 200), ("ball3d", 64, 200), ("walljump", 64, 200), ("basic", 64, 200),
+                                           ("gridworld", 128, 200), ("gridworld", 64, 16400)])
+def test_native_rollout_equals_stepwise_composition(task, hidden, N):
     """tma_rollout_collect (fused multi-step kernel for H=64 on gridworld/push/ball3d, per-step launches otherwise)
     == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same RNG counters)."""
     from three_mlagents_amd import _lib
     from three_mlagents_amd.ppo import PPO
     from three_mlagents_amd.vec_env import HipVecEnv
 
-    N, T = 200, {"ball3d": 230, "gridworld": 130, "walljump": 170}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
+    # N = 200: two-wave fused kernel (one tile per block); N = 16400: >= 1024 tiles, the four-tiles-per-block single-wave kernel
+    T = {"ball3d": 230, "gridworld": 130, "walljump": 170}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
     env = HipVecEnv(task, N, seed=3, ring_depth=16)
     model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
     assert model.collect_rollouts()
