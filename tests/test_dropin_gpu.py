@@ -112,6 +112,8 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     assert os.path.exists(tmp_path / "runs" / "basic" / "t1" / "eval" / "evaluations.npz")
     prog = (tmp_path / "runs" / "basic" / "t1" / "tb" / "progress.csv").read_text().splitlines()
     assert "rollout/ep_rew_mean" in prog[0] and "train/approx_kl" in prog[0] and len(prog) >= 2
+    mon = (tmp_path / "runs" / "basic" / "t1" / "monitor" / "0.monitor.csv").read_text().splitlines()  # SB3 Monitor layout (aggregate rows)
+    assert mon[0].startswith("#{") and mon[1] == "r,l,t,n" and len(mon) >= 3 and len(mon[2].split(",")) == 4
     cli.main(["evaluate", "basic", "basic_policy_t1.zip", "--episodes", "3"])
     ev = json.loads(capsys.readouterr().out)
     assert ev["episodes"] == 3 and len(ev["episode_lengths"]) == 3

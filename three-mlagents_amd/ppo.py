@@ -334,6 +334,7 @@ class PPO:
                               "rollout/episodes": cnt, "train/n_updates": self._n_updates})
                 self.logger_values = stats
                 self._write_progress(stats)
+                self._write_monitor(s_ret, s_len, cnt, time.time() - t0)
                 if self.verbose >= 1 and self.rank == 0:
                     print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
         cb.on_training_end()
@@ -351,6 +352,22 @@ class PPO:
             if new:
                 f.write(",".join(keys) + "\n")
             f.write(",".join(repr(float(stats[k])) for k in keys) + "\n")
+
+    def _write_monitor(self, sum_ret: float, sum_len: float, count: float, elapsed: float) -> None:
+        """SB3 Monitor file (`<monitor_dir>/0.monitor.csv`, the directory training.make_vector_env passes; reference
+        training.py:85-86): header line + `r,l,t` rows.  The device keeps Monitor SUMS, not one record per episode, so a row is the
+        mean return / mean length of the `n` episodes that finished since the previous row (documented deviation)."""
+        mdir = getattr(self.env, "monitor_dir", None)
+        if not mdir or self.rank != 0 or not count:
+            return
+        os.makedirs(mdir, exist_ok=True)
+        path = os.path.join(str(mdir), "0.monitor.csv")
+        new = not os.path.exists(path)
+        with open(path, "a", encoding="utf-8") as f:
+            if new:
+                f.write("#" + json.dumps({"t_start": time.time() - elapsed, "env_id": getattr(self.env, "task_id", None), "aggregate": True}) + "\n")
+                f.write("r,l,t,n\n")
+            f.write(f"{sum_ret / count:.6f},{sum_len / count:.3f},{elapsed:.6f},{int(count)}\n")
 
     # -- inference ------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
