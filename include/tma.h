@@ -177,6 +177,11 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
  * itself (one launch instead of three).  Falls back to tma_ppo_adam_step(grad_scale = 1) for shapes without that fast path. */
 int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
                             double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int64_t last_count);
+/* Profiling aid for bench.py's roofline object: when enabled, tma_ppo_minibatch_grad brackets its DOMINANT kernel (the persistent
+ * forward+backward kernel; for two-pass shapes both passes; not the advantage pass, not the slab reduction) with HIP events recorded on
+ * the stream it launches on; tma_debug_last_grad_kernel_us waits for the last bracketed launch and returns its duration. */
+int tma_debug_time_grad_kernel(int enable);
+int tma_debug_last_grad_kernel_us(float *us_out);
 /* out8: sums since the last call of {policy_loss, value_sq_err, entropy, approx_kl, clipped, n_samples}, then the last
  * total grad norm and clip coefficient.  Synchronises `stream`. */
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream);

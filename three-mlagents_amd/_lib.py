@@ -76,6 +76,8 @@ SIGNATURES = {
     "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
     "tma_ppo_workspace_bytes": (_i64, [_pd]),
     "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
+    "tma_debug_time_grad_kernel": (_i32, [_i32]),
+    "tma_debug_last_grad_kernel_us": (_i32, [C.POINTER(C.c_float)]),
     "tma_ppo_epoch_prepare": (_i32, [C.POINTER(Rollout), C.POINTER(Minibatch), _i64, _pd, _vp, _vp]),
     "tma_ppo_adam_step": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "tma_ppo_adam_step_local": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i64]),

@@ -1681,6 +1681,24 @@ static int launch_sync(float *params, const PLayout &L, hipStream_t s) {
     return TMA_OK;
 }
 
+// profiling aid (tma_debug_time_grad_kernel): HIP events around the dominant kernel of tma_ppo_minibatch_grad, on its stream
+static bool g_time_grad = false;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static bool g_ev_valid = false;
+struct GradTimer {
+    hipStream_t s;
+    bool on;
+    explicit GradTimer(hipStream_t st) : s(st), on(g_time_grad && g_ev0 && g_ev1) {
+        if (on) (void)hipEventRecord(g_ev0, s);
+    }
+    ~GradTimer() {
+        if (on) {
+            (void)hipEventRecord(g_ev1, s);
+            g_ev_valid = true;
+        }
+    }
+};
+
 // where slab_reduce_kernel leaves its sum-of-squares partials (one per 64 parameters) for tma_ppo_adam_step_local
 static double *sq_partials(char *ws, const PLayout &L) {
     const int n = (int)ceil_div(L.P, 64);
@@ -2254,7 +2272,11 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, adv_part, nbk, slabs, slots);
             return TMA_OK;
         };
-        int lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
+        int lrc;
+        {
+            GradTimer timer(s);
+            lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
+        }
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L));
@@ -2301,7 +2323,11 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             };
             return d->continuous ? both(std::true_type{}) : both(std::false_type{});
         };
-        int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+        int lrc;
+        {
+            GradTimer timer(s);
+            lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+        }
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
@@ -2341,7 +2367,11 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             };
             return d->continuous ? both(std::true_type{}) : both(std::false_type{});
         };
-        int lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+        int lrc;
+        {
+            GradTimer timer(s);
+            lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+        }
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad, -1, 0, 0, sq_partials(ws, L));
@@ -2448,6 +2478,26 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
             params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
             (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
     TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_debug_time_grad_kernel(int enable) {
+    if (enable && !g_ev0) {
+        TMA_HIP(hipEventCreate(&g_ev0));
+        TMA_HIP(hipEventCreate(&g_ev1));
+    }
+    g_time_grad = enable != 0;
+    g_ev_valid = false;
+    return TMA_OK;
+}
+
+int tma_debug_last_grad_kernel_us(float *us_out) {
+    if (!us_out) return fail(TMA_ERR_INVALID, "us_out is null");
+    if (!g_ev_valid) return fail(TMA_ERR_INVALID, "no timed tma_ppo_minibatch_grad launch (enable tma_debug_time_grad_kernel first; column-parallel / H=64 paths only)");
+    TMA_HIP(hipEventSynchronize(g_ev1));
+    float ms = 0.0f;
+    TMA_HIP(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+    *us_out = ms * 1e3f;
     return TMA_OK;
 }
 
