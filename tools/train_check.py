@@ -7,9 +7,10 @@ from three_mlagents_amd.ppo import PPO
 from three_mlagents_amd.training import make_vector_env
 from three_mlagents_amd.evaluation import evaluate_policy
 
-for task, H, iters in (("gridworld", 64, 12), ("push", 64, 12), ("ball3d", 64, 12), ("walljump", 64, 12)):
+for task, H, iters, dt in (("gridworld", 64, 12, "f32"), ("push", 64, 12, "f32"), ("ball3d", 64, 12, "f32"), ("walljump", 64, 12, "f32"),
+                           ("ball3d", 256, 12, "bf16"), ("push", 256, 12, "bf16"), ("gridworld", 256, 6, "f32")):
     env = make_vector_env(task, n_envs=4096, seed=1)
-    model = PPO("MlpPolicy", env, n_steps=256, batch_size=32768, n_epochs=4, ent_coef=0.01, seed=1, policy_kwargs={"net_arch": [H, H]})
+    model = PPO("MlpPolicy", env, n_steps=256, batch_size=32768, n_epochs=4, ent_coef=0.01, seed=1, policy_kwargs={"net_arch": [H, H], "mfma_dtype": dt})
     ev = make_vector_env(task, n_envs=256, seed=10_001)
     r0, _ = evaluate_policy(model, ev, n_eval_episodes=512, deterministic=False)
     t0 = time.time()
@@ -19,5 +20,5 @@ for task, H, iters in (("gridworld", 64, 12), ("push", 64, 12), ("ball3d", 64, 1
         hist.append(round(model.logger_values["rollout/ep_rew_mean"], 3))
     torch.cuda.synchronize()
     r1, _ = evaluate_policy(model, ev, n_eval_episodes=512, deterministic=False)
-    print(f"{task}: eval return {r0:.3f} -> {r1:.3f} after {iters * 4096 * 256 / 1e6:.1f}M steps in {time.time() - t0:.2f}s; rollout ep_rew_mean per iteration {hist}", flush=True)
+    print(f"{task} {H}x{H} {dt}: eval return {r0:.3f} -> {r1:.3f} after {iters * 4096 * 256 / 1e6:.1f}M steps in {time.time() - t0:.2f}s; rollout ep_rew_mean per iteration {hist}", flush=True)
     env.close(); ev.close()
