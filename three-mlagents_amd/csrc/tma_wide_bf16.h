@@ -206,6 +206,13 @@ __host__ __device__ inline int fwd_wide_bf_smem_bytes(int D, int H) {
     return (32 * (Kp1 + 16) + 2 * 32 * (H + 16)) * 2;
 }
 
+constexpr int bf_ring_slots(int stream_len, int cap) {
+    int r = 1;
+    for (int d = 1; d <= cap; d++)
+        if (stream_len % d == 0) r = d;
+    return r;
+}
+
 // Gradient of one minibatch for ONE net, persistent over row groups of M = 16*MT samples.
 //
 // Latency plan (one wave per SIMD, so nothing but this wave's own loads in flight hides the L2 round trip):
@@ -227,7 +234,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                                                   const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                   double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net) {
     constexpr int M = 16 * MT, MK = MT / 2, H = 64 * NTW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
-    constexpr int R = 4 * NTW, SL = 2 * KS2 * NTW;
+    // weight stream of a row group: [layer-1 fragments when KS1C > 1: k-step outer, tile inner] [layer-2 forward] [layer-2 input-gradient]
+    constexpr int S1 = KS1C > 1 ? KS1C * NTW : 0, SL = S1 + 2 * KS2 * NTW;
+    constexpr int R = bf_ring_slots(SL, 4 * NTW);  // largest divisor of SL not above four k-steps of fragments (slots are static registers)
     constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
     constexpr int NX = PF ? 2 * MT * KS1C : 1;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
@@ -294,8 +303,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // ---- weight operands: ring over the two H x H streams, resident small fragments ----
     int nt0l = nt0;  // laundered copy (see the asm in the group loop): keeps the fragment address arithmetic scalar and inside the loop
     auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
-        if (s < SL / 2) return bf_frag(W.fW2, (nt0l + s % NTW) * KS2 + s / NTW, lane);
-        const int t = s - SL / 2;
+        if (s < S1) return bf_frag(W.fW1, (nt0l + s % NTW) * (KS1C > 0 ? KS1C : 1) + s / NTW, lane);
+        const int u = s - S1;
+        if (u < KS2 * NTW) return bf_frag(W.fW2, (nt0l + u % NTW) * KS2 + u / NTW, lane);
+        const int t = u - KS2 * NTW;
         return bf_frag(W.bW2, (nt0l + t % NTW) * KS2 + t / NTW, lane);
     };
     bf16x8 ring[R], w1r[NTW];  // w1r: layer-1 fragments (D <= 32), re-issued at the end of P5 for the next group
@@ -397,6 +408,21 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                     for (int j = 0; j < NTW; j++) acc[j][mt] = mfma_bf(a, w1r[j], acc[j][mt]);
                 }
+            } else if constexpr (KS1C > 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS1C; ks++) {
+                    bf16x8 a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) a[mt] = a_frag(Xa, ldx, 16 * mt + r16, ks, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        const int s = ks * NTW + j;
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[mt], ring[s % R], acc[j][mt]);
+                        ring[s % R] = sload((s + R) % SL);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll 2
                 for (int ks = 0; ks < KS1; ks++) {
@@ -455,7 +481,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
 #pragma unroll
                 for (int j = 0; j < NTW; j++) {
-                    const int s = ks * NTW + j;
+                    const int s = S1 + ks * NTW + j;
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[ks & 1][mt], ring[s % R], acc[j][mt]);
                     ring[s % R] = sload((s + R) % SL);
@@ -651,7 +677,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
 #pragma unroll
                 for (int j = 0; j < NTW; j++) {
-                    const int s = SL / 2 + ns * NTW + j;
+                    const int s = S1 + KS2 * NTW + ns * NTW + j;
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) dh1[j][mt] = mfma_bf(a[ns & 1][mt], ring[s % R], dh1[j][mt]);
                     ring[s % R] = sload((s + R) % SL);
