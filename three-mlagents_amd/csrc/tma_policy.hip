@@ -814,10 +814,11 @@ struct LossStats {
 template <bool CONT>
 __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
                                                  const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
-                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane) {
+                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4) {
     const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+        if (r < r_lo || r >= r_hi) continue;  // (wave-uniform) a caller may split the four rows of a lane group over two waves
         const int row = g * 4 + r;
         const int64_t off = row_off[row];
         const bool valid = off >= 0;
@@ -2286,10 +2287,11 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     if (L.bf16) {
         const int MTc = 2;
         const int smemw = grad_wide_bf_smem_bytes(L.D, L.H, MTc);
-        // 256 blocks = one per CU.  A policy-net row group costs ~1.3x a value-net one (loss on the head waves), so the policy net
-        // gets 9/16 of the blocks; with fewer row groups than that, one block per group.
+        // 256 blocks = one per CU.  A policy-net row group costs 1.15-1.3x a value-net one (the loss), so the policy net gets
+        // 136 or 144 of the blocks; with fewer row groups than that, one block per group.
         const int64_t groups = ceil_div(mbi->count, 16 * MTc);
-        const int n_pi = (int)(groups < 144 ? groups : 144), n_vf = (int)(groups < 112 ? groups : 112);
+        const int cap_pi = d->continuous ? 144 : 136, cap_vf = 256 - cap_pi;  // (Categorical loss is cheaper than the DiagGaussian one)
+        const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
         if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab

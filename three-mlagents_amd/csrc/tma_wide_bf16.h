@@ -199,7 +199,7 @@ __host__ __device__ inline int grad_wide_bf_smem_bytes(int D, int H, int MT) {
     const int M = 16 * MT, Kp1 = (D + 31) & ~31;
     const int bf = M * (Kp1 + 16) + Kp1 * M + 2 * M * (H + 16) + 2 * H * M + M * 48 + 32 * M;
     // + f32: dz3, meta, scratch, head partial sums [4 waves][MT][2][64][4], biases [2H + 32]; f64: stats [MT][4][5]; i64: row offsets x2
-    return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + MT * 4 * 5 * 8 + 2 * M * 8;
+    return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + 4 * 4 * 5 * 8 + 2 * M * 8;
 }
 __host__ __device__ inline int fwd_wide_bf_smem_bytes(int D, int H) {
     const int Kp1 = (D + 31) & ~31;
@@ -276,8 +276,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M), *meta = dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
     float *hpart = scratch + 128;              // [4 waves][MT][2][64 lanes][4]: split-K partial head outputs
     float *bias = hpart + 4 * MT * 2 * 256;    // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
-    double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [MT][4][5] loss statistics (lanes r16 == 0 of the head waves)
-    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + MT * 4 * 5), *row_off_next = row_off + M;
+    double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [4 waves][4][5] loss statistics (lanes r16 == 0)
+    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + 4 * 4 * 5), *row_off_next = row_off + M;
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     }
     for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
         bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
-    if (threadIdx.x < MT * 4 * 5) stat_lds[threadIdx.x] = 0.0;
+    if (threadIdx.x < 4 * 4 * 5) stat_lds[threadIdx.x] = 0.0;
     // ---- weight operands: ring over the two H x H streams, resident small fragments ----
     int nt0l = nt0;  // laundered copy (see the asm in the group loop): keeps the fragment address arithmetic scalar and inside the loop
     auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
@@ -538,9 +538,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         __syncthreads();
         TMA_TICK(4);
         TMA_RELANE();
-        // ---- P3b: loss on row tile `wave`; dz3 as bf16 in both layouts ----
-        if (wave < MT && !(dbg & 4)) {
-            const int mt = wave;
+        // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2*(wave >> 1) .. +1 of each lane group) ----
+        static_assert(MT == 2, "the loss / dz3 split below assumes two row tiles and four waves");
+        if (!(dbg & 4)) {
+            const int mt = wave & 1, r_lo = 2 * (wave >> 1);
             f32x4 out[NT3];
 #pragma unroll
             for (int q = 0; q < NT3; q++) {
@@ -553,10 +554,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                       lane);
+                                       lane, r_lo, r_lo + 2);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
+                    if (r < r_lo || r >= r_lo + 2) continue;
                     const int row = g * 4 + r;
                     const bool valid = row_off[mt * 16 + row] >= 0;
                     const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
@@ -565,10 +567,17 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
             }
             if (MAIN && r16 == 0) {  // only these lanes carry statistics (policy_loss_tile / the value branch accumulate under r16 == 0)
-                double *sl = stat_lds + (mt * 4 + g) * 5;
+                double *sl = stat_lds + (wave * 4 + g) * 5;
                 sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
             }
-            {  // Z3a[m][a]: lane = (row, 8-column chunk)
+        }
+        __syncthreads();
+        // ---- P3c: dz3 as bf16 in both layouts: waves 0 / 1 write Z3a of tile 0 / 1, waves 2 / 3 write Z3t (+ head bias sums) ----
+        TMA_RELANE();
+        if (!(dbg & 4)) {
+            const int mt = wave & 1;
+            const float *dzt = dz3 + mt * 16 * ld3;
+            if (wave < 2) {  // Z3a[m][a]: lane = (row, 8-column chunk)
                 bf16x8 v;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -576,8 +585,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     v[j] = (bf16_t)(a < 16 * NT3 ? dzt[r16 * ld3 + a] : 0.0f);
                 }
                 *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
-            }
-            {  // Z3t[a][m]: lane = (a, 8-sample half of the tile); the f32 column sum feeds the head bias gradient
+            } else {  // Z3t[a][m]: lane = (a, 8-sample half of the tile); the f32 column sum feeds the head bias gradient
                 const int a = lane & 31, half = lane >> 5;
                 bf16x8 v;
                 float c = 0.0f;
@@ -804,24 +812,22 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         float v0 = dlsd[0], v1 = dlsd[1];
         v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
         v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-        if (wave < MT) {
-            if (lane < 32) scratch[wave * 32 + lane] = v;
+        if (wave >= 2) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
+            if (lane < 32) scratch[(wave - 2) * 32 + lane] = v;
         }
         __syncthreads();
         if (wave == 0 && lane < 32) {
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < MT; w++) s += scratch[w * 32 + lane];
+            const float s = scratch[lane] + scratch[32 + lane];
             if (lane < NOUT) gb3[lane] = s;
         }
         __syncthreads();
-        if constexpr (IS_PI && CONT) {
-            if (wave < MT && g == 0) scratch[wave * 32 + r16] = v0, scratch[wave * 32 + 16 + r16] = v1;
+        if constexpr (IS_PI && CONT) {  // every wave ran the loss on half the rows of a tile
+            if (g == 0) scratch[wave * 32 + r16] = v0, scratch[wave * 32 + 16 + r16] = v1;
             __syncthreads();
             if (wave == 0 && lane < 32) {
                 float s = 0.0f;
 #pragma unroll
-                for (int w = 0; w < MT; w++) s += scratch[w * 32 + lane];
+                for (int w = 0; w < 4; w++) s += scratch[w * 32 + lane];
                 if (lane < A) slab[L.log_std + lane] = s;
             }
         }
@@ -829,7 +835,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     __syncthreads();
     if (MAIN && threadIdx.x < 5) {
         double ssum = 0.0;
-        for (int w = 0; w < MT * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
+        for (int w = 0; w < 4 * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
         const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
         if (q >= 0) stat_slot[q] += ssum;
     }
