@@ -29,10 +29,12 @@ constexpr int MAX_GRAD_BLOCKS = 2048;
 constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
 constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
 constexpr int64_t WS_BYTES = WS_SLABS;
-constexpr int BF_SLABS = 160;  // bf16 wide kernel: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
+constexpr int BF_SLABS = 160;  // column-parallel kernels: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
 constexpr int64_t OFFS_CAP = 1 << 22;
 constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch
 constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_kernel for policies beyond the 256 slots at WS_NORM_PART  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
+
+static inline int slab_cap(const PLayout &L) { return (L.bf16 || L.fr_pi >= 0) ? BF_SLABS : H64_BLOCKS; }  // partial-gradient slabs in the workspace
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -1313,13 +1315,15 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
-                                                               double *__restrict__ stat_slots) {
+                                                               double *__restrict__ stat_slots, int n_pi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
-    float *slab = slabs + (int64_t)pair * L.P;
-    double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
-    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, n_pairs, pair);
+    // blocks [0, n_pi): policy net, [n_pi, gridDim.x): value net (the policy net's row group costs more: it gets more blocks)
+    const bool is_pi = (int)blockIdx.x < n_pi;
+    const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
+    float *slab = slabs + (int64_t)b * L.P;
+    double *slot = stat_slots + (int64_t)b * 8;
+    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b);
 }
 
 #include "tma_wide_bf16.h"
@@ -1705,7 +1709,7 @@ static double *sq_partials(char *ws, const PLayout &L) {
     const int n = (int)ceil_div(L.P, 64);
     if (n <= 256) return reinterpret_cast<double *>(ws + WS_NORM_PART);
     if (n > WIDE_SQ_SLOTS) return nullptr;
-    return reinterpret_cast<double *>(ws + WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES);
+    return reinterpret_cast<double *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES);
 }
 
 static int check_dims(const tma_policy_dims *d) {
@@ -2136,7 +2140,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8;
+    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8;
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -2242,7 +2246,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     double *adv_part = reinterpret_cast<double *>(ws + WS_ADV_PART);
     int nbk = (int)ceil_div(mbi->count, 1024);
     if (nbk > ADV_BLOCKS) nbk = ADV_BLOCKS;
-    const int64_t offs_base = WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4;
+    const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
     if (prepared) {  // tma_ppo_epoch_prepare left this minibatch's partials and the epoch's offsets in the workspace
         int stride = (int)ceil_div(mbi->prepared_batch, 1024);
         if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
@@ -2340,8 +2344,10 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     if ((L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 8 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
         // column-parallel register-accumulating kernel + deterministic slab reduction
         const int smemw = grad_wide_smem_bytes(L);
-        int64_t pairs = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
-        if (pairs > H64_BLOCKS) pairs = H64_BLOCKS;
+        const int64_t groups = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
+        const int cap_pi = d->continuous ? 136 : 128, cap_vf = 256 - cap_pi;  // measured: the Categorical head leaves the two nets balanced
+        const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
+        const int64_t pairs = n_pi;  // slabs in use (the value net uses the first n_vf of them)
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         // dW1: D <= 32 in registers; D in 161..176 (Crawler's 172: 11 k-tiles) by a second pass that keeps only dW1 in registers;
         // any other width accumulates it in place in the slab
@@ -2352,7 +2358,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         }
         auto launch = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(2 * pairs)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots);
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi);
             return TMA_OK;
         };
         auto pick = [&](auto ntw) -> int {
@@ -2376,7 +2382,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         }
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)pairs, L.P, grad, -1, 0, 0, sq_partials(ws, L));
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
@@ -2411,7 +2417,7 @@ int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int
     if (epoch->start != 0 || epoch->count != total) return fail(TMA_ERR_INVALID, "epoch descriptor must cover [0, T*N)");
     const PLayout L = layout_of(d);
     char *ws = static_cast<char *>(workspace);
-    const int64_t offs_base = WS_SLABS + (int64_t)(L.bf16 ? BF_SLABS : H64_BLOCKS) * L.P * 4;
+    const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
     int stride = (int)ceil_div(batch_size, 1024);
     if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
     const int64_t n_mb = ceil_div(total, batch_size);
