@@ -915,6 +915,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     float *meta = dz3 + M * ld3;
     int64_t *row_off = reinterpret_cast<int64_t *>(meta + M * 4);
     float *scratch = reinterpret_cast<float *>(row_off + M);  // 64 floats
+    float *hpart = scratch + 64;  // [4 waves][2 tiles][2][64 lanes][4]: split-K partial head outputs
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
@@ -1066,12 +1067,47 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
         TMA_RELANE();
-        // ---- P3: head + loss: wave mt (0, 1) takes row tile mt ----
+        // ---- P3a: split-K head: wave w multiplies k-steps [w*H/16, (w+1)*H/16) of h2 for both row tiles; all of its weight loads
+        // go out together (one L2 round trip per group instead of a dependent load per k-step on two waves) ----
+        {
+            constexpr int HKS = H / 16;  // k-steps of 4 per wave
+            float w3[HKS][NT3];
+#pragma unroll
+            for (int i = 0; i < HKS; i++)
+#pragma unroll
+                for (int q = 0; q < NT3; q++) {
+                    const int k = 4 * (wave * HKS + i) + g, col = 16 * q + r16;
+                    w3[i][q] = col < NOUT ? Q.W3t[(int64_t)k * NOUT + col] : 0.0f;
+                }
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                f32x4 part[NT3];
+#pragma unroll
+                for (int q = 0; q < NT3; q++) part[q] = z4;
+#pragma unroll
+                for (int i = 0; i < HKS; i++) {
+                    const float a = h2[(mt * 16 + r16) * ld + 4 * (wave * HKS + i) + g];
+#pragma unroll
+                    for (int q = 0; q < NT3; q++) part[q] = mfma16(a, w3[i][q], part[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * 2 + mt) * 2 + q) * 64 + lane) * 4) = part[q];
+            }
+        }
+        __syncthreads();
+        TMA_RELANE();
+        // ---- P3b: loss: wave mt (0, 1) takes row tile mt ----
         if (wave < 2) {
             const int mt = wave;
-            const float *hh = h2 + mt * 16 * ld;
             f32x4 out[NT3];
-            dense_head<NT3>(hh, ld, H, Q.W3t, Q.b3, NOUT, out, lane);
+#pragma unroll
+            for (int q = 0; q < NT3; q++) {
+                const int col = 16 * q + r16;
+                const float b = col < NOUT ? Q.b3[col] : 0.0f;
+                out[q] = f32x4{b, b, b, b};
+#pragma unroll
+                for (int w = 0; w < 4; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * 2 + mt) * 2 + q) * 64 + lane) * 4);
+            }
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
@@ -1341,7 +1377,7 @@ __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
 
 static int grad_wide_smem_bytes(const PLayout &L) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64) * 4;
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + 4 * 2 * 2 * 256) * 4;
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
