@@ -916,6 +916,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     int64_t *row_off = reinterpret_cast<int64_t *>(meta + M * 4);
     float *scratch = reinterpret_cast<float *>(row_off + M);  // 64 floats
     float *hpart = scratch + 64;  // [4 waves][2 tiles][2][64 lanes][4]: split-K partial head outputs
+    float *bias = hpart + 4 * 2 * 2 * 256;  // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
     const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
@@ -937,6 +938,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
     for (int q = 0; q < NT3; q++) ab3[q] = 0.0f;
     LossStats st;
+    for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
+        bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
+    __syncthreads();
     // The two H x H weight streams of a row group (layer-2 forward, then layer-2 input-gradient) come from the fragment-major f32
     // images (PLayout::fr_pi) through a register ring of R fragments: one 16-byte load per lane feeds four k-steps (8 MFMAs), and
     // the slot a fragment is consumed from is reloaded at once with the fragment R positions further down the cyclic stream --
@@ -994,8 +998,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             f32x4 acc[NTW][2];
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
-                const float bias = Q.b1[n_base + 16 * j + r16];
-                acc[j][0] = acc[j][1] = f32x4{bias, bias, bias, bias};
+                const float bias_v = bias[n_base + 16 * j + r16];
+                acc[j][0] = acc[j][1] = f32x4{bias_v, bias_v, bias_v, bias_v};
             }
             if constexpr (NQ1C > 0) {
 #pragma unroll
@@ -1044,8 +1048,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live), weights through the ring ----
 #pragma unroll
         for (int j = 0; j < NTW; j++) {
-            const float bias = Q.b2[n_base + 16 * j + r16];
-            f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
+            const float bias_v = bias[H + n_base + 16 * j + r16];
+            f32x4 c0 = f32x4{bias_v, bias_v, bias_v, bias_v}, c1 = c0;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const int s = S1 + j * NQ + q;
@@ -1103,7 +1107,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int q = 0; q < NT3; q++) {
                 const int col = 16 * q + r16;
-                const float b = col < NOUT ? Q.b3[col] : 0.0f;
+                const float b = bias[2 * H + col];
                 out[q] = f32x4{b, b, b, b};
 #pragma unroll
                 for (int w = 0; w < 4; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * 2 + mt) * 2 + q) * 64 + lane) * 4);
@@ -1377,7 +1381,7 @@ __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
 
 static int grad_wide_smem_bytes(const PLayout &L) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + 4 * 2 * 2 * 256) * 4;
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + 4 * 2 * 2 * 256 + 2 * L.H + 32) * 4;
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
