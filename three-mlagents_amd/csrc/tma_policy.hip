@@ -1024,6 +1024,28 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            } else if constexpr (KT1C == 1 || KT1C == 2) {  // D <= 32: at most 8 k-steps, all weight loads issued together
+                constexpr int KSC = 4 * KT1C;
+                float w1[KSC][NTW];
+#pragma unroll
+                for (int ks = 0; ks < KSC; ks++)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        const int k = 4 * ks + g;
+                        w1[ks][j] = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < KSC; ks++) {
+                    if (ks < KS1) {
+                        const int k = 4 * ks + g;
+                        const float a0 = X[r16 * ldx + k], a1 = X[(16 + r16) * ldx + k];
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) {
+                            acc[j][0] = mfma16(a0, w1[ks][j], acc[j][0]);
+                            acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
+                        }
+                    }
+                }
             } else
             for (int ks = 0; ks < KS1; ks++) {
                 const int k = 4 * ks + g;
@@ -1154,15 +1176,25 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = z4;
             const int NS = (NOUT + 3) >> 2;
-            for (int ns = 0; ns < NS; ns++) {
-                const int n = 4 * ns + g;
-                const bool ok = n < NOUT;
-                const float a0 = dz3[r16 * ld3 + n], a1 = dz3[(16 + r16) * ld3 + n];
+            constexpr int NSC = 4 * NT3;  // n_out <= 16 * NT3: all head weights of this wave's columns fetched in one round trip
+            float w3b[NSC][NTW];
+#pragma unroll
+            for (int ns = 0; ns < NSC; ns++)
 #pragma unroll
                 for (int j = 0; j < NTW; j++) {
-                    const float w = ok ? Q.W3[(int64_t)n * H + n_base + 16 * j + r16] : 0.0f;
-                    acc[j][0] = mfma16(a0, w, acc[j][0]);
-                    acc[j][1] = mfma16(a1, w, acc[j][1]);
+                    const int n = 4 * ns + g;
+                    w3b[ns][j] = n < NOUT ? Q.W3[(int64_t)n * H + n_base + 16 * j + r16] : 0.0f;
+                }
+#pragma unroll
+            for (int ns = 0; ns < NSC; ns++) {
+                if (ns < NS) {
+                    const int n = 4 * ns + g;
+                    const float a0 = dz3[r16 * ld3 + n], a1 = dz3[(16 + r16) * ld3 + n];
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        acc[j][0] = mfma16(a0, w3b[ns][j], acc[j][0]);
+                        acc[j][1] = mfma16(a1, w3b[ns][j], acc[j][1]);
+                    }
                 }
             }
 #pragma unroll
