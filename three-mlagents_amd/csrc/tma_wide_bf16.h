@@ -164,12 +164,15 @@ __device__ __forceinline__ void bf_head(const bf16_t *A2, int ld, int row0, int 
     for (int w = 0; w < 4; w++)
 #pragma unroll
         for (int q = 0; q < NT3; q++) part[w][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // partial w covers the k-steps the gradient kernel's wave w takes: w*KS2/4 .. (KS2 % 4 == 0: its own h2 columns), else w, w + 4
+    const bool ownk = (KS2 & 3) == 0;
+    const int hk = (KS2 + 3) >> 2;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const int ks = w + 4 * i;
-            if (ks < KS2) {
+            const int ks = ownk ? w * hk + i : w + 4 * i;
+            if (i < hk && ks < KS2) {
                 const bf16x8 a = a_frag(A2, ld, row0 + r16, ks, g);
 #pragma unroll
                 for (int q = 0; q < NT3; q++) part[w][q] = mfma_bf(a, bf_frag(W3img, q * KS2 + ks, lane), part[w][q]);
@@ -334,14 +337,16 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
     };
     auto fetch_obs = [&]() {  // rows named by row_off_next (visible after a barrier)
+        // Issue only: the loaded value is NOT touched here (masking it with `ok` would make the compiler wait for the HBM round trip on
+        // the spot); invalid elements load a clamped address and are zeroed at commit time.  Indices come from the per-phase lane copy.
         if constexpr (PF) {
+            const int tid = wave * 64 + lane;
 #pragma unroll
             for (int i = 0; i < NX; i++) {
-                const int e = threadIdx.x + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const int e = tid + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
                 const int64_t off = row_off_next[row];
-                const bool ok = off >= 0 && c < D;  // branchless: a clamped address is always loadable
-                const float x = rb.obs[ok ? off * D + c : 0];
-                px[i] = ok ? x : 0.0f;
+                const bool ok = off >= 0 && c < D;
+                px[i] = rb.obs[ok ? off * D + c : 0];
             }
         }
     };
@@ -366,10 +371,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             row_off[mrow] = poff;
         }
         if constexpr (PF) {
+            const int tid = wave * 64 + lane;
 #pragma unroll
             for (int i = 0; i < NX; i++) {
-                const int e = threadIdx.x + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
-                const bf16_t v = (bf16_t)px[i];
+                const int e = tid + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const bool ok = row_off_next[row] >= 0 && c < D;  // row_off_next still names THIS group's rows (next fetch_meta: end of P2)
+                const bf16_t v = (bf16_t)(ok ? px[i] : 0.0f);
                 Xa[row * ldx + c] = v;
                 Xt[t_off<MT>(c, row)] = v;
             }
@@ -456,13 +463,36 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         TMA_TICK(2);
         TMA_RELANE();
         // ---- P2: layer 2 forward through the weight ring ----
-        constexpr int HK = (KS2 + 3) / 4;  // head k-steps per wave (split-K over the four waves: ks = wave, wave + 4, ...)
+        // split-K head over the four waves.  KS2 % 4 == 0 (H = 128 / 256): wave w takes the k-steps of ITS OWN h2 columns
+        // (ks = w*HK .. w*HK + HK - 1), so its partial product needs no barrier after the layer-2 epilogue; H = 192: ks = w, w + 4.
+        constexpr int HK = (KS2 + 3) / 4;
+        constexpr bool OWNK = KS2 % 4 == 0;
+        auto head_ks = [&](int i) { return OWNK ? wave * HK + i : wave + 4 * i; };
         bf16x8 w3f[HK * NT3];
+        auto head_partial = [&]() {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                f32x4 part[NT3];
+#pragma unroll
+                for (int q = 0; q < NT3; q++) part[q] = z4;
+#pragma unroll
+                for (int i = 0; i < HK; i++) {
+                    const int ks = head_ks(i);
+                    if (ks < KS2) {
+                        const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                        for (int q = 0; q < NT3; q++) part[q] = mfma_bf(a, w3f[i * NT3 + q], part[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * MT + mt) * 2 + q) * 64 + lane) * 4) = part[q];
+            }
+        };
         if (!(dbg & 32)) {
 #pragma unroll
             for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase
 #pragma unroll
-                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (wave + 4 * i < KS2 ? wave + 4 * i : 0), lane);
+                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (head_ks(i) < KS2 ? head_ks(i) : 0), lane);
             f32x4 acc[NTW][MT];
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
@@ -506,36 +536,23 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     *t_quad<MT>(T2, n, mt, g) = q;
                 }
             }
+            if constexpr (OWNK) {  // head partial over this wave's own h2 columns: straight after its epilogue, no barrier in between
+                if (!(dbg & 4)) head_partial();
+            }
         }
         __syncthreads();
         TMA_TICK(3);
         TMA_RELANE();
-        // ---- P3a: split-K head: every wave multiplies its k-steps of h2 for all row tiles, partial sums through LDS ----
+        // ---- P3a: (H = 192 only) split-K head partials; otherwise they were produced behind the layer-2 epilogue ----
         bf16x8 w3b[NTW];  // head input-gradient fragments for P4, in flight behind the head
 #pragma unroll
         for (int j = 0; j < NTW; j++) w3b[j] = bf_frag(W.bW3, nt0l + j, lane);
         if (has_next) fetch_obs();
         __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4)) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                f32x4 part[NT3];
-#pragma unroll
-                for (int q = 0; q < NT3; q++) part[q] = z4;
-#pragma unroll
-                for (int i = 0; i < HK; i++) {
-                    const int ks = wave + 4 * i;
-                    if (ks < KS2) {
-                        const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
-#pragma unroll
-                        for (int q = 0; q < NT3; q++) part[q] = mfma_bf(a, w3f[i * NT3 + q], part[q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * MT + mt) * 2 + q) * 64 + lane) * 4) = part[q];
-            }
+        if constexpr (!OWNK) {
+            if (!(dbg & 4)) head_partial();
+            __syncthreads();
         }
-        __syncthreads();
         TMA_TICK(4);
         TMA_RELANE();
         // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2*(wave >> 1) .. +1 of each lane group) ----

@@ -47,7 +47,8 @@ for i in range(0, len(args), 4):
     if os.environ.get("TMA_PHASE_DUMP") and dt == "bf16":
         grad(); torch.cuda.synchronize()
         ws = m.workspace
-        tail = ws[-64 * 4:].cpu().numpy().view("int64")  # last 64 int32 of the offsets cache
+        end_offs = ws.numel() - (((1 << 22) // 1024 + (1 << 22) // 256) * 16 + 8192 * 8)  # offsets cache ends before the epoch / norm partials
+        tail = ws[end_offs - 64 * 4:end_offs].cpu().numpy().view("int64")  # last 64 int32 of the offsets cache
         names = ["tail(prev P6 end)", "P0 commit", "P1", "P2", "P3a", "P3b", "P4", "P5", "P6+after-loop"]
         for role, o in (("pi", 0), ("vf", 12)):
             v = tail[o:o + 9]
