@@ -324,12 +324,19 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     int64_t poff = -1;
     const int mrow = wave * (M / 4) + lane0;  // sample row whose metadata this lane gathers (lanes < M/4 of every wave: the Feistel
     const bool mlane = lane0 < M / 4;         // permutation arithmetic is spread over the four waves instead of skewing wave 0)
-    auto fetch_meta = [&](int64_t grp) {
+    int32_t noff = -1;  // cached buffer offset of this lane's row in the NEXT group, loaded one phase before fetch_meta needs it
+    auto fetch_off = [&](int64_t grp) {  // (cache present) issue only; j beyond the minibatch reads a clamped entry that fetch_meta ignores
+        if (mb.offs && mlane) {
+            const int64_t j = grp * M + mrow;
+            noff = mb.offs[j < mb.count ? j : 0];
+        }
+    };
+    auto fetch_meta = [&](int64_t grp, bool have_noff) {
         if (mlane) {
             const int64_t j = grp * M + mrow;
             poff = -1, pm0 = pm1 = pm2 = pm3 = 0.0f;
             if (j < mb.count) {
-                poff = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
+                poff = mb.offs ? (int64_t)(have_noff ? noff : mb.offs[j]) : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
                 if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
             }
@@ -352,7 +359,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     };
     const int64_t n_groups = (mb.count + M - 1) / M;
     if (block_net < n_groups) {
-        fetch_meta(block_net);
+        fetch_meta(block_net, false);
         __syncthreads();
         fetch_obs();
     }
@@ -397,6 +404,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         constexpr int dbg = 0;
 #endif
         const bool has_next = grp + n_blocks_net < n_groups && !(dbg & 1);  // block-uniform
+        fetch_off(grp + n_blocks_net);  // consumed by fetch_meta at the end of P2
         TMA_TICK(1);
         TMA_RELANE();
         // ---- P1: layer 1 forward ----
@@ -521,7 +529,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             // Next group's sample gathers (HBM-latency loads) go out HERE and at the top of P3: vmcnt retires in order, so the
             // first wait on a load issued after them also waits for them -- and from here on P3 / P4 / the first half of P5 only
             // consume fragments that are already in flight.
-            if (has_next) fetch_meta(grp + n_blocks_net);
+            if (has_next) fetch_meta(grp + n_blocks_net, true);
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 const int n = n_base + 16 * j + r16;
@@ -547,7 +555,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         bf16x8 w3b[NTW];  // head input-gradient fragments for P4, in flight behind the head
 #pragma unroll
         for (int j = 0; j < NTW; j++) w3b[j] = bf_frag(W.bW3, nt0l + j, lane);
-        if (has_next) fetch_obs();
+        fetch_obs();  // unconditional (a last group re-reads stale rows that are never committed): the load count after w3b stays known,
+                      // so P4's wait for w3b is a counted vmcnt, not vmcnt(0) on these HBM gathers
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!OWNK) {
             if (!(dbg & 4)) head_partial();
