@@ -673,12 +673,20 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
     constexpr int NV = DT > 0 ? DP_CT / 4 : 1;  // observation values per lane: 16 rows x DP_CT floats / 64 lanes
     int64_t pf_off = -1;
     float pf_m0 = 0.0f, pf_m1 = 0.0f, pf_m2 = 0.0f, pf_m3 = 0.0f, pf_x[NV];
+    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
+    int32_t pf_noff = -1;  // cached sample offset of the tile AFTER the one being fetched: its load latency never sits in front of the gathers
+    bool have_noff = false;
     auto fetch = [&](int64_t tl) {
         pf_off = -1, pf_m0 = pf_m1 = pf_m2 = pf_m3 = 0.0f;
+        const int32_t my_noff = pf_noff;
+        if (mb.offs && lane < 16) {
+            const int64_t j2 = ((tl + tile_stride) << 4) + lane;
+            pf_noff = mb.offs[j2 < mb.count ? j2 : 0];
+        }
         if (lane < 16 && tl < n_tiles) {
             const int64_t j = (tl << 4) + lane;
             if (j < mb.count) {
-                pf_off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
+                pf_off = mb.offs ? (int64_t)(have_noff ? my_noff : mb.offs[j]) : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 if constexpr (IS_PI) {
                     pf_m0 = rb.log_probs[pf_off];
                     pf_m1 = rb.advantages[pf_off];
@@ -710,8 +718,8 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
             }
         }
     };
-    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
     fetch((int64_t)block_net * wpb + wave);
+    have_noff = true;
     for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
         commit();
         if constexpr (DT == 0) load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
