@@ -1080,18 +1080,28 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         for (int j = 0; j < NTW; j++) {
             const float bias_v = bias[H + n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias_v, bias_v, bias_v, bias_v}, c1 = c0;
+            // explicit pipeline, fenced per fragment: A operands one fragment ahead (LDS), the ring slot reloaded right behind its use
+            float a0[2][4], a1[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a0[0][i] = h1[r16 * ld + 4 * i + g], a1[0][i] = h1[(16 + r16) * ld + 4 * i + g];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const int s = S1 + j * NQ + q;
+                if (q + 1 < NQ) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int k = 16 * (q + 1) + 4 * i + g;
+                        a0[(q + 1) & 1][i] = h1[r16 * ld + k], a1[(q + 1) & 1][i] = h1[(16 + r16) * ld + k];
+                    }
+                }
                 const f32x4 w4 = ring[s % R];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int k = 16 * q + 4 * i + g;
-                    c0 = mfma16(h1[r16 * ld + k], w4[i], c0);
-                    c1 = mfma16(h1[(16 + r16) * ld + k], w4[i], c1);
+                    c0 = mfma16(a0[q & 1][i], w4[i], c0);
+                    c1 = mfma16(a1[q & 1][i], w4[i], c1);
                 }
                 ring[s % R] = sload((s + R) % SL);
-                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -1247,18 +1257,27 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 f32x4 c0 = z4, c1 = z4;
+                float a0[2][4], a1[2][4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) a0[0][i] = h2[r16 * ld + 4 * i + g], a1[0][i] = h2[(16 + r16) * ld + 4 * i + g];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const int s = S1 + NTW * NQ + j * NQ + q;
+                    if (q + 1 < NQ) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int n = 16 * (q + 1) + 4 * i + g;
+                            a0[(q + 1) & 1][i] = h2[r16 * ld + n], a1[(q + 1) & 1][i] = h2[(16 + r16) * ld + n];
+                        }
+                    }
                     const f32x4 w4 = ring[s % R];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const int n = 16 * q + 4 * i + g;
-                        c0 = mfma16(h2[r16 * ld + n], w4[i], c0);
-                        c1 = mfma16(h2[(16 + r16) * ld + n], w4[i], c1);
+                        c0 = mfma16(a0[q & 1][i], w4[i], c0);
+                        c1 = mfma16(a1[q & 1][i], w4[i], c1);
                     }
                     ring[s % R] = sload((s + R) % SL);
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 dz1[j][0] = c0, dz1[j][1] = c1;
             }
