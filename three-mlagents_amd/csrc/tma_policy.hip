@@ -1565,13 +1565,23 @@ __device__ __forceinline__ void scatter_derived_h64(float *params, const PLayout
     if (x < n_out) params[img + IMG_B3 + x] = val;
 }
 
+// sum-of-squares partials of the (scaled) gradient, one per 64 parameters -- the same values, in the same order, slab_reduce_kernel
+// leaves for an un-reduced gradient; used when the gradient was all-reduced (or accumulated) after the reduction kernel ran
+__global__ __launch_bounds__(64) void grad_sumsq64_kernel(const float *__restrict__ grad, int P, float scale, double *__restrict__ sq_part) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const float gv = e < P ? grad[e] * scale : 0.0f;
+    double sq = (double)gv * (double)gv;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
+}
+
 // tma_ppo_adam_step_local, H == 64 fast path: one thread per parameter over ceil(P / 256) blocks.  The norm comes from the
 // sum-of-squares partials slab_reduce_kernel left (every block folds them in the same fixed order), and each thread writes its
 // updated parameter to the flat buffer AND to its derived copies / image slots -- no single-block optimizer, no refresh launch.
 __global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
                                                                float *__restrict__ v, PLayout L, const double *__restrict__ sq_part, int n_part,
                                                                float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt, float eps,
-                                                               double *norm_out) {
+                                                               double *norm_out, float scale) {
     __shared__ double red[4];
     __shared__ float coef_s;
     double a = (int)threadIdx.x < n_part ? sq_part[threadIdx.x] : 0.0;
@@ -1590,7 +1600,7 @@ __global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict
     __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= L.P) return;
-    const float gv = grad[e] * coef_s;
+    const float gv = (grad[e] * scale) * coef_s;
     grad[e] = 0.0f;
     float mm = m[e], vv = v[e];
     mm = mm + (gv - mm) * (1.0f - beta1);
@@ -1656,7 +1666,7 @@ __device__ __forceinline__ void scatter_derived_wide(float *params, const PLayou
 __global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
                                                                 float *__restrict__ v, PLayout L, const double *__restrict__ sq_part, int n_part,
                                                                 float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt, float eps,
-                                                                double *norm_out) {
+                                                                double *norm_out, float scale) {
     __shared__ double red[4];
     __shared__ float coef_s;
     double a = 0.0;
@@ -1676,7 +1686,7 @@ __global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restric
     __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= L.P) return;
-    const float gv = grad[e] * coef_s;
+    const float gv = (grad[e] * scale) * coef_s;
     grad[e] = 0.0f;
     float mm = m[e], vv = v[e];
     mm = mm + (gv - mm) * (1.0f - beta1);
@@ -2541,6 +2551,25 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
     double *norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const double step_size = lr / bc1, bc2_sqrt = sqrt(bc2);
+    double *sqp = sq_partials(ws, L);
+    const bool scat_h64 = L.img_pi >= 0 && L.P <= 64 * 256, scat_wide = L.bf16 || L.fr_pi >= 0;
+    if (sqp && (scat_h64 || scat_wide)) {
+        // layouts whose derived copies the optimizer kernel scatters itself: norm partials of the (all-reduced, scaled) gradient, then
+        // ONE multi-block Adam + scatter launch -- two launches instead of three to five
+        const int n_part = (int)ceil_div(L.P, 64);
+        grad_sumsq64_kernel<<<dim3((unsigned)n_part), dim3(64), 0, s>>>(grad, L.P, (float)grad_scale, sqp);
+        TMA_LAUNCH_CHECK();
+        if (scat_h64)
+            adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, sqp, n_part,
+                                                                                             (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
+                                                                                             (float)bc2_sqrt, (float)eps, norm_out, (float)grad_scale);
+        else
+            adam_scatter_wide_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, sqp, n_part,
+                                                                                              (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
+                                                                                              (float)bc2_sqrt, (float)eps, norm_out, (float)grad_scale);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     if (L.P <= 32768) {
         opt_small_kernel<<<dim3(1), dim3(1024), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, (float)grad_scale, (float)max_grad_norm, (float)step_size,
                                                         (float)beta1, (float)beta2, (float)bc2_sqrt, (float)eps, norm_out);
@@ -2579,11 +2608,11 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
     if (h64)
         adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
             params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
-            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
+            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f);
     else
         adam_scatter_wide_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
             params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
-            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT));
+            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }
