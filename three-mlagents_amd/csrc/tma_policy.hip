@@ -992,11 +992,23 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
         {
+            // batches of 8 loads issued before the first store: one HBM round trip per batch instead of one per element
             const int Dp = (D + 3) & ~3, tot = M * Dp;
-            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-                const int row = e / Dp, c = e - row * Dp;
-                const int64_t off = row_off[row];
-                X[row * ldx + c] = (off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f;
+            constexpr int NB = 8;
+            for (int e0 = threadIdx.x; e0 < tot; e0 += 256 * NB) {
+                float t[NB];
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int e = e0 + 256 * i, row = e < tot ? e / Dp : 0, c = e - row * Dp;
+                    const int64_t off = row_off[row];
+                    t[i] = rb.obs[(e < tot && off >= 0 && c < D) ? off * D + c : 0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int e = e0 + 256 * i, row = e < tot ? e / Dp : 0, c = e - row * Dp;
+                    if (e < tot) X[row * ldx + c] = (row_off[row] >= 0 && c < D) ? t[i] : 0.0f;
+                }
             }
         }
         __syncthreads();

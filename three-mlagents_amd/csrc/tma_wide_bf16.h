@@ -389,12 +389,28 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         } else {
             __syncthreads();
-            for (int e = threadIdx.x; e < M * Kp1; e += blockDim.x) {
-                const int row = e / Kp1, c = e - row * Kp1;
-                const int64_t off = row_off[row];
-                const bf16_t v = (bf16_t)((off >= 0 && c < D) ? rb.obs[off * D + c] : 0.0f);
-                Xa[row * ldx + c] = v;
-                Xt[t_off<MT>(c, row)] = v;
+            // Direct gather (no cross-phase prefetch registers at this width).  The loads of a batch are all issued before the first
+            // one is converted: written as one load-convert-store per iteration the loop pays the HBM round trip per ELEMENT
+            // (2*MT*KS1 of them per thread -- 46 % of the Crawler kernel when it was measured that way).
+            constexpr int NB = KS1C > 0 ? 2 * MT * KS1C : 4;  // M * Kp1 / 256 = 2 * MT * KS1 elements per thread
+            static_assert(KS1C > 0 || MT % 2 == 0, "runtime-width batches of 4 need 2 * MT * KS1 divisible by 4");
+            const int tid = wave * 64 + lane;
+            for (int e0 = tid; e0 < M * Kp1; e0 += 256 * NB) {
+                float t[NB];
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int e = e0 + 256 * i, row = e / Kp1, c = e - row * Kp1;
+                    const int64_t off = row_off[row];
+                    t[i] = rb.obs[(off >= 0 && c < D) ? off * D + c : 0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int e = e0 + 256 * i, row = e / Kp1, c = e - row * Kp1;
+                    const bf16_t v = (bf16_t)((row_off[row] >= 0 && c < D) ? t[i] : 0.0f);
+                    Xa[row * ldx + c] = v;
+                    Xt[t_off<MT>(c, row)] = v;
+                }
             }
         }
         __syncthreads();
