@@ -320,7 +320,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
     }
     // ---- prefetch registers for the next group's samples ----
-    float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
+    float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX], ptouch[2] = {0.0f, 0.0f};
     int64_t poff = -1;
     const int mrow = wave * (M / 4) + lane0;  // sample row whose metadata this lane gathers (lanes < M/4 of every wave: the Feistel
     const bool mlane = lane0 < M / 4;         // permutation arithmetic is spread over the four waves instead of skewing wave 0)
@@ -354,6 +354,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const int64_t off = row_off_next[row];
                 const bool ok = off >= 0 && c < D;
                 px[i] = rb.obs[ok ? off * D + c : 0];
+            }
+        } else {
+            // Wider rows are gathered directly at P0; here they are only TOUCHED -- one dword per 64 bytes of every row, two
+            // loads per thread -- so that the gather finds its lines (and their translations) in L2 instead of paying a
+            // random-row HBM / TLB round trip at the top of the group.  The values are consumed (discarded) after P0's gather.
+            const int tid = wave * 64 + lane, nch = (D * 4 + 63) / 64 + 1;  // 64-byte pieces a row can straddle
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int q = tid + 256 * i, row = q / nch, ch = q - row * nch;
+                const int64_t off = row_off_next[row < M ? row : 0];
+                const int c = 16 * ch < D ? 16 * ch : D - 1;
+                ptouch[i] = rb.obs[(row < M && off >= 0) ? off * D + c : 0];
             }
         }
     };
@@ -389,29 +401,50 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         } else {
             __syncthreads();
-            // Direct gather (no cross-phase prefetch registers at this width).  The loads of a batch are all issued before the first
-            // one is converted: written as one load-convert-store per iteration the loop pays the HBM round trip per ELEMENT
-            // (2*MT*KS1 of them per thread -- 46 % of the Crawler kernel when it was measured that way).
-            constexpr int NB = KS1C > 0 ? 2 * MT * KS1C : 4;  // M * Kp1 / 256 = 2 * MT * KS1 elements per thread
-            static_assert(KS1C > 0 || MT % 2 == 0, "runtime-width batches of 4 need 2 * MT * KS1 divisible by 4");
-            const int tid = wave * 64 + lane;
-            for (int e0 = tid; e0 < M * Kp1; e0 += 256 * NB) {
-                float t[NB];
+            // Direct gather (no cross-phase prefetch registers at this width).  Wave w takes rows 8w .. 8w+7 (MT = 2), lane l the
+            // columns l, l + 64, ...: the row's buffer offset is wave-uniform (scalar base + lane offset: no 64-bit per-lane
+            // address arithmetic -- the element-indexed form of this loop was instruction-bound, 9k cycles per group), all loads
+            // of a column chunk are in flight before the first is converted, and a thread's 8 rows of one column are exactly
+            // one 16-byte chunk of the T image (one ds_write_b128, conflict-free under the chunk swizzle).
+            static_assert(MT == 2, "direct gather: 8 rows per wave = one T-image chunk");
+            constexpr int RW = 8;
+            typedef const float __attribute__((address_space(1))) *gf_ptr;
+            gf_ptr rbase[RW];
+            bool rok[RW];
 #pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int e = e0 + 256 * i, row = e / Kp1, c = e - row * Kp1;
-                    const int64_t off = row_off[row];
-                    t[i] = rb.obs[(off >= 0 && c < D) ? off * D + c : 0];
+            for (int i = 0; i < RW; i++) {
+                const int64_t off = row_off[wave * RW + i];
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)off >> 32));
+                const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
+                rok[i] = offu >= 0;
+                rbase[i] = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (rok[i] ? offu * D : 0)));
+            }
+            constexpr int KCC = KS1C > 0 ? (32 * KS1C + 63) / 64 : 1;  // compile-time width: every column chunk in one batch
+            const int c_end = KS1C > 0 ? 64 * KCC : Kp1;
+            for (int c0 = 0; c0 < c_end; c0 += 64 * KCC) {
+                float t[KCC][RW];
+#pragma unroll
+                for (int k = 0; k < KCC; k++) {
+                    const int c = c0 + 64 * k + lane;
+#pragma unroll
+                    for (int i = 0; i < RW; i++) t[k][i] = rbase[i][c < D ? c : 0];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int e = e0 + 256 * i, row = e / Kp1, c = e - row * Kp1;
-                    const bf16_t v = (bf16_t)((row_off[row] >= 0 && c < D) ? t[i] : 0.0f);
-                    Xa[row * ldx + c] = v;
-                    Xt[t_off<MT>(c, row)] = v;
+                for (int k = 0; k < KCC; k++) {
+                    const int c = c0 + 64 * k + lane;
+                    if (c < Kp1) {
+                        bf16x8 col;
+#pragma unroll
+                        for (int i = 0; i < RW; i++) {
+                            col[i] = (bf16_t)((rok[i] && c < D) ? t[k][i] : 0.0f);
+                            Xa[(wave * RW + i) * ldx + c] = col[i];
+                        }
+                        *reinterpret_cast<bf16x8 *>(Xt + t_off<MT>(c, wave * RW)) = col;
+                    }
                 }
             }
+            asm volatile("" ::"v"(ptouch[0]), "v"(ptouch[1]));  // the L2 touches of fetch_obs end here
         }
         __syncthreads();
 #ifdef TMA_BF_PHASE_DEBUG
