@@ -320,7 +320,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
     }
     // ---- prefetch registers for the next group's samples ----
-    float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX], ptouch[2] = {0.0f, 0.0f};
+    float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
     const int mrow = wave * (M / 4) + lane0;  // sample row whose metadata this lane gathers (lanes < M/4 of every wave: the Feistel
     const bool mlane = lane0 < M / 4;         // permutation arithmetic is spread over the four waves instead of skewing wave 0)
@@ -354,18 +354,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const int64_t off = row_off_next[row];
                 const bool ok = off >= 0 && c < D;
                 px[i] = rb.obs[ok ? off * D + c : 0];
-            }
-        } else {
-            // Wider rows are gathered directly at P0; here they are only TOUCHED -- one dword per 64 bytes of every row, two
-            // loads per thread -- so that the gather finds its lines (and their translations) in L2 instead of paying a
-            // random-row HBM / TLB round trip at the top of the group.  The values are consumed (discarded) after P0's gather.
-            const int tid = wave * 64 + lane, nch = (D * 4 + 63) / 64 + 1;  // 64-byte pieces a row can straddle
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int q = tid + 256 * i, row = q / nch, ch = q - row * nch;
-                const int64_t off = row_off_next[row < M ? row : 0];
-                const int c = 16 * ch < D ? 16 * ch : D - 1;
-                ptouch[i] = rb.obs[(row < M && off >= 0) ? off * D + c : 0];
             }
         }
     };
@@ -444,7 +432,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     }
                 }
             }
-            asm volatile("" ::"v"(ptouch[0]), "v"(ptouch[1]));  // the L2 touches of fetch_obs end here
         }
         __syncthreads();
 #ifdef TMA_BF_PHASE_DEBUG
