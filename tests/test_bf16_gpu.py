@@ -178,6 +178,23 @@ def test_bf16_minibatch_gradient(D, H, A, cont, B):
     assert abs(-st[2] / n - stats_emu["entropy_loss"]) < 2e-3 and abs(st[4] / n - stats_emu["clip_fraction"]) < 2e-3
 
 
+@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (40, 256, 7, True), (172, 128, 20, True), (50, 192, 4, False)])
+def test_bf16_dw1_from_cached_dz1_equals_recompute_pass(D, H, A, cont, monkeypatch):
+    """Two-pass layouts (observations 33..64 / 161..192 wide): dW1 from the dz1 images PASS 0 leaves in the workspace (PASS 2)
+    is bit-identical to dW1 from the recomputed chain (PASS 1, the path minibatches beyond the cache take)."""
+    T, N, B = 64, 600, 33000
+    pol, sd = _policies(D, H, A, cont)
+    obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, cont, T, N)
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(2))
+    bufs = dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret)
+    g_cache, st_cache, _ = _hip_grad(pol, bufs, T, N, perm, 5, B, HP)
+    monkeypatch.setenv("TMA_NO_DZ1_CACHE", "1")
+    g_recompute, st_recompute, _ = _hip_grad(pol, bufs, T, N, perm, 5, B, HP)
+    assert torch.equal(g_cache, g_recompute)
+    assert list(st_cache) == list(st_recompute)
+    assert g_cache.abs().sum().item() > 0
+
+
 @pytest.mark.parametrize("D,H,A,cont", [(6, 256, 5, False), (172, 256, 20, True)])
 def test_bf16_rollout_and_update_share_the_forward(D, H, A, cont):
     """old_log_prob from policy_act fed back into the update: ratio must be exactly 1 on the first epoch (approx_kl == 0,

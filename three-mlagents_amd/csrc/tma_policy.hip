@@ -34,6 +34,9 @@ constexpr int64_t OFFS_CAP = 1 << 22;
 constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch
 constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_kernel for policies beyond the 256 slots at WS_NORM_PART  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
+constexpr int64_t DZ1_CAP = 1 << 18;  // samples per minibatch whose dz1 images fit the workspace cache (bf16 two-pass layouts only)
+static inline bool bf_two_pass(const PLayout &L) { return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192)); }
+static inline int64_t dz1_cache_bytes(const PLayout &L) { return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : 0; }  // both nets, bf16
 static inline int slab_cap(const PLayout &L) { return (L.bf16 || L.fr_pi >= 0) ? BF_SLABS : H64_BLOCKS; }  // partial-gradient slabs in the workspace
 
 struct Net {
@@ -2261,7 +2264,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8;
+    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L);
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -2423,11 +2426,15 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, n_pi, L);
             TMA_LAUNCH_CHECK();
         }
-        auto launch = [&](auto k) -> int {
+        auto launch = [&](auto k, bf16_t *dz1) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi);
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
             return TMA_OK;
         };
+        // two-pass layouts: minibatches that fit the dz1 cache take PASS 0 (which leaves dz1 there) + PASS 2 (dW1 from the cache)
+        // instead of PASS 0 + PASS 1 (dW1 from a recomputed forward / backward chain); the results are bit-identical
+        bf16_t *const dz1_cache = (bf_two_pass(L) && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))  // (env: test hook for the fallback)
+            ? reinterpret_cast<bf16_t *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
         // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2) two passes; 161..192 (Crawler's 172) -> (0, 6) two
         // passes; else runtime width, one pass with dW1 in the slab
         auto pick = [&](auto ntw) -> int {
@@ -2435,17 +2442,21 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             auto both = [&](auto cont) -> int {
                 constexpr bool C = decltype(cont)::value;
                 switch (variant) {
-                    case 0: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 1, 1, 0>);
-                    case 1: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 2, 1, 0>);
+                    case 0: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 1, 1, 0>, nullptr);
+                    case 1: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 2, 1, 0>, nullptr);
                     case 2: {
-                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 0>);
-                        return rc2 ? rc2 : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 1>);
+                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 0>, dz1_cache);
+                        if (rc2) return rc2;
+                        return dz1_cache ? launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 2>, dz1_cache)
+                                         : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 1>, nullptr);
                     }
                     case 3: {
-                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 0>);
-                        return rc2 ? rc2 : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 1>);
+                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 0>, dz1_cache);
+                        if (rc2) return rc2;
+                        return dz1_cache ? launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 2>, dz1_cache)
+                                         : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 1>, nullptr);
                     }
-                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>);
+                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>, nullptr);
                 }
             };
             return d->continuous ? both(std::true_type{}) : both(std::false_type{});

@@ -235,7 +235,8 @@ constexpr int bf_ring_slots(int stream_len, int cap) {
 template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C, int PASS>
 __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                   const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
-                                                  double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net) {
+                                                  double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net,
+                                                  bf16_t *__restrict__ dz1c) {
     constexpr int M = 16 * MT, MK = MT / 2, H = 64 * NTW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
     // weight stream of a row group: [layer-1 fragments when KS1C > 1: k-step outer, tile inner] [layer-2 forward] [layer-2 input-gradient]
     constexpr int S1 = KS1C > 1 ? KS1C * NTW : 0, SL = S1 + 2 * KS2 * NTW;
@@ -270,10 +271,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     const int Kp1 = KS1C > 0 ? 32 * KS1C : ((D + 31) & ~31), KS1 = Kp1 >> 5, KT1 = Kp1 >> 4, ldx = Kp1 + 16;
     constexpr bool MAIN = PASS == 0;
     constexpr bool two_pass = KT1C == 0 && KS1C > 0;
-    static_assert(PASS == 0 || two_pass, "PASS 1 exists only for wide observations of compile-time width");
-    constexpr bool acc_w1 = KT1C > 0 || PASS == 1;              // dW1 in registers
+    static_assert(PASS == 0 || two_pass, "PASS 1 / 2 exist only for wide observations of compile-time width");
+    // PASS 2 replaces PASS 1 when the minibatch fits the dz1 cache of the workspace (dz1c != nullptr in both launches): PASS 0 leaves
+    // every group's dz1 image (bf16, the T-image layout of T1: H x M, 16 KB at H = 256) in HBM and PASS 2 only gathers the
+    // observation rows again and runs the dW1 MFMAs on those images -- the same bf16 operands in the same order as PASS 1, so the
+    // two give identical bits, without recomputing the forward / backward chain.
+    constexpr bool acc_w1 = KT1C > 0 || PASS >= 1;              // dW1 in registers
     constexpr bool rmw_w1 = KT1C == 0 && KS1C == 0;             // dW1 accumulated in the slab (runtime width)
-    constexpr int KT1A = KT1C > 0 ? KT1C : (PASS == 1 ? 2 * KS1C : 1);
+    constexpr int KT1A = KT1C > 0 ? KT1C : (PASS >= 1 ? 2 * KS1C : 1);
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *Xt = Xa + M * ldx, *A1 = Xt + Kp1 * M, *A2 = A1 + M * lda;
     bf16_t *T1 = A2 + M * lda, *T2 = T1 + H * M, *Z3a = T2 + H * M, *Z3t = Z3a + M * ldz;
     float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M), *meta = dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
@@ -313,8 +318,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         return bf_frag(W.bW2, (nt0l + t % NTW) * KS2 + t / NTW, lane);
     };
     bf16x8 ring[R], w1r[NTW];  // w1r: layer-1 fragments (D <= 32), re-issued at the end of P5 for the next group
+    if constexpr (PASS != 2) {
 #pragma unroll
-    for (int s = 0; s < R; s++) ring[s] = sload(s);
+        for (int s = 0; s < R; s++) ring[s] = sload(s);
+    }
     if constexpr (KS1C == 1) {
 #pragma unroll
         for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
@@ -337,8 +344,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             poff = -1, pm0 = pm1 = pm2 = pm3 = 0.0f;
             if (j < mb.count) {
                 poff = mb.offs ? (int64_t)(have_noff ? noff : mb.offs[j]) : sample_offset(mb, mb.start + j, rb.T, rb.N);
-                pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
-                if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
+                if constexpr (PASS != 2) {
+                    pm0 = rb.log_probs[poff], pm1 = rb.advantages[poff], pm2 = rb.returns[poff];
+                    if constexpr (!CONT) pm3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[poff]);
+                }
             }
             row_off_next[mrow] = poff;
         }
@@ -372,6 +381,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l);
         TMA_TICK(0);
         TMA_RELANE();
+        bf16x8 zc[NTW][MK];  // PASS 2: this wave's dz1 fragments of the group, in flight under the observation gather
+        if constexpr (PASS == 2) {
+            const bf16_t *gi = dz1c + grp * (int64_t)(H * M);
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) {
+                    const int row = n_base + 16 * j + r16;
+                    zc[j][kk] = *reinterpret_cast<const bf16x8 *>(gi + row * (16 * MT) + 8 * ((4 * kk + g) ^ t_swz<MT>(row)));
+                }
+            fetch_off(grp + n_blocks_net);
+        }
         // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
         if (mlane) {
             meta[mrow * 4 + 0] = pm0, meta[mrow * 4 + 1] = pm1, meta[mrow * 4 + 2] = pm2, meta[mrow * 4 + 3] = pm3;
@@ -434,6 +455,20 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        if constexpr (PASS == 2) {
+            if (grp + n_blocks_net < n_groups) fetch_meta(grp + n_blocks_net, true);
+#pragma unroll
+            for (int kt = 0; kt < KT1A; kt++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) {
+                    const bf16x8 a = t_frag<MT>(Xt, 16 * kt + r16, kk, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) aW1[kt][j] = mfma_bf(a, zc[j][kk], aW1[kt][j]);
+                }
+            __syncthreads();  // the T image of the observations is consumed; row_off_next names the next group's rows
+            fetch_obs();
+            continue;
+        }
 #ifdef TMA_BF_PHASE_DEBUG
         const int dbg = hp.debug;  // timing attribution builds only: skipping phases perturbs register allocation
 #else
@@ -788,6 +823,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T1, n_base + 16 * j + r16, kk, g);
+            if constexpr (two_pass && MAIN) {
+                if (dz1c) {  // (block-uniform) leave this group's dz1 image for PASS 2: 16 lanes x 64 B rows = 1 KiB contiguous per store
+                    bf16_t *gi = dz1c + grp * (int64_t)(H * M);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++)
+#pragma unroll
+                        for (int kk = 0; kk < MK; kk++) {
+                            const int row = n_base + 16 * j + r16;
+                            *reinterpret_cast<bf16x8 *>(gi + row * (16 * MT) + 8 * ((4 * kk + g) ^ t_swz<MT>(row))) = zb[j][kk];
+                        }
+                }
+            }
             if constexpr (acc_w1) {
 #pragma unroll
                 for (int kt = 0; kt < KT1A; kt++)
@@ -906,7 +953,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 template <bool CONT, int NTW, int MT, int KT1C, int KS1C, int PASS>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                   const float *__restrict__ ws_adv, float *__restrict__ slabs,
-                                                                  double *__restrict__ stat_slots, int n_pi) {
+                                                                  double *__restrict__ stat_slots, int n_pi, bf16_t *__restrict__ dz1,
+                                                                  int64_t dz1_net_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem_bf[];
     // blocks [0, n_pi): policy net, [n_pi, gridDim.x): value net.  Block b of a net owns slab b (its net's parameters only) and
     // statistics slot b (policy: entries 0, 2.. ; value: entry 1 -- disjoint, so a policy and a value block may share a slot).
@@ -914,6 +962,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *_
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
-    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b);
+    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b, dz1);
+    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b,
+                                                                   dz1 ? dz1 + dz1_net_stride : nullptr);
 }
