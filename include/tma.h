@@ -156,7 +156,8 @@ typedef struct {
     int normalize_advantage;
 } tma_ppo_hparams;
 
-/* bytes of the update workspace for a policy shape (loss-stat slots, norm partials, partial-gradient slabs) */
+/* bytes of the update workspace for a policy shape (loss-stat slots, norm partials, partial-gradient slabs, sample-offset cache;
+ * bf16 layouts with 33..64 or 161..192 observations: + a dz1 cache of 2 * 262144 * hidden bf16 for the dW1 launch) */
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d);
 /* PPO.train inner loop body up to loss.backward(): accumulates d(loss)/d(params) into grad[n_trainable] (caller zeroes it
  * once; tma_ppo_adam_step re-zeroes it) and loss statistics into the workspace. */
