@@ -157,7 +157,8 @@ typedef struct {
 } tma_ppo_hparams;
 
 /* bytes of the update workspace for a policy shape (loss-stat slots, norm partials, partial-gradient slabs, sample-offset cache;
- * bf16 layouts with 33..64 or 161..192 observations: + a dz1 cache of 2 * 262144 * hidden bf16 for the dW1 launch) */
+ * bf16 layouts with 33..64 or 161..192 observations: + a dz1 cache of 2 * 262144 * hidden bf16 for the dW1 launch; f32 layouts with
+ * hidden 128/192/256 and 161..176 observations: the same in f32) */
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d);
 /* PPO.train inner loop body up to loss.backward(): accumulates d(loss)/d(params) into grad[n_trainable] (caller zeroes it
  * once; tma_ppo_adam_step re-zeroes it) and loss statistics into the workspace. */

@@ -211,6 +211,23 @@ def test_wide_policy_column_parallel_kernel(D, H, A, cont):
     assert abs(-st[2] / B - stats_ref["entropy_loss"]) < 1e-4 and abs(st[4] / B - stats_ref["clip_fraction"]) < 1e-6
 
 
+@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (165, 128, 4, False), (176, 192, 3, False)])
+def test_wide_dw1_from_cached_dz1_equals_recompute_pass(D, H, A, cont, monkeypatch):
+    """Crawler-width observations (161..176): the second launch computes dW1 from the dz1 operands the first one left in the
+    workspace; beyond the cache (or with the test hook) it recomputes the chain instead -- the two must agree bit for bit."""
+    T, N, B = 64, 600, 33000
+    pol, sd = _policy(D, H, A, cont)
+    obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, cont, T, N)
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(2))
+    bufs = dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret)
+    g_cache, st_cache, _ = _hip_grad(pol, bufs, T, N, perm, 5, B, HP)
+    monkeypatch.setenv("TMA_NO_DZ1_CACHE", "1")
+    g_recompute, st_recompute, _ = _hip_grad(pol, bufs, T, N, perm, 5, B, HP)
+    assert torch.equal(g_cache, g_recompute)
+    assert list(st_cache) == list(st_recompute)
+    assert g_cache.abs().sum().item() > 0
+
+
 def test_full_batch_feistel_permutation_is_a_bijection():
     """The on-device minibatch permutation visits every sample exactly once: with normalisation off, the gradient of
     the whole buffer taken as 5 permuted minibatches (scaled by their sizes) equals the one-shot identity-order gradient."""

@@ -36,7 +36,10 @@ constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_k
 
 constexpr int64_t DZ1_CAP = 1 << 18;  // samples per minibatch whose dz1 images fit the workspace cache (bf16 two-pass layouts only)
 static inline bool bf_two_pass(const PLayout &L) { return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192)); }
-static inline int64_t dz1_cache_bytes(const PLayout &L) { return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : 0; }  // both nets, bf16
+static inline bool f32_two_pass(const PLayout &L) { return !L.bf16 && L.fr_pi >= 0 && L.D > 160 && L.D <= 176; }
+static inline int64_t dz1_cache_bytes(const PLayout &L) {  // both nets; bf16 images or f32 MFMA operands
+    return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : (f32_two_pass(L) ? 2 * DZ1_CAP * L.H * 4 : 0);
+}
 static inline int slab_cap(const PLayout &L) { return (L.bf16 || L.fr_pi >= 0) ? BF_SLABS : H64_BLOCKS; }  // partial-gradient slabs in the workspace
 
 struct Net {
@@ -904,7 +907,11 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
 template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
-                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net,
+                                               float *__restrict__ dz1c) {
+    // dz1c (two-pass widths, minibatches that fit the workspace cache): PASS 0 leaves every row group's dz1 there as the B operands
+    // of the dW1 MFMAs ([group][wave][tile][lane][8 floats]); PASS 2 re-gathers the observation rows and runs only those MFMAs
+    // -- same operands, same order as PASS 1 (the recompute pass, kept for larger minibatches), hence the same bits.
     constexpr int M = 32, H = 64 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (same two measures as tma_wide_bf16.h: the weight pointers are laundered once per row group so LICM cannot hoist the
@@ -967,10 +974,21 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         return frag_f32(fr + half * H * H, (nt0 + t / NQ) * NQ + t % NQ, lane0);
     };
     f32x4 ring[R];
+    if constexpr (PASS != 2) {
 #pragma unroll
-    for (int s = 0; s < R; s++) ring[s] = sload(s);
+        for (int s = 0; s < R; s++) ring[s] = sload(s);
+    }
     const int64_t n_groups = (mb.count + M - 1) / M;
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
+        f32x4 zc[NTW][2];  // PASS 2: cached dz1 operands of this wave, in flight under the gathers of P0
+        if constexpr (PASS == 2) {
+            const float *gi = dz1c + (grp * 4 + wave) * (int64_t)(NTW * 512);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+                zc[j][0] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8);
+                zc[j][1] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8 + 4);
+            }
+        }
         {
             const float *pl = launder_uniform(params);
             Q = IS_PI ? pi_net(pl, L) : vf_net(pl, L);
@@ -1016,6 +1034,22 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
         TMA_RELANE();
+        if constexpr (PASS == 2) {
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+#pragma unroll
+                for (int kt = 0; kt < KT1A; kt++) {
+                    const int krow = kt * 16 + r16;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) {
+                        const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
+                        aW1[kt][j] = mfma16(a, zc[j][sidx >> 2][sidx & 3], aW1[kt][j]);
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- P1: layer 1 forward, this wave's columns, both row tiles ----
         {
             f32x4 acc[NTW][2];
@@ -1321,6 +1355,13 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 c += bf[sidx];
             }
             ab1[j] += c;
+            if constexpr (MAIN && KT1C < 0) {
+                if (dz1c) {  // (block-uniform) first of two passes: leave the dW1 operands for PASS 2
+                    float *gi = dz1c + (grp * 4 + wave) * (int64_t)(NTW * 512) + (j * 64 + lane) * 8;
+                    *reinterpret_cast<f32x4 *>(gi) = f32x4{bf[0], bf[1], bf[2], bf[3]};
+                    *reinterpret_cast<f32x4 *>(gi + 4) = f32x4{bf[4], bf[5], bf[6], bf[7]};
+                }
+            }
             if constexpr (acc_w1) {
 #pragma unroll
                 for (int kt = 0; kt < KT1A; kt++) {
@@ -1429,15 +1470,16 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
-                                                               double *__restrict__ stat_slots, int n_pi) {
+                                                               double *__restrict__ stat_slots, int n_pi, float *__restrict__ dz1,
+                                                               int64_t dz1_net_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // blocks [0, n_pi): policy net, [n_pi, gridDim.x): value net (the policy net's row group costs more: it gets more blocks)
     const bool is_pi = (int)blockIdx.x < n_pi;
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b);
-    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b);
+    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1 ? dz1 + dz1_net_stride : nullptr);
 }
 
 #include "tma_wide_bf16.h"
@@ -2488,11 +2530,14 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
             TMA_LAUNCH_CHECK();
         }
-        auto launch = [&](auto k) -> int {
+        auto launch = [&](auto k, float *dz1 = nullptr) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi);
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
             return TMA_OK;
         };
+        // (as on the bf16 path) minibatches that fit the dz1 cache: chain pass + dW1 from the cached operands; else chain + recompute
+        float *const dz1_cache = (f32_two_pass(L) && kt1 == 11 && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
+            ? reinterpret_cast<float *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
         auto pick = [&](auto ntw) -> int {
             constexpr int NTWc = decltype(ntw)::value;
             auto both = [&](auto cont) -> int {
@@ -2500,8 +2545,9 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
                 if (kt1 == 1) return launch(ppo_grad_wide_kernel<C, NTWc, 1>);
                 if (kt1 == 2) return launch(ppo_grad_wide_kernel<C, NTWc, 2>);
                 if (kt1 == 11) {
-                    const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0, 11>);
-                    return rc2 ? rc2 : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1, 11>);
+                    const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0, 11>, dz1_cache);
+                    if (rc2) return rc2;
+                    return dz1_cache ? launch(ppo_grad_wide_kernel<C, NTWc, 11, 2, 11>, dz1_cache) : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1, 11>);
                 }
                 return launch(ppo_grad_wide_kernel<C, NTWc, 0>);
             };
