@@ -1005,30 +1005,49 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
             if (j < mb.count) {
                 off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
-                m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
-                if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+                if constexpr (PASS != 2) {
+                    m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
+                    if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
+                }
             }
             meta[threadIdx.x * 4 + 0] = m0, meta[threadIdx.x * 4 + 1] = m1, meta[threadIdx.x * 4 + 2] = m2, meta[threadIdx.x * 4 + 3] = m3;
             row_off[threadIdx.x] = off;
         }
         __syncthreads();
         {
-            // batches of 8 loads issued before the first store: one HBM round trip per batch instead of one per element
-            const int Dp = (D + 3) & ~3, tot = M * Dp;
-            constexpr int NB = 8;
-            for (int e0 = threadIdx.x; e0 < tot; e0 += 256 * NB) {
-                float t[NB];
+            // Wave w gathers rows 8w .. 8w+7, lane l the columns l, l + 64, ...: the row's buffer offset is wave-uniform (scalar base +
+            // lane offset, no 64-bit per-lane address arithmetic) and a whole batch of loads is in flight before the first store.
+            // (The element-indexed form of this loop -- e = tid + 256 i, row = e / D -- was instruction-bound at Crawler width.)
+            typedef const float __attribute__((address_space(1))) *gf_ptr;
+            gf_ptr rbase[8];
+            bool rok[8];
 #pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int e = e0 + 256 * i, row = e < tot ? e / Dp : 0, c = e - row * Dp;
-                    const int64_t off = row_off[row];
-                    t[i] = rb.obs[(e < tot && off >= 0 && c < D) ? off * D + c : 0];
+            for (int i = 0; i < 8; i++) {
+                const int64_t off = row_off[wave * 8 + i];
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)off >> 32));
+                const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
+                rok[i] = offu >= 0;
+                rbase[i] = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (rok[i] ? offu * D : 0)));
+            }
+            const int Dp = (D + 3) & ~3;
+            for (int c0 = 0; c0 < Dp; c0 += 192) {
+                float t[3][8];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int c = c0 + 64 * k + lane;
+                    if (c0 + 64 * k < Dp) {  // (uniform) narrow observations: one column chunk
+#pragma unroll
+                        for (int i = 0; i < 8; i++) t[k][i] = rbase[i][c < D ? c : 0];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int e = e0 + 256 * i, row = e < tot ? e / Dp : 0, c = e - row * Dp;
-                    if (e < tot) X[row * ldx + c] = (row_off[row] >= 0 && c < D) ? t[i] : 0.0f;
+                for (int k = 0; k < 3; k++) {
+                    const int c = c0 + 64 * k + lane;
+                    if (c0 + 64 * k < Dp && c < Dp) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) X[(wave * 8 + i) * ldx + c] = (rok[i] && c < D) ? t[k][i] : 0.0f;
+                    }
                 }
             }
         }
@@ -1036,16 +1055,15 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         TMA_RELANE();
         if constexpr (PASS == 2) {
 #pragma unroll
-            for (int j = 0; j < NTW; j++) {
+            for (int kt = 0; kt < KT1A; kt++) {  // (per accumulator the same sidx order as P6 of PASS 1; the A operand is read once per k-tile)
+                const int krow = kt * 16 + r16;
+                float a[8];
 #pragma unroll
-                for (int kt = 0; kt < KT1A; kt++) {
-                    const int krow = kt * 16 + r16;
+                for (int sidx = 0; sidx < 8; sidx++) a[sidx] = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
 #pragma unroll
-                    for (int sidx = 0; sidx < 8; sidx++) {
-                        const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
-                        aW1[kt][j] = mfma16(a, zc[j][sidx >> 2][sidx & 3], aW1[kt][j]);
-                    }
-                }
+                for (int j = 0; j < NTW; j++)
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) aW1[kt][j] = mfma16(a[sidx], zc[j][sidx >> 2][sidx & 3], aW1[kt][j]);
             }
             __syncthreads();
             continue;
