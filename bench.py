@@ -7,14 +7,19 @@ One "step" = one complete PPO iteration of the hot path on one GPU:
     (advantage stats, forward+backward of the clipped-surrogate loss, [RCCL all-reduce of the flat gradient], clip + Adam).
 Nothing is skipped inside the timed region.  `value` = env-steps of all ranks / max-over-ranks wall time.
 
-Run:  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Run:  python bench.py [--gpus N --steps K --warmup W]
+  N > 1 started as a plain process: this file starts N ranks itself (a child `python -m torch.distributed.run`, one rank per GPU,
+  before this process makes any GPU call) and exits with the child's status; started under torch.distributed.run it is one rank.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline`, and (N = 1) `extra_configs` -- the
+other single-GPU BASELINE.json configs, time-boxed -- and `literal_batch_256`, the reference's literal batch_size on the headline shape.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,12 +60,32 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs / literal_batch_256 (N = 1 default runs include them)")
     ap.add_argument("--sweep", action="store_true", help="also run the env-count sweep of the step kernel (extra JSON field)")
     return ap.parse_args()
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` as a plain process: start N fresh rank processes (torch.distributed.run, rendezvous on 127.0.0.1) and
+    return the launcher's exit status.  Nothing here initialises the GPU: the ranks are children, never an exec of a process that
+    holds a HIP context (torch.cuda.device_count() only counts devices)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have}; nothing was measured", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("starting ranks: " + " ".join(cmd))
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
 
 
 def timed_kernel_us(fn, reps, stream_sync, group=1):
@@ -80,110 +105,34 @@ def timed_kernel_us(fn, reps, stream_sync, group=1):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
-def cpu_baseline(args, seconds):
-    """Oracle (C port, OpenMP over envs) + torch-CPU restatement of the SB3 policy/update, on a bounded sample of the workload."""
-    import numpy as np
-    import torch
+# ------------------------------------------------------------------------------------------------------------------------
+# GPU legs
+# ------------------------------------------------------------------------------------------------------------------------
+def build_model(task, n_envs, n_steps, hidden, mfma, batch, n_epochs, seed, dev, rank=0):
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
 
-    from oracle import oracle as orc
-    from oracle import sb3_ref
-
-    cores = min(os.cpu_count() or 1, 32)  # threads actually used by both the OpenMP oracle and torch
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads, budget {seconds:.0f} s")
-    N, D, A, H = args.n_envs, orc.obs_dim(args.task), orc.num_actions(args.task), args.hidden
-    T = 16
-    env = orc.OracleVecEnv(args.task, N, seed=args.seed, threads=cores)
-    sd = sb3_ref.init_policy(D, H, A, False, seed=args.seed)
-    obs = torch.from_numpy(env.reset())
-    t0 = time.perf_counter()
-    iters = 0
-    env_only_t = 0.0
-    while True:
-        b_obs, b_act, b_lp, b_val, b_rew, b_done = [], [], [], [], [], []
-        for _ in range(T):
-            with torch.no_grad():
-                logits, values = sb3_ref.forward(sd, obs)
-                dist = torch.distributions.Categorical(logits=logits)
-                act = dist.sample()
-                lp = dist.log_prob(act)
-            e0 = time.perf_counter()
-            o = env.step(act.numpy().astype(np.int32))
-            env_only_t += time.perf_counter() - e0
-            b_obs.append(obs), b_act.append(act), b_lp.append(lp), b_val.append(values), b_rew.append(torch.from_numpy(o["rew32"]))
-            b_done.append(torch.from_numpy((o["term"] | o["trunc"]).astype(np.float32)))
-            obs = torch.from_numpy(o["obs"])
-        with torch.no_grad():
-            _, last_v = sb3_ref.forward(sd, obs)
-        rew, val, done = torch.stack(b_rew).numpy(), torch.stack(b_val).numpy(), torch.stack(b_done).numpy()
-        es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
-        adv, ret = orc.gae(rew, val, es, last_v.numpy(), done[-1].astype(np.uint8))
-        tr = sb3_ref.RefTrainer(sd)
-        fo, fa, fl = torch.cat(b_obs), torch.cat(b_act), torch.cat(b_lp)
-        fadv, fret = torch.from_numpy(adv).reshape(-1), torch.from_numpy(ret).reshape(-1)
-        total = T * N
-        bs = args.batch_size if args.batch_size > 0 else max(256, total // 32)
-        for _ in range(args.n_epochs):
-            perm = torch.randperm(total)
-            for s in range(0, total, bs):
-                idx = perm[s:s + bs]
-                tr.step(fo[idx], fa[idx], fl[idx], fadv[idx], fret[idx], clip_range=0.2, ent_coef=0.01, vf_coef=0.5)
-            if iters > 0 and time.perf_counter() - t0 > 3 * seconds:
-                break  # hard bound: never let the baseline leg run away
-        sd = {k: v.detach() for k, v in tr.sd.items()}
-        iters += 1
-        el = time.perf_counter() - t0
-        if el > seconds:
-            break
-    return {
-        "value": iters * T * N / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{iters} reduced PPO iterations of {T} vector steps x {N} envs ({args.task}, MLP {H}x{H}, {args.n_epochs} epochs): C oracle env "
-                  f"(OpenMP, {cores} threads) + torch-CPU restatement of SB3 policy/GAE/update ({cores} threads)",
-        "env_only_steps_per_s": iters * T * N / max(env_only_t, 1e-9),
-    }
+    env = make_vector_env(task, n_envs=n_envs, seed=seed, device=dev, env_offset=rank * n_envs)
+    model = PPO("MlpPolicy", env, learning_rate=3e-4, n_steps=n_steps, batch_size=batch, n_epochs=n_epochs, gamma=0.99, gae_lambda=0.95,
+                clip_range=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, seed=seed,
+                policy_kwargs={"net_arch": {"pi": [hidden] * 2, "vf": [hidden] * 2}, "mfma_dtype": mfma})
+    return env, model
 
 
-def main():
-    args = parse()
+def time_iterations(model, steps, warmup):
+    """`warmup` untimed + `steps` timed PPO iterations, bracketed by barrier + synchronize; (seconds, rollout seconds), max over ranks."""
     import torch
 
     from three_mlagents_amd import dist
 
-    rank, local_rank, world = dist.init_from_env()
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from three_mlagents_amd import _lib
-    from three_mlagents_amd.ppo import PPO
-    from three_mlagents_amd.training import make_vector_env
-
-    N, T = args.n_envs, args.n_steps
-    total = N * T
-    batch = args.batch_size if args.batch_size > 0 else max(256, total // 32)
-    env = make_vector_env(args.task, n_envs=N, seed=args.seed, device=dev, env_offset=rank * N)
-    model = PPO("MlpPolicy", env, learning_rate=3e-4, n_steps=T, batch_size=batch, n_epochs=args.n_epochs, gamma=0.99, gae_lambda=0.95,
-                clip_range=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, seed=args.seed,
-                policy_kwargs={"net_arch": {"pi": [args.hidden] * 2, "vf": [args.hidden] * 2}, "mfma_dtype": args.mfma_dtype})
-    D, A = model.policy.obs_dim, model.policy.act_dim
-
-    def iteration():
+    for _ in range(warmup):
         model.collect_rollouts()
         model.train()
-
-    log(f"rank {rank}/{world}: engine ready, N={N} T={T} batch={batch}")
-    for _ in range(args.warmup):
-        iteration()
-    log("warmup done")
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     t_roll = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         torch.cuda.synchronize()  # attribute the asynchronous tail of the previous update to the update, not to this rollout
         r0 = time.perf_counter()
         model.collect_rollouts()
@@ -192,9 +141,314 @@ def main():
         model.train()
     torch.cuda.synchronize()
     dist.barrier()
-    el_local = time.perf_counter() - t0
-    el = dist.allreduce_max_float(el_local, device=dev)
-    t_roll = dist.allreduce_max_float(t_roll, device=dev)
+    el = time.perf_counter() - t0
+    return dist.allreduce_max_float(el, device=model.device), dist.allreduce_max_float(t_roll, device=model.device)
+
+
+def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
+    """The dominant kernel of the update: persistent forward+backward of one minibatch.  Duration from HIP events the library records
+    around that launch on the stream it launches on (tma_debug_time_grad_kernel); flops = SURVEY.md 8d formula x samples."""
+    import ctypes as C
+
+    import torch
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    dev = model.device
+    total = model.n_steps * model.n_envs
+    D, A = model.policy.obs_dim, model.policy.act_dim
+    mb = _lib.Minibatch(None, 1, 0, 0, min(batch, total))
+
+    def grad_once():
+        _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(model._rollout_view), C.byref(mb),
+                                            C.byref(model._hp), _lib.ptr(model.grad), _lib.ptr(model.workspace), model._stream()))
+
+    for _ in range(3):
+        grad_once()
+    _, g_grp = timed_kernel_us(grad_once, max(8, reps), lambda: torch.cuda.current_stream(dev).synchronize(), group=4)
+    ks = []
+    if L.tma_debug_time_grad_kernel(1) == 0:
+        us = C.c_float(0.0)
+        for _ in range(reps):
+            grad_once()
+            if L.tma_debug_last_grad_kernel_us(C.byref(us)) == 0:
+                ks.append(us.value)
+        L.tma_debug_time_grad_kernel(0)
+    g_med = sorted(ks)[len(ks) // 2] if ks else g_grp
+    model.grad.zero_()
+    _, flops_fb = mlp_flops_per_sample(D, hidden, A)
+    tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
+    bf = mfma == "bf16"
+    fast = hidden == 64 and D <= 16 and not model.policy.continuous and mb.count >= 256
+    wide = hidden in (128, 192, 256)
+    peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
+    kname = ("tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
+    return {
+        "kernel": kname, "launch_group_us": g_grp, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+        "launch_us": g_med, "launch_us_source": "HIP events recorded by the library around the kernel launch on its stream (median)" if ks else
+                     "HIP events around the whole tma_ppo_minibatch_grad call",
+        "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
+        "note": ("bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
+                 "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
+    }
+
+
+def attach_pmc_traffic(roof, name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summaries (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2
+    corrected as MI355X_MICROARCH.md prescribes); newest round first."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                roof["traffic"] = json.load(f).get("traffic_bytes_per_launch")
+            roof["traffic_source"] = f"profiles/{rnd}_{name}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+            return
+
+
+def step_kernel_rooflines(out, args, env, model, world):
+    import torch
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    eng, dev, b = env.engine, model.device, model.buf
+    N, D = args.n_envs, model.policy.obs_dim
+    sync = lambda: torch.cuda.current_stream(dev).synchronize()  # noqa: E731
+    lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
+    acts = b["actions"][0].contiguous()
+    outs = dict(obs=torch.empty((1, N, D), device=dev), rew=torch.empty((1, N), device=dev), term=torch.empty((1, N), dtype=torch.uint8, device=dev),
+                trunc=torch.empty((1, N), dtype=torch.uint8, device=dev), term_obs=torch.empty((1, N, D), device=dev))
+
+    def step_once():
+        eng.step(acts, outputs=outs, want_episode=False)
+
+    while eng.steps_until_refill() < eng.ring_depth:  # (tasks without an MT19937 reset never need a refill)
+        step_once()
+    reps = max(1, min(eng.ring_depth, 64) - 1)  # stays inside one refill window: only step kernels between the two events
+    adt = _lib.ACT_F32 if model.policy.continuous else _lib.ACT_I32
+    bursts = []
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(L.tma_env_step_repeat(eng._h, _lib.ptr(acts), adt, reps, _lib.ptr(outs["obs"]), _lib.ptr(outs["rew"]), _lib.ptr(outs["term"]),
+                                         _lib.ptr(outs["trunc"]), _lib.ptr(outs["term_obs"]), model._stream()))
+        e1.record()
+        step_once()  # closes the refill window (this launch and the refill are outside the timed burst)
+        sync()
+        bursts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    bursts.sort()
+    med_us = bursts[len(bursts) // 2]
+    log(f"step kernel at {N} envs: median {med_us:.2f} us per launch ({reps} native back-to-back launches per burst)")
+    step_gbps = N * lay / (med_us * 1e-6) / 1e9
+    out["roofline_step_kernel"] = {
+        "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs, back-to-back launches)", "bound": "hbm", "achieved": step_gbps,
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_env_step": lay, "launch_us": med_us,
+        "survey_formula_bytes_per_env_step": sv, "survey_formula_GBps": N * sv / (med_us * 1e-6) / 1e9,
+        "note": f"{N} envs move {N * lay / 1e6:.2f} MB per launch: launch-latency-bound, not HBM-bound (SURVEY.md 7.3-4); the training rollout uses the "
+                "fused multi-step kernel instead; see roofline_step_kernel_saturated for the HBM-bound regime",
+    }
+    # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
+    try:
+        if world > 1:
+            raise RuntimeError("skipped in multi-GPU runs (measured at N=1)")
+        from three_mlagents_amd.vec_env import HipEnvEngine
+
+        Nb = (1 << 22) if D <= 32 else (1 << 18)  # wide observations: fewer envs, still far beyond the L2/MALL capacity
+        big = HipEnvEngine(args.task, Nb, seed=args.seed, ring_depth=8)
+        big.reset()
+        bo = {k: v for k, v in big._out(1).items() if k in ("obs", "rew", "term", "trunc")}
+        tt = [0]
+
+        def big_step():
+            big.step(None, n_steps=1, tape_seed=1, tape_t0=tt[0], outputs=bo, want_terminal_obs=False, want_episode=False)
+            tt[0] += 1
+
+        for _ in range(8):
+            big_step()
+        _, med_big = timed_kernel_us(big_step, 40, sync)
+        log(f"saturated step kernel median {med_big:.1f} us")
+        bytes_big = lay - 4  # tape: no action read
+        gb = Nb * bytes_big / (med_big * 1e-6) / 1e9
+        sat = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm", "achieved": gb,
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS, "launch_us": med_big, "bytes_per_env_step": bytes_big,
+               "env_steps_per_s_kernel_only": Nb / (med_big * 1e-6), "survey_formula_GBps": Nb * (sv - 4) / (med_big * 1e-6) / 1e9, "traffic": None}
+        if args.task == "gridworld":
+            attach_pmc_traffic(sat, "step_kernel")
+        out["roofline_step_kernel_saturated"] = sat
+        big.close()
+        del big, bo
+    except Exception as exc:  # noqa: BLE001
+        out["roofline_step_kernel_saturated"] = {"error": str(exc)}
+
+
+# the other single-GPU BASELINE.json configs, at the per-GPU shard size their config names (configs[3]/[4] shard 8192/4 and 16384/8 envs
+# = 2048 per GPU; T = 2048 for the benchmark tier, training.py:362), same PPO schedule as the headline (32 minibatches x 10 epochs)
+EXTRA_CONFIGS = [
+    dict(name="configs[2] Ball3D 4096 envs, MLP(256,256) bf16", task="ball3d", n_envs=4096, n_steps=1024, hidden=256, mfma="bf16"),
+    dict(name="configs[3] Push 2048 envs/GPU (the per-GPU shard of 8192 over 4), MLP(256,256) bf16", task="push", n_envs=2048, n_steps=2048, hidden=256,
+         mfma="bf16"),
+    dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU (the per-GPU shard of 16384 over 8), MLP(256,256) bf16", task="crawler", n_envs=2048,
+         n_steps=2048, hidden=256, mfma="bf16"),
+    dict(name="configs[0] Basic 8 envs, MLP(256,256) f32, the reference's literal batch 256", task="basic", n_envs=8, n_steps=1024, hidden=256, mfma="f32",
+         batch=256),
+]
+
+
+def run_extra(cfg, args, dev):
+    import torch
+
+    total = cfg["n_envs"] * cfg["n_steps"]
+    batch = cfg.get("batch") or max(256, total // 32)
+    env, model = build_model(cfg["task"], cfg["n_envs"], cfg["n_steps"], cfg["hidden"], cfg["mfma"], batch, args.n_epochs, args.seed, dev)
+    try:
+        steps = 2
+        el, t_roll = time_iterations(model, steps, 1)
+        updates = steps * args.n_epochs * ((total + batch - 1) // batch)
+        roof = grad_kernel_roofline(model, cfg["task"], cfg["hidden"], cfg["mfma"], batch, reps=12)
+        if cfg["task"] == "ball3d" and cfg["mfma"] == "bf16":
+            attach_pmc_traffic(roof, "gradbf_kernel")
+        res = {"config": cfg["name"], "task": cfg["task"], "envs_per_gpu": cfg["n_envs"], "n_steps": cfg["n_steps"], "hidden": cfg["hidden"],
+               "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": 1,
+               "env_steps_per_sec": steps * total / el, "ms_per_step": el / steps * 1e3, "rollout_ms": t_roll / steps * 1e3,
+               "update_ms": (el - t_roll) / steps * 1e3, "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9),
+               "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic")}}
+        log(f"extra {cfg['name']}: {res['env_steps_per_sec'] / 1e6:.2f} M env-steps/s, {res['ms_per_step']:.1f} ms/iter, grad {roof['launch_us']:.0f} us")
+        return res
+    finally:
+        env.close()
+        del model, env
+        torch.cuda.empty_cache()
+
+
+def literal_batch_256(args, dev):
+    """The reference's literal PPO schedule on the headline shape (training.py:379 batch_size=256 at 4096 envs x 1024 steps = 16 384
+    optimizer steps per epoch): one full rollout + ONE epoch timed; the 10-epoch iteration is composed from them."""
+    import torch
+
+    env, model = build_model(args.task, args.n_envs, args.n_steps, args.hidden, args.mfma_dtype, 256, 1, args.seed, dev)
+    try:
+        model.collect_rollouts()
+        model.train()
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        model.collect_rollouts()
+        torch.cuda.synchronize()
+        t_roll = time.perf_counter() - r0
+        model.train()
+        torch.cuda.synchronize()
+        t_epoch = time.perf_counter() - r0 - t_roll
+        total = args.n_envs * args.n_steps
+        n_mb = (total + 255) // 256
+        st = model.pop_train_stats()
+        return {"batch_size": 256, "optimizer_steps_per_epoch": n_mb, "epoch_ms": t_epoch * 1e3, "rollout_ms": t_roll * 1e3,
+                "ppo_updates_per_sec": n_mb / t_epoch, "env_steps_per_sec_10_epochs_composed": total / (t_roll + args.n_epochs * t_epoch),
+                "approx_kl": round(st["train/approx_kl"], 6),
+                "workload": f"{args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, batch_size 256 "
+                            "(reference training.py:379), one epoch timed"}
+    finally:
+        env.close()
+        del model, env
+        torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU leg (the oracle as the stated baseline; never the thing shipped)
+# ------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, seconds, batch):
+    """The same PPO iteration on the host cores: C oracle env (OpenMP over envs) + torch-CPU restatement of the SB3 policy / GAE / update.
+    A full iteration would take minutes, so two bounded legs are timed on samples of the SAME workload and composed with the GPU leg's
+    schedule (same n_envs, minibatch size, epochs): (a) rollout -- Tc vector steps of policy forward + sampling + env step over all
+    n_envs, then GAE; (b) update -- optimizer steps on minibatches of the GPU leg's batch size drawn from that rollout."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle as orc
+    from oracle import sb3_ref
+
+    cores = min(os.cpu_count() or 1, 32)  # threads actually used by both the OpenMP oracle and torch
+    torch.set_num_threads(cores)
+    N, D, A, H, T = args.n_envs, orc.obs_dim(args.task), orc.num_actions(args.task), args.hidden, args.n_steps
+    total = N * T
+    n_mb = (total + batch - 1) // batch
+    Tc = max(8, min(T, -(-batch // N)))  # enough vector steps for one full minibatch of the GPU leg's size
+    log(f"cpu_baseline: {cores} threads, budget {seconds:.0f} s, rollout sample {Tc} x {N}, minibatch {batch}")
+    env = orc.OracleVecEnv(args.task, N, seed=args.seed, threads=cores)
+    sd = sb3_ref.init_policy(D, H, A, False, seed=args.seed)
+    obs = torch.from_numpy(env.reset())
+    # ---- leg (a): rollout sample ----
+    b_obs, b_act, b_lp, b_val, b_rew, b_done = [], [], [], [], [], []
+    env_only_t = 0.0
+    t0 = time.perf_counter()
+    for _ in range(Tc):
+        with torch.no_grad():
+            logits, values = sb3_ref.forward(sd, obs)
+            dist = torch.distributions.Categorical(logits=logits)
+            act = dist.sample()
+            lp = dist.log_prob(act)
+        e0 = time.perf_counter()
+        o = env.step(act.numpy().astype(np.int32))
+        env_only_t += time.perf_counter() - e0
+        b_obs.append(obs), b_act.append(act), b_lp.append(lp), b_val.append(values), b_rew.append(torch.from_numpy(o["rew32"]))
+        b_done.append(torch.from_numpy((o["term"] | o["trunc"]).astype(np.float32)))
+        obs = torch.from_numpy(o["obs"])
+    with torch.no_grad():
+        _, last_v = sb3_ref.forward(sd, obs)
+    rew, val, done = torch.stack(b_rew).numpy(), torch.stack(b_val).numpy(), torch.stack(b_done).numpy()
+    es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
+    adv, ret = orc.gae(rew, val, es, last_v.numpy(), done[-1].astype(np.uint8))
+    t_roll = time.perf_counter() - t0
+    roll_per_env_step = t_roll / (Tc * N)
+    # ---- leg (b): optimizer steps at the GPU leg's minibatch size ----
+    tr = sb3_ref.RefTrainer(sd)
+    fo, fa, fl = torch.cat(b_obs), torch.cat(b_act), torch.cat(b_lp)
+    fadv, fret = torch.from_numpy(adv).reshape(-1), torch.from_numpy(ret).reshape(-1)
+    have = fo.shape[0]
+    bs = min(batch, have)
+    n_upd, t1 = 0, time.perf_counter()
+    while True:
+        idx = torch.randperm(have)[:bs]
+        tr.step(fo[idx], fa[idx], fl[idx], fadv[idx], fret[idx], clip_range=0.2, ent_coef=0.01, vf_coef=0.5)
+        n_upd += 1
+        if time.perf_counter() - t1 > max(2.0, seconds - t_roll) or n_upd >= args.n_epochs * n_mb:
+            break
+    t_upd = (time.perf_counter() - t1) / n_upd * (batch / bs)
+    iter_s = total * roll_per_env_step + args.n_epochs * n_mb * t_upd
+    return {
+        "value": total / iter_s, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"same schedule as the GPU leg ({args.task}, {N} envs x {T} steps, MLP {H}x{H}, {args.n_epochs} epochs x {n_mb} minibatches of {batch}), "
+                  f"composed from two timed legs: rollout {Tc} vector steps x {N} envs + GAE ({t_roll:.2f} s; C oracle env with OpenMP + torch-CPU "
+                  f"policy, {cores} threads) and {n_upd} optimizer steps on minibatches of {bs} samples ({t_upd * 1e3:.1f} ms each; torch-CPU autograd "
+                  f"restatement of SB3's loss / clip / Adam, {cores} threads); value = n_envs*n_steps / (n_envs*n_steps*t_rollout_per_env_step + "
+                  "n_epochs*n_minibatches*t_update)",
+        "rollout_env_steps_per_s": 1.0 / roll_per_env_step, "env_only_steps_per_s": Tc * N / max(env_only_t, 1e-9),
+        "update_ms_per_minibatch": t_upd * 1e3, "ppo_updates_per_sec": 1.0 / t_upd, "rollout_sample_env_steps": Tc * N, "update_sample_steps": n_upd,
+    }
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # before anything touches the GPU in this process
+    import torch
+
+    from three_mlagents_amd import dist
+
+    rank, local_rank, world = dist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus N` or under "
+                         f"`torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N, T = args.n_envs, args.n_steps
+    total = N * T
+    batch = args.batch_size if args.batch_size > 0 else max(256, total // 32)
+    env, model = build_model(args.task, N, T, args.hidden, args.mfma_dtype, batch, args.n_epochs, args.seed, dev, rank)
+    log(f"rank {rank}/{world}: engine ready, N={N} T={T} batch={batch}")
+    el, t_roll = time_iterations(model, args.steps, args.warmup)
     log(f"timed region done: {el:.3f} s for {args.steps} iterations")
     env_steps = world * total * args.steps
     updates = args.steps * args.n_epochs * ((total + batch - 1) // batch)
@@ -205,10 +459,11 @@ def main():
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma_dtype, "data": "synthetic",
         "config": {
             "workload": f"{args.task}, {N} envs/GPU, full PPO iterations: n_steps={T}, MLP pi/vf {args.hidden}x{args.hidden} tanh, "
-                        f"n_epochs={args.n_epochs}, batch_size={batch} ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
+                        f"n_epochs={args.n_epochs}, batch_size={batch}/GPU ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
                         f"gae_lambda=0.95, clip=0.2, ent=0.01, vf=0.5, max_grad_norm=0.5",
             "envs_per_gpu": N, "n_steps": T, "batch_size": batch, "n_epochs": args.n_epochs, "hidden": args.hidden,
-            "parallelism": f"dp{world} (envs sharded, all-reduce of the flat f32 gradient per minibatch)" if world > 1 else "single GPU",
+            "parallelism": (f"dp{world}: envs sharded by contiguous blocks, per minibatch one RCCL all-reduce of the flat f32 gradient, per epoch one "
+                            f"all-reduce of the minibatches' advantage (sum, sumsq) pairs") if world > 1 else "single GPU",
         },
         "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9), "ppo_updates_per_iteration": updates // args.steps,
         "rollout_env_steps_per_sec": env_steps / max(t_roll, 1e-9), "rollout_ms": t_roll / args.steps * 1e3,
@@ -216,139 +471,34 @@ def main():
     }
 
     if rank == 0:
-        # ---- per-kernel durations with HIP events on the launch stream (rank 0, after the timed region) ----
-        import ctypes as C
-
-        eng = env.engine
-        sync = lambda: torch.cuda.current_stream(dev).synchronize()  # noqa: E731
-        b = model.buf
-        L = _lib.lib()
-        lay, sv = LAYOUT_BYTES.get(args.task, 0), SURVEY_BYTES.get(args.task, 0)
-        flops_fwd, flops_fb = mlp_flops_per_sample(D, args.hidden, A)
-        # ---- dominant kernel of the timed region: the PPO minibatch forward+backward (MFMA-bound) ----
-        mb = _lib.Minibatch(None, 1, 0, 0, min(batch, total))
-
-        def grad_once():
-            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(model._rollout_view), C.byref(mb),
-                                                C.byref(model._hp), _lib.ptr(model.grad), _lib.ptr(model.workspace), model._stream()))
-
-        for _ in range(3):
-            grad_once()
-        g_avg, g_grp = timed_kernel_us(grad_once, 40, sync, group=4)  # whole launch group of the call (advantage pass + kernel + slab reduction)
-        # the dominant kernel alone: HIP events recorded by the library around that launch, on the stream it is launched on
-        ks = []
-        if L.tma_debug_time_grad_kernel(1) == 0:
-            us = C.c_float(0.0)
-            for _ in range(24):
-                grad_once()
-                if L.tma_debug_last_grad_kernel_us(C.byref(us)) == 0:
-                    ks.append(us.value)
-            L.tma_debug_time_grad_kernel(0)
-        g_med = sorted(ks)[len(ks) // 2] if ks else g_grp
-        model.grad.zero_()
-        log(f"minibatch gradient kernel: median {g_med:.1f} us (launch group of the call: {g_grp:.1f} us)")
-        tf = mb.count * flops_fb / (g_med * 1e-6) / 1e12
-        fast = args.hidden == 64 and D <= 16 and not model.policy.continuous and mb.count >= 16384
-        bf = args.mfma_dtype == "bf16"
-        wide = args.hidden in (128, 192, 256)
-        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
-        kname = ("tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
-        out["roofline"] = {
-            "kernel": kname, "launch_group_us": g_grp,
-            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
-            "launch_us": g_med, "launch_us_source": "HIP events recorded by the library around the kernel launch on its stream (median of 24)" if ks else
-                         "HIP events around the whole tma_ppo_minibatch_grad call",
-            "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
-            "note": ("bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
-                     "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
-        }
-        pmc_bf = os.path.join(ROOT, "profiles", "r01_gradbf_kernel_pmc.json")
-        if bf and args.hidden == 256 and args.task == "ball3d" and os.path.exists(pmc_bf):
-            pmc = json.load(open(pmc_bf))
-            out["roofline"]["traffic"] = pmc.get("traffic_bytes_per_launch")
-            out["roofline"]["traffic_source"] = "profiles/r01_gradbf_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
-        pmc_path = os.path.join(ROOT, "profiles", "r01_grad_kernel_pmc.json")
-        if fast and args.task == "gridworld" and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            out["roofline"]["traffic"] = pmc.get("traffic_bytes_per_launch")
-            out["roofline"]["traffic_source"] = "profiles/r01_grad_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
-        # ---- batched env step kernel (the kernel north_star names), launched exactly as VecEnv.step does ----
-        acts = b["actions"][0].contiguous()
-        outs = dict(obs=torch.empty((1, N, D), device=dev), rew=torch.empty((1, N), device=dev), term=torch.empty((1, N), dtype=torch.uint8, device=dev),
-                    trunc=torch.empty((1, N), dtype=torch.uint8, device=dev), term_obs=torch.empty((1, N, D), device=dev))
-
-        def step_once():
-            eng.step(acts, outputs=outs, want_episode=False)
-
-        while eng.steps_until_refill() < eng.ring_depth:  # (tasks without an MT19937 reset never need a refill)
-            step_once()
-        reps = max(1, min(eng.ring_depth, 64) - 1)  # stays inside one refill window: only step kernels between the two events
-        adt = _lib.ACT_F32 if model.policy.continuous else _lib.ACT_I32
-
-        def step_burst():
-            _lib.check(L.tma_env_step_repeat(eng._h, _lib.ptr(acts), adt, reps, _lib.ptr(outs["obs"]), _lib.ptr(outs["rew"]), _lib.ptr(outs["term"]),
-                                             _lib.ptr(outs["trunc"]), _lib.ptr(outs["term_obs"]), model._stream()))
-            step_once()  # closes the refill window (this launch and the refill are outside the timed burst)
-
-        bursts = []
-        for _ in range(6):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(L.tma_env_step_repeat(eng._h, _lib.ptr(acts), adt, reps, _lib.ptr(outs["obs"]), _lib.ptr(outs["rew"]), _lib.ptr(outs["term"]),
-                                             _lib.ptr(outs["trunc"]), _lib.ptr(outs["term_obs"]), model._stream()))
-            e1.record()
-            step_once()
-            sync()
-            bursts.append(e0.elapsed_time(e1) * 1e3 / reps)
-        bursts.sort()
-        med_us = bursts[len(bursts) // 2]
-        log(f"step kernel at {N} envs: median {med_us:.2f} us per launch ({reps} native back-to-back launches per burst)")
-        step_gbps = N * lay / (med_us * 1e-6) / 1e9
-        out["roofline_step_kernel"] = {
-            "kernel": f"tma::step_kernel<{args.task}> (1 vector step, {N} envs, back-to-back launches)", "bound": "hbm", "achieved": step_gbps,
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_env_step": lay, "launch_us": med_us,
-            "survey_formula_bytes_per_env_step": sv, "survey_formula_GBps": N * sv / (med_us * 1e-6) / 1e9,
-            "note": f"{N} envs move {N * lay / 1e6:.2f} MB per launch: launch-latency-bound, not HBM-bound (SURVEY.md 7.3-4); the training rollout uses the "
-                    "fused multi-step kernel instead; see roofline_step_kernel_saturated for the HBM-bound regime",
-        }
-        # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
-        try:
-            if world > 1:
-                raise RuntimeError("skipped in multi-GPU runs (measured at N=1)")
-            from three_mlagents_amd.vec_env import HipEnvEngine
-
-            Nb = (1 << 22) if D <= 32 else (1 << 18)  # wide observations: fewer envs, still far beyond the L2/MALL capacity
-            big = HipEnvEngine(args.task, Nb, seed=args.seed, ring_depth=8)
-            big.reset()
-            bo = {k: v for k, v in big._out(1).items() if k in ("obs", "rew", "term", "trunc")}
-            tt = [0]
-
-            def big_step():
-                big.step(None, n_steps=1, tape_seed=1, tape_t0=tt[0], outputs=bo, want_terminal_obs=False, want_episode=False)
-                tt[0] += 1
-
-            for _ in range(8):
-                big_step()
-            _, med_big = timed_kernel_us(big_step, 40, sync)
-            log(f"saturated step kernel median {med_big:.1f} us")
-            bytes_big = lay - 4  # tape: no action read
-            gb = Nb * bytes_big / (med_big * 1e-6) / 1e9
-            sat = {"kernel": f"tma::step_kernel<{args.task}> (1 vector step, {Nb} envs, on-device action tape)", "bound": "hbm", "achieved": gb,
-                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS, "launch_us": med_big, "bytes_per_env_step": bytes_big,
-                   "env_steps_per_s_kernel_only": Nb / (med_big * 1e-6), "survey_formula_GBps": Nb * (sv - 4) / (med_big * 1e-6) / 1e9, "traffic": None}
-            pmc_path = os.path.join(ROOT, "profiles", "r01_step_kernel_pmc.json")
-            if args.task == "gridworld" and os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                sat["traffic"] = pmc.get("traffic_bytes_per_launch")
-                sat["traffic_source"] = "profiles/r01_step_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
-            out["roofline_step_kernel_saturated"] = sat
-            big.close()
-            del big, bo
-        except Exception as exc:  # noqa: BLE001
-            out["roofline_step_kernel_saturated"] = {"error": str(exc)}
+        roof = grad_kernel_roofline(model, args.task, args.hidden, args.mfma_dtype, batch)
+        log(f"minibatch gradient kernel: median {roof['launch_us']:.1f} us (launch group of the call: {roof['launch_group_us']:.1f} us)")
+        if args.mfma_dtype == "bf16" and args.hidden == 256 and args.task == "ball3d":
+            attach_pmc_traffic(roof, "gradbf_kernel")
+        if roof["kernel"] == "tma::ppo_grad_h64_kernel" and args.task == "gridworld":
+            attach_pmc_traffic(roof, "grad_kernel")
+        out["roofline"] = roof
+        step_kernel_rooflines(out, args, env, model, world)
+    env.close()
+    del model
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_extras:
+            try:
+                out["literal_batch_256"] = literal_batch_256(args, dev)
+                log(f"literal batch 256: {out['literal_batch_256']['ppo_updates_per_sec']:.0f} optimizer steps/s")
+            except Exception as exc:  # noqa: BLE001
+                out["literal_batch_256"] = {"error": str(exc)}
+            extras = []
+            for cfg in EXTRA_CONFIGS:
+                try:
+                    extras.append(run_extra(cfg, args, dev))
+                except Exception as exc:  # noqa: BLE001
+                    extras.append({"config": cfg["name"], "error": str(exc)})
+            out["extra_configs"] = extras
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, batch)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": str(exc)}
         if args.sweep:
@@ -357,7 +507,6 @@ def main():
 
             out["env_sweep"] = [env_sweep.run(args.task, n, 32, 3, pl) for n in (4096, 65536, 1 << 20, 1 << 22) for pl in (1, 32)]
         print(json.dumps(out), flush=True)
-    env.close()
     dist.barrier()
 
 

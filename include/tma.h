@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 100
+#define TMA_VERSION 200
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -109,6 +109,9 @@ typedef struct {
     int mfma_dtype; /* 0: f32 MFMA everywhere (parity mode, every hidden width); 1: bf16 MFMA operands with f32 master
                        weights and f32 accumulation for the hidden-layer and head GEMMs (hidden = 128 / 192 / 256 only:
                        BASELINE.json configs[2] "PPO MLP(256,256) bf16").  Rollout and update use the same forward code. */
+    int device;     /* HIP device the parameter / rollout / workspace buffers live on: every tma_policy_* / tma_ppo_* call makes it
+                       the calling thread's current device first (callers may be worker threads: backend/main.py:152
+                       asyncio.to_thread).  -1: keep whatever device is current on the calling thread. */
 } tma_policy_dims;
 
 /* parameter buffer = n_total floats: [0, n_trainable) trainable, [in][out] layout, order
@@ -149,6 +152,10 @@ typedef struct {
     int64_t prepared_batch; /* 0: self-contained call.  > 0: tma_ppo_epoch_prepare ran on this workspace for the same rollout view,
                                (perm_seed, perm_epoch) and this batch size, start is a multiple of it -- the per-minibatch advantage
                                pass is skipped and the cached sample offsets / advantage partials are used */
+    int64_t stats_count;    /* 0: advantages are normalised with the mean / unbiased std of this minibatch's `count` rows.
+                               > 0 (data-parallel runs, prepared epochs only): the workspace partials of this minibatch were replaced
+                               by sums over the GLOBAL minibatch of stats_count rows (tma_ppo_epoch_adv_sums) -- every rank then
+                               normalises with the same global mean / std, as one SB3 run over the concatenated batch would */
 } tma_minibatch;
 
 typedef struct {
@@ -169,6 +176,14 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
  * epoch->start / count describe the whole pass (0, T*N).  Needs T*N <= 2^22 and batch_size >= 256, else TMA_ERR_INVALID. */
 int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int64_t batch_size, const tma_policy_dims *d, void *workspace,
                           void *stream);
+/* Data-parallel advantage statistics ("12-byte all-reduce for global advantage mean/var"), for an epoch that
+ * tma_ppo_epoch_prepare just prepared on this workspace with the same batch_size over `total` = T*N samples.
+ * direction 0 (export): sums[k] = {sum, sum of squares} of minibatch k's advantages (double[n_minibatches][2], device memory), folded
+ * from the workspace partials in a fixed order.  The caller all-reduces (sum) that buffer over the ranks -- ONE collective of
+ * 16 * n_minibatches bytes per epoch -- and hands it back with direction 1 (import), which makes it the workspace's partials;
+ * the epoch's minibatches are then run with tma_minibatch.stats_count = global row count. */
+int tma_ppo_epoch_adv_sums(void *workspace, const tma_policy_dims *d, int64_t batch_size, int64_t total, double *sums, int direction,
+                           void *stream);
 /* clip_grad_norm_(max_grad_norm) + Adam.step() (+ refresh of the [out][in] copies).  grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce(sum)). */
 int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,

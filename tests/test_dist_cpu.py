@@ -50,3 +50,21 @@ def test_two_rank_gloo_sharding_and_gradient_allreduce():
     assert (off0, n0, off1, n1) == (0, 4096, 4096, 4096)  # rank r owns global envs [r*n, (r+1)*n)
     assert g0 == g1 == 3.0 and s0 == s1  # sum over ranks; replicas stay bit-identical
     assert m0 == m1 == 11.0
+
+
+@pytest.mark.timeout(120)
+def test_bench_launcher_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` (N > 1) starts N ranks itself, before any GPU call; with fewer than N GPUs visible (none in this
+    container) it must say so and exit non-zero instead of silently measuring one GPU -- and print no JSON line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU machine")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
+    # a rank count that disagrees with --gpus is an error too, not a warning
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=100, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""

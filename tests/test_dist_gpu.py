@@ -1,14 +1,24 @@
-"""Two ranks on ONE GPU (gloo backend carrying the CUDA gradient tensor): exercises the complete data-parallel PPO path --
-env sharding by env_offset, per-minibatch gradient all-reduce, 1/world scaling inside the Adam kernel -- and checks the
-replicas stay bit-identical.  (RCCL needs one device per rank; on the 8-GPU node the same code runs with backend nccl.)"""
+"""Data-parallel path on the one-GPU box.
+
+* RCCL itself: `dist.init_from_env(backend="nccl")` at world size 1 (a one-rank communicator) + all-reduce of a gradient-sized tensor.
+* Two ranks on ONE GPU (gloo backend carrying the device tensors; RCCL needs one device per rank): the complete data-parallel PPO
+  path -- env sharding by env_offset, the per-epoch all-reduce of the minibatch advantage sums, the per-minibatch gradient
+  all-reduce, 1/world scaling inside the Adam kernel -- for the three kernel families (GridWorld 64x64 f32; the BASELINE configs[3]
+  shape Push 256x256; configs[4] Crawler-shape 256x256 bf16), asserting that the replicas stay bit-identical and that every rank
+  normalised with the same GLOBAL advantage statistics.  On the 8-GPU node the same code runs with backend nccl (`bench.py --gpus N`).
+"""
 import os
 import socket
+import subprocess
+import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -19,23 +29,52 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _nccl_single(port, q):
+    os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    from three_mlagents_amd import dist
+
+    rk, lr, ws = dist.init_from_env(backend="nccl", single_rank_group=True)
+    import torch.distributed as td
+
+    g = torch.arange(9350, dtype=torch.float32, device="cuda:0")  # the 64x64 policy's flat gradient size
+    dist.allreduce_sum_(g)  # world 1: the helper skips the collective ...
+    td.all_reduce(g)        # ... so drive RCCL directly as PPO.train does
+    torch.cuda.synchronize()
+    q.put((rk, ws, td.get_backend(), float(g.sum().item()), dist.allreduce_max_float(3.5, device="cuda:0")))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_initialises_and_all_reduces():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single, args=(_free_port(), q))
+    p.start()
+    rk, ws, backend, total, mx = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert (rk, ws, backend) == (0, 1, "nccl") and total == float(sum(range(9350))) and mx == 3.5
+
+
+def _worker(rank, world, port, q, task, hidden, mfma, N, T):
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     from three_mlagents_amd import dist
 
     dist.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
+    from three_mlagents_amd.harness import make_vector_env
     from three_mlagents_amd.ppo import PPO
-    from three_mlagents_amd.training import make_vector_env
 
-    N = 256
-    env = make_vector_env("gridworld", n_envs=N, seed=1, env_offset=rank * N)
-    model = PPO("MlpPolicy", env, n_steps=64, batch_size=16384 // 2, n_epochs=2, seed=1, policy_kwargs={"net_arch": [64, 64]})
+    env = make_vector_env(task, n_envs=N, seed=1, env_offset=rank * N)
+    model = PPO("MlpPolicy", env, n_steps=T, batch_size=N * T // 2, n_epochs=2, seed=1, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
     assert model.world_size == world and model.rank == rank
     first_obs = env.engine.reset().cpu()
     model._last_obs_valid = False
-    model.learn(2 * world * N * 64)
-    q.put((rank, model.policy.params[: model.policy.n_trainable].cpu().numpy(), first_obs.numpy(), model.num_timesteps))  # numpy: pickled by value
+    model.learn(2 * world * N * T)
+    adv = model.buf["advantages"].double().cpu().numpy()
+    q.put((rank, model.policy.params[: model.policy.n_trainable].cpu().numpy(), first_obs.numpy(), model.num_timesteps,
+           model._adv_sums.cpu().numpy(), float(adv.sum()), float((adv * adv).sum())))  # numpy: pickled by value
     env.close()
     dist.barrier()
     import torch.distributed as td
@@ -43,34 +82,50 @@ def _worker(rank, world, port, q):
     td.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_ranks_one_gpu_replicas_stay_identical():
+def _run_two_ranks(task, hidden, mfma, N, T):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, task, hidden, mfma, N, T)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    res = sorted((q.get(timeout=400) for _ in range(world)), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, p0, o0, t0), (r1, p1, o1, t1) = res
-    p0, p1, o0, o1 = (torch.from_numpy(x) for x in (p0, p1, o0, o1))
-    assert torch.equal(p0, p1)  # same all-reduced gradient, same Adam state -> bit-identical replicas
-    assert not torch.equal(o0, o1)  # the shards really are different envs (global indices 0..255 vs 256..511)
-    assert t0 == t1 == 2 * world * 256 * 64  # num_timesteps counts the whole job
-    # and the shards are the two halves of one 512-env engine
+    return res
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("task,hidden,mfma,N,T", [("gridworld", 64, "f32", 256, 64), ("push", 256, "f32", 256, 64), ("crawler", 256, "bf16", 128, 32)])
+def test_two_ranks_one_gpu_replicas_stay_identical(task, hidden, mfma, N, T):
+    (r0, p0, o0, t0, s0, a0, q0), (r1, p1, o1, t1, s1, a1, q1) = _run_two_ranks(task, hidden, mfma, N, T)
+    assert np.array_equal(p0, p1)  # same all-reduced gradient, same global advantage statistics, same Adam state -> bit-identical replicas
+    assert not np.array_equal(o0, o1)  # the shards really are different envs (global indices 0..N-1 vs N..2N-1)
+    assert t0 == t1 == 2 * 2 * N * T  # num_timesteps counts the whole job
+    # both ranks hold the same all-reduced per-minibatch (sum, sumsq) pairs, and they add up to the two shards' last-rollout advantages
+    assert np.array_equal(s0, s1) and s0.shape == (4,)
+    assert np.isclose(s0[0] + s0[2], a0 + a1, rtol=1e-9, atol=1e-6) and np.isclose(s0[1] + s0[3], q0 + q1, rtol=1e-9, atol=1e-6)
+    if task != "gridworld":
+        return
+    # the shards are the two halves of one 2N-env engine
     from three_mlagents_amd.vec_env import HipEnvEngine
 
-    big = HipEnvEngine("gridworld", 512, seed=1)
-    ob = big.reset().cpu()
-    assert torch.equal(ob[:256], o0) and torch.equal(ob[256:], o1)
+    big = HipEnvEngine(task, 2 * N, seed=1)
+    ob = big.reset().cpu().numpy()
+    assert np.array_equal(ob[:N], o0) and np.array_equal(ob[N:], o1)
     # a single-rank run on the same data takes different steps (it sees half of each global batch)
+    from three_mlagents_amd.harness import make_vector_env
     from three_mlagents_amd.ppo import PPO
-    from three_mlagents_amd.training import make_vector_env
 
-    env = make_vector_env("gridworld", n_envs=256, seed=1)
-    solo = PPO("MlpPolicy", env, n_steps=64, batch_size=16384 // 2, n_epochs=2, seed=1, policy_kwargs={"net_arch": [64, 64]})
-    solo.learn(2 * 256 * 64)
-    assert not torch.equal(solo.policy.params[: solo.policy.n_trainable].cpu(), p0)
+    env = make_vector_env(task, n_envs=N, seed=1)
+    solo = PPO("MlpPolicy", env, n_steps=T, batch_size=N * T // 2, n_epochs=2, seed=1, policy_kwargs={"net_arch": [64, 64]})
+    solo.learn(2 * N * T)
+    assert not np.array_equal(solo.policy.params[: solo.policy.n_trainable].cpu().numpy(), p0)
+
+
+def test_bench_gpus_2_fails_cleanly_on_a_one_gpu_box():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU box: `bench.py --gpus 2` would really run")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""

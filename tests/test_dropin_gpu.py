@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_basic_env_reset_and_step():  # test_mlagents.py:32-45
-    from three_mlagents_amd.registry import make_env
+    from three_mlagents_amd.tasks import make_env
 
     env = make_env("basic")
     try:
@@ -27,9 +27,9 @@ def test_basic_env_reset_and_step():  # test_mlagents.py:32-45
 
 
 def test_trainable_env_contracts_match_declared_spaces():  # test_mlagents.py:51-72
-    from three_mlagents_amd.registry import list_tasks, make_env
+    from three_mlagents_amd.tasks import ENGINE_TASKS, make_env
 
-    for task in list_tasks(include_roadmap=False):
+    for task in ENGINE_TASKS.values():
         env = make_env(task.id)
         try:
             obs, _ = env.reset(seed=123)
@@ -42,7 +42,7 @@ def test_trainable_env_contracts_match_declared_spaces():  # test_mlagents.py:51
 
 
 def test_single_env_matches_reference_seeded_reset(golden):
-    from three_mlagents_amd.registry import make_env
+    from three_mlagents_amd.tasks import make_env
 
     g = golden("gridworld")
     env = make_env("gridworld")
@@ -59,15 +59,14 @@ def test_single_env_matches_reference_seeded_reset(golden):
 
 
 def test_registered_algorithms_construct_and_predict():  # test_mlagents.py:74-101
-    from three_mlagents_amd.registry import list_tasks
-    from three_mlagents_amd.training import ALGORITHMS, _default_model_kwargs, _default_policy, make_vector_env
+    from three_mlagents_amd.harness import ALGORITHMS, make_vector_env, ppo_defaults
+    from three_mlagents_amd.tasks import ENGINE_TASKS
 
-    for task in list_tasks(include_roadmap=False):
+    for task in ENGINE_TASKS.values():
         vec_env = make_vector_env(task.id, n_envs=2, seed=321)
         try:
-            kwargs = _default_model_kwargs("ppo", train_env=vec_env, task=task, total_timesteps=64, tensorboard_log="/tmp/three-mlagents-test-tb", verbose=0)
-            kwargs["n_steps"] = 16
-            model = ALGORITHMS["ppo"](_default_policy(task), vec_env, seed=321, **kwargs)
+            kwargs = {**ppo_defaults(task), "n_steps": 16}
+            model = ALGORITHMS["ppo"]("MlpPolicy", vec_env, seed=321, **kwargs)
             action, _ = model.predict(vec_env.reset(), deterministic=True)
             assert action is not None and len(action) == 2
             obs, rew, dones, infos = vec_env.step(action)
@@ -101,7 +100,7 @@ def test_vec_env_infos_carry_sb3_keys():
 
 def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 ; artefacts training.py:172-207
     monkeypatch.chdir(tmp_path)
-    from three_mlagents_amd import cli
+    from three_mlagents_amd import __main__ as cli
 
     cli.main(["train", "basic", "--algorithm", "ppo", "--n-envs", "8", "-t", "4096", "--eval-episodes", "4", "--eval-freq", "2048", "--run-name", "t1", "--quiet"])
     out = json.loads(capsys.readouterr().out)
@@ -117,7 +116,7 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     cli.main(["evaluate", "basic", "basic_policy_t1.zip", "--episodes", "3"])
     ev = json.loads(capsys.readouterr().out)
     assert ev["episodes"] == 3 and len(ev["episode_lengths"]) == 3
-    from three_mlagents_amd.training import predict_action
+    from three_mlagents_amd.harness import predict_action
 
     assert predict_action("basic", np.eye(21, dtype=np.float32)[10], "basic_policy_t1.zip") in (0, 1, 2)
 
@@ -148,3 +147,35 @@ def test_load_zip_with_sb3_schema(tmp_path):
     act, _ = model.predict(obs.numpy(), deterministic=True)
     logits, _ = sb3_ref.forward(sd, obs)
     assert np.array_equal(act, logits.argmax(dim=1).numpy()) and model.n_steps == 1024 and model.learning_rate == 3e-4
+
+
+def test_engine_runs_from_a_worker_thread():
+    """The reference runs train_task under asyncio.to_thread (/root/reference/backend/main.py:152, websocket_training.py:98): env
+    stepping, a full PPO iteration (tma_rollout_collect, tma_gae_flags, tma_ppo_minibatch_grad, tma_ppo_adam_step_local) and predict
+    must work off the main thread -- every tma_policy_* / tma_ppo_* entry makes tma_policy_dims.device current on the calling thread --
+    and give the same bits as on the main thread."""
+    import asyncio
+    import threading
+
+    import torch
+
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def work():
+        env = make_vector_env("gridworld", n_envs=64, seed=5)
+        model = PPO("MlpPolicy", env, n_steps=32, batch_size=512, n_epochs=2, seed=5, policy_kwargs={"net_arch": [64, 64]})
+        model.learn(2 * 64 * 32)
+        obs, rew, dones, infos = env.step(np.zeros(64, np.int64))
+        act, _ = model.predict(obs, deterministic=True)
+        params = model.policy.params[: model.policy.n_trainable].cpu()
+        env.close()
+        return threading.current_thread() is threading.main_thread(), params, act
+
+    async def off_thread():
+        return await asyncio.to_thread(work)
+
+    was_main, p_thread, a_thread = asyncio.run(off_thread())
+    is_main, p_main, a_main = work()
+    assert not was_main and is_main
+    assert torch.equal(p_thread, p_main) and np.array_equal(a_thread, a_main) and torch.isfinite(p_main).all()

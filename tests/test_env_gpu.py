@@ -54,8 +54,10 @@ def test_golden_rollouts_from_reference(golden, task):
     inexact = _run_golden(task, g, "", ring_depth=8)
     inexact += _run_golden(task, g, "b_", ring_depth=2)
     print(f"[{task}] elements not bit-identical to the reference: {inexact}")
-    if task != "ball3d":
-        assert inexact == 0
+    # Ball3D: the GPU's sin(double) may differ from the generating host's libm in the last ulp, which the 1e-5 bound inside _cmp
+    # absorbs; observed so far: 0 elements.  Bounded so that a regression to "thousands of 1-ulp differences" cannot pass silently
+    # (the fixtures hold ~2e5 compared elements: 0.1 % of them).
+    assert inexact == 0 if task != "ball3d" else inexact <= 200, inexact
 
 
 @pytest.mark.parametrize("task", TASKS)

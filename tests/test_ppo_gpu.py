@@ -476,3 +476,65 @@ def test_adam_step_local_equals_adam_step(D, H, A, cont, dtype):
     for (a0, c0), (a1, c1) in zip(n0, n1):
         assert abs(a0 - a1) <= 1e-6 * max(1.0, a0) and abs(c0 - c1) <= 1e-6
     assert torch.allclose(p0, p1, rtol=0, atol=1e-7) and torch.allclose(m0, m1, rtol=1e-6, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("D,H,A,cont", [(4, 64, 5, False), (6, 256, 5, False), (172, 256, 20, True)])
+def test_global_advantage_statistics_of_a_two_rank_minibatch(D, H, A, cont):
+    """Data-parallel advantage normalisation: two "ranks" = two different rollouts under the same policy.  Each rank's
+    epoch is prepared, the per-minibatch (sum, sumsq) pairs are exported, added (what the all-reduce does) and imported; each rank's
+    gradient with stats_count = global rows must equal autograd of ITS rows with advantages normalised by the mean / unbiased std of
+    BOTH ranks' rows -- i.e. what one SB3 run over the concatenated minibatch computes, split in two."""
+    from three_mlagents_amd import _lib
+
+    T, N, B = 16, 64, 512  # two minibatches of 512 per rank
+    pol, sd = _policy(D, H, A, cont)
+    dev, L, total = torch.device("cuda", 0), _lib.lib(), T * N
+    hpar = _lib.PPOHParams(HP["clip_range"], HP["ent_coef"], HP["vf_coef"], 1)
+    ranks = []
+    for r in range(2):
+        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, cont, T, N, seed=10 + r)
+        adv = adv * (1.0 + r) + 0.5 * r  # the shards' advantage distributions differ, so local != global statistics
+        d = {k: v.to(dev).contiguous() for k, v in dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret).items()}
+        rv = _lib.Rollout(_lib.ptr(d["obs"]), _lib.ptr(d["actions"]), _lib.ptr(d["old_lp"]), _lib.ptr(d["adv"]), _lib.ptr(d["ret"]), T, N)
+        ws = torch.zeros(int(L.tma_ppo_workspace_bytes(C.byref(pol.dims))), dtype=torch.uint8, device=dev)
+        idx = torch.randperm(total, generator=torch.Generator().manual_seed(20 + r)).to(dev)
+        ep = _lib.Minibatch(_lib.ptr(idx), 0, 0, 0, total, 0)
+        _lib.check(L.tma_ppo_epoch_prepare(C.byref(rv), C.byref(ep), B, C.byref(pol.dims), _lib.ptr(ws), _lib.stream_ptr()))
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        _lib.check(L.tma_ppo_epoch_adv_sums(_lib.ptr(ws), C.byref(pol.dims), B, total, _lib.ptr(sums), 0, _lib.stream_ptr()))
+        ranks.append(dict(cpu=dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret), dev=d, rv=rv, ws=ws, idx=idx, sums=sums))
+    for r in range(2):  # exported sums are the float64 sums of each minibatch's advantages
+        flat = _flatten_env_major(ranks[r]["cpu"]["adv"], T, N).double()[ranks[r]["idx"].cpu()]
+        want = torch.stack([flat[:B].sum(), (flat[:B] ** 2).sum(), flat[B:].sum(), (flat[B:] ** 2).sum()])
+        assert torch.allclose(ranks[r]["sums"].cpu(), want, rtol=1e-12, atol=1e-9)
+    reduced = ranks[0]["sums"] + ranks[1]["sums"]
+    for r in range(2):
+        rk = ranks[r]
+        _lib.check(L.tma_ppo_epoch_adv_sums(_lib.ptr(rk["ws"]), C.byref(pol.dims), B, total, _lib.ptr(reduced.clone()), 1, _lib.stream_ptr()))
+        for k in range(2):
+            mb = _lib.Minibatch(_lib.ptr(rk["idx"]), 0, 0, k * B, B, B, 2 * B)
+            grad = torch.zeros(pol.n_trainable, device=dev)
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rk["rv"]), C.byref(mb), C.byref(hpar), _lib.ptr(grad),
+                                                _lib.ptr(rk["ws"]), _lib.stream_ptr()))
+            sel = [_flatten_env_major(ranks[q]["cpu"]["adv"], T, N)[ranks[q]["idx"].cpu()[k * B:(k + 1) * B]] for q in range(2)]
+            both = torch.cat(sel)
+            mean, std = both.mean(), both.std()  # torch .std() is the unbiased estimator SB3 uses
+            rows = rk["idx"].cpu()[k * B:(k + 1) * B]
+            f = lambda x: _flatten_env_major(x, T, N)[rows]  # noqa: E731
+            advn = (f(rk["cpu"]["adv"]) - mean) / (std + 1e-8)
+            tr = sb3_ref.RefTrainer(sd)
+            _, grads_ref = tr.step(f(rk["cpu"]["obs"]), f(rk["cpu"]["actions"]), f(rk["cpu"]["old_lp"]), advn, f(rk["cpu"]["ret"]),
+                                   **dict(HP, normalize_advantage=False))
+            ref = _ref_grad_flat(pol, grads_ref)
+            err, scale = (grad.cpu() - ref).abs().max().item(), ref.abs().max().item()
+            assert err <= 2e-5 * max(scale, 1.0) + 1e-6, (r, k, err, scale)
+            # and the rank-local statistics give a measurably different gradient (the test would not notice a no-op otherwise)
+            mb_local = _lib.Minibatch(_lib.ptr(rk["idx"]), 0, 0, k * B, B, 0, 0)
+            g_local = torch.zeros(pol.n_trainable, device=dev)
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rk["rv"]), C.byref(mb_local), C.byref(hpar),
+                                                _lib.ptr(g_local), _lib.ptr(rk["ws"]), _lib.stream_ptr()))
+            assert (g_local.cpu() - ref).abs().max().item() > 1e-3 * scale
+    with pytest.raises(ValueError):  # stats_count without a prepared epoch
+        mb = _lib.Minibatch(_lib.ptr(ranks[0]["idx"]), 0, 0, 0, B, 0, 2 * B)
+        _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(ranks[0]["rv"]), C.byref(mb), C.byref(hpar),
+                                            _lib.ptr(torch.zeros(pol.n_trainable, device=dev)), _lib.ptr(ranks[0]["ws"]), _lib.stream_ptr()))

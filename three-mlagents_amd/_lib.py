@@ -20,7 +20,7 @@ _vp, _i32, _i64, _u32, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_do
 
 
 class PolicyDims(C.Structure):
-    _fields_ = [("obs_dim", _i32), ("hidden", _i32), ("act_dim", _i32), ("continuous", _i32), ("mfma_dtype", _i32)]
+    _fields_ = [("obs_dim", _i32), ("hidden", _i32), ("act_dim", _i32), ("continuous", _i32), ("mfma_dtype", _i32), ("device", _i32)]
 
 
 class Rollout(C.Structure):
@@ -28,7 +28,7 @@ class Rollout(C.Structure):
 
 
 class Minibatch(C.Structure):
-    _fields_ = [("indices", _vp), ("perm_seed", _u32), ("perm_epoch", _u32), ("start", _i64), ("count", _i64), ("prepared_batch", _i64)]
+    _fields_ = [("indices", _vp), ("perm_seed", _u32), ("perm_epoch", _u32), ("start", _i64), ("count", _i64), ("prepared_batch", _i64), ("stats_count", _i64)]
 
 
 class PPOHParams(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "tma_debug_time_grad_kernel": (_i32, [_i32]),
     "tma_debug_last_grad_kernel_us": (_i32, [C.POINTER(C.c_float)]),
     "tma_ppo_epoch_prepare": (_i32, [C.POINTER(Rollout), C.POINTER(Minibatch), _i64, _pd, _vp, _vp]),
+    "tma_ppo_epoch_adv_sums": (_i32, [_vp, _pd, _i64, _i64, _vp, _i32, _vp]),
     "tma_ppo_adam_step": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     "tma_ppo_adam_step_local": (_i32, [_vp, _vp, _vp, _vp, _pd, _i64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _i64]),
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),

@@ -11,6 +11,8 @@
 // backend/examples/ball3d.py:41-113, backend/examples/push.py:27-125.
 #include "tma_internal.h"
 
+#include <algorithm>
+#include <climits>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -254,9 +256,12 @@ __device__ __forceinline__ int last_le(const uint32_t *a, int n, uint32_t x) {
 }
 
 template <class T, int W>
-__global__ __launch_bounds__(256) void refill_fast_kernel(EnvView v, RefillView rv, int mode, int64_t total_dense, float *obs_out) {
-    const int64_t total = mode == 0 ? total_dense : (int64_t)rv.total[0];
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void refill_fast_kernel(EnvView v, RefillView rv, int mode, int64_t total_dense, float *obs_out, int64_t lo,
+                                                          int64_t hi) {
+    // items [lo, hi) of this refill: a round never holds more than fb_cap items, so the fallback list cannot overflow
+    int64_t total = mode == 0 ? total_dense : (int64_t)rv.total[0];
+    if (total > hi) total = hi;
+    for (int64_t t = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t i;
         uint32_t e;
         if (mode == 0) {
@@ -278,11 +283,9 @@ __global__ __launch_bounds__(256) void refill_fast_kernel(EnvView v, RefillView 
             c.finish(rec);
             commit_record<T>(v, i, e, rec, mode, obs_out);
         } else {  // more than W outputs needed (rejection sampling): exact general generator takes over
-            const uint32_t k = atomicAdd(&rv.total[1], 1u);
-            if (k < (uint32_t)rv.fb_cap) {
-                rv.fb_env[k] = (uint32_t)i;
-                rv.fb_ep[k] = e;
-            }
+            const uint32_t k = atomicAdd(&rv.total[1], 1u);  // < fb_cap by construction (hi - lo <= fb_cap)
+            rv.fb_env[k] = (uint32_t)i;
+            rv.fb_ep[k] = e;
         }
     }
 }
@@ -367,8 +370,9 @@ static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_
 using namespace tma;
 
 template <class T, int W>
-static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, unsigned threads, float *obs_out, hipStream_t s) {
-    refill_fast_kernel<T, W><<<dim3(blocks), dim3(threads), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out);
+static void launch_fast(tma_env *h, int mode, int64_t total_dense, unsigned blocks, unsigned threads, float *obs_out, hipStream_t s, int64_t lo,
+                        int64_t hi) {
+    refill_fast_kernel<T, W><<<dim3(blocks), dim3(threads), 0, s>>>(h->v, h->rv, mode, total_dense, obs_out, lo, hi);
 }
 
 static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
@@ -403,11 +407,18 @@ static int launch_seed(tma_env *h, int mode, float *obs_out, hipStream_t s) {
             }
             if (blocks > 16384) blocks = 16384;
             if (blocks < 1) blocks = 1;
-            if (h->small_window) launch_fast<T, T::Fast::W_SMALL>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s);
-            else launch_fast<T, T::Fast::W>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s);
-            TMA_LAUNCH_CHECK();
-            refill_fallback_kernel<T><<<dim3(FB_BLOCKS), dim3(256), 0, s>>>(h->v, h->rv, h->mt_scratch, mode, obs_out);
-            TMA_LAUNCH_CHECK();
+            // rounds of at most fb_cap items each: every item of a round may need the general generator and still fits the fallback
+            // list (one round up to 2^20 items -- every BASELINE shape; at most four rounds beyond, see tma_env_create)
+            const int64_t max_items = mode == 0 ? total_dense : h->v.N * (int64_t)h->v.D;
+            for (int64_t lo = 0; lo < max_items; lo += h->rv.fb_cap) {
+                if (lo > 0) TMA_HIP(hipMemsetAsync(h->rv.total + 1, 0, sizeof(uint32_t), s));
+                const int64_t hi = lo + h->rv.fb_cap;
+                if (h->small_window) launch_fast<T, T::Fast::W_SMALL>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s, lo, hi);
+                else launch_fast<T, T::Fast::W>(h, mode, total_dense, (unsigned)blocks, threads, obs_out, s, lo, hi);
+                TMA_LAUNCH_CHECK();
+                refill_fallback_kernel<T><<<dim3(FB_BLOCKS), dim3(256), 0, s>>>(h->v, h->rv, h->mt_scratch, mode, obs_out);
+                TMA_LAUNCH_CHECK();
+            }
             return (int)TMA_OK;
         }
     });
@@ -459,13 +470,14 @@ META_GETTER(tma_task_act_dim, adim)
 META_GETTER(tma_task_state_dim, sdim)
 META_GETTER(tma_task_max_episode_steps, maxsteps)
 
+static int env_alloc(tma_env *h, int task, int64_t num_envs, int ring_depth);
+
 int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, uint32_t env_offset, int ring_depth, tma_env **out) {
     if (!out) return fail(TMA_ERR_INVALID, "tma_env_create: out is null");
     if (task < 0 || task >= TMA_NUM_TASKS) return fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
     if (num_envs < 1) return fail(TMA_ERR_INVALID, "num_envs must be >= 1 (got %lld)", (long long)num_envs);
     if (ring_depth < 2 || ring_depth > 4096) return fail(TMA_ERR_INVALID, "ring_depth must be in [2, 4096] (got %d)", ring_depth);
     TMA_HIP(hipSetDevice(device));
-    const TaskMeta &m = kMeta[task];
     tma_env *h = new (std::nothrow) tma_env();
     if (!h) return fail(TMA_ERR_INVALID, "out of host memory");
     memset(h, 0, sizeof(*h));
@@ -476,6 +488,20 @@ int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, u
     v.D = ring_depth;
     v.seed_base = seed_base;
     v.env_offset = env_offset;
+    const int rc = env_alloc(h, task, num_envs, ring_depth);
+    if (rc) {  // e.g. out of HBM at millions of envs: give back what was allocated (destroy tolerates the zeroed members); *out untouched
+        tma_env_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return TMA_OK;
+}
+
+}  // extern "C"
+
+static int env_alloc(tma_env *h, int task, int64_t num_envs, int ring_depth) {
+    const TaskMeta &m = kMeta[task];
+    EnvView &v = h->v;
     const size_t n = (size_t)num_envs;
     TMA_HIP(hipMalloc(&v.st, sizeof(uint32_t) * n * m.sw));
     TMA_HIP(hipMemset(v.st, 0, sizeof(uint32_t) * n * m.sw));
@@ -492,19 +518,22 @@ int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, u
     if (m.uses_mt) {
         RefillView &rv = h->rv;
         rv.nb = (int)ceil_div(num_envs, 256);
-        rv.fb_cap = FB_CAP;
+        // fallback-list capacity = items per refill round: 2^20, or a quarter of the largest possible refill beyond 4 M items
+        const int64_t max_items = num_envs * (int64_t)(ring_depth + 1);
+        rv.fb_cap = (int)std::min<int64_t>(std::max<int64_t>(FB_CAP, ceil_div(max_items, 4)), (int64_t)INT_MAX);
         TMA_HIP(hipMalloc(&rv.first_ep, sizeof(uint32_t) * n));
         TMA_HIP(hipMalloc(&rv.env_off, sizeof(uint32_t) * n));
         TMA_HIP(hipMalloc(&rv.block_sum, sizeof(uint32_t) * rv.nb));
         TMA_HIP(hipMalloc(&rv.block_off, sizeof(uint32_t) * rv.nb));
         TMA_HIP(hipMalloc(&rv.total, sizeof(uint32_t) * 2));
-        TMA_HIP(hipMalloc(&rv.fb_env, sizeof(uint32_t) * FB_CAP));
-        TMA_HIP(hipMalloc(&rv.fb_ep, sizeof(uint32_t) * FB_CAP));
+        TMA_HIP(hipMalloc(&rv.fb_env, sizeof(uint32_t) * (size_t)rv.fb_cap));
+        TMA_HIP(hipMalloc(&rv.fb_ep, sizeof(uint32_t) * (size_t)rv.fb_cap));
         TMA_HIP(hipMalloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)FB_BLOCKS * 256));
     }
-    *out = h;
     return TMA_OK;
 }
+
+extern "C" {
 
 int tma_env_destroy(tma_env *h) {
     if (!h) return TMA_OK;

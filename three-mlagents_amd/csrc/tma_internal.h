@@ -50,7 +50,7 @@ struct RefillView {
 }  // namespace tma
 
 constexpr int FB_BLOCKS = 16;      // fallback kernel grid (16 x 256 threads, 2.5 KB of MT19937 scratch each)
-constexpr int FB_CAP = 1 << 20;    // fallback item capacity per refill
+constexpr int FB_CAP = 1 << 20;    // smallest fallback-list capacity = items per refill round (tma_env_create scales it with N * ring_depth)
 
 struct tma_env {
     int task, device;

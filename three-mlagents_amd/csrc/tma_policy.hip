@@ -279,6 +279,7 @@ struct Minibatch {
     int64_t start, count, total;  // rows [start, start+count) of the permuted buffer of `total` samples
     const int32_t *offs;          // optional: offs[j] = buffer offset of minibatch row j (written by adv_partial_kernel), saves the
                                   // permutation arithmetic in the gradient kernel
+    int64_t stats_n;              // rows the advantage partials were summed over: count, or the global minibatch under data parallelism
 };
 
 __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {
@@ -339,6 +340,32 @@ __global__ void adv_final_kernel(const double *partials, int n_part, int64_t cou
         if (var < 0.0) var = 0.0;
         ws_adv[0] = (float)mean;
         ws_adv[1] = (float)sqrt(var);
+    }
+}
+
+// data-parallel epochs (tma_ppo_epoch_adv_sums): one wave per minibatch k.  EXPORT folds the minibatch's partials (the slots
+// adv_partial_kernel filled, same order as adv_final_kernel) into sums[k] = {sum, sumsq}; IMPORT writes the all-reduced pair back as
+// partial 0 and zeroes the minibatch's other slots, so every consumer of the partials sees the global sums.
+template <bool IMPORT>
+__global__ __launch_bounds__(64) void adv_epoch_sums_kernel(double *partials, int stride, int64_t batch, int64_t total, double *sums) {
+    const int64_t k = blockIdx.x, s0 = k * batch;
+    const int64_t cnt = (s0 + batch <= total) ? batch : total - s0;
+    int nb = (int)((cnt + 1023) / 1024);
+    if (nb > stride) nb = stride;
+    double *part = partials + 2 * k * stride;
+    if constexpr (IMPORT) {
+        for (int j = threadIdx.x; j < nb; j += 64) {
+            part[2 * j] = j == 0 ? sums[2 * k] : 0.0;
+            part[2 * j + 1] = j == 0 ? sums[2 * k + 1] : 0.0;
+        }
+    } else {
+        double a = 0.0, b = 0.0;
+        for (int j = threadIdx.x; j < nb; j += 64) a += part[2 * j], b += part[2 * j + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            b += __shfl_down(b, o, 64);
+        }
+        if (threadIdx.x == 0) sums[2 * k] = a, sums[2 * k + 1] = b;
     }
 }
 
@@ -658,7 +685,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
             bsum += __shfl_down(bsum, o, 64);
         }
         if (threadIdx.x == 0) {
-            const double n = (double)mb.count, mean = a / n;
+            const double n = (double)mb.stats_n, mean = a / n;
             double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
             if (var < 0.0) var = 0.0;
             adv_ms[0] = (float)mean;
@@ -1905,12 +1932,25 @@ static int check_dims(const tma_policy_dims *d) {
         if (d->act_dim < 1 || d->act_dim > 32) return fail(TMA_ERR_INVALID, "Box action dim must be in [1, 32] (got %d)", d->act_dim);
     } else if (d->act_dim < 2 || d->act_dim > 16)
         return fail(TMA_ERR_INVALID, "Discrete action count must be in [2, 16] (got %d)", d->act_dim);
+    if (d->device < -1) return fail(TMA_ERR_INVALID, "device must be >= 0, or -1 for the calling thread's current device (got %d)", d->device);
     if (d->mfma_dtype != 0 && d->mfma_dtype != 1) return fail(TMA_ERR_INVALID, "mfma_dtype must be 0 (f32) or 1 (bf16), got %d", d->mfma_dtype);
     if (d->mfma_dtype == 1) {
         if (d->hidden != 128 && d->hidden != 192 && d->hidden != 256)
             return fail(TMA_ERR_INVALID, "the bf16 MFMA path covers hidden widths 128 / 192 / 256 (got %d)", d->hidden);
         if (grad_wide_bf_smem_bytes(d->obs_dim, d->hidden, 2) > 160 * 1024)
             return fail(TMA_ERR_INVALID, "obs_dim %d too wide for the bf16 LDS tile", d->obs_dim);
+    }
+    return TMA_OK;
+}
+
+// entry points that launch kernels: validate the shape, then make the policy's device current on the calling thread
+static int enter(const tma_policy_dims *d) {
+    const int rc = check_dims(d);
+    if (rc) return rc;
+    if (d->device >= 0) {
+        int cur = -1;
+        TMA_HIP(hipGetDevice(&cur));
+        if (cur != d->device) TMA_HIP(hipSetDevice(d->device));
     }
     return TMA_OK;
 }
@@ -2347,7 +2387,7 @@ int tma_policy_param_offsets(const tma_policy_dims *d, int32_t *out13) {
 }
 
 int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params) return fail(TMA_ERR_INVALID, "params is null");
     const PLayout L = layout_of(d);
@@ -2356,7 +2396,7 @@ int tma_policy_sync(float *params, const tma_policy_dims *d, void *stream) {
 
 int tma_policy_act(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
                    uint32_t env_offset, int deterministic, void *actions_out, float *values_out, float *logp_out, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !obs || !actions_out || !values_out || !logp_out) return fail(TMA_ERR_INVALID, "tma_policy_act: null buffer");
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act: n must be >= 1");
@@ -2367,7 +2407,7 @@ int tma_policy_act(const float *params, const tma_policy_dims *d, const float *o
 int tma_policy_act_bootstrap(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, uint32_t rng_seed, uint32_t rng_step,
                              uint32_t env_offset, void *actions_out, float *values_out, float *logp_out, const float *prev_terminal_obs,
                              const uint8_t *prev_truncated, double gamma, float *prev_rewards_inout, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !obs || !actions_out || !values_out || !logp_out) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: null buffer");
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_act_bootstrap: n must be >= 1");
@@ -2385,7 +2425,7 @@ int tma_policy_act_bootstrap(const float *params, const tma_policy_dims *d, cons
 }
 
 int tma_policy_values(const float *params, const tma_policy_dims *d, const float *obs, int64_t n, float *values_out, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !obs || !values_out) return fail(TMA_ERR_INVALID, "tma_policy_values: null buffer");
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_values: n must be >= 1");
@@ -2394,7 +2434,7 @@ int tma_policy_values(const float *params, const tma_policy_dims *d, const float
 
 int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const float *terminal_obs, const uint8_t *truncated, int64_t n, double gamma,
                          float *rewards_inout, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !terminal_obs || !truncated || !rewards_inout) return fail(TMA_ERR_INVALID, "tma_policy_bootstrap: null buffer");
     if (n < 1) return fail(TMA_ERR_INVALID, "tma_policy_bootstrap: n must be >= 1");
@@ -2403,7 +2443,7 @@ int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const fl
 
 int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
                            float *grad, void *workspace, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !rb || !mbi || !hp || !grad || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_minibatch_grad: null argument");
     if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
@@ -2415,8 +2455,14 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     hipStream_t s = (hipStream_t)stream;
     const PLayout L = layout_of(d);
     Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
-    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr};
+    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr, mbi->count};
     const bool prepared = mbi->prepared_batch > 0;
+    if (mbi->stats_count != 0) {
+        if (!prepared || mbi->stats_count < mbi->count)
+            return fail(TMA_ERR_INVALID, "stats_count %lld needs a prepared epoch (tma_ppo_epoch_prepare + tma_ppo_epoch_adv_sums) and must be >= count %lld",
+                        (long long)mbi->stats_count, (long long)mbi->count);
+        M.stats_n = mbi->stats_count;
+    }
     if (prepared && (mbi->prepared_batch < 256 || total > OFFS_CAP || mbi->start % mbi->prepared_batch != 0 || mbi->count > mbi->prepared_batch))
         return fail(TMA_ERR_INVALID, "minibatch [%lld, +%lld) does not match the prepared epoch split (batch %lld)", (long long)mbi->start,
                     (long long)mbi->count, (long long)mbi->prepared_batch);
@@ -2446,7 +2492,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     }
     if (hpar.normalize_advantage) {
         if (!h64) {  // the H = 64 kernel folds the partials itself
-            adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, mbi->count, ws_adv);
+            adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, M.stats_n, ws_adv);
             TMA_LAUNCH_CHECK();
         }
     }
@@ -2603,7 +2649,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
 
 int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int64_t batch_size, const tma_policy_dims *d, void *workspace,
                           void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!rb || !epoch || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_epoch_prepare: null argument");
     if (!rb->advantages || rb->T < 1 || rb->N < 1) return fail(TMA_ERR_INVALID, "rollout view: advantages / T / N");
@@ -2618,16 +2664,35 @@ int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int
     if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
     const int64_t n_mb = ceil_div(total, batch_size);
     if (n_mb > 65535) return fail(TMA_ERR_INVALID, "too many minibatches per epoch (%lld)", (long long)n_mb);
-    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr};
+    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr, total};
     adv_partial_kernel<<<dim3(stride, (unsigned)n_mb), dim3(256), 0, (hipStream_t)stream>>>(
         rb->advantages, M, rb->T, rb->N, reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4), reinterpret_cast<int32_t *>(ws + offs_base), batch_size);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }
 
+int tma_ppo_epoch_adv_sums(void *workspace, const tma_policy_dims *d, int64_t batch_size, int64_t total, double *sums, int direction, void *stream) {
+    int rc = enter(d);
+    if (rc) return rc;
+    if (!workspace || !sums) return fail(TMA_ERR_INVALID, "tma_ppo_epoch_adv_sums: null argument");
+    if (batch_size < 256 || total < 1 || total > OFFS_CAP) return fail(TMA_ERR_INVALID, "tma_ppo_epoch_adv_sums: same limits as tma_ppo_epoch_prepare");
+    if (direction != 0 && direction != 1) return fail(TMA_ERR_INVALID, "direction must be 0 (export) or 1 (import)");
+    const PLayout L = layout_of(d);
+    char *ws = static_cast<char *>(workspace);
+    const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
+    int stride = (int)ceil_div(batch_size, 1024);
+    if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+    const unsigned n_mb = (unsigned)ceil_div(total, batch_size);
+    double *partials = reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4);
+    if (direction == 0) adv_epoch_sums_kernel<false><<<dim3(n_mb), dim3(64), 0, (hipStream_t)stream>>>(partials, stride, batch_size, total, sums);
+    else adv_epoch_sums_kernel<true><<<dim3(n_mb), dim3(64), 0, (hipStream_t)stream>>>(partials, stride, batch_size, total, sums);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
 int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr, double beta1,
                       double beta2, double eps, double max_grad_norm, double grad_scale, void *workspace, void *stream) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step: null buffer");
     if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
@@ -2675,7 +2740,7 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
 
 int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
                             double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int64_t last_count) {
-    int rc = check_dims(d);
+    int rc = enter(d);
     if (rc) return rc;
     if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_adam_step_local: null buffer");
     if (step < 1) return fail(TMA_ERR_INVALID, "Adam step index must be >= 1");
@@ -2726,6 +2791,8 @@ int tma_debug_last_grad_kernel_us(float *us_out) {
 
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {
     if (!workspace || !out8_host) return fail(TMA_ERR_INVALID, "null argument");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, workspace) == hipSuccess) (void)hipSetDevice(attr.device);  // callers may be worker threads
     hipStream_t s = (hipStream_t)stream;
     std::vector<double> tmpv(MAX_GRAD_BLOCKS * 8 + 2);
     double *tmp = tmpv.data();

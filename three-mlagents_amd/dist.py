@@ -29,14 +29,16 @@ def rank() -> int:
     return td.get_rank() if is_initialized() else 0
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """Initialise from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  Returns (rank, local_rank, world)."""
+def init_from_env(backend: str | None = None, single_rank_group: bool = False) -> tuple[int, int, int]:
+    """Initialise from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  Returns (rank, local_rank, world).
+    A world of one needs no process group and gets none, unless `single_rank_group` asks for it (exercises the RCCL
+    communicator on a one-GPU box)."""
     import torch.distributed as td
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", str(rk)))
-    if ws > 1 and not is_initialized():
+    if (ws > 1 or single_rank_group) and not is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

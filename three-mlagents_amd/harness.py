@@ -1,0 +1,155 @@
+"""Train / evaluate harness over the HIP engine: the callers either side of `model.learn()`.
+
+Seams: S2 `make_vector_env(task_id, *, n_envs, seed, monitor_dir)` and S3 `ALGORITHMS["ppo"]`, plus a short
+`train_task` / `evaluate_model` / `predict_action` harness with the reference's call signatures, artefact layout
+(`policies/<prefix>_<run_id>.zip`, `runs/<task>/<run_id>/{monitor,eval,tb}/`, `metadata.json`) and error types, so that callers
+written against /root/reference/backend/mlagents/training.py (`cli.py:70-95`, `main.py:149-184`) keep working.  It is written from
+that interface description, not from the reference's source; the reference's own orchestration module can equally stay in place
+with three one-line substitutions.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+import json
+import os
+import secrets
+import statistics
+import time
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+
+from . import tasks
+from .callbacks import CallbackList, EvalCallback
+from .evaluation import evaluate_policy
+from .ppo import PPO
+from .vec_env import HipVecEnv
+
+POLICIES_DIR = Path("policies")
+RUNS_DIR = Path("runs")
+ALGORITHMS: dict[str, type] = {"ppo": PPO}  # the one algorithm north_star puts on the GPU
+_SB3_NAMES = {"a2c", "dqn", "ppo", "sac", "td3"}  # what the reference's table accepts (training.py:31-37)
+
+# (name, type, default) -- the reference's request / result records (training.py:40-68); `device` is an engine-only extra
+_REQUEST = [("task_id", str), ("total_timesteps", "int | None", None), ("algorithm", "str | None", None), ("seed", int, 1),
+            ("n_envs", "int | None", None), ("eval_episodes", "int | None", None), ("eval_freq", int, 10_000), ("deterministic_eval", bool, True),
+            ("policy", "str | None", None), ("run_name", "str | None", None), ("save_policy", bool, True), ("verbose", int, 1),
+            ("device", "str | None", None)]
+_RESULT = [("task_id", str), ("algorithm", str), ("run_id", str), ("model_filename", str), ("model_path", str), ("run_dir", str),
+           ("mean_reward", float), ("std_reward", float), ("eval_episodes", int), ("total_timesteps", int), ("metadata_path", str)]
+TrainConfig = dataclasses.make_dataclass("TrainConfig", [f if len(f) == 2 else (f[0], f[1], dataclasses.field(default=f[2])) for f in _REQUEST], frozen=True)
+TrainResult = dataclasses.make_dataclass("TrainResult", _RESULT, frozen=True)
+
+
+def make_vector_env(task_id: str, *, n_envs: int, seed: int, monitor_dir=None, device=None, env_offset: int = 0) -> HipVecEnv:
+    """Seam S2.  Env `rank` of the vector starts from seed + env_offset + rank; Monitor sums are kept by the step kernel."""
+    venv = HipVecEnv(tasks.resolve(task_id).kernel, int(n_envs), seed=seed, device=device, env_offset=env_offset)
+    venv.monitor_dir = monitor_dir
+    return venv
+
+
+def ppo_defaults(task: tasks.EngineTask) -> dict[str, Any]:
+    """Hyper-parameters the reference hands to SB3's PPO (value table: training.py:361-391)."""
+    width = [256, 256]
+    extra = {"mfma_dtype": "bf16"} if os.environ.get("TMA_MFMA_DTYPE", "").lower() == "bf16" else {}  # engine knob, BASELINE configs[2]
+    return dict(learning_rate=3e-4, n_steps=task.ppo_n_steps, batch_size=256, n_epochs=10, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
+                ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs={"net_arch": {"pi": width, "vf": list(width)}, **extra})
+
+
+def _algorithm_for(requested: str | None) -> tuple[str, str | None]:
+    """-> (engine algorithm, name it stands in for).  An explicit non-PPO request is an error; a task whose catalogue default is
+    another SB3 algorithm (the reference defaults most tasks to DQN) runs the engine's PPO and the substitution is recorded."""
+    if requested is None:
+        return "ppo", None
+    want = requested.lower()
+    if want in ALGORITHMS:
+        return want, None
+    known = "an SB3 algorithm without an MI355X implementation" if want in _SB3_NAMES else "not a known algorithm"
+    raise ValueError(f"Unsupported algorithm '{requested}' ({known}). Use one of {sorted(ALGORITHMS)}.")
+
+
+class _Run:
+    """Directory layout of one training run."""
+
+    def __init__(self, task: tasks.EngineTask, run_id: str):
+        self.id, self.root = run_id, RUNS_DIR / task.id / run_id
+        self.monitor, self.eval, self.tb, self.best = (self.root / d for d in ("monitor", "eval", "tb", "best_model"))
+        for d in (POLICIES_DIR, self.monitor, self.eval, self.tb):
+            d.mkdir(parents=True, exist_ok=True)
+        self.zip_name = f"{task.policy_prefix}_{run_id}.zip"
+        self.zip_path = POLICIES_DIR / self.zip_name
+        self.metadata = self.root / "metadata.json"
+
+
+def train_task(config, *, callback=None, model_kwargs=None):
+    task = tasks.resolve(config.task_id)
+    algo, _ = _algorithm_for(config.algorithm)
+    budget = int(config.total_timesteps or task.total_timesteps)
+    n_envs = int(config.n_envs or task.n_envs)
+    episodes = int(config.eval_episodes or task.eval_episodes)
+    run = _Run(task, config.run_name or f"{task.id}_{algo}_{time.strftime('%Y%m%d_%H%M%S')}_{secrets.token_hex(4)}")
+    with contextlib.ExitStack() as stack:
+        def opened(n, seed_shift, mon=None):
+            e = make_vector_env(task.id, n_envs=n, seed=config.seed + seed_shift, monitor_dir=mon, device=config.device)
+            stack.callback(e.close)
+            return e
+
+        venv, eval_env = opened(n_envs, 0, run.monitor), opened(1, 10_000)  # the eval env is seeded 10 000 past the training seed
+        hp = {**ppo_defaults(task), "tensorboard_log": str(run.tb), "verbose": config.verbose, **(model_kwargs or {})}
+        model = ALGORITHMS[algo](config.policy or "MlpPolicy", venv, seed=config.seed, **hp)
+        ev = dict(n_eval_episodes=episodes, deterministic=config.deterministic_eval)
+        hooks = [EvalCallback(eval_env, log_path=str(run.eval), best_model_save_path=str(run.best), verbose=config.verbose,
+                              eval_freq=max(config.eval_freq // n_envs, 1), **ev)]  # eval_freq counts vector steps
+        hooks += [callback] if callback is not None else []
+        model.learn(total_timesteps=budget, callback=CallbackList(hooks), progress_bar=False)
+        if config.save_policy:
+            model.save(run.zip_path)
+        returns, lengths = evaluate_policy(model, eval_env, return_episode_rewards=True, **ev)
+        mean, std = statistics.fmean(returns), statistics.pstdev(returns)
+        from . import __version__
+
+        run.metadata.write_text(json.dumps({
+            "task": task.card(), "config": dataclasses.asdict(config), "algorithm": algo, "run_id": run.id, "model_filename": run.zip_name,
+            "model_path": str(run.zip_path), "mean_reward": mean, "std_reward": std, "episode_rewards": list(map(float, returns)),
+            "episode_lengths": list(map(int, lengths)), "train_log": model.logger_values,
+            "software": {"three_mlagents_amd": __version__, "engine": "libtma_hip.so (gfx950)"}, "created_at": time.strftime("%Y-%m-%dT%H:%M:%S%z"),
+        }, indent=2, default=str), encoding="utf-8")
+    return TrainResult(task.id, algo, run.id, run.zip_name, str(run.zip_path), str(run.root), mean, std, episodes, budget, str(run.metadata))
+
+
+def find_policy(task: tasks.EngineTask, name_or_path=None) -> Path:
+    """A path, a file name under policies/, or None for the newest zip of the task; FileNotFoundError otherwise."""
+    if name_or_path is None:
+        newest = max(POLICIES_DIR.glob(f"{task.policy_prefix}_*.zip"), default=None, key=lambda p: p.name)
+        if newest is None:
+            raise FileNotFoundError(f"No policy zip for task '{task.id}' under {POLICIES_DIR}/.")
+        return newest
+    for cand in (Path(name_or_path), POLICIES_DIR / str(name_or_path)):
+        if cand.is_file():
+            return cand
+    raise FileNotFoundError(f"Model not found: {name_or_path}")
+
+
+def load_model(task, name_or_path=None):
+    task = tasks.resolve(task) if isinstance(task, str) else task
+    return PPO.load(find_policy(task, name_or_path))
+
+
+def evaluate_model(task_id, name_or_path, *, episodes=None, deterministic=True, seed=10_001):
+    """-> dict(task_id, model, episodes, mean_reward, std_reward, episode_rewards, episode_lengths)"""
+    task = tasks.resolve(task_id)
+    path = find_policy(task, name_or_path)
+    model = PPO.load(path)
+    n = int(episodes or task.eval_episodes)
+    with contextlib.closing(make_vector_env(task.id, n_envs=1, seed=seed)) as env:
+        returns, lengths = evaluate_policy(model, env, n_eval_episodes=n, deterministic=deterministic, return_episode_rewards=True)
+    return {"task_id": task.id, "model": str(path), "episodes": n, "mean_reward": statistics.fmean(returns), "std_reward": statistics.pstdev(returns),
+            "episode_rewards": list(map(float, returns)), "episode_lengths": list(map(int, lengths))}
+
+
+def predict_action(task_id, obs, model_filename=None):
+    """Deterministic action for one observation: int for Discrete tasks, list of floats for Box tasks."""
+    action, _ = load_model(task_id, model_filename).predict(np.float32(obs), deterministic=True)
+    return action.tolist() if getattr(action, "ndim", 0) else int(action)

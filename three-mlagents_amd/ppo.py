@@ -61,9 +61,11 @@ class HipActorCriticPolicy:
         if mfma_dtype not in ("f32", "bf16"):
             raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', got {mfma_dtype!r}")
         self.mfma_dtype = mfma_dtype
-        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0, 1 if mfma_dtype == "bf16" else 0)
         self.obs_dim, self.act_dim, self.continuous, self.hidden = int(obs_dim), int(act_dim), bool(continuous), int(hidden)
         self.device = torch.device(device)
+        # dims.device: every tma_policy_* / tma_ppo_* call makes it the calling thread's HIP device (learn() may run in a worker thread)
+        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0, 1 if mfma_dtype == "bf16" else 0,
+                                    self.device.index if self.device.index is not None else -1)
         nt, ntot = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().tma_policy_param_count(C.byref(self.dims), C.byref(nt), C.byref(ntot)))
         self.n_trainable, self.n_total = nt.value, ntot.value
@@ -122,8 +124,15 @@ class HipActorCriticPolicy:
         return sd
 
     # -- kernels ---------------------------------------------------------------------------
+    def _rows(self, obs: torch.Tensor) -> torch.Tensor:
+        """[n, obs_dim] float32 on the policy's device, or ValueError (the kernels read n * obs_dim floats whatever the tensor holds;
+        SB3 raises the same for a mis-shaped observation)."""
+        if obs.dim() != 2 or obs.shape[1] != self.obs_dim or obs.shape[0] < 1:
+            raise ValueError(f"observations must have shape [n, {self.obs_dim}], got {tuple(obs.shape)}")
+        return obs.to(self.device, torch.float32).contiguous()
+
     def act(self, obs: torch.Tensor, *, rng_seed: int = 0, rng_step: int = 0, env_offset: int = 0, deterministic: bool = False):
-        obs = obs.to(self.device, torch.float32).contiguous()
+        obs = self._rows(obs)
         n = obs.shape[0]
         if self.continuous:
             actions = torch.empty((n, self.act_dim), dtype=torch.float32, device=self.device)
@@ -137,7 +146,7 @@ class HipActorCriticPolicy:
         return actions, values, logp
 
     def predict_values(self, obs: torch.Tensor) -> torch.Tensor:
-        obs = obs.to(self.device, torch.float32).contiguous()
+        obs = self._rows(obs)
         values = torch.empty((obs.shape[0],), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().tma_policy_values(_lib.ptr(self.params), C.byref(self.dims), _lib.ptr(obs), obs.shape[0], _lib.ptr(values),
                                                 _lib.stream_ptr(self.device)))
@@ -253,9 +262,13 @@ class PPO:
                     keep_going = False
                     break
             t = te
+        self._rollout_counter += 1  # sampling counters (rng_step0) are never reused, also after an interrupted rollout
         if not keep_going:
+            # a callback stopped the rollout: the envs already advanced to step t, whose observation sits in slot t of the buffer --
+            # keep slot T current (SB3 keeps _last_obs current on every step) so a later learn(reset_num_timesteps=False) continues
+            if t < T:
+                self.buf["obs"][T].copy_(self.buf["obs"][t])
             return False
-        self._rollout_counter += 1
         b = self.buf
         _lib.check(L.tma_gae_flags(_lib.ptr(b["rewards"]), _lib.ptr(b["values"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]),
                                    _lib.ptr(b["last_values"]), self.gamma, self.gae_lambda, T, self.n_envs, _lib.ptr(b["advantages"]),
@@ -270,14 +283,30 @@ class PPO:
         scale = 1.0 / self.world_size
         perm_seed = (self.seed * 2654435761 + 12345) & 0xFFFFFFFF
         can_prepare = total <= (1 << 22) and self.batch_size >= 256  # limits of tma_ppo_epoch_prepare (include/tma.h)
+        # data parallel: every rank normalises a minibatch's advantages with the mean / std of the GLOBAL minibatch (the rows of all
+        # ranks), as one SB3 run over the concatenated batch would -- one all-reduce of 16 B per minibatch, once per epoch
+        global_stats = self.world_size > 1 and self.normalize_advantage
+        if global_stats and not can_prepare:
+            raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
+        if global_stats and getattr(self, "_adv_sums", None) is None:
+            self._adv_sums = torch.zeros(2 * ((total + self.batch_size - 1) // self.batch_size), dtype=torch.float64, device=self.device)
         for _ in range(self.n_epochs):
             if can_prepare:  # one launch per epoch: sample offsets of the permutation + advantage partials of every minibatch
                 ep = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, 0, total, 0)
                 _lib.check(L.tma_ppo_epoch_prepare(C.byref(self._rollout_view), C.byref(ep), self.batch_size, C.byref(self.policy.dims),
                                                    _lib.ptr(self.workspace), self._stream()))
+                if global_stats:
+                    import torch.distributed as tdist
+
+                    for direction in (0, 1):  # export the per-minibatch (sum, sumsq) pairs, all-reduce, import
+                        _lib.check(L.tma_ppo_epoch_adv_sums(_lib.ptr(self.workspace), C.byref(self.policy.dims), self.batch_size, total,
+                                                            _lib.ptr(self._adv_sums), direction, self._stream()))
+                        if direction == 0:
+                            tdist.all_reduce(self._adv_sums)
             for start in range(0, total, self.batch_size):
-                mb = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, start, min(self.batch_size, total - start),
-                                    self.batch_size if can_prepare else 0)
+                count = min(self.batch_size, total - start)
+                mb = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, start, count, self.batch_size if can_prepare else 0,
+                                    count * self.world_size if global_stats else 0)
                 _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
                                                     C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
                 if self.world_size > 1:
@@ -376,6 +405,8 @@ class PPO:
         single = obs.dim() == 1
         if single:
             obs = obs.unsqueeze(0)
+        if obs.dim() != 2 or obs.shape[1] != self.policy.obs_dim:
+            raise ValueError(f"observation must have shape [{self.policy.obs_dim}] or [n, {self.policy.obs_dim}], got {tuple(np.shape(observation))}")
         self._predict_counter = getattr(self, "_predict_counter", 0) + 1
         actions, _, _ = self.policy.act(obs, rng_seed=self.seed ^ 0x5EED, rng_step=self._predict_counter, deterministic=deterministic)
         a = actions.cpu().numpy()
@@ -410,8 +441,9 @@ class PPO:
 
         sd = self.policy.state_dict()
         opt = {"state": {}, "param_groups": [{"lr": self.learning_rate, "betas": (0.9, 0.999), "eps": 1e-5, "weight_decay": 0,
-                                               "amsgrad": False, "params": list(range(len(sd)))}],
-               "tma_flat": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self._adam_step}}
+                                               "amsgrad": False, "params": list(range(len(sd)))}]}
+        if getattr(self, "exp_avg", None) is not None:  # (a model loaded without an env has a policy but no optimizer state)
+            opt["tma_flat"] = {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self._adam_step}
         with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
             z.writestr("data", json.dumps(self._data(), indent=2, default=str))
             z.writestr("policy.pth", _pth(sd))
@@ -431,8 +463,12 @@ class PPO:
             data = json.loads(z.read("data").decode())
             sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
             try:
-                opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=False)
-            except Exception:  # noqa: BLE001 - a zip written by stable-baselines3 itself (optimizer pickles need SB3)
+                # the payload this engine writes is dicts / tuples / ints / tensors: the restricted unpickler is enough, and a zip whose
+                # name came from an API caller never executes pickled code.  Anything else (a zip written by SB3 itself) -> no optimizer state
+                opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+                if not isinstance(opt, dict):
+                    opt = {}
+            except Exception:  # noqa: BLE001
                 opt = {}
         # zips written by stable-baselines3 carry their own `data` schema: recover the policy shape from the state_dict,
         # whose keys/shapes are SB3's (mlp_extractor.policy_net.{0,2}, mlp_extractor.value_net.{0,2}, action_net, value_net, log_std)

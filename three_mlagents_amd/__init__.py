@@ -1,7 +1,7 @@
 """Importable alias of the `three-mlagents_amd/` package directory (a hyphen is not a valid module name).
 
 `import three_mlagents_amd` executes three-mlagents_amd/__init__.py with this module's __path__ pointing there,
-so `three_mlagents_amd.registry`, `.training`, `.vec_env`, ... resolve to the files in that directory.
+so `three_mlagents_amd.harness`, `.ppo`, `.vec_env`, ... resolve to the files in that directory.
 """
 import os as _os
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from three_mlagents_amd import _lib
 from three_mlagents_amd.ppo import PPO
-from three_mlagents_amd.training import make_vector_env
+from three_mlagents_amd.harness import make_vector_env
 
 env = make_vector_env("gridworld", n_envs=4096, seed=1)
 m = PPO("MlpPolicy", env, n_steps=256, batch_size=131072, n_epochs=1, seed=1, policy_kwargs={"net_arch": [64, 64]})

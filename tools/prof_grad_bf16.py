@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from three_mlagents_amd import _lib
 from three_mlagents_amd.ppo import PPO
-from three_mlagents_amd.training import make_vector_env
+from three_mlagents_amd.harness import make_vector_env
 
 task, H, dt = (sys.argv[1:] + ["ball3d", "256", "bf16"])[:3]
 env = make_vector_env(task, n_envs=4096, seed=1)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from three_mlagents_amd import _lib
 from three_mlagents_amd.ppo import PPO
-from three_mlagents_amd.training import make_vector_env
+from three_mlagents_amd.harness import make_vector_env
 
 
 def med_us(fn, reps=30, group=4):

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from three_mlagents_amd.ppo import PPO
-from three_mlagents_amd.training import make_vector_env
+from three_mlagents_amd.harness import make_vector_env
 from three_mlagents_amd.evaluation import evaluate_policy
 
 for task, H, iters, dt in (("gridworld", 64, 12, "f32"), ("push", 64, 12, "f32"), ("ball3d", 64, 12, "f32"), ("walljump", 64, 12, "f32"),
