@@ -41,7 +41,7 @@ def _nccl_single(port, q):
     dist.allreduce_sum_(g)  # world 1: the helper skips the collective ...
     td.all_reduce(g)        # ... so drive RCCL directly as PPO.train does
     torch.cuda.synchronize()
-    q.put((rk, ws, td.get_backend(), float(g.sum().item()), dist.allreduce_max_float(3.5, device="cuda:0")))
+    q.put((rk, ws, td.get_backend(), float(g.double().sum().item()), dist.allreduce_max_float(3.5, device="cuda:0")))
     td.destroy_process_group()
 
 
