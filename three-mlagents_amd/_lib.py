@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libtma_hip.so")
+SO_PATH = os.environ.get("TMA_LIB_PATH") or os.path.join(_HERE, "csrc", "libtma_hip.so")  # (TMA_LIB_PATH: diagnostic builds of the same ABI)
 
 TMA_OK, TMA_ERR_INVALID, TMA_ERR_UNKNOWN_TASK, TMA_ERR_HIP = 0, 1, 2, 3
 ACT_I32, ACT_I64, ACT_F32 = 0, 1, 2

@@ -1,0 +1,808 @@
+// tma_h64.hip -- PPO minibatch forward + loss + backward for H = 64 policies (BASELINE configs[1]: GridWorld, PPO MLP(64,64)).
+//
+// Replaces, for SB3's default-width MlpPolicy, what PPO.train computes per minibatch between RolloutBuffer.get and
+// optimizer.step (stable-baselines3 2.9.0, third party; constructed at /root/reference/backend/mlagents/training.py:150, driven by
+// model.learn() at training.py:166-170; formulas: SURVEY.md Appendix C.3 / C.5).  tma_policy.hip dispatches here.
+#include "tma_ppo_types.h"
+
+#include <cstdlib>
+
+namespace tma {
+
+// ------------------------------------------------------------------------------------------
+// H = 64 specialisation (BASELINE configs[1]): persistent waves keep the WHOLE parameter gradient of both nets in MFMA
+// accumulators (210 VGPRs) while they walk their share of the 16-sample tiles -- dW += X^T.dZ is accumulated through the
+// MFMA C operand, so there is no per-tile gradient traffic at all.  At the end the 4 waves of a block are summed through
+// LDS and the block writes ONE partial-gradient slab with plain stores; slab_reduce_kernel sums the slabs in a fixed order
+// (bitwise reproducible, no float atomics: the per-tile atomics of the generic kernel serialise on a 37 KB buffer).
+// Requirements: H == 64, D <= 16, Discrete head (A <= 16).
+// ------------------------------------------------------------------------------------------
+struct NetAcc {
+    f32x4 w1[1][4];
+    f32x4 w2[4][4];
+    f32x4 w3[4][1];
+    float b1[4], b2[4], b3[1];
+};
+
+__device__ __forceinline__ void zero_acc(NetAcc &a) {
+    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a.w1[0][j] = z;
+        a.w3[j][0] = z;
+        a.b1[j] = 0.0f;
+        a.b2[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a.w2[i][j] = z;
+    }
+    a.b3[0] = 0.0f;
+}
+
+template <int KT, int NT>
+__device__ __forceinline__ void bwd_weight_acc(const float *xin, int ldx, int K, const float *dz, int ldz, int N, f32x4 (&accW)[KT][NT],
+                                               float (&accb)[NT], int lane) {
+    (void)K, (void)N;
+    const int r16 = lane & 15, g = lane >> 4;
+    float bf[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = nt * 16 + r16;
+#pragma unroll
+        for (int s = 0; s < 4; s++) bf[nt][s] = dz[(4 * s + g) * ldz + col];  // dz tiles are written with zeros in columns >= N
+        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const int krow = kt * 16 + r16;
+        float a[4];
+        // rows krow >= K read whatever follows in LDS: they only feed accumulator rows k >= K, which flush_segment never stores
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[s] = xin[(4 * s + g) * ldx + krow];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
+    }
+}
+
+// wave -> LDS staging of one [K][N] segment (+ its bias), then block sum -> slab
+// PERM (version-2 head, one output tile): accumulator / tile column m stands for output a(m) = (m >> 2) + 4 (m & 3)
+template <int KT, int NT, bool PERM = false>
+__device__ __forceinline__ void flush_segment(float *stage_all, int wave, int wpb, int K, int N, const f32x4 (&accW)[KT][NT], float (&accb)[NT],
+                                              float *slab_w, float *slab_b, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int seg = K * N + N;
+    float *stage = stage_all + wave * seg;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = kt * 16 + g * 4 + r, n = PERM ? (r16 >> 2) + 4 * (r16 & 3) : nt * 16 + r16;
+                if (k < K && n < N) stage[k * N + n] = accW[kt][nt][r];
+            }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        float v = accb[nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int n = PERM ? (r16 >> 2) + 4 * (r16 & 3) : nt * 16 + r16;
+        if (g == 0 && n < N) stage[K * N + n] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < seg; e += blockDim.x) {
+        float sum = stage_all[e];
+        for (int w = 1; w < wpb; w++) sum += stage_all[w * seg + e];
+        if (e < K * N) slab_w[e] = sum;
+        else slab_b[e - K * N] = sum;
+    }
+    __syncthreads();
+}
+
+// One launch, 2 x n_slabs blocks: even blocks carry the POLICY net, odd blocks the VALUE net (the two MLPs share nothing,
+// SB3 net_arch=dict(pi=..., vf=...)), so a wave holds only ~105 accumulator registers and two blocks fit per CU.
+template <bool IS_PI, int DT>  // DT > 0: compile-time observation width (folds the LDS addressing), 0: runtime L.D
+__device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                              const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
+                                              double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+    __shared__ float adv_ms[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int H = 64;
+    const int D = DT > 0 ? DT : L.D, A = L.A;
+    const int ldx = ((D + 3) & ~3) + 2;
+    constexpr int ld = H + 2, ld3 = 34;
+    const int per_wave = 16 * (ldx + 2 * ld + ld3) + 16 * 8;
+    float *wimg = smem;  // this net's weight image, staged once per block
+    float *X = smem + IMG_FLOATS + (int64_t)wave * per_wave;
+    // the input-gradient tiles overwrite the activations they are derived from, element for element (dz2 over h2, dz1 over h1)
+    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2, *dzB = h1, *dz3 = h2 + 16 * ld;
+    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
+    float *meta = reinterpret_cast<float *>(row_off + 16);
+    const float invB = 1.0f / (float)mb.count;
+    const int NOUT = IS_PI ? A : 1;
+    const int KS1 = (D + 3) >> 2;
+    stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
+    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {  // fold the minibatch advantage partials (same order as adv_final_kernel)
+        double a = 0.0, bsum = 0.0;
+        for (int k = threadIdx.x; k < n_part; k += 64) a += adv_part[2 * k], bsum += adv_part[2 * k + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            bsum += __shfl_down(bsum, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            const double n = (double)mb.stats_n, mean = a / n;
+            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            adv_ms[0] = (float)mean;
+            adv_ms[1] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
+    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
+    NetAcc acc;
+    zero_acc(acc);
+    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
+    const int64_t n_tiles = (mb.count + 15) >> 4;
+    // The gather of a tile (permutation index, 3-4 scalars and the observation row per sample: dependent global loads) is
+    // issued one tile AHEAD into registers and committed to LDS at the top of the next iteration, so its latency hides
+    // under the current tile's MFMA work instead of stalling every tile (compile-time D only).
+    constexpr int DP_CT = (DT + 3) & ~3;
+    constexpr int NV = DT > 0 ? DP_CT / 4 : 1;  // observation values per lane: 16 rows x DP_CT floats / 64 lanes
+    int64_t pf_off = -1;
+    float pf_m0 = 0.0f, pf_m1 = 0.0f, pf_m2 = 0.0f, pf_m3 = 0.0f, pf_x[NV];
+    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
+    int32_t pf_noff = -1;  // cached sample offset of the tile AFTER the one being fetched: its load latency never sits in front of the gathers
+    bool have_noff = false;
+    auto fetch = [&](int64_t tl) {
+        pf_off = -1, pf_m0 = pf_m1 = pf_m2 = pf_m3 = 0.0f;
+        const int32_t my_noff = pf_noff;
+        if (mb.offs && lane < 16) {
+            const int64_t j2 = ((tl + tile_stride) << 4) + lane;
+            pf_noff = mb.offs[j2 < mb.count ? j2 : 0];
+        }
+        if (lane < 16 && tl < n_tiles) {
+            const int64_t j = (tl << 4) + lane;
+            if (j < mb.count) {
+                pf_off = mb.offs ? (int64_t)(have_noff ? my_noff : mb.offs[j]) : sample_offset(mb, mb.start + j, rb.T, rb.N);
+                if constexpr (IS_PI) {
+                    pf_m0 = rb.log_probs[pf_off];
+                    pf_m1 = rb.advantages[pf_off];
+                    pf_m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[pf_off]);
+                } else {
+                    pf_m2 = rb.returns[pf_off];
+                }
+            }
+        }
+        if constexpr (DT > 0) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) {
+                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
+                const int64_t orow = __shfl(pf_off, row, 64);
+                pf_x[q] = (orow >= 0 && c < DT) ? rb.obs[orow * DT + c] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&]() {
+        if (lane < 16) {
+            meta[lane * 4 + 0] = pf_m0, meta[lane * 4 + 1] = pf_m1, meta[lane * 4 + 2] = pf_m2, meta[lane * 4 + 3] = pf_m3;
+            row_off[lane] = pf_off;
+        }
+        if constexpr (DT > 0) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) {
+                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
+                X[row * ldx + c] = pf_x[q];
+            }
+        }
+    };
+    fetch((int64_t)block_net * wpb + wave);
+    have_noff = true;
+    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
+        commit();
+        if constexpr (DT == 0) load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
+        fetch(tile + tile_stride);
+        dense64_tanh_lds<0>(X, ldx, KS1, wimg + IMG_W1, wimg + IMG_B1, h1, ld, lane);
+        dense64_tanh_lds<16>(h1, ld, 16, wimg + IMG_W2F, wimg + IMG_B2, h2, ld, lane);
+        f32x4 out[1];
+        out[0] = dense64_head_lds(h2, ld, wimg + IMG_W3F, wimg + IMG_B3, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = g * 4 + r;
+            const bool valid = row_off[row] >= 0;
+            if constexpr (IS_PI) {
+                const bool colok = r16 < A;
+                const float x = colok ? out[0][r] : -INFINITY;
+                const float m = gmax16(x);
+                const float e = colok ? expf(x - m) : 0.0f;
+                const float s = gsum16(e);
+                const float lse = m + logf(s);
+                const float lp = colok ? x - lse : 0.0f;
+                const float p = e / s;
+                const int act = __float_as_int(meta[row * 4 + 3]);
+                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                const float ent = -gsum16(p * lp);
+                const float old = meta[row * 4 + 0];
+                const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+                const float ratio = expf(lpa - old);
+                const float pl1 = advn * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+                const float pl2 = advn * rc;
+                const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+                float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
+                dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
+                dz3[row * ld3 + r16] = colok ? dl : 0.0f;
+                if (valid && r16 == 0) {
+                    st_a += (double)(-fminf(pl1, pl2));
+                    st_ent += (double)ent;
+                    st_kl += (double)((ratio - 1.0f) - (lpa - old));
+                    st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+                    st_n += 1.0;
+                }
+            } else {
+                const float diff = out[0][r] - meta[row * 4 + 2];
+                dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                if (valid && r16 == 0) st_a += (double)(diff * diff);
+            }
+        }
+        bwd_weight_acc<4, 1>(h2, ld, H, dz3, ld3, NOUT, acc.w3, acc.b3, lane);
+        dense64_bwd_input_lds<4>(dz3, ld3, wimg + IMG_W3B, h2, ld, dzA, ld, lane);
+        bwd_weight_acc<4, 4>(h1, ld, H, dzA, ld, H, acc.w2, acc.b2, lane);
+        dense64_bwd_input_lds<16>(dzA, ld, wimg + IMG_W2B, h1, ld, dzB, ld, lane);
+        bwd_weight_acc<1, 4>(X, ldx, D, dzB, ld, H, acc.w1, acc.b1, lane);
+    }
+    __syncthreads();
+    flush_segment<1, 4>(smem, wave, wpb, D, H, acc.w1, acc.b1, slab + (IS_PI ? L.pW1t : L.vW1t), slab + (IS_PI ? L.pb1 : L.vb1), lane);
+    flush_segment<4, 4>(smem, wave, wpb, H, H, acc.w2, acc.b2, slab + (IS_PI ? L.pW2t : L.vW2t), slab + (IS_PI ? L.pb2 : L.vb2), lane);
+    flush_segment<4, 1>(smem, wave, wpb, H, NOUT, acc.w3, acc.b3, slab + (IS_PI ? L.pW3t : L.vW3t), slab + (IS_PI ? L.pb3 : L.vb3), lane);
+    double st[5] = {st_a, st_ent, st_kl, st_clip, st_n};
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0)
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < wpb; w++) s += red[w * 5 + threadIdx.x];
+        // slot layout {policy_loss, value_sq_err, entropy, approx_kl, clipped, n}
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += s;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Version 2 of the tile chain: the TRANSPOSED register chain.
+//
+// Every GEMM of the chain is computed as  out^T[feature][sample] = W^T . in^T  -- the WEIGHTS are the MFMA A operand (M = output
+// features) and the ACTIVATIONS the B operand (N = the tile's 16 samples).  The C layout of v_mfma_f32_16x16x4_f32 (register r of
+// lane (g, s) = C[4g + r][s]) is then exactly the B-operand layout of the next GEMM, provided the contraction runs over the
+// features in the order k-step (j, r) <-> {16j + 4g' + r : g' = 0..3}: the B operand of k-step (j, r) IS accumulator register r of
+// output tile j, untouched.  The contraction order is free (the A operand follows it: same LDS weight images, rows read in the
+// permuted order), so the whole forward chain, tanh, the loss and the backward input-gradient chain stay in REGISTERS: no
+// activation ever makes an LDS round trip on the dependent path (version 1 wrote every layer's output to LDS and read it back as the
+// A operand: six write -> read latencies per tile with the matrix pipe idle behind each).
+// LDS now only carries (a) the weight images, read with addresses that do not depend on the chain, and (b) write-only copies of
+// h1, h2, dz3, dz2, dz1 and the observation tile in [sample][feature] form, which the weight-gradient MFMAs (dW += x^T . dz, the
+// contraction runs over SAMPLES there) read back transposed, off the dependent path.
+// Observations and per-sample scalars go straight from global memory to registers, one tile ahead.
+// Activation tiles: [16][68] floats with the column index XOR-ed by 16 * (row & 1): the b128 stores of the chain (lane (g, s) holds
+// four consecutive features of sample s) and the transposed b32 reads of the weight-gradient operands are both conflict-free.
+// ------------------------------------------------------------------------------------------
+#ifdef TMA_H64_TICKS  // diagnostic build only (make CXXFLAGS+=-DTMA_H64_TICKS): per-phase issue-time stamps of wave 0 of blocks 0 / 1
+__device__ unsigned long long g_h64_ticks[2][16];
+#define H64_TICK(i)                                                                          \
+    do {                                                                                     \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                          \
+        if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][i] += _t - tick_prev;          \
+        tick_prev = __builtin_amdgcn_s_memtime();                                            \
+    } while (0)
+#else
+#define H64_TICK(i) do {} while (0)
+#endif
+constexpr int LDT = 68;
+constexpr int T_PER_WAVE = 2 * 16 * LDT + 256 + 256;  // slot A, slot B, dz3 [16][16], X [16][16]
+__device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ ((row & 1) << 4)); }
+
+// all-reduce over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the lane groups holding one sample's 16 head outputs): VALU only
+template <class F>
+__device__ __forceinline__ float xg_reduce(float v, F op) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xg_sum(float v) { return xg_reduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float xg_max(float v) { return xg_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+
+// lane (g, s) stores features 16mt + 4g .. + 3 of sample s: one b128 per output tile
+__device__ __forceinline__ void store_tile_t(float *tile, const f32x4 (&v)[4], int r16, int g) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4 *>(tile + tsw(r16, 16 * mt + 4 * g)) = v[mt];
+}
+
+// accW[kt][nt] += x[16 samples][16kt..]^T . dz[16 samples][16nt..]; accb[nt] += column sums of dz.  Operands are read transposed
+// (sample on the lane group / k index, feature on lane & 15) from [sample][feature] tiles: XS / ZS = swizzled [16][LDT] tile, else
+// a plain [16][16] tile.
+template <int KT, int NT, bool XS, bool ZS>
+__device__ __forceinline__ void bwd_weight_acc_t(const float *xin, const float *dz, f32x4 (&accW)[KT][NT], float (&accb)[NT], int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    float bf[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) bf[nt][s] = ZS ? dz[tsw(4 * s + g, nt * 16 + r16)] : dz[(4 * s + g) * 16 + r16];
+        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        float a[4];
+        // (plain X tile: feature columns >= D hold stale LDS bytes; they only feed accumulator rows k >= D, which flush_segment never stores)
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[s] = XS ? xin[tsw(4 * s + g, kt * 16 + r16)] : xin[(4 * s + g) * 16 + r16];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
+    }
+}
+
+// ---- block reduction of the gradient accumulators (version 2): every wave stages its registers lane-for-lane (register-major:
+// conflict-free b32 stores at immediate offsets), then wave w sums registers w, w + 8, ... over the eight copies in wave order (the order
+// of flush_segment, so the bits match) and stores them to the slab.  Two halves of <= 56 registers keep the staging inside the tile
+// region's 112 KiB; all eight waves stay busy in both phases, against three store / barrier / strided-sum / barrier rounds before.
+constexpr int FL_HALF = 56, FL_REGS = 105;
+__device__ __forceinline__ float acc_reg(const NetAcc &a, int idx) {  // idx is a compile-time constant after unrolling
+    if (idx < 16) return a.w1[0][idx >> 2][idx & 3];
+    if (idx < 80) return a.w2[(idx - 16) >> 4][((idx - 16) >> 2) & 3][idx & 3];
+    if (idx < 96) return a.w3[(idx - 80) >> 2][0][idx & 3];
+    if (idx < 100) return a.b1[idx - 96];
+    if (idx < 104) return a.b2[idx - 100];
+    return a.b3[0];
+}
+// slab element of accumulator register idx in lane `lane` (-1: padding, nothing to store)
+template <bool IS_PI>
+__device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L, int D, int NOUT) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int perm = (r16 >> 2) + 4 * (r16 & 3);  // head: tile column m <-> output a(m)
+    if (idx < 16) {
+        const int k = 4 * g + (idx & 3), n = (idx >> 2) * 16 + r16;
+        return k < D ? (IS_PI ? L.pW1t : L.vW1t) + k * 64 + n : -1;
+    }
+    if (idx < 80) {
+        const int t = idx - 16, k = (t >> 4) * 16 + 4 * g + (t & 3), n = ((t >> 2) & 3) * 16 + r16;
+        return (IS_PI ? L.pW2t : L.vW2t) + k * 64 + n;
+    }
+    if (idx < 96) {
+        const int t = idx - 80, k = (t >> 2) * 16 + 4 * g + (t & 3);
+        return perm < NOUT ? (IS_PI ? L.pW3t : L.vW3t) + k * NOUT + perm : -1;
+    }
+    if (g != 0) return -1;  // bias sums are replicated over the lane groups
+    if (idx < 100) return (IS_PI ? L.pb1 : L.vb1) + (idx - 96) * 16 + r16;
+    if (idx < 104) return (IS_PI ? L.pb2 : L.vb2) + (idx - 100) * 16 + r16;
+    return perm < NOUT ? (IS_PI ? L.pb3 : L.vb3) + perm : -1;
+}
+template <bool IS_PI>
+__device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, NetAcc &acc, const PLayout &L, int D, int NOUT, float *slab) {
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc.b1[nt] = xg_sum(acc.b1[nt]), acc.b2[nt] = xg_sum(acc.b2[nt]);
+    acc.b3[0] = xg_sum(acc.b3[0]);
+    // the sums stay in registers until both halves are done: a barrier behind global stores would wait out their round trip
+    // (__syncthreads drains vmcnt), so every store is issued after the last barrier
+    float sums[2][7];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int base = half * FL_HALF, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
+        if (half) __syncthreads();  // half 0's copies have been read
+#pragma unroll
+        for (int i = 0; i < FL_HALF; i++)
+            if (i < cnt) stage[(wave * FL_HALF + i) * 64 + lane] = acc_reg(acc, base + i);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int i = wave + 8 * q;
+            float sum = 0.0f;
+            if (i < cnt) {
+                sum = stage[i * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 8; w++) sum += stage[(w * FL_HALF + i) * 64 + lane];
+            }
+            sums[half][q] = sum;
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int i = wave + 8 * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
+            const int off = i < cnt ? slab_offset_t<IS_PI>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
+            if (off >= 0) slab[off] = sums[half][q];
+        }
+}
+
+// out[mt] += sum over the 16 k-steps (j, r) of  A = wrow[(16j + r) * 64 floats] (a lane's four output-tile operands: one b128)  x  B = in[j][r].
+// The weight reads do not depend on the chain: they are issued two k-steps ahead of the MFMAs that consume them and the scheduler is
+// fenced per k-step -- left alone, hipcc issues each pair of reads AFTER the previous eight MFMAs and waits out the LDS latency with
+// the matrix pipe drained.
+__device__ __forceinline__ void chain64(const float *wrow, const f32x4 (&in)[4], f32x4 (&out)[4]) {
+    f32x4 wq[3];
+    wq[0] = *reinterpret_cast<const f32x4 *>(wrow);
+    wq[1] = *reinterpret_cast<const f32x4 *>(wrow + 64);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i + 2 < 16) wq[(i + 2) % 3] = *reinterpret_cast<const f32x4 *>(wrow + (16 * ((i + 2) >> 2) + ((i + 2) & 3)) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w = wq[i % 3];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) out[mt] = mfma16(w[mt], in[i >> 2][i & 3], out[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool IS_PI, int DT>
+__device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
+                                               const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
+                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+#ifdef TMA_H64_TICKS
+    const unsigned long long kern_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    __shared__ float adv_ms[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;  // r16: the tile's sample this lane works for (and the A operand's row); g: lane group
+    (void)0;
+    const int D = DT > 0 ? DT : L.D, A = L.A;
+    constexpr int KS1C = DT > 0 ? (DT + 3) / 4 : 4;  // layer-1 k-steps held in registers (runtime D: up to 16 features)
+    const int KS1 = (D + 3) >> 2;
+    float *wimg = smem;  // this net's weight image, staged once per block
+    float *slotA = smem + IMG_FLOATS + wave * T_PER_WAVE, *slotB = slotA + 16 * LDT, *dz3t = slotB + 16 * LDT, *Xt = dz3t + 256;
+    const float invB = 1.0f / (float)mb.count;
+    const int NOUT = IS_PI ? A : 1;
+    // (the first tile's two dependent global round trips -- sample offset, then its rows -- run under the image staging)
+    const int64_t n_tiles = (mb.count + 15) >> 4;
+    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
+    auto offset_of = [&](int64_t tl) -> int32_t {
+        const int64_t j = (tl << 4) + r16;
+        const int64_t jc = j < mb.count ? j : 0;
+        return mb.offs ? mb.offs[jc] : (int32_t)sample_offset(mb, mb.start + jc, rb.T, rb.N);
+    };
+    int32_t nx_off = offset_of((int64_t)block_net * wpb + wave);
+    int32_t pf_off = 0;
+    float pf_x[KS1C], pf_m0 = 0.0f, pf_m1 = 0.0f;
+    int32_t pf_act = 0;
+    auto fetch = [&](int64_t tl) {
+        pf_off = nx_off;
+        nx_off = offset_of(tl + tile_stride);
+        const int64_t row = pf_off;
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ks++) {
+            const int c = 4 * ks + g;
+            pf_x[ks] = rb.obs[row * D + (c < D ? c : 0)];
+        }
+        if constexpr (IS_PI) {
+            pf_m0 = rb.log_probs[row];
+            pf_m1 = rb.advantages[row];
+            pf_act = static_cast<const int32_t *>(rb.actions)[row];
+        } else {
+            pf_m0 = rb.returns[row];
+        }
+    };
+    fetch((int64_t)block_net * wpb + wave);
+    stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
+    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {  // fold the minibatch advantage partials (same order as adv_final_kernel)
+        double a = 0.0, bsum = 0.0;
+        for (int k = threadIdx.x; k < n_part; k += 64) a += adv_part[2 * k], bsum += adv_part[2 * k + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            bsum += __shfl_down(bsum, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            const double n = (double)mb.stats_n, mean = a / n;
+            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            adv_ms[0] = (float)mean;
+            adv_ms[1] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
+    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
+    NetAcc acc;
+    zero_acc(acc);
+    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0;
+    float st_clip = 0.0f, st_n = 0.0f;  // counts: exact in float (a lane sees far fewer than 2^24 samples)
+    // ---- gather, one tile ahead, straight into registers (offset_of / fetch above): the sample's buffer offset is fetched one stage
+    // earlier still, so the dependent hop (offset -> rows) never waits.  Loads are issued from clamped addresses and masked when the tile
+    // is consumed (a select on a value just loaded would make the compiler wait for it at the issue point).
+    // the two waves a SIMD hosts (w and w + 4) run the same program: started together they tend to stay in lockstep -- both in their
+    // MFMA-dense phases, then both in their VALU phases -- so the second half of the block starts a fraction of a tile later
+    if (wave >= 4)
+        for (int q = 0; q < hp.debug; q++) __builtin_amdgcn_s_sleep(100);
+#ifdef TMA_H64_TICKS
+    const bool tick_on = block_net == 0 && wave == 0;
+    unsigned long long tick_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long loop_t0 = tick_prev, loop_r0 = __builtin_amdgcn_s_memrealtime();
+    if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][12] += loop_t0 - kern_t0;
+#endif
+    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
+        H64_TICK(15);
+        // ---- commit the prefetched tile ----
+        const bool valid = ((tile << 4) + r16) < mb.count;
+        float xb[KS1C];
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ks++) xb[ks] = (valid && 4 * ks + g < D) ? pf_x[ks] : 0.0f;
+        const float m0 = pf_m0, m1 = pf_m1;
+        const int act = pf_act;
+        fetch(tile + tile_stride);
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ks++)
+            if (ks < KS1) Xt[r16 * 16 + 4 * ks + g] = xb[ks];
+        // ---- layer 1: h1^T = tanh(W1^T . x^T + b1) ----
+        f32x4 h1[4], h2[4];
+        {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) h1[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B1 + 16 * mt + 4 * g);
+#pragma unroll
+            for (int ks = 0; ks < KS1C; ks++) {
+                if (ks < KS1) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W1 + (4 * ks + g) * 64 + r16 * 4);
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(w[mt], xb[ks], h1[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h1[mt][r] = tma_tanh(h1[mt][r]);
+        }
+        H64_TICK(0);
+        store_tile_t(slotA, h1, r16, g);
+        // ---- layer 2: the B operand of k-step (j, r) is register r of h1's tile j ----
+        {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) h2[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B2 + 16 * mt + 4 * g);
+            chain64(wimg + IMG_W2F + 4 * g * 64 + r16 * 4, h1, h2);
+            H64_TICK(1);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h2[mt][r] = tma_tanh(h2[mt][r]);
+        }
+        store_tile_t(slotB, h2, r16, g);
+        H64_TICK(2);
+        // ---- head: the A operand's row m = lane & 15 carries output a(m) = (m >> 2) + 4 (m & 3), so register r of lane group g' is output
+        // g' + 4r: the n_out <= 8 real outputs sit in registers 0..1 and the head's input-gradient GEMM below needs ceil(n_out / 4) k-steps
+        // instead of 4.  Two accumulators halve the dependent MFMA chain.
+        const int acol = (r16 >> 2) + 4 * (r16 & 3);
+        f32x4 o0 = f32x4{wimg[IMG_B3 + g], wimg[IMG_B3 + g + 4], wimg[IMG_B3 + g + 8], wimg[IMG_B3 + g + 12]}, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float w = wimg[IMG_W3F + (16 * j + 4 * g + r) * 16 + acol];
+                if ((4 * j + r) & 1) o1 = mfma16(w, h2[j][r], o1);
+                else o0 = mfma16(w, h2[j][r], o0);
+            }
+        H64_TICK(3);
+        f32x4 dz3;
+        if constexpr (IS_PI) {
+            float x[4], e[4], lp[4], p[4];
+            bool ok[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                ok[r] = g + 4 * r < A;
+                x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
+                m = fmaxf(m, x[r]);
+            }
+            m = xg_max(m);
+            float ssum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                e[r] = ok[r] ? expf(x[r] - m) : 0.0f;
+                ssum += e[r];
+            }
+            ssum = xg_sum(ssum);
+            const float lse = m + logf(ssum);
+            float lpa = 0.0f, ent = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                lp[r] = ok[r] ? x[r] - lse : 0.0f;
+                p[r] = e[r] / ssum;
+                lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
+                ent += p[r] * lp[r];
+            }
+            lpa = xg_sum(lpa);
+            ent = -xg_sum(ent);
+            const float old = m0;
+            const float advn = (m1 - amean) / (astd + 1e-8f);
+            const float ratio = expf(lpa - old);
+            const float pl1 = advn * ratio;
+            const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+            const float pl2 = advn * rc;
+            const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float dl = g_lp * (((g + 4 * r == act) ? 1.0f : 0.0f) - p[r]);
+                dl += valid ? (hp.ent_coef * invB) * (p[r] * (lp[r] + ent)) : 0.0f;
+                dz3[r] = ok[r] ? dl : 0.0f;
+            }
+            if (valid && g == 0) {
+                st_a += (double)(-fminf(pl1, pl2));
+                st_ent += (double)ent;
+                st_kl += (double)((ratio - 1.0f) - (lpa - old));
+                st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0f : 0.0f;
+                st_n += 1.0f;
+            }
+        } else {
+            const float diff = (o0[0] + o1[0]) - m0;
+            const bool mine = valid && g == 0;
+            dz3 = f32x4{mine ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f, 0.0f, 0.0f, 0.0f};
+            if (mine) st_a += (double)(diff * diff);
+        }
+        H64_TICK(4);
+        *reinterpret_cast<f32x4 *>(dz3t + r16 * 16 + 4 * g) = dz3;  // (column m = 4g + r of the tile <-> output a(m), undone by flush_segment)
+        H64_TICK(4);
+        // ---- dh2^T = W3 . dz3^T: k-step r contracts over the outputs {g' + 4r}; registers r >= ceil(n_out / 4) of dz3 are zero ----
+        f32x4 d[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) d[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (4 * r < NOUT) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W3B + (g + 4 * r) * 64 + r16 * 4);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) d[mt] = mfma16(w[mt], dz3[r], d[mt]);
+            }
+        }
+        // dW3 (off the dependent path) right behind the chain's MFMAs: the pipe works on it while dh2 matures and dz2 is formed
+        bwd_weight_acc_t<4, 1, true, false>(slotB, dz3t, acc.w3, acc.b3, lane);
+        H64_TICK(5);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[mt][r] = d[mt][r] * (1.0f - h2[mt][r] * h2[mt][r]);
+        store_tile_t(slotB, h2, r16, g);  // dz2 over h2 (dW3 has read h2: LDS operations of one wave execute in order)
+        H64_TICK(6);
+        // ---- dh1^T = W2 . dz2^T (chain), then dW2 (64 MFMAs, off the path) with dz1 = dh1 * (1 - h1^2) formed between its k-tiles ----
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) d[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        chain64(wimg + IMG_W2B + 4 * g * 64 + r16 * 4, h2, d);
+        H64_TICK(7);
+        {
+            float bf[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                for (int sk = 0; sk < 4; sk++) bf[nt][sk] = slotB[tsw(4 * sk + g, nt * 16 + r16)];
+                acc.b2[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+            }
+            float av[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+                for (int sk = 0; sk < 4; sk++) av[kt][sk] = slotA[tsw(4 * sk + g, kt * 16 + r16)];
+            // h1 is not kept in registers across the head / loss / layer-2 work: its LDS copy (slot A) is read back in the lane's own C-layout
+            // positions (the b128 pattern of the store: conflict-free); every read of slot A is issued before dz1 overwrites it below
+            f32x4 hh[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) hh[mt] = *reinterpret_cast<const f32x4 *>(slotA + tsw(r16, 16 * mt + 4 * g));
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sk = 0; sk < 4; sk++)
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) acc.w2[kt][nt] = mfma16(av[kt][sk], bf[nt][sk], acc.w2[kt][nt]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) h1[kt][r] = d[kt][r] * (1.0f - hh[kt][r] * hh[kt][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_tile_t(slotA, h1, r16, g);  // dz1 over h1
+        H64_TICK(8);
+        bwd_weight_acc_t<1, 4, false, true>(Xt, slotA, acc.w1, acc.b1, lane);
+        H64_TICK(9);
+    }
+#ifdef TMA_H64_TICKS
+    const unsigned long long loop_t1 = __builtin_amdgcn_s_memtime();
+    if (tick_on && lane == 0) {
+        g_h64_ticks[IS_PI ? 0 : 1][10] += loop_t1 - loop_t0;
+        g_h64_ticks[IS_PI ? 0 : 1][11] += __builtin_amdgcn_s_memrealtime() - loop_r0;
+    }
+#endif
+    __syncthreads();
+#ifdef TMA_H64_TICKS
+    if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][14] += __builtin_amdgcn_s_memtime() - loop_t1;  // waiting for the block's slowest wave
+#endif
+    // loss statistics first (their LDS scratch sits behind the staging area; the barriers inside flush_all_t publish it), the slab
+    // stores last: nothing waits behind a global store
+    double *red = reinterpret_cast<double *>(smem + 8 * FL_HALF * 64);
+    double st[5] = {st_a, st_ent, st_kl, (double)st_clip, (double)st_n};
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
+    if (lane == 0)
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
+    flush_all_t<IS_PI>(smem, wave, lane, acc, L, D, NOUT, slab);  // (8 waves per block: tma_launch_grad_h64)
+#ifdef TMA_H64_TICKS
+    if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][13] += __builtin_amdgcn_s_memtime() - loop_t1;
+#endif
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < wpb; w++) s += red[w * 5 + threadIdx.x];
+        // slot layout {policy_loss, value_sq_err, entropy, approx_kl, clipped, n}
+        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
+        if (q >= 0) stat_slot[q] += s;
+    }
+}
+
+template <int DT, int VER>
+__global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                              const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
+                                                              double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    float *slab = slabs + (int64_t)pair * L.P;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if constexpr (VER == 1) {
+        if ((blockIdx.x & 1) == 0) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+        else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    } else {
+        if ((blockIdx.x & 1) == 0) grad_h64t_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+        else grad_h64t_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    }
+}
+
+}  // namespace tma
+
+using namespace tma;
+
+static int grad_h64_smem_bytes(const PLayout &L, int wpb, int ver) {
+    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
+    const int per_wave = ver == 1 ? 16 * (ldx + 2 * ld + 34) + 16 * 8 : T_PER_WAVE;
+    const int tile = (IMG_FLOATS + wpb * per_wave) * 4;
+    const int flush = wpb * (L.H * L.H + L.H) * 4;
+    return tile > flush ? tile : flush;
+}
+
+// H = 64 persistent gradient kernel over one minibatch (>= 256 samples): 2 x n_pairs blocks of 8 waves, block pair p writes slab p.
+// Returns the number of slabs written through *n_slabs_out (the caller runs slab_reduce_kernel over them).
+int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R, const Minibatch &M, const HParams &hpar, const double *adv_part,
+                        int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s) {
+    static const int ver = getenv("TMA_H64_V1") ? 1 : 2;  // (development switch: the round-1 LDS-round-trip tile chain)
+    static const int stagger = getenv("TMA_H64_STAGGER") ? atoi(getenv("TMA_H64_STAGGER")) : 0;
+    HParams hps = hpar;
+    hps.debug = stagger;
+    const int64_t tiles = ceil_div(M.count, 16);
+    const int wpb4 = 8, smem4 = grad_h64_smem_bytes(L, wpb4, ver);
+    int64_t blocks4 = ceil_div(tiles, wpb4);
+    if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
+    auto launch = [&](auto k) -> int {
+        if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
+        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots);
+        return TMA_OK;
+    };
+    int rc;
+    if (ver == 1) rc = L.D == 4 ? launch(ppo_grad_h64_kernel<4, 1>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6, 1>) : launch(ppo_grad_h64_kernel<0, 1>));
+    else rc = L.D == 4 ? launch(ppo_grad_h64_kernel<4, 2>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6, 2>) : launch(ppo_grad_h64_kernel<0, 2>));
+    if (rc) return rc;
+    TMA_LAUNCH_CHECK();
+    *n_slabs_out = (int)blocks4;
+    return TMA_OK;
+}
+
+#ifdef TMA_H64_TICKS
+extern "C" int tma_debug_h64_ticks(unsigned long long *out32, int reset) {
+    TMA_HIP(hipDeviceSynchronize());
+    if (out32) TMA_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_h64_ticks), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {};
+        TMA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_h64_ticks), z, sizeof(z)));
+    }
+    return TMA_OK;
+}
+#endif

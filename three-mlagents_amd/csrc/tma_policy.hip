@@ -11,7 +11,7 @@
 //   clip_grad_norm_(max_grad_norm) + torch.optim.Adam(eps=1e-5).step()            -> grad_sumsq_kernel + adam_kernel
 // Formulas: SURVEY.md Appendix C.3 / C.5.  "Parity unpinned" at this boundary (SB3 is not importable here); checked
 // against a torch-CPU autograd restatement in tests/.
-#include "tma_mlp.h"
+#include "tma_ppo_types.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -20,27 +20,6 @@
 
 namespace tma {
 
-constexpr int WS_ADV = 0;             // float[2]: minibatch advantage mean, std
-constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-squares partials
-constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
-constexpr int WS_ADV_PART = 4096;     // byte offset of double[128][2] advantage (sum, sumsq) partials
-constexpr int WS_STATS = 8192;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
-constexpr int MAX_GRAD_BLOCKS = 2048;
-constexpr int64_t WS_SLABS = WS_STATS + (int64_t)MAX_GRAD_BLOCKS * 8 * 8;  // byte offset of float[H64_BLOCKS][P] partial-gradient slabs
-constexpr int H64_BLOCKS = 128;  // block PAIRS (policy block + value block): 256 blocks = one per CU, a single round
-constexpr int64_t WS_BYTES = WS_SLABS;
-constexpr int BF_SLABS = 160;  // column-parallel kernels: up to 160 policy-net blocks (+ value-net blocks sharing the first slabs)
-constexpr int64_t OFFS_CAP = 1 << 22;
-constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16;  // advantage partials of every minibatch of an epoch
-constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_kernel for policies beyond the 256 slots at WS_NORM_PART  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
-
-constexpr int64_t DZ1_CAP = 1 << 18;  // samples per minibatch whose dz1 images fit the workspace cache (bf16 two-pass layouts only)
-static inline bool bf_two_pass(const PLayout &L) { return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192)); }
-static inline bool f32_two_pass(const PLayout &L) { return !L.bf16 && L.fr_pi >= 0 && L.D > 160 && L.D <= 176; }
-static inline int64_t dz1_cache_bytes(const PLayout &L) {  // both nets; bf16 images or f32 MFMA operands
-    return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : (f32_two_pass(L) ? 2 * DZ1_CAP * L.H * 4 : 0);
-}
-static inline int slab_cap(const PLayout &L) { return (L.bf16 || L.fr_pi >= 0) ? BF_SLABS : H64_BLOCKS; }  // partial-gradient slabs in the workspace
 
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
@@ -273,21 +252,6 @@ __global__ __launch_bounds__(256) void policy_fwd_kernel(const float *__restrict
 // ------------------------------------------------------------------------------------------
 // minibatch advantage statistics (mean, unbiased std) -- one block; SB3 PPO.train normalize_advantage
 // ------------------------------------------------------------------------------------------
-struct Minibatch {
-    const int64_t *indices;  // optional explicit flat (env-major: f = i*T + t) indices
-    uint32_t perm_seed, perm_epoch;
-    int64_t start, count, total;  // rows [start, start+count) of the permuted buffer of `total` samples
-    const int32_t *offs;          // optional: offs[j] = buffer offset of minibatch row j (written by adv_partial_kernel), saves the
-                                  // permutation arithmetic in the gradient kernel
-    int64_t stats_n;              // rows the advantage partials were summed over: count, or the global minibatch under data parallelism
-};
-
-__device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {
-    const int64_t f = mb.indices ? mb.indices[j] : (int64_t)perm_index(mb.perm_seed, mb.perm_epoch, (uint32_t)j, (uint32_t)mb.total);
-    const int64_t i = f / T, t = f - i * T;  // swap_and_flatten: (T, N) -> env-major
-    return t * N + i;
-}
-
 // pass 1: up to ADV_BLOCKS blocks, each sums a contiguous slice of the (permuted) minibatch -> (sum, sum of squares) partials
 constexpr int ADV_BLOCKS = 128;
 // gridDim.y > 1 (tma_ppo_epoch_prepare): blockIdx.y = minibatch k of an epoch split into chunks of `batch` rows; partials and
@@ -372,19 +336,6 @@ __global__ __launch_bounds__(64) void adv_epoch_sums_kernel(double *partials, in
 // ------------------------------------------------------------------------------------------
 // PPO minibatch forward + loss + backward.  One wave per 16 samples, gradient accumulated with float atomics.
 // ------------------------------------------------------------------------------------------
-struct Rollout {
-    const float *obs;
-    const void *actions;
-    const float *log_probs, *advantages, *returns;
-    int T;
-    int64_t N;
-};
-struct HParams {
-    float clip_range, ent_coef, vf_coef;
-    int normalize_advantage;
-    int debug;  // TMA_BF_DEBUG (profiling aid, default 0): bit mask of phases the bf16 wide kernel skips -- timing attribution only
-};
-
 // Even blocks carry the POLICY net, odd blocks the VALUE net (they share nothing).  The input-gradient tiles overwrite the
 // activations they derive from (dz2 over h2, dz1 over h1), so a wave needs X + 2 activation tiles of LDS and four waves fit.
 template <bool CONT, bool IS_PI>
@@ -562,283 +513,6 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
     if ((blockIdx.x & 1) == 0) grad_generic_body<CONT, true>(params, L, rb, mb, hp, ws_adv, grad, slot, smem, n_pairs, pair);
     else grad_generic_body<CONT, false>(params, L, rb, mb, hp, ws_adv, grad, slot, smem, n_pairs, pair);
 }
-
-// ------------------------------------------------------------------------------------------
-// H = 64 specialisation (BASELINE configs[1]): persistent waves keep the WHOLE parameter gradient of both nets in MFMA
-// accumulators (210 VGPRs) while they walk their share of the 16-sample tiles -- dW += X^T.dZ is accumulated through the
-// MFMA C operand, so there is no per-tile gradient traffic at all.  At the end the 4 waves of a block are summed through
-// LDS and the block writes ONE partial-gradient slab with plain stores; slab_reduce_kernel sums the slabs in a fixed order
-// (bitwise reproducible, no float atomics: the per-tile atomics of the generic kernel serialise on a 37 KB buffer).
-// Requirements: H == 64, D <= 16, Discrete head (A <= 16).
-// ------------------------------------------------------------------------------------------
-struct NetAcc {
-    f32x4 w1[1][4];
-    f32x4 w2[4][4];
-    f32x4 w3[4][1];
-    float b1[4], b2[4], b3[1];
-};
-
-__device__ __forceinline__ void zero_acc(NetAcc &a) {
-    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        a.w1[0][j] = z;
-        a.w3[j][0] = z;
-        a.b1[j] = 0.0f;
-        a.b2[j] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) a.w2[i][j] = z;
-    }
-    a.b3[0] = 0.0f;
-}
-
-template <int KT, int NT>
-__device__ __forceinline__ void bwd_weight_acc(const float *xin, int ldx, int K, const float *dz, int ldz, int N, f32x4 (&accW)[KT][NT],
-                                               float (&accb)[NT], int lane) {
-    (void)K, (void)N;
-    const int r16 = lane & 15, g = lane >> 4;
-    float bf[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int col = nt * 16 + r16;
-#pragma unroll
-        for (int s = 0; s < 4; s++) bf[nt][s] = dz[(4 * s + g) * ldz + col];  // dz tiles are written with zeros in columns >= N
-        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
-        const int krow = kt * 16 + r16;
-        float a[4];
-        // rows krow >= K read whatever follows in LDS: they only feed accumulator rows k >= K, which flush_segment never stores
-#pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = xin[(4 * s + g) * ldx + krow];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
-    }
-}
-
-// wave -> LDS staging of one [K][N] segment (+ its bias), then block sum -> slab
-template <int KT, int NT>
-__device__ __forceinline__ void flush_segment(float *stage_all, int wave, int wpb, int K, int N, const f32x4 (&accW)[KT][NT], float (&accb)[NT],
-                                              float *slab_w, float *slab_b, int lane) {
-    const int r16 = lane & 15, g = lane >> 4;
-    const int seg = K * N + N;
-    float *stage = stage_all + wave * seg;
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = kt * 16 + g * 4 + r, n = nt * 16 + r16;
-                if (k < K && n < N) stage[k * N + n] = accW[kt][nt][r];
-            }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        float v = accb[nt];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        const int n = nt * 16 + r16;
-        if (g == 0 && n < N) stage[K * N + n] = v;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < seg; e += blockDim.x) {
-        float sum = stage_all[e];
-        for (int w = 1; w < wpb; w++) sum += stage_all[w * seg + e];
-        if (e < K * N) slab_w[e] = sum;
-        else slab_b[e - K * N] = sum;
-    }
-    __syncthreads();
-}
-
-// One launch, 2 x n_slabs blocks: even blocks carry the POLICY net, odd blocks the VALUE net (the two MLPs share nothing,
-// SB3 net_arch=dict(pi=..., vf=...)), so a wave holds only ~105 accumulator registers and two blocks fit per CU.
-template <bool IS_PI, int DT>  // DT > 0: compile-time observation width (folds the LDS addressing), 0: runtime L.D
-__device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
-                                              const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
-                                              double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
-    __shared__ float adv_ms[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    constexpr int H = 64;
-    const int D = DT > 0 ? DT : L.D, A = L.A;
-    const int ldx = ((D + 3) & ~3) + 2;
-    constexpr int ld = H + 2, ld3 = 34;
-    const int per_wave = 16 * (ldx + 2 * ld + ld3) + 16 * 8;
-    float *wimg = smem;  // this net's weight image, staged once per block
-    float *X = smem + IMG_FLOATS + (int64_t)wave * per_wave;
-    // the input-gradient tiles overwrite the activations they are derived from, element for element (dz2 over h2, dz1 over h1)
-    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld, *dzA = h2, *dzB = h1, *dz3 = h2 + 16 * ld;
-    int64_t *row_off = reinterpret_cast<int64_t *>(dz3 + 16 * ld3);
-    float *meta = reinterpret_cast<float *>(row_off + 16);
-    const float invB = 1.0f / (float)mb.count;
-    const int NOUT = IS_PI ? A : 1;
-    const int KS1 = (D + 3) >> 2;
-    stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
-    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {  // fold the minibatch advantage partials (same order as adv_final_kernel)
-        double a = 0.0, bsum = 0.0;
-        for (int k = threadIdx.x; k < n_part; k += 64) a += adv_part[2 * k], bsum += adv_part[2 * k + 1];
-        for (int o = 32; o > 0; o >>= 1) {
-            a += __shfl_down(a, o, 64);
-            bsum += __shfl_down(bsum, o, 64);
-        }
-        if (threadIdx.x == 0) {
-            const double n = (double)mb.stats_n, mean = a / n;
-            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
-            if (var < 0.0) var = 0.0;
-            adv_ms[0] = (float)mean;
-            adv_ms[1] = (float)sqrt(var);
-        }
-    }
-    __syncthreads();
-    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
-    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
-    NetAcc acc;
-    zero_acc(acc);
-    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0, st_clip = 0.0, st_n = 0.0;
-    const int64_t n_tiles = (mb.count + 15) >> 4;
-    // The gather of a tile (permutation index, 3-4 scalars and the observation row per sample: dependent global loads) is
-    // issued one tile AHEAD into registers and committed to LDS at the top of the next iteration, so its latency hides
-    // under the current tile's MFMA work instead of stalling every tile (compile-time D only).
-    constexpr int DP_CT = (DT + 3) & ~3;
-    constexpr int NV = DT > 0 ? DP_CT / 4 : 1;  // observation values per lane: 16 rows x DP_CT floats / 64 lanes
-    int64_t pf_off = -1;
-    float pf_m0 = 0.0f, pf_m1 = 0.0f, pf_m2 = 0.0f, pf_m3 = 0.0f, pf_x[NV];
-    const int64_t tile_stride = (int64_t)n_blocks_net * wpb;
-    int32_t pf_noff = -1;  // cached sample offset of the tile AFTER the one being fetched: its load latency never sits in front of the gathers
-    bool have_noff = false;
-    auto fetch = [&](int64_t tl) {
-        pf_off = -1, pf_m0 = pf_m1 = pf_m2 = pf_m3 = 0.0f;
-        const int32_t my_noff = pf_noff;
-        if (mb.offs && lane < 16) {
-            const int64_t j2 = ((tl + tile_stride) << 4) + lane;
-            pf_noff = mb.offs[j2 < mb.count ? j2 : 0];
-        }
-        if (lane < 16 && tl < n_tiles) {
-            const int64_t j = (tl << 4) + lane;
-            if (j < mb.count) {
-                pf_off = mb.offs ? (int64_t)(have_noff ? my_noff : mb.offs[j]) : sample_offset(mb, mb.start + j, rb.T, rb.N);
-                if constexpr (IS_PI) {
-                    pf_m0 = rb.log_probs[pf_off];
-                    pf_m1 = rb.advantages[pf_off];
-                    pf_m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[pf_off]);
-                } else {
-                    pf_m2 = rb.returns[pf_off];
-                }
-            }
-        }
-        if constexpr (DT > 0) {
-#pragma unroll
-            for (int q = 0; q < NV; q++) {
-                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
-                const int64_t orow = __shfl(pf_off, row, 64);
-                pf_x[q] = (orow >= 0 && c < DT) ? rb.obs[orow * DT + c] : 0.0f;
-            }
-        }
-    };
-    auto commit = [&]() {
-        if (lane < 16) {
-            meta[lane * 4 + 0] = pf_m0, meta[lane * 4 + 1] = pf_m1, meta[lane * 4 + 2] = pf_m2, meta[lane * 4 + 3] = pf_m3;
-            row_off[lane] = pf_off;
-        }
-        if constexpr (DT > 0) {
-#pragma unroll
-            for (int q = 0; q < NV; q++) {
-                const int e = lane + 64 * q, row = e / DP_CT, c = e - row * DP_CT;
-                X[row * ldx + c] = pf_x[q];
-            }
-        }
-    };
-    fetch((int64_t)block_net * wpb + wave);
-    have_noff = true;
-    for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
-        commit();
-        if constexpr (DT == 0) load_obs_tile(rb.obs, row_off, D, X, ldx, lane);
-        fetch(tile + tile_stride);
-        dense64_tanh_lds<0>(X, ldx, KS1, wimg + IMG_W1, wimg + IMG_B1, h1, ld, lane);
-        dense64_tanh_lds<16>(h1, ld, 16, wimg + IMG_W2F, wimg + IMG_B2, h2, ld, lane);
-        f32x4 out[1];
-        out[0] = dense64_head_lds(h2, ld, wimg + IMG_W3F, wimg + IMG_B3, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = g * 4 + r;
-            const bool valid = row_off[row] >= 0;
-            if constexpr (IS_PI) {
-                const bool colok = r16 < A;
-                const float x = colok ? out[0][r] : -INFINITY;
-                const float m = gmax16(x);
-                const float e = colok ? expf(x - m) : 0.0f;
-                const float s = gsum16(e);
-                const float lse = m + logf(s);
-                const float lp = colok ? x - lse : 0.0f;
-                const float p = e / s;
-                const int act = __float_as_int(meta[row * 4 + 3]);
-                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                const float ent = -gsum16(p * lp);
-                const float old = meta[row * 4 + 0];
-                const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
-                const float ratio = expf(lpa - old);
-                const float pl1 = advn * ratio;
-                const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
-                const float pl2 = advn * rc;
-                const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
-                float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
-                dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
-                dz3[row * ld3 + r16] = colok ? dl : 0.0f;
-                if (valid && r16 == 0) {
-                    st_a += (double)(-fminf(pl1, pl2));
-                    st_ent += (double)ent;
-                    st_kl += (double)((ratio - 1.0f) - (lpa - old));
-                    st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
-                    st_n += 1.0;
-                }
-            } else {
-                const float diff = out[0][r] - meta[row * 4 + 2];
-                dz3[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
-                if (valid && r16 == 0) st_a += (double)(diff * diff);
-            }
-        }
-        bwd_weight_acc<4, 1>(h2, ld, H, dz3, ld3, NOUT, acc.w3, acc.b3, lane);
-        dense64_bwd_input_lds<4>(dz3, ld3, wimg + IMG_W3B, h2, ld, dzA, ld, lane);
-        bwd_weight_acc<4, 4>(h1, ld, H, dzA, ld, H, acc.w2, acc.b2, lane);
-        dense64_bwd_input_lds<16>(dzA, ld, wimg + IMG_W2B, h1, ld, dzB, ld, lane);
-        bwd_weight_acc<1, 4>(X, ldx, D, dzB, ld, H, acc.w1, acc.b1, lane);
-    }
-    __syncthreads();
-    flush_segment<1, 4>(smem, wave, wpb, D, H, acc.w1, acc.b1, slab + (IS_PI ? L.pW1t : L.vW1t), slab + (IS_PI ? L.pb1 : L.vb1), lane);
-    flush_segment<4, 4>(smem, wave, wpb, H, H, acc.w2, acc.b2, slab + (IS_PI ? L.pW2t : L.vW2t), slab + (IS_PI ? L.pb2 : L.vb2), lane);
-    flush_segment<4, 1>(smem, wave, wpb, H, NOUT, acc.w3, acc.b3, slab + (IS_PI ? L.pW3t : L.vW3t), slab + (IS_PI ? L.pb3 : L.vb3), lane);
-    double st[5] = {st_a, st_ent, st_kl, st_clip, st_n};
-#pragma unroll
-    for (int q = 0; q < 5; q++)
-        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
-    double *red = reinterpret_cast<double *>(smem);
-    if (lane == 0)
-        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
-    __syncthreads();
-    if (threadIdx.x < 5) {
-        double s = 0.0;
-        for (int w = 0; w < wpb; w++) s += red[w * 5 + threadIdx.x];
-        // slot layout {policy_loss, value_sq_err, entropy, approx_kl, clipped, n}
-        const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
-        if (q >= 0) stat_slot[q] += s;
-    }
-}
-
-template <int DT>
-__global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
-                                                              const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
-                                                              double *__restrict__ stat_slots) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
-    float *slab = slabs + (int64_t)pair * L.P;
-    double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
-    else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // Wide policies (H = 128 / 256: the reference's default net_arch is 256x256, training.py:363-365): column-parallel blocks.
@@ -1959,12 +1633,6 @@ static int fwd_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
     return wpb * (16 * (ldx + 2 * ld) + 32) * 4;
 }
-static int grad_h64_smem_bytes(const PLayout &L, int wpb) {
-    const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    const int tile = (IMG_FLOATS + wpb * (16 * (ldx + 2 * ld + 34) + 16 * 8)) * 4;
-    const int flush = wpb * (L.H * L.H + L.H) * 4;
-    return tile > flush ? tile : flush;
-}
 static int grad_smem_bytes(const PLayout &L, int wpb) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
     return wpb * (16 * (ldx + 2 * ld + 34) + 16 * 8) * 4;
@@ -2497,23 +2165,15 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         }
     }
     if (h64) {
-        // register-accumulating persistent kernel + deterministic slab reduction
-        const int wpb4 = 8, smem4 = grad_h64_smem_bytes(L, wpb4);
-        int64_t blocks4 = ceil_div(tiles, wpb4);
-        if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
+        // register-accumulating persistent kernel (tma_h64.hip) + deterministic slab reduction
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        auto launch = [&](auto k) -> int {
-            if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
-            k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hpar, adv_part, nbk, slabs, slots);
-            return TMA_OK;
-        };
+        int blocks4 = 0;
         int lrc;
         {
             GradTimer timer(s);
-            lrc = L.D == 4 ? launch(ppo_grad_h64_kernel<4>) : (L.D == 6 ? launch(ppo_grad_h64_kernel<6>) : launch(ppo_grad_h64_kernel<0>));
+            lrc = tma_launch_grad_h64(params, L, R, M, hpar, adv_part, nbk, slabs, slots, &blocks4, s);
         }
         if (lrc) return lrc;
-        TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;

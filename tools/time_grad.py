@@ -43,7 +43,16 @@ for i in range(0, len(args), 4):
 
     for _ in range(3):
         grad(), act()
-    print(f"{task} H={H} {dt} B={B}: grad {med_us(grad):.1f} us   act(4096) {med_us(act):.1f} us", flush=True)
+    ks = []
+    if L.tma_debug_time_grad_kernel(1) == 0:  # the persistent kernel alone (events recorded by the library around that launch)
+        us = C.c_float(0.0)
+        for _ in range(20):
+            grad()
+            if L.tma_debug_last_grad_kernel_us(C.byref(us)) == 0:
+                ks.append(us.value)
+        L.tma_debug_time_grad_kernel(0)
+    kern = sorted(ks)[len(ks) // 2] if ks else float("nan")
+    print(f"{task} H={H} {dt} B={B}: grad call {med_us(grad):.1f} us (kernel alone {kern:.1f} us)   act(4096) {med_us(act):.1f} us", flush=True)
     if os.environ.get("TMA_PHASE_DUMP") and dt == "bf16":
         grad(); torch.cuda.synchronize()
         ws = m.workspace
