@@ -10,7 +10,7 @@
 
 namespace tma {
 
-constexpr int GAE_UNROLL = 8;
+constexpr int GAE_UNROLL = 16;  // rows of loads in flight ahead of the dependent chain (3 arrays x 16 rows per lane)
 
 // FLAGS=false: SB3 layout (float episode_starts[T][N] + final dones[N]).  FLAGS=true: engine layout, done flags
 // terminated/truncated[T][N] where episode_starts[t+1] == done[t], so next_non_terminal at step t is 1 - done[t].
@@ -78,6 +78,12 @@ __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rewa
     }
 }
 
+// The recurrence over t is evaluated exactly as SB3 does (one rounded f32 chain per env): a segment-parallel scan would compose the
+// affine maps A_t = delta_t + c_t * A_{t+1} in a different rounding order and lose bit-exactness, so the parallelism is over envs only.
+// Up to 16 384 envs run as single-wave blocks -- 4096 envs then sit on 64 CUs (one wave each, every load of the 16-row window in flight)
+// instead of on 16.
+static inline int gae_block(int64_t N) { return N <= 16384 ? 64 : 256; }
+
 }  // namespace tma
 
 extern "C" int tma_gae(const float *rewards, const float *values, const float *episode_starts, const float *last_values,
@@ -89,7 +95,8 @@ extern "C" int tma_gae(const float *rewards, const float *values, const float *e
     if (T < 1 || N < 1) return fail(TMA_ERR_INVALID, "tma_gae: T and N must be >= 1 (got T=%d N=%lld)", T, (long long)N);
     // SB3 multiplies the python floats gamma*gae_lambda in float64, then the product meets the float32 arrays
     const float gl = (float)(gamma * gae_lambda);
-    gae_kernel<false><<<dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    const int bs = gae_block(N);
+    gae_kernel<false><<<dim3((unsigned)ceil_div(N, bs)), dim3(bs), 0, (hipStream_t)stream>>>(
         rewards, values, episode_starts, last_values, dones, nullptr, nullptr, (float)gamma, gl, T, N, adv_out, ret_out);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
@@ -103,7 +110,8 @@ extern "C" int tma_gae_flags(const float *rewards, const float *values, const ui
         return fail(TMA_ERR_INVALID, "tma_gae_flags: null buffer");
     if (T < 1 || N < 1) return fail(TMA_ERR_INVALID, "tma_gae_flags: T and N must be >= 1 (got T=%d N=%lld)", T, (long long)N);
     const float gl = (float)(gamma * gae_lambda);
-    gae_kernel<true><<<dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    const int bs = gae_block(N);
+    gae_kernel<true><<<dim3((unsigned)ceil_div(N, bs)), dim3(bs), 0, (hipStream_t)stream>>>(
         rewards, values, nullptr, last_values, nullptr, terminated, truncated, (float)gamma, gl, T, N, adv_out, ret_out);
     TMA_LAUNCH_CHECK();
     return TMA_OK;

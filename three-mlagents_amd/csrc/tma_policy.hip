@@ -21,16 +21,6 @@
 namespace tma {
 
 
-struct Net {
-    const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
-};
-__device__ __forceinline__ Net pi_net(const float *p, const PLayout &L) {
-    return Net{p + L.pW1t, p + L.pb1, p + L.pW2t, p + L.pb2, p + L.pW3t, p + L.pb3, p + L.pW2, p + L.pW3};
-}
-__device__ __forceinline__ Net vf_net(const float *p, const PLayout &L) {
-    return Net{p + L.vW1t, p + L.vb1, p + L.vW2t, p + L.vb2, p + L.vW3t, p + L.vb3, p + L.vW2, p + L.vW3};
-}
-
 __device__ __forceinline__ void build_image_elem(float *params, const PLayout &L, int img, int e, int W1t, int b1, int W2t, int b2, int W3t, int b3,
                                                  int n_out) {
     const int D = L.D, H = 64;
@@ -523,88 +513,6 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
 // ITS slab of the gradient with plain stores (no atomics; slab_reduce_kernel folds the blocks in a fixed order).
 // Activations of the row group live in block-shared LDS; __syncthreads separates the layers.
 // ------------------------------------------------------------------------------------------
-struct LossStats {
-    double a = 0.0, ent = 0.0, kl = 0.0, clip = 0.0, n = 0.0;
-};
-
-// clipped-surrogate + entropy gradient wrt the head outputs of one 16-row tile (C layout), written to dz3[16][ld3]
-template <bool CONT>
-__device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
-                                                 const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
-                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4) {
-    const int r16 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (r < r_lo || r >= r_hi) continue;  // (wave-uniform) a caller may split the four rows of a lane group over two waves
-        const int row = g * 4 + r;
-        const int64_t off = row_off[row];
-        const bool valid = off >= 0;
-        const float old = meta[row * 4 + 0];
-        const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
-        float lpa, ent;
-        float d[2] = {0.0f, 0.0f}, sd[2] = {1.0f, 1.0f}, p = 0.0f, lp = 0.0f;
-        int act = 0;
-        if constexpr (!CONT) {
-            const bool colok = r16 < A;
-            const float x = colok ? acc[0][r] : -INFINITY;
-            const float m = gmax16(x);
-            const float e = colok ? expf(x - m) : 0.0f;
-            const float s = gsum16(e);
-            const float lse = m + logf(s);
-            lp = colok ? x - lse : 0.0f;
-            p = e / s;
-            act = __float_as_int(meta[row * 4 + 3]);
-            lpa = gsum16((r16 == act) ? lp : 0.0f);
-            ent = -gsum16(p * lp);
-        } else {
-            float lpsum = 0.0f, entsum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = 16 * j + r16;
-                if (col < A) {
-                    const float lsd = log_std[col];
-                    sd[j] = expf(lsd);
-                    const float a = valid ? static_cast<const float *>(actions)[off * A + col] : 0.0f;
-                    d[j] = a - acc[j][r];
-                    lpsum += -(d[j] * d[j]) / (2.0f * (sd[j] * sd[j])) - lsd - 0.9189385332046727f;
-                    entsum += 1.4189385332046727f + lsd;
-                }
-            }
-            lpa = gsum16(lpsum);
-            ent = gsum16(entsum);
-        }
-        const float ratio = expf(lpa - old);
-        const float pl1 = advn * ratio;
-        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
-        const float pl2 = advn * rc;
-        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
-        if constexpr (!CONT) {
-            float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
-            dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
-            dz3[row * ld3 + r16] = (r16 < A) ? dl : 0.0f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = 16 * j + r16;
-                const float var = sd[j] * sd[j];
-                dz3[row * ld3 + col] = (col < A) ? g_lp * (d[j] / var) : 0.0f;
-                if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
-            }
-        }
-        if (valid && r16 == 0) {
-            st.a += (double)(-fminf(pl1, pl2));
-            st.ent += (double)ent;
-            st.kl += (double)((ratio - 1.0f) - (lpa - old));
-            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
-            st.n += 1.0;
-        }
-    }
-}
-
-// KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32), 0: layer-1 gradient accumulated in the slab, -1: dW1 skipped
-// (first of two passes).  PASS 1 = second pass for wide observations of known width: the forward / backward chain is recomputed and
-// ONLY dW1 (KT1C k-tiles) is accumulated and stored -- every other store is compiled out, so the MFMAs feeding only them vanish.
-// NQ1C > 0: layer-1 weights (16 * NQ1C >= D rows) also run through the ring, from the fragment image PLayout::fr1_pi.
 template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
@@ -2027,6 +1935,12 @@ static int launch_fwd(const float *params, const tma_policy_dims *d, const float
 
 using namespace tma;
 
+int tma_launch_slab_zero_w1(float *slabs, int n_slabs, const PLayout &L, hipStream_t s) {
+    slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, n_slabs, L);
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
 extern "C" {
 
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
@@ -2178,62 +2092,14 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
-    if (L.bf16) {
-        const int MTc = 2;
-        const int smemw = grad_wide_bf_smem_bytes(L.D, L.H, MTc);
-        // 256 blocks = one per CU.  A policy-net row group costs 1.15-1.3x a value-net one (the loss), so the policy net gets
-        // 136 or 144 of the blocks; with fewer row groups than that, one block per group.
-        const int64_t groups = ceil_div(mbi->count, 16 * MTc);
-        const int cap_pi = d->continuous ? 144 : 136, cap_vf = 256 - cap_pi;  // (Categorical loss is cheaper than the DiagGaussian one)
-        const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
+    if (L.bf16) {  // column-parallel bf16-MFMA kernel (tma_bf16.hip) + deterministic slab reduction
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
-        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
-        if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab
-            slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, n_pi, L);
-            TMA_LAUNCH_CHECK();
-        }
-        auto launch = [&](auto k, bf16_t *dz1) -> int {
-            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smemw));
-            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
-            return TMA_OK;
-        };
-        // two-pass layouts: minibatches that fit the dz1 cache take PASS 0 (which leaves dz1 there) + PASS 2 (dW1 from the cache)
-        // instead of PASS 0 + PASS 1 (dW1 from a recomputed forward / backward chain); the results are bit-identical
-        bf16_t *const dz1_cache = (bf_two_pass(L) && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))  // (env: test hook for the fallback)
-            ? reinterpret_cast<bf16_t *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
-        // (KT1C, KS1C): D <= 16 -> (1, 1); D <= 32 -> (2, 1); D <= 64 -> (0, 2) two passes; 161..192 (Crawler's 172) -> (0, 6) two
-        // passes; else runtime width, one pass with dW1 in the slab
-        auto pick = [&](auto ntw) -> int {
-            constexpr int NTWc = decltype(ntw)::value;
-            auto both = [&](auto cont) -> int {
-                constexpr bool C = decltype(cont)::value;
-                switch (variant) {
-                    case 0: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 1, 1, 0>, nullptr);
-                    case 1: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 2, 1, 0>, nullptr);
-                    case 2: {
-                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 0>, dz1_cache);
-                        if (rc2) return rc2;
-                        return dz1_cache ? launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 2>, dz1_cache)
-                                         : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 2, 1>, nullptr);
-                    }
-                    case 3: {
-                        const int rc2 = launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 0>, dz1_cache);
-                        if (rc2) return rc2;
-                        return dz1_cache ? launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 2>, dz1_cache)
-                                         : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 1>, nullptr);
-                    }
-                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>, nullptr);
-                }
-            };
-            return d->continuous ? both(std::true_type{}) : both(std::false_type{});
-        };
-        int lrc;
+        int n_pi = 0, n_vf = 0, lrc;
         {
             GradTimer timer(s);
-            lrc = L.H == 256 ? pick(std::integral_constant<int, 4>{}) : (L.H == 192 ? pick(std::integral_constant<int, 3>{}) : pick(std::integral_constant<int, 2>{}));
+            lrc = tma_launch_grad_wide_bf(params, L, R, M, hpar, ws_adv, slabs, slots, ws, &n_pi, &n_vf, s);
         }
         if (lrc) return lrc;
-        TMA_LAUNCH_CHECK();
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;

@@ -54,8 +54,107 @@ struct HParams {
     int debug;  // TMA_BF_DEBUG (profiling aid, default 0): bit mask of phases the bf16 wide kernel skips -- timing attribution only
 };
 
+struct Net {
+    const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
+};
+__device__ __forceinline__ Net pi_net(const float *p, const PLayout &L) {
+    return Net{p + L.pW1t, p + L.pb1, p + L.pW2t, p + L.pb2, p + L.pW3t, p + L.pb3, p + L.pW2, p + L.pW3};
+}
+__device__ __forceinline__ Net vf_net(const float *p, const PLayout &L) {
+    return Net{p + L.vW1t, p + L.vb1, p + L.vW2t, p + L.vb2, p + L.vW3t, p + L.vb3, p + L.vW2, p + L.vW3};
+}
+
+
+struct LossStats {
+    double a = 0.0, ent = 0.0, kl = 0.0, clip = 0.0, n = 0.0;
+};
+
+// clipped-surrogate + entropy gradient wrt the head outputs of one 16-row tile (C layout), written to dz3[16][ld3]
+template <bool CONT>
+__device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
+                                                 const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
+                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4) {
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r < r_lo || r >= r_hi) continue;  // (wave-uniform) a caller may split the four rows of a lane group over two waves
+        const int row = g * 4 + r;
+        const int64_t off = row_off[row];
+        const bool valid = off >= 0;
+        const float old = meta[row * 4 + 0];
+        const float advn = (meta[row * 4 + 1] - amean) / (astd + 1e-8f);
+        float lpa, ent;
+        float d[2] = {0.0f, 0.0f}, sd[2] = {1.0f, 1.0f}, p = 0.0f, lp = 0.0f;
+        int act = 0;
+        if constexpr (!CONT) {
+            const bool colok = r16 < A;
+            const float x = colok ? acc[0][r] : -INFINITY;
+            const float m = gmax16(x);
+            const float e = colok ? expf(x - m) : 0.0f;
+            const float s = gsum16(e);
+            const float lse = m + logf(s);
+            lp = colok ? x - lse : 0.0f;
+            p = e / s;
+            act = __float_as_int(meta[row * 4 + 3]);
+            lpa = gsum16((r16 == act) ? lp : 0.0f);
+            ent = -gsum16(p * lp);
+        } else {
+            float lpsum = 0.0f, entsum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = 16 * j + r16;
+                if (col < A) {
+                    const float lsd = log_std[col];
+                    sd[j] = expf(lsd);
+                    const float a = valid ? static_cast<const float *>(actions)[off * A + col] : 0.0f;
+                    d[j] = a - acc[j][r];
+                    lpsum += -(d[j] * d[j]) / (2.0f * (sd[j] * sd[j])) - lsd - 0.9189385332046727f;
+                    entsum += 1.4189385332046727f + lsd;
+                }
+            }
+            lpa = gsum16(lpsum);
+            ent = gsum16(entsum);
+        }
+        const float ratio = expf(lpa - old);
+        const float pl1 = advn * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+        const float pl2 = advn * rc;
+        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+        if constexpr (!CONT) {
+            float dl = g_lp * (((r16 == act) ? 1.0f : 0.0f) - p);
+            dl += valid ? (hp.ent_coef * invB) * (p * (lp + ent)) : 0.0f;
+            dz3[row * ld3 + r16] = (r16 < A) ? dl : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = 16 * j + r16;
+                const float var = sd[j] * sd[j];
+                dz3[row * ld3 + col] = (col < A) ? g_lp * (d[j] / var) : 0.0f;
+                if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
+            }
+        }
+        if (valid && r16 == 0) {
+            st.a += (double)(-fminf(pl1, pl2));
+            st.ent += (double)ent;
+            st.kl += (double)((ratio - 1.0f) - (lpa - old));
+            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+            st.n += 1.0;
+        }
+    }
+}
+
+// KT1C: k-tiles of dW1 kept in registers (1: D <= 16, 2: D <= 32), 0: layer-1 gradient accumulated in the slab, -1: dW1 skipped
+// (first of two passes).  PASS 1 = second pass for wide observations of known width: the forward / backward chain is recomputed and
+// ONLY dW1 (KT1C k-tiles) is accumulated and stored -- every other store is compiled out, so the MFMAs feeding only them vanish.
+// NQ1C > 0: layer-1 weights (16 * NQ1C >= D rows) also run through the ring, from the fragment image PLayout::fr1_pi.
 }  // namespace tma
 
 // tma_h64.hip: the H = 64 persistent gradient kernel (internal, not part of the C ABI)
 int tma_launch_grad_h64(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
                         const double *adv_part, int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s);
+
+// tma_bf16.hip: the column-parallel bf16-MFMA gradient kernel (hidden 128 / 192 / 256); `ws` is the update workspace (dz1 cache)
+int tma_launch_grad_wide_bf(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
+                            const float *ws_adv, float *slabs, double *slots, char *ws, int *n_pi_out, int *n_vf_out, hipStream_t s);
+// tma_policy.hip: zero the layer-1 weight columns of every slab (layouts that accumulate dW1 in place)
+int tma_launch_slab_zero_w1(float *slabs, int n_slabs, const tma::PLayout &L, hipStream_t s);

@@ -1,6 +1,6 @@
 // tma_wide_bf16.h -- bf16-MFMA variant of the column-parallel wide-policy kernels (hidden = 128 / 192 / 256).
 //
-// Included by tma_policy.hip inside namespace tma, after Net / Rollout / Minibatch / HParams / policy_loss_tile.
+// Included inside namespace tma (after tma_ppo_types.h) by tma_policy.hip (forward kernels, image builder) and tma_bf16.hip (gradient kernel).
 //
 // Why a second data path: BASELINE.json configs[2] names "PPO MLP(256,256) bf16".  With f32 MFMA operands the 256-wide
 // update re-streams 0.5 MB of f32 weights from L2 for every 32-sample row group and issues 4 flops/lane/cycle; with
@@ -77,7 +77,7 @@ __device__ __forceinline__ bf16x8 a_frag(const bf16_t *A, int ld, int row, int k
 }
 
 // rebuilds the fragment-major bf16 images of both nets from the f32 master weights ([in][out] flat layout)
-__global__ void build_bf16_images_kernel(float *params, PLayout L) {
+static __global__ void build_bf16_images_kernel(float *params, PLayout L) {
     const int D = L.D, H = L.H;
     const int Kp1 = (D + 31) & ~31, KS1 = Kp1 / 32, KS2 = H / 32;
     for (int net = 0; net < 2; net++) {
@@ -198,8 +198,16 @@ __device__ __forceinline__ BfNetPtr bf_net_ptr(const float *params, const PLayou
 }
 
 // LDS bytes of the gradient kernel for a row group of M = 16*MT samples
+// MT = 4 (64-row groups): one wave per row tile runs the whole head + loss, so there are no split-K partial sums; and from H = 192 on
+// dz3 (f32) and its two bf16 images live in the A1 image, which is dead between the layer-2 forward pass and the next group
+__host__ __device__ inline bool bf_alias_z3(int H, int MT) { return MT == 4 && H >= 192; }
 __host__ __device__ inline int grad_wide_bf_smem_bytes(int D, int H, int MT) {
     const int M = 16 * MT, Kp1 = (D + 31) & ~31;
+    if (MT == 4) {
+        const int z3 = bf_alias_z3(H, MT) ? 0 : (M * 48 + 32 * M) * 2 + M * 34 * 4;
+        const int bf4 = M * (Kp1 + 16) + Kp1 * M + 2 * M * (H + 16) + 2 * H * M;
+        return bf4 * 2 + z3 + (M * 4 + 128 + 2 * H + 32) * 4 + 4 * 4 * 5 * 8 + 2 * M * 8;
+    }
     const int bf = M * (Kp1 + 16) + Kp1 * M + 2 * M * (H + 16) + 2 * H * M + M * 48 + 32 * M;
     // + f32: dz3, meta, scratch, head partial sums [4 waves][MT][2][64][4], biases [2H + 32]; f64: stats [MT][4][5]; i64: row offsets x2
     return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + 4 * 4 * 5 * 8 + 2 * M * 8;
@@ -240,7 +248,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     constexpr int M = 16 * MT, MK = MT / 2, H = 64 * NTW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
     // weight stream of a row group: [layer-1 fragments when KS1C > 1: k-step outer, tile inner] [layer-2 forward] [layer-2 input-gradient]
     constexpr int S1 = KS1C > 1 ? KS1C * NTW : 0, SL = S1 + 2 * KS2 * NTW;
-    constexpr int R = bf_ring_slots(SL, 4 * NTW);  // largest divisor of SL not above four k-steps of fragments (slots are static registers)
+    // largest divisor of SL not above four k-steps of fragments (slots are static registers); 64-row groups: two k-steps (each k-step is
+    // twice the MFMA work, and the accumulators of four row tiles need the registers)
+    constexpr int R = bf_ring_slots(SL, (MT == 4 ? 2 : 4) * NTW);
     constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
     constexpr int NX = PF ? 2 * MT * KS1C : 1;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
@@ -280,10 +290,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     constexpr bool rmw_w1 = KT1C == 0 && KS1C == 0;             // dW1 accumulated in the slab (runtime width)
     constexpr int KT1A = KT1C > 0 ? KT1C : (PASS >= 1 ? 2 * KS1C : 1);
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *Xt = Xa + M * ldx, *A1 = Xt + Kp1 * M, *A2 = A1 + M * lda;
-    bf16_t *T1 = A2 + M * lda, *T2 = T1 + H * M, *Z3a = T2 + H * M, *Z3t = Z3a + M * ldz;
-    float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M), *meta = dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
-    float *hpart = scratch + 128;              // [4 waves][MT][2][64 lanes][4]: split-K partial head outputs
-    float *bias = hpart + 4 * MT * 2 * 256;    // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
+    bf16_t *T1 = A2 + M * lda, *T2 = T1 + H * M;
+    constexpr bool Z3_IN_A1 = MT == 4 && H >= 192;  // == bf_alias_z3(H, MT): A1 is dead from the barrier behind P2 to the next group's P1
+    bf16_t *Z3a = Z3_IN_A1 ? A1 : T2 + H * M, *Z3t = Z3a + M * ldz;
+    float *dz3 = reinterpret_cast<float *>(Z3t + 32 * M);
+    float *meta = Z3_IN_A1 ? reinterpret_cast<float *>(T2 + H * M) : dz3 + M * ld3, *scratch = meta + M * 4;  // scratch: 128 floats
+    float *hpart = scratch + 128;              // MT = 2: [4 waves][MT][2][64 lanes][4] split-K partial head outputs (MT = 4: none)
+    float *bias = hpart + (MT == 4 ? 0 : 4 * MT * 2 * 256);  // b1[H], b2[H], b3[32] (zero padded): LDS copies, no global load in front of a phase
     double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [4 waves][4][5] loss statistics (lanes r16 == 0)
     int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + 4 * 4 * 5), *row_off_next = row_off + M;
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
@@ -313,6 +326,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
         if (s < S1) return bf_frag(W.fW1, (nt0l + s % NTW) * (KS1C > 0 ? KS1C : 1) + s / NTW, lane);
         const int u = s - S1;
+        if constexpr (MT == 4) {
+            // 64-row groups walk each H x H stream in two halves of NTW / 2 column tiles (k-step outer, tile inner within a half): the four
+            // row tiles of half the columns are all the accumulators a phase holds at once (32 registers instead of 64)
+            constexpr int NH = NTW / 2, PER = KS2 * NH;
+            const int v = u % (2 * PER), jh = v / PER, rem = v % PER, j = jh * NH + rem % NH, ks = rem / NH;
+            return bf_frag(u < 2 * PER ? W.fW2 : W.bW2, (nt0l + j) * KS2 + ks, lane);
+        }
         if (u < KS2 * NTW) return bf_frag(W.fW2, (nt0l + u % NTW) * KS2 + u / NTW, lane);
         const int t = u - KS2 * NTW;
         return bf_frag(W.bW2, (nt0l + t % NTW) * KS2 + t / NTW, lane);
@@ -567,11 +587,69 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * MT + mt) * 2 + q) * 64 + lane) * 4) = part[q];
             }
         };
+        bf16x8 w3all[MT == 4 ? KS2 * NT3 : 1];  // MT = 4: every head fragment (this wave runs the whole head of its row tile)
         if (!(dbg & 32)) {
+            if constexpr (MT == 4) {
 #pragma unroll
-            for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase
+                for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
-                for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (head_ks(i) < KS2 ? head_ks(i) : 0), lane);
+                    for (int q = 0; q < NT3; q++) w3all[ks * NT3 + q] = bf_frag(W.fW3, q * KS2 + ks, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase
+#pragma unroll
+                    for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (head_ks(i) < KS2 ? head_ks(i) : 0), lane);
+            }
+            if constexpr (MT == 4) {
+                static_assert(NTW % 2 == 0 && S1 == 0, "64-row groups: even column-tile count, single layer-1 k-step");
+                constexpr int NH = NTW / 2;
+#pragma unroll
+                for (int jh = 0; jh < 2; jh++) {
+                    f32x4 acc[NH][MT];
+#pragma unroll
+                    for (int jj = 0; jj < NH; jj++) {
+                        const float b = bias[H + n_base + 16 * (jh * NH + jj) + r16];
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[jj][mt] = f32x4{b, b, b, b};
+                    }
+                    bf16x8 a[2][2];  // A fragments of two row tiles, half a k-step ahead
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+                        for (int hb = 0; hb < 2; hb++) {
+                            const int cur = hb, nb_ks = hb ? ks + 1 : ks, nb_h = hb ? 0 : 1;
+                            if (nb_ks < KS2) {
+#pragma unroll
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = a_frag(A1, lda, 16 * (nb_h * 2 + mt) + r16, nb_ks, g);
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < NH; jj++) {
+                                const int sp = jh * KS2 * NH + ks * NH + jj;
+#pragma unroll
+                                for (int mt = 0; mt < 2; mt++) acc[jj][hb * 2 + mt] = mfma_bf(a[cur][mt], ring[sp % R], acc[jj][hb * 2 + mt]);
+                                if (hb) ring[sp % R] = sload((sp + R) % SL);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    if (jh == 1 && has_next) fetch_meta(grp + n_blocks_net, true);  // (placement: see the 32-row path below)
+#pragma unroll
+                    for (int jj = 0; jj < NH; jj++) {
+                        const int n = n_base + 16 * (jh * NH + jj) + r16;
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) {
+                            bf16x4 q;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                q[r] = (bf16_t)tma_tanh(acc[jj][mt][r]);
+                                A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                            }
+                            *t_quad<MT>(T2, n, mt, g) = q;
+                        }
+                    }
+                }
+            } else {
             f32x4 acc[NTW][MT];
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
@@ -579,23 +657,30 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) acc[j][mt] = f32x4{b, b, b, b};
             }
-            bf16x8 a[2][MT];  // A fragments one k-step ahead (the scheduler is fenced per k-step: the pipeline below is explicit)
+            // A fragments one k-step ahead (the scheduler is fenced per k-step: the pipeline below is explicit).  64-row groups: half a
+            // k-step ahead -- tiles 2, 3 of the step are read while tiles 0, 1 multiply (16 registers instead of 32)
+            constexpr int AH = MT == 4 ? 2 : MT;  // row tiles per A-fragment batch
+            bf16x8 a[2][AH];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
-                if (ks + 1 < KS2) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) a[(ks + 1) & 1][mt] = a_frag(A1, lda, 16 * mt + r16, ks + 1, g);
+                for (int hb = 0; hb < MT / AH; hb++) {
+                    const int cur = (ks * (MT / AH) + hb) & 1, nb_ks = hb + 1 < MT / AH ? ks : ks + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
+                    if (nb_ks < KS2) {
+#pragma unroll
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = a_frag(A1, lda, 16 * (nb_h * AH + mt) + r16, nb_ks, g);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        const int s = S1 + ks * NTW + j;
+#pragma unroll
+                        for (int mt = 0; mt < AH; mt++) acc[j][hb * AH + mt] = mfma_bf(a[cur][mt], ring[s % R], acc[j][hb * AH + mt]);
+                        if (hb + 1 == MT / AH) ring[s % R] = sload((s + R) % SL);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int j = 0; j < NTW; j++) {
-                    const int s = S1 + ks * NTW + j;
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[ks & 1][mt], ring[s % R], acc[j][mt]);
-                    ring[s % R] = sload((s + R) % SL);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             // Next group's sample gathers (HBM-latency loads) go out HERE and at the top of P3: vmcnt retires in order, so the
             // first wait on a load issued after them also waits for them -- and from here on P3 / P4 / the first half of P5 only
@@ -615,7 +700,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     *t_quad<MT>(T2, n, mt, g) = q;
                 }
             }
-            if constexpr (OWNK) {  // head partial over this wave's own h2 columns: straight after its epilogue, no barrier in between
+            }
+            if constexpr (OWNK && MT != 4) {  // head partial over this wave's own h2 columns: straight after its epilogue, no barrier in between
                 if (!(dbg & 4)) head_partial();
             }
         }
@@ -629,6 +715,81 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         fetch_obs();  // unconditional (a last group re-reads stale rows that are never committed): the load count after w3b stays known,
                       // so P4's wait for w3b is a counted vmcnt, not vmcnt(0) on these HBM gathers
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MT == 4) {
+            // ---- P3 (64-row groups): wave w owns row tile w -- whole head (the split-K summation order of bf_head, so the rollout's
+            // log-probabilities still match bit for bit), loss, and both bf16 images of dz3, with no block barrier in between ----
+            TMA_TICK(4);
+            if (!(dbg & 4)) {
+                const int mt = wave;
+                f32x4 part[4][NT3];
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int q = 0; q < NT3; q++) part[w][q] = z4;
+#pragma unroll
+                for (int i = 0; i < HK; i++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int ks = OWNK ? w * HK + i : w + 4 * i;
+                        if (ks < KS2) {
+                            const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                            for (int q = 0; q < NT3; q++) part[w][q] = mfma_bf(a, w3all[ks * NT3 + q], part[w][q]);
+                        }
+                    }
+                f32x4 out[NT3];
+#pragma unroll
+                for (int q = 0; q < NT3; q++) {
+                    const float b = bias[2 * H + 16 * q + r16];
+                    out[q] = f32x4{b, b, b, b};
+#pragma unroll
+                    for (int w = 0; w < 4; w++) out[q] += part[w][q];
+                }
+                LossStats st;
+                float *dzt = dz3 + mt * 16 * ld3;
+                if constexpr (IS_PI) {
+                    policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
+                                           lane);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = g * 4 + r;
+                        const bool valid = row_off[mt * 16 + row] >= 0;
+                        const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
+                        dzt[row * ld3 + r16] = (valid && r16 == 0) ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                        if (valid && r16 == 0) st.a += (double)(diff * diff);
+                    }
+                }
+                if (MAIN && r16 == 0) {
+                    double *sl = stat_lds + (wave * 4 + g) * 5;
+                    sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
+                }
+                // dz3 of this tile as bf16, row-major (Z3a) and transposed (Z3t); the f32 column sums feed the head bias gradient.
+                // (dzt was written by this wave: LDS operations of one wave execute in order, no barrier needed)
+                {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int a = 8 * g + j;
+                        v[j] = (bf16_t)(a < 16 * NT3 ? dzt[r16 * ld3 + a] : 0.0f);
+                    }
+                    *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
+                }
+                {
+                    const int a = lane & 31, half = lane >> 5;
+                    bf16x8 v;
+                    float c = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float x = a < 16 * NT3 ? dzt[(8 * half + j) * ld3 + a] : 0.0f;
+                        c += x;
+                        v[j] = (bf16_t)x;
+                    }
+                    ab3 += c;
+                    *reinterpret_cast<bf16x8 *>(Z3t + t_off<MT>(a, 16 * mt + 8 * half)) = v;
+                }
+            }
+        } else {
         if constexpr (!OWNK) {
             if (!(dbg & 4)) head_partial();
             __syncthreads();
@@ -636,7 +797,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         TMA_TICK(4);
         TMA_RELANE();
         // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2*(wave >> 1) .. +1 of each lane group) ----
-        static_assert(MT == 2, "the loss / dz3 split below assumes two row tiles and four waves");
+        static_assert(MT == 2 || MT == 4, "the loss / dz3 split below assumes two row tiles and four waves");
         if (!(dbg & 4)) {
             const int mt = wave & 1, r_lo = 2 * (wave >> 1);
             f32x4 out[NT3];
@@ -696,6 +857,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 *reinterpret_cast<bf16x8 *>(Z3t + t_off<MT>(a, 16 * mt + 8 * half)) = v;
             }
         }
+        }
         __syncthreads();
         TMA_TICK(5);
         TMA_RELANE();
@@ -741,53 +903,126 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         TMA_TICK(6);
         TMA_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dh1 = dz2 . W2^T for this wave's columns (weight ring) ----
-        f32x4 dh1[NTW][MT];
+        f32x4 dh1[MT == 4 ? 1 : NTW][MT];  // (64-row groups form dh1 half by half further down)
+        if constexpr (MT != 4) {
 #pragma unroll
-        for (int j = 0; j < NTW; j++)
+            for (int j = 0; j < NTW; j++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) dh1[j][mt] = z4;
+                for (int mt = 0; mt < MT; mt++) dh1[j][mt] = z4;
+        }
         if (!(dbg & 2)) {
             bf16x8 zb[NTW][MK];
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T2, n_base + 16 * j + r16, kk, g);
-            bf16x8 ta[4][MK];  // T1 fragments three k-tiles ahead
+            constexpr int TA = MT == 4 ? 2 : 4, TAH = TA - 1;  // T1 fragments TAH k-tiles ahead (64-row groups: one, the k-tile is twice the work)
+            bf16x8 ta[TA][MK];
 #pragma unroll
-            for (int kt = 0; kt < 3; kt++)
+            for (int kt = 0; kt < TAH; kt++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) ta[kt][kk] = t_frag<MT>(T1, 16 * kt + r16, kk, g);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < KT2; kt++) {
-                if (kt + 3 < KT2) {
+                if (kt + TAH < KT2) {
 #pragma unroll
-                    for (int kk = 0; kk < MK; kk++) ta[(kt + 3) & 3][kk] = t_frag<MT>(T1, 16 * (kt + 3) + r16, kk, g);
+                    for (int kk = 0; kk < MK; kk++) ta[(kt + TAH) % TA][kk] = t_frag<MT>(T1, 16 * (kt + TAH) + r16, kk, g);
                 }
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++)
 #pragma unroll
-                    for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma_bf(ta[kt & 3][kk], zb[j][kk], aW2[kt][j]);
+                    for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma_bf(ta[kt % TA][kk], zb[j][kk], aW2[kt][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            TMA_RELANE();
-            bf16x8 a[2][MT];
+            if constexpr (MT == 4) {
+                if constexpr (KS1C == 1) {  // next group's layer-1 fragments
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
+                    for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0l + j, lane);
+                }
+            }
+        }
+        if constexpr (MT == 4) {
+            // 64-row groups: the barrier sits between dW2 (which reads every row of T1) and dh1, so that each half of dh1 can be turned into
+            // dz1 -- in place in this wave's own rows of T1 -- as soon as it is complete, and only 32 of its registers are live at a time
+            __syncthreads();
+            TMA_TICK(7);
+            TMA_RELANE();
+            constexpr int NH = NTW / 2;
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int jh = 0; jh < 2; jh++) {
+                    f32x4 dh[NH][MT];
+#pragma unroll
+                    for (int jj = 0; jj < NH; jj++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) dh[jj][mt] = z4;
+                    bf16x8 a[2][2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
+#pragma unroll
+                    for (int ns = 0; ns < KS2; ns++)
+#pragma unroll
+                        for (int hb = 0; hb < 2; hb++) {
+                            const int cur = hb, nb_ns = hb ? ns + 1 : ns, nb_h = hb ? 0 : 1;
+                            if (nb_ns < KS2) {
+#pragma unroll
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = a_frag(A2, lda, 16 * (nb_h * 2 + mt) + r16, nb_ns, g);
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < NH; jj++) {
+                                const int sp = KS2 * NTW + jh * KS2 * NH + ns * NH + jj;
+#pragma unroll
+                                for (int mt = 0; mt < 2; mt++) dh[jj][hb * 2 + mt] = mfma_bf(a[cur][mt], ring[sp % R], dh[jj][hb * 2 + mt]);
+                                if (hb) ring[sp % R] = sload((sp + R) % SL);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < NH; jj++) {
+                        const int j = jh * NH + jj, n = n_base + 16 * j + r16;
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) {
+                            bf16x4 *tq = t_quad<MT>(T1, n, mt, g);
+                            const bf16x4 h4 = *tq;
+                            bf16x4 q;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const float h = (float)h4[r];
+                                const float dz = dh[jj][mt][r] * (1.0f - h * h);
+                                ab1[j] += dz;
+                                q[r] = (bf16_t)dz;
+                            }
+                            *tq = q;
+                        }
+                    }
+                }
+            }
+        } else {
+        if (!(dbg & 2)) {
+            TMA_RELANE();
+            constexpr int AH = MT == 4 ? 2 : MT;
+            bf16x8 a[2][AH];
+#pragma unroll
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
 #pragma unroll
             for (int ns = 0; ns < KS2; ns++) {
-                if (ns + 1 < KS2) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) a[(ns + 1) & 1][mt] = a_frag(A2, lda, 16 * mt + r16, ns + 1, g);
+                for (int hb = 0; hb < MT / AH; hb++) {
+                    const int cur = (ns * (MT / AH) + hb) & 1, nb_ns = hb + 1 < MT / AH ? ns : ns + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
+                    if (nb_ns < KS2) {
+#pragma unroll
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = a_frag(A2, lda, 16 * (nb_h * AH + mt) + r16, nb_ns, g);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) {
+                        const int s = S1 + KS2 * NTW + ns * NTW + j;
+#pragma unroll
+                        for (int mt = 0; mt < AH; mt++) dh1[j][hb * AH + mt] = mfma_bf(a[cur][mt], ring[s % R], dh1[j][hb * AH + mt]);
+                        if (hb + 1 == MT / AH) ring[s % R] = sload((s + R) % SL);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int j = 0; j < NTW; j++) {
-                    const int s = S1 + KS2 * NTW + ns * NTW + j;
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) dh1[j][mt] = mfma_bf(a[ns & 1][mt], ring[s % R], dh1[j][mt]);
-                    ring[s % R] = sload((s + R) % SL);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (KS1C == 1) {  // next group's layer-1 fragments: P6 + P0 of latency cover
 #pragma unroll
@@ -816,6 +1051,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
                 *tq = q;
             }
+        }
         }
         {
             bf16x8 zb[NTW][MK];
@@ -921,12 +1157,15 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         float v0 = dlsd[0], v1 = dlsd[1];
         v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
         v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-        if (wave >= 2) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
+        if constexpr (MT == 4) {  // every wave holds the column sums of its row tile
+            if (lane < 32) scratch[wave * 32 + lane] = v;
+        } else if (wave >= 2) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
             if (lane < 32) scratch[(wave - 2) * 32 + lane] = v;
         }
         __syncthreads();
         if (wave == 0 && lane < 32) {
-            const float s = scratch[lane] + scratch[32 + lane];
+            float s = scratch[lane] + scratch[32 + lane];
+            if constexpr (MT == 4) s = (s + scratch[64 + lane]) + scratch[96 + lane];
             if (lane < NOUT) gb3[lane] = s;
         }
         __syncthreads();

@@ -58,7 +58,7 @@ for i in range(0, len(args), 4):
         ws = m.workspace
         end_offs = ws.numel() - (((1 << 22) // 1024 + (1 << 22) // 256) * 16 + 8192 * 8)  # offsets cache ends before the epoch / norm partials
         tail = ws[end_offs - 64 * 4:end_offs].cpu().numpy().view("int64")  # last 64 int32 of the offsets cache
-        names = ["tail(prev P6 end)", "P0 commit", "P1", "P2", "P3a", "P3b", "P4", "P5", "P6+after-loop"]
+        names = ["tail: P6 (MT4: dh1+dz1+dW1) of prev group", "P0 commit", "P1 L1", "P2 L2fwd", "P3a", "P3 head+loss+Z3", "P4 dW3+dz2", "P5 (MT4: dW2 only)", "after loop"]
         for role, o in (("pi", 0), ("vf", 12)):
             v = tail[o:o + 9]
             print("   ", role, "cycles:", {n: int(x) for n, x in zip(names, v)}, "sum", int(v.sum()))
