@@ -85,7 +85,9 @@ def test_bf16_forward(D, H, A, cont):
 
 def _emulated_grad(sd, obs, actions, old_lp, adv, ret, hp):
     """Gradient of the PPO loss with the kernel's rounding points: bf16 weights / activations / back-propagated deltas as
-    GEMM operands, f32 everywhere else (loss, bias gradients, accumulation).  Returns (grads in SB3 naming, stats)."""
+    GEMM operands, f32 everywhere else (loss, accumulation).  The hidden-layer bias gradients are the column sums of the SAME bf16
+    deltas the weight gradients use (ones^T . dz on the MFMA -- what torch.autocast(bfloat16) computes too: grad_output is bf16
+    there); the head bias gradient sums the f32 loss gradient.  Returns (grads in SB3 naming, stats)."""
     cont = "log_std" in sd
     X = _bf(obs)
     acts, outs = {}, {}
@@ -117,10 +119,10 @@ def _emulated_grad(sd, obs, actions, old_lp, adv, ret, hp):
         grads[f"{head}.weight"], grads[f"{head}.bias"] = z3.t() @ h2, dz3.sum(0)
         dz2 = (z3 @ _bf(sd[f"{head}.weight"])) * (1 - h2 * h2)
         z2 = _bf(dz2)
-        grads[f"mlp_extractor.{prefix}.2.weight"], grads[f"mlp_extractor.{prefix}.2.bias"] = z2.t() @ h1, dz2.sum(0)
+        grads[f"mlp_extractor.{prefix}.2.weight"], grads[f"mlp_extractor.{prefix}.2.bias"] = z2.t() @ h1, z2.sum(0)
         dz1 = (z2 @ _bf(sd[f"mlp_extractor.{prefix}.2.weight"])) * (1 - h1 * h1)
         z1 = _bf(dz1)
-        grads[f"mlp_extractor.{prefix}.0.weight"], grads[f"mlp_extractor.{prefix}.0.bias"] = z1.t() @ X, dz1.sum(0)
+        grads[f"mlp_extractor.{prefix}.0.weight"], grads[f"mlp_extractor.{prefix}.0.bias"] = z1.t() @ X, z1.sum(0)
     if cont:
         grads["log_std"] = ls.grad
     stats = dict(policy_loss=pl.item(), value_loss=vl.item(), entropy_loss=(-entropy.mean()).item(),

@@ -22,11 +22,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units (5 instructions instead of ocml's ~40).
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units (5 instructions instead of ocml's ~40: v_mul, v_exp, v_add, v_rcp and
+// one explicit v_fma -- the library is built with -ffp-contract=off, which would split 1 - 2r into a multiply and a subtract).
 // Absolute error <= ~2e-7 over the whole range (saturates cleanly to +-1); the parity tolerance is 1e-5.
 __device__ __forceinline__ float tma_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x) = 2^(2x log2 e)
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // Flat parameter buffer (floats).  [0, P) is the trainable region in [in][out] ("t") layout; [P, total) holds the

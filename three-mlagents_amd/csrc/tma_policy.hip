@@ -1692,9 +1692,38 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
     auto hidden = [&](const Net &Q, bool is_pi) {  // X -> h1 -> h2 for this wave's columns, both row tiles
         if constexpr (BF) {
             const BfNetPtr W = bf_net_ptr(params, L, is_pi);
+            // every layer-2 weight fragment and bias of this wave is requested BEFORE layer 1 runs (the net of a block never changes, so
+            // the loads are also loop-invariant for the grid-stride modes): the 32 KiB stream's L2 round trips sit under the observation
+            // staging, layer 1 and its barrier instead of in front of every other k-step.  Same k order per accumulator as
+            // bf_hidden_layer, hence the same bits (the update kernel's forward pass must reproduce these log-probabilities).
+            constexpr int KS2 = H / 32;
+            bf16x8 w2[NTW][KS2];
+            float b2v[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) {
+#pragma unroll
+                for (int ks = 0; ks < KS2; ks++) w2[j][ks] = bf_frag(W.fW2, (wave * NTW + j) * KS2 + ks, lane);
+                b2v[j] = Q.b2[n_base + 16 * j + r16];
+            }
             bf_hidden_layer<NTW, 2, false>(Xa, ldxb, Kp1 >> 5, W.fW1, Q.b1, A1, lda, nullptr, n_base, lane);
             __syncthreads();
-            bf_hidden_layer<NTW, 2, false>(A1, lda, H / 32, W.fW2, Q.b2, A2, lda, nullptr, n_base, lane);
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) {
+                    const bf16x8 a = a_frag(A1, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) acc[j][mt] = mfma_bf(a, w2[j][ks], acc[j][mt]);
+                }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) A2[(16 * mt + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][mt][r]);
             __syncthreads();
             return;
         }

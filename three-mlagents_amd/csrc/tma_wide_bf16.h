@@ -306,11 +306,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     BfNetPtr W = bf_net_ptr(params, L, IS_PI);
     const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bf16_t one_bf = (bf16_t)1.0f;
+    const bf16x8 ones8 = bf16x8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
     f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
-    float ab1[NTW], ab2[NTW], ab3 = 0.0f, dlsd[2] = {0.0f, 0.0f};
+    f32x4 aB1[NTW], aB2[NTW];  // hidden-layer bias gradients: column sums of dz as ones^T . dz on the MFMA (every row of the tile holds the sum)
+    float ab3 = 0.0f, dlsd[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
-        ab1[j] = ab2[j] = 0.0f;
+        aB1[j] = aB2[j] = z4;
 #pragma unroll
         for (int i = 0; i < KT1A; i++) aW1[i][j] = z4;
 #pragma unroll
@@ -891,7 +894,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     for (int r = 0; r < 4; r++) {
                         const float h = (float)h4[r];
                         const float dz = dh[r] * (1.0f - h * h);
-                        ab2[j] += dz;
                         q[r] = (bf16_t)dz;
                         A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                     }
@@ -916,6 +918,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T2, n_base + 16 * j + r16, kk, g);
+            if constexpr (MAIN) {  // db2 += ones^T . dz2 (the bf16 deltas the weight gradient uses, f32 accumulate)
+#pragma unroll
+                for (int j = 0; j < NTW; j++)
+#pragma unroll
+                    for (int kk = 0; kk < MK; kk++) aB2[j] = mfma_bf(ones8, zb[j][kk], aB2[j]);
+            }
             constexpr int TA = MT == 4 ? 2 : 4, TAH = TA - 1;  // T1 fragments TAH k-tiles ahead (64-row groups: one, the k-tile is twice the work)
             bf16x8 ta[TA][MK];
 #pragma unroll
@@ -990,7 +998,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             for (int r = 0; r < 4; r++) {
                                 const float h = (float)h4[r];
                                 const float dz = dh[jj][mt][r] * (1.0f - h * h);
-                                ab1[j] += dz;
                                 q[r] = (bf16_t)dz;
                             }
                             *tq = q;
@@ -1046,7 +1053,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int r = 0; r < 4; r++) {
                     const float h = (float)h4[r];
                     const float dz = dh1[j][mt][r] * (1.0f - h * h);
-                    ab1[j] += dz;
                     q[r] = (bf16_t)dz;
                 }
                 *tq = q;
@@ -1059,6 +1065,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T1, n_base + 16 * j + r16, kk, g);
+            if constexpr (MAIN) {  // db1 += ones^T . dz1
+#pragma unroll
+                for (int j = 0; j < NTW; j++)
+#pragma unroll
+                    for (int kk = 0; kk < MK; kk++) aB1[j] = mfma_bf(ones8, zb[j][kk], aB1[j]);
+            }
             if constexpr (two_pass && MAIN) {
                 if (dz1c) {  // (block-uniform) leave this group's dz1 image for PASS 2: 16 lanes x 64 B rows = 1 KiB contiguous per store
                     bf16_t *gi = dz1c + grp * (int64_t)(H * M);
@@ -1136,10 +1148,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
         }
         if constexpr (MAIN) {
-            float v1 = ab1[j], v2 = ab2[j];
-            v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-            v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
-            if (g == 0) gb1[col] = v1, gb2[col] = v2;
+            if (g == 0) gb1[col] = aB1[j][0], gb2[col] = aB2[j][0];  // (rows of the ones^T . dz tiles are identical)
 #pragma unroll
             for (int q = 0; q < NT3; q++)
 #pragma unroll
