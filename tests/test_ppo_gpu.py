@@ -325,19 +325,23 @@ def test_gae_flags_equals_sb3_layout():
     assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref)
 
 
-@pytest.mark.parametrize("task,hidden,N", [("gridworld", 64, 200), ("push", 64, 200), ("ball3d", 64, 200), ("walljump", 64, 200), ("basic", 64, 200),
-                                           ("gridworld", 128, 200), ("gridworld", 64, 16400)])
-def test_native_rollout_equals_stepwise_composition(task, hidden, N):
-    """tma_rollout_collect (fused multi-step kernel for H=64 on gridworld/push/ball3d, per-step launches otherwise)
-    == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same RNG counters)."""
+@pytest.mark.parametrize("task,hidden,N,mfma", [("gridworld", 64, 200, "f32"), ("push", 64, 200, "f32"), ("ball3d", 64, 200, "f32"), ("walljump", 64, 200, "f32"),
+                                                ("basic", 64, 200, "f32"), ("gridworld", 128, 200, "f32"), ("gridworld", 64, 16400, "f32"),
+                                                # the 256-wide bf16 fused chunk (register-resident layer-2 weights, 32-env row groups; 200 = a ragged last group)
+                                                ("ball3d", 256, 200, "bf16"), ("gridworld", 256, 200, "bf16"), ("push", 256, 96, "bf16"), ("basic", 256, 40, "bf16"),
+                                                ("walljump", 256, 64, "bf16"), ("ball3d", 256, 200, "f32")])
+def test_native_rollout_equals_stepwise_composition(task, hidden, N, mfma):
+    """tma_rollout_collect (fused multi-step kernels: H=64 on gridworld/push/ball3d/walljump, 256-wide bf16 on every Discrete task;
+    per-step launches otherwise) == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same
+    RNG counters)."""
     from three_mlagents_amd import _lib
     from three_mlagents_amd.ppo import PPO
     from three_mlagents_amd.vec_env import HipVecEnv
 
     # N = 200: two-wave fused kernel (one tile per block); N = 16400: >= 1024 tiles, the four-tiles-per-block single-wave kernel
-    T = {"ball3d": 230, "gridworld": 130, "walljump": 170}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
+    T = {"ball3d": 230, "gridworld": 130, "walljump": 170, "basic": 60}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
     env = HipVecEnv(task, N, seed=3, ring_depth=16)
-    model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
+    model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
     assert model.collect_rollouts()
     b = {k: v.clone() for k, v in model.buf.items()}
     env2 = HipVecEnv(task, N, seed=3, ring_depth=16)
@@ -355,7 +359,7 @@ def test_native_rollout_equals_stepwise_composition(task, hidden, N):
         obs = out["obs"][0].clone()
         assert torch.equal(obs, b["obs"][t + 1])
     assert torch.equal(model.policy.predict_values(obs), b["last_values"])
-    if task in ("gridworld", "ball3d", "walljump"):
+    if task in ("gridworld", "ball3d", "walljump", "basic"):
         assert int(b["truncated"].sum()) > 0  # the timeout-bootstrap branch was exercised
     # GAE of the rollout vs the oracle on the same planes
     done = (b["terminated"] | b["truncated"]).float().cpu().numpy()

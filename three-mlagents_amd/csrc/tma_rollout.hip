@@ -6,8 +6,13 @@
 // and, after the last step, last_values = V(obs[T]).  Reference call path: model.learn() at
 // /root/reference/backend/mlagents/training.py:166-170 -> SB3 collect_rollouts (SURVEY.md §3.1 hot loop A, App. C.6).
 #include "tma_internal.h"
-#include "tma_mlp.h"
+#include "tma_ppo_types.h"
 
+#include <cstdlib>
+
+namespace tma {
+#include "tma_wide_bf16.h"  // bf16 fragment helpers and image layout shared with the update / forward kernels
+}  // namespace tma
 
 namespace tma {
 
@@ -332,6 +337,289 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused rollout chunk for the reference's default 256 x 256 policy on the bf16 MFMA (BASELINE configs[2] / [3] shapes: Ball3D, Push, ...
+// with observations of up to 32 floats and a Discrete head): ONE launch advances every env by n_steps vector steps.
+// A block of 8 waves owns a row group of 32 envs for the whole chunk.  Waves 0..3 carry the POLICY net, waves 4..7 the VALUE net, each
+// wave 64 output columns of both hidden layers -- and every weight fragment a wave needs (4 of W1, 32 of W2, 8 of the head for the two
+// head waves of a net: 176 registers) is loaded ONCE per launch and stays in registers, so a vector step touches global memory only
+// to write its results (and to read a reset record when an episode ends).  Per step: layer 1 -> barrier -> layer 2 -> barrier ->
+// {policy head, softmax, sample, env step of the 32 owner lanes, next observation into LDS | value head} -> barrier, and -- only when a
+// row hit its time limit in this step (block-uniform flag) -- the value net once more on the terminal observations for the timeout bootstrap.
+// The non-fused path pays two launches, the observation's HBM round trip and four dependent L2 weight-load latencies per step
+// (13.5 us per vector step at 4096 envs); the forward arithmetic here is instruction for instruction that of policy_fwd_wide_kernel<BF>
+// (same k order per accumulator, same split-K head order), so actions, log-probs, values and rewards are bit-identical to it.
+// ------------------------------------------------------------------------------------------
+struct WideLds {
+    static constexpr int M = 32, H = 256, NTW = 4, KS2 = H / 32, LDA = H + 16, LDX = 48;  // LDX: 32 observation columns + 16 (A-image stride rule)
+    // observation + terminal-observation images, two activation images per net, W1 fragments [8 waves][4][64 lanes][8], head fragments
+    // [2 nets][8][64][8] (only the layer-2 fragments -- 128 registers a wave -- stay in registers), bootstrap scratch
+    static constexpr int bytes() { return (2 * M * LDX + 4 * M * LDA + 8 * NTW * 512 + 2 * KS2 * 512) * 2 + (32 + 32 + 4) * 4; }
+};
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
+                                                                       uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    constexpr int M = WideLds::M, H = WideLds::H, NTW = WideLds::NTW, KS2 = WideLds::KS2, lda = WideLds::LDA, ldx = WideLds::LDX, D = T::OBS;
+    static_assert(D <= 32 && T::NACT > 0, "fused wide rollout: observations of up to 32 floats, Discrete actions");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool is_pi = wave < 4;
+    const int w4 = wave & 3, n_base = w4 * 16 * NTW, mt = w4 & 1;  // mt: the row tile the two head waves of a net (w4 < 2) finish
+    const int A = L.A;
+    bf16_t *Xa = reinterpret_cast<bf16_t *>(smem_w), *XTa = Xa + M * ldx;
+    bf16_t *A1 = XTa + M * ldx + (is_pi ? 0 : 2 * M * lda), *A2 = A1 + M * lda;  // per-net activation images
+    bf16_t *W1l = XTa + M * ldx + 4 * M * lda + wave * NTW * 512, *W3l = XTa + M * ldx + 4 * M * lda + 8 * NTW * 512 + (is_pi ? 0 : KS2 * 512);
+    float *rw = reinterpret_cast<float *>(XTa + M * ldx + 4 * M * lda + 8 * NTW * 512 + 2 * KS2 * 512);  // [32] reward of a truncated row before the bootstrap
+    int *trf = reinterpret_cast<int *>(rw + 32), *flag = trf + 32;               // [32] row truncated in this step; [1] any of them
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x * M;
+    // ---- this wave's weights: registers for the whole launch ----
+    const Net Q = is_pi ? pi_net(params, L) : vf_net(params, L);
+    const BfNetPtr W = bf_net_ptr(params, L, is_pi);
+    bf16x8 w2[NTW][KS2];
+    float b1v[NTW], b2v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        // layer-1 fragments (one k-step of 32, zero rows beyond D) and the head fragments wait in LDS: a fragment is the wave's own 1 KiB
+        // (16 bytes per lane, conflict-free), read back right where the MFMA needs it
+        *reinterpret_cast<bf16x8 *>(W1l + (j * 64 + lane) * 8) = bf_frag(W.fW1, w4 * NTW + j, lane);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) w2[j][ks] = bf_frag(W.fW2, (w4 * NTW + j) * KS2 + ks, lane);
+        b1v[j] = Q.b1[n_base + 16 * j + r16];
+        b2v[j] = Q.b2[n_base + 16 * j + r16];
+    }
+    if (w4 == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) *reinterpret_cast<bf16x8 *>(W3l + (ks * 64 + lane) * 8) = bf_frag(W.fW3, ks, lane);
+    }
+    const int n_out = is_pi ? A : 1;
+    const float b3v = r16 < n_out ? Q.b3[r16] : 0.0f;
+    // ---- env state of the 32 owner lanes (policy head waves 0 / 1, lanes r16 < 4: row = 16 mt + 4 g + r16) ----
+    const int my_row = mt * 16 + g * 4 + r16;
+    const int64_t i = row0 + my_row;
+    const bool owner = wave < 2 && r16 < 4 && i < N;
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    if (owner) {
+        T::unpack(v.st, N, i, s);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int e = threadIdx.x; e < M * ldx; e += blockDim.x) {  // observation image of step t0 (columns >= D stay zero for the whole launch)
+        const int row = e / ldx, c = e - row * ldx;
+        Xa[e] = (bf16_t)((row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f);
+        XTa[e] = (bf16_t)0.0f;
+    }
+    if (threadIdx.x == 0) flag[0] = 0;
+    __syncthreads();
+    // X -> A1 -> A2 for this wave's 64 columns and both row tiles: the arithmetic of bf_hidden_layer with the fragments already in registers
+    auto hidden = [&](const bf16_t *X) {
+        f32x4 acc[NTW][2];
+#pragma unroll
+        for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+#pragma unroll
+        for (int m2 = 0; m2 < 2; m2++) {
+            const bf16x8 a = a_frag(X, ldx, 16 * m2 + r16, 0, g);
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W1l + (j * 64 + lane) * 8), acc[j][m2]);
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; j++)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; m2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; m2++) {
+                const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+#pragma unroll
+                for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
+            }
+#pragma unroll
+        for (int j = 0; j < NTW; j++)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; m2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+        __syncthreads();
+    };
+    // head of row tile mt in the summation order of bf_head (four partial sums over k-steps 2w', 2w' + 1, added to the bias in order)
+    auto head = [&]() -> f32x4 {
+        f32x4 part[4];
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++) part[wq] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++) {
+                const int ks = wq * 2 + i2;
+                part[wq] = mfma_bf(a_frag(A2, lda, 16 * mt + r16, ks, g), *reinterpret_cast<const bf16x8 *>(W3l + (ks * 64 + lane) * 8), part[wq]);
+            }
+        f32x4 out = f32x4{b3v, b3v, b3v, b3v};
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++) out += part[wq];
+        return out;
+    };
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        hidden(Xa);  // (two barriers inside: every wave of the block takes part)
+        if (w4 < 2) {
+            const f32x4 acc = head();
+            if (!is_pi) {
+                if (r16 == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + mt * 16 + g * 4 + r;
+                        if (row < N) b.values[(int64_t)t * N + row] = acc[r];
+                    }
+            } else {
+                int my_act = 0;
+                float my_lp = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + mt * 16 + g * 4 + r;
+                    const bool colok = r16 < A;
+                    const float x = colok ? acc[r] : -INFINITY;
+                    const float m = gmax16(x);
+                    const float e = colok ? expf(x - m) : 0.0f;
+                    const float sm = gsum16(e);
+                    const float lse = m + logf(sm);
+                    const float lp = x - lse;
+                    const float c = gscan16(e / sm);
+                    const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                    const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                    const int act = min((int)cnt, A - 1);
+                    const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                    if (r16 == r) my_act = act, my_lp = lpa;
+                }
+                bool tr_flag = false;
+                if (owner) {
+                    const int64_t off = (int64_t)t * N + i;
+                    b.actions[off] = my_act;
+                    b.log_probs[off] = my_lp;
+                    double r;
+                    bool done;
+                    T::step(s, my_act, nullptr, r, done);
+                    const int steps = T::steps(s);
+                    bool te, tr;
+                    if constexpr (T::NATIVE_TRUNC_RULE) {  // backend/mlagents/envs.py:76
+                        te = done;
+                        tr = (steps >= T::MAXSTEPS) && !te;
+                    } else {  // adapter rule, backend/mlagents/envs.py:139-145
+                        const bool hit = steps >= T::MAXSTEPS;
+                        te = done && !hit;
+                        tr = hit;
+                    }
+                    er += r;
+                    const float rew32 = (float)r;
+                    b.terminated[off] = (uint8_t)te;
+                    b.truncated[off] = (uint8_t)tr;
+                    float o[D];
+                    if (te || tr) {
+                        if (tr) {
+                            T::obs(s, o);
+#pragma unroll
+                            for (int c = 0; c < D; c++) XTa[my_row * ldx + c] = (bf16_t)o[c];
+                            rw[my_row] = rew32;
+                        }
+                        sret += er, slen += (double)steps, scnt += 1.0;
+                        er = 0.0;
+                        ce += 1;
+                        if constexpr (T::USES_MT) {
+                            uint32_t rec[T::RW > 0 ? T::RW : 1];
+                            const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
+#pragma unroll
+                            for (int q = 0; q < T::RW; q++) rec[q] = slot[(int64_t)q * N];
+                            T::from_rec(rec, s);
+                        } else {
+                            T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+                        }
+                    }
+                    T::obs(s, o);
+                    float *dst = b.obs + ((int64_t)(t + 1) * N + i) * D;
+#pragma unroll
+                    for (int c = 0; c < D; c++) dst[c] = o[c];
+#pragma unroll
+                    for (int c = 0; c < D; c++) Xa[my_row * ldx + c] = (bf16_t)o[c];  // every layer-1 read of this step's image is behind hidden()'s barriers
+                    if (!tr) b.rewards[off] = rew32;  // truncated rows: the value head waves write reward + bootstrap below
+                    trf[my_row] = tr ? 1 : 0;
+                    tr_flag = tr;
+                }
+                if (__ballot(tr_flag) != 0ull && lane == 0) atomicOr(flag, 1);
+            }
+        }
+        __syncthreads();
+        if (flag[0]) {  // (block-uniform) timeout bootstrap of this step: rewards = reward + gamma * V(terminal observation) where truncated
+            if (!is_pi) {
+                hidden(XTa);
+                if (w4 < 2) {
+                    const f32x4 vt = head();
+                    if (r16 == 0)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = mt * 16 + g * 4 + r;
+                            if (row0 + row < N && trf[row]) {
+                                const float gv = gamma * vt[r];
+                                b.rewards[(int64_t)t * N + row0 + row] = rw[row] + gv;
+                            }
+                        }
+                }
+            } else {
+                __syncthreads();  // the policy waves keep the value waves' two barriers company
+                __syncthreads();
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) flag[0] = 0;
+            if (threadIdx.x < 32) trf[threadIdx.x] = 0;
+            __syncthreads();
+        }
+    }
+    if (owner) {
+        T::pack(v.st, N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    if (wave < 2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sret += __shfl_down(sret, o, 64);
+            slen += __shfl_down(slen, o, 64);
+            scnt += __shfl_down(scnt, o, 64);
+        }
+        if (lane == 0 && scnt > 0.0) {
+            double *slot = v.stats + (row0 >> 8) * 3;
+            atomicAdd(slot + 0, sret);
+            atomicAdd(slot + 1, slen);
+            atomicAdd(slot + 2, scnt);
+        }
+    }
+}
+
+template <class T>
+static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
+                             uint32_t rng_step0, float gamma, hipStream_t s) {
+    if constexpr (T::OBS <= 32 && T::NACT > 0) {
+        auto k = rollout_chunk_wide_bf_kernel<T>;
+        const int smem = WideLds::bytes();
+        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    } else {
+        return fail(TMA_ERR_INVALID, "no fused wide rollout for this task");
+    }
+}
+
 template <class T>
 static int launch_chunk(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed, uint32_t rng_step0,
                         float gamma, hipStream_t s) {
@@ -370,6 +658,34 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     const bool fused = L.img_pi >= 0 && env->is_reset &&
                        (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D || env->task == TMA_TASK_WALLJUMP) &&
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
+    // 256-wide bf16 policies on the Discrete tasks with observations of up to 32 floats: fused chunk with register-resident weights
+    static const bool no_wide_fused = getenv("TMA_NO_WIDE_FUSED") != nullptr;  // test hook: the per-step composition
+    const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && !d->continuous && env->is_reset && env->task != TMA_TASK_CRAWLER &&
+                            d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
+    if (fused_wide) {
+        TMA_HIP(hipSetDevice(env->device));
+        ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
+        int t = t_begin;
+        while (t < t_end) {
+            int left = 0;
+            int rc = tma_env_steps_until_refill(env, &left);
+            if (rc) return rc;
+            const int n = left < (t_end - t) ? left : (t_end - t);
+            rc = dispatch_task(env->task, [&](auto task) {
+                using TT = decltype(task);
+                return launch_chunk_wide<TT>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            });
+            if (rc) return rc;
+            rc = tma_env_internal_after_steps(env, n, stream);
+            if (rc) return rc;
+            t += n;
+        }
+        if (compute_last_values && t_end == T) {
+            if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
+            return tma_policy_values(params, d, b->obs + (int64_t)T * N * d->obs_dim, N, b->last_values, stream);
+        }
+        return TMA_OK;
+    }
     if (fused) {
         TMA_HIP(hipSetDevice(env->device));
         ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
