@@ -36,8 +36,14 @@ def run(task, n, depth, iters, per_launch):
     steps = iters * depth
     sps = n * steps / (ms * 1e-3)
     eng.close()
-    return dict(task=task, n_envs=n, ring_depth=depth, steps_per_launch=per_launch, vector_steps=steps, ms=ms, env_steps_per_s=sps,
-                alg_GBps=sps * B_STEP[task] / 1e9, frac_of_8TBps=sps * B_STEP[task] / 8e12)
+    rec = dict(task=task, n_envs=n, ring_depth=depth, steps_per_launch=per_launch, vector_steps=steps, ms=ms, env_steps_per_s=sps)
+    if per_launch == 1:  # state in and out of HBM every step: the SURVEY 8d bytes are what the launch moves
+        rec.update(alg_GBps=sps * B_STEP[task] / 1e9, frac_of_8TBps=sps * B_STEP[task] / 8e12)
+    else:  # the state stays in registers between the steps of a launch: only outputs (obs + reward + 2 flags) leave per step; NOT a roofline figure
+        out_bytes = {"basic": 84 + 6, "gridworld": 16 + 6, "ball3d": 24 + 6, "push": 16 + 6, "crawler": 688 + 6}[task]
+        rec.update(output_bytes_per_env_step=out_bytes, output_GBps=sps * out_bytes / 1e9,
+                   note="multi-step launch: state is register-resident, SURVEY-formula bytes do not apply; throughput figure only")
+    return rec
 
 
 if __name__ == "__main__":
