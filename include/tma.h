@@ -194,6 +194,14 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
  * itself (one launch instead of three).  Falls back to tma_ppo_adam_step(grad_scale = 1) for shapes without that fast path. */
 int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *exp_avg_sq, const tma_policy_dims *d, int64_t step, double lr,
                             double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int64_t last_count);
+/* One whole epoch of PPO.train on ONE GPU in a single call: [tma_ppo_epoch_prepare] + for every minibatch of batch_size rows of the
+ * (perm_seed, perm_epoch) permutation: tma_ppo_minibatch_grad + tma_ppo_adam_step_local, issued natively with no host-language round trip
+ * in between (at the reference's literal batch_size = 256 and 4096 envs an epoch is 16 384 optimizer steps: backend/mlagents/training.py:379).
+ * first_step = Adam step index of the epoch's first minibatch (>= 1); grad must be zero on entry and is zero on return.  Bit-identical to the
+ * per-minibatch calls. */
+int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
+                              int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
+                              double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
 /* Profiling aid for bench.py's roofline object: when enabled, tma_ppo_minibatch_grad brackets its DOMINANT kernel (the persistent
  * forward+backward kernel; for two-pass shapes both passes; not the advantage pass, not the slab reduction) with HIP events recorded on
  * the stream it launches on; tma_debug_last_grad_kernel_us waits for the last bracketed launch and returns its duration. */

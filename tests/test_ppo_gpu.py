@@ -542,3 +542,51 @@ def test_global_advantage_statistics_of_a_two_rank_minibatch(D, H, A, cont):
         mb = _lib.Minibatch(_lib.ptr(ranks[0]["idx"]), 0, 0, 0, B, 0, 2 * B)
         _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(ranks[0]["rv"]), C.byref(mb), C.byref(hpar),
                                             _lib.ptr(torch.zeros(pol.n_trainable, device=dev)), _lib.ptr(ranks[0]["ws"]), _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("task,hidden,mfma,batch", [("gridworld", 64, "f32", 256), ("gridworld", 64, "f32", 4096), ("ball3d", 256, "bf16", 2048), ("push", 64, "f32", 1024)])
+def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch):
+    """tma_ppo_train_epoch_local (one call per epoch) against the same epoch issued minibatch by minibatch through tma_ppo_epoch_prepare +
+    tma_ppo_minibatch_grad + tma_ppo_adam_step_local: bit-identical parameters, derived images and optimizer state; deterministic.
+    (batch 256 / 1024 / 2048 on 64-wide nets also exercise the small-minibatch gradient kernel: 4-wave blocks, one tile per wave.)"""
+    from three_mlagents_amd import _lib
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def build():
+        env = make_vector_env(task, n_envs=64, seed=4)
+        m = PPO("MlpPolicy", env, n_steps=64, batch_size=batch, n_epochs=2, seed=4, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
+        m.collect_rollouts()
+        return env, m
+
+    env_a, a = build()
+    a.train()  # native epoch loop
+    env_b, b = build()
+    assert torch.equal(a.buf["advantages"], b.buf["advantages"]) and torch.equal(a.buf["obs"], b.buf["obs"])
+    L, total = _lib.lib(), 64 * 64
+    perm_seed = (b.seed * 2654435761 + 12345) & 0xFFFFFFFF
+    step = 0
+    for epoch in range(2):
+        prepared = batch >= 256
+        if prepared:
+            ep = _lib.Minibatch(None, perm_seed, epoch, 0, total, 0)
+            _lib.check(L.tma_ppo_epoch_prepare(C.byref(b._rollout_view), C.byref(ep), batch, C.byref(b.policy.dims), _lib.ptr(b.workspace), b._stream()))
+        for start in range(0, total, batch):
+            cnt = min(batch, total - start)
+            mb = _lib.Minibatch(None, perm_seed, epoch, start, cnt, batch if prepared else 0)
+            _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(b.policy.params), C.byref(b.policy.dims), C.byref(b._rollout_view), C.byref(mb), C.byref(b._hp),
+                                                _lib.ptr(b.grad), _lib.ptr(b.workspace), b._stream()))
+            step += 1
+            _lib.check(L.tma_ppo_adam_step_local(_lib.ptr(b.policy.params), _lib.ptr(b.grad), _lib.ptr(b.exp_avg), _lib.ptr(b.exp_avg_sq),
+                                                 C.byref(b.policy.dims), step, b.learning_rate, 0.9, 0.999, 1e-5, b.max_grad_norm, _lib.ptr(b.workspace),
+                                                 b._stream(), cnt))
+    pa, pb = a.policy.params.cpu(), b.policy.params.cpu()  # trainable region AND every derived copy / image
+    assert a._adam_step == step and torch.isfinite(pa).all()
+    assert torch.equal(pa, pb) and torch.equal(a.exp_avg.cpu(), b.exp_avg.cpu()) and torch.equal(a.exp_avg_sq.cpu(), b.exp_avg_sq.cpu())
+    sa, sb = a.pop_train_stats(), b.pop_train_stats()
+    assert sa["train/n_samples"] == sb["train/n_samples"] == 2 * total and abs(sa["train/approx_kl"] - sb["train/approx_kl"]) < 1e-6
+    env_c, c = build()
+    c.train()
+    assert torch.equal(c.policy.params.cpu(), pa)  # run-to-run bitwise reproducible
+    for e in (env_a, env_b, env_c):
+        e.close()

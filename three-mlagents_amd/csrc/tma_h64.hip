@@ -386,14 +386,15 @@ __device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L
     if (idx < 104) return (IS_PI ? L.pb2 : L.vb2) + (idx - 100) * 16 + r16;
     return perm < NOUT ? (IS_PI ? L.pb3 : L.vb3) + perm : -1;
 }
-template <bool IS_PI>
+template <bool IS_PI, int NWV = 8>  // NWV: waves per block (8; small-minibatch blocks: 4)
 __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, NetAcc &acc, const PLayout &L, int D, int NOUT, float *slab) {
+    constexpr int QN = (FL_HALF + NWV - 1) / NWV;
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) acc.b1[nt] = xg_sum(acc.b1[nt]), acc.b2[nt] = xg_sum(acc.b2[nt]);
     acc.b3[0] = xg_sum(acc.b3[0]);
     // the sums stay in registers until both halves are done: a barrier behind global stores would wait out their round trip
     // (__syncthreads drains vmcnt), so every store is issued after the last barrier
-    float sums[2][7];
+    float sums[2][QN];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int base = half * FL_HALF, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
@@ -403,13 +404,13 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
             if (i < cnt) stage[(wave * FL_HALF + i) * 64 + lane] = acc_reg(acc, base + i);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int i = wave + 8 * q;
+        for (int q = 0; q < QN; q++) {
+            const int i = wave + NWV * q;
             float sum = 0.0f;
             if (i < cnt) {
                 sum = stage[i * 64 + lane];
 #pragma unroll
-                for (int w = 1; w < 8; w++) sum += stage[(w * FL_HALF + i) * 64 + lane];
+                for (int w = 1; w < NWV; w++) sum += stage[(w * FL_HALF + i) * 64 + lane];
             }
             sums[half][q] = sum;
         }
@@ -417,8 +418,8 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
 #pragma unroll
     for (int half = 0; half < 2; half++)
 #pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int i = wave + 8 * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
+        for (int q = 0; q < QN; q++) {
+            const int i = wave + NWV * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
             const int off = i < cnt ? slab_offset_t<IS_PI>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
             if (off >= 0) slab[off] = sums[half][q];
         }
@@ -443,7 +444,8 @@ __device__ __forceinline__ void chain64(const float *wrow, const f32x4 (&in)[4],
     }
 }
 
-template <bool IS_PI, int DT>
+// DIRECT (small minibatches): 4-wave blocks, one wave per SIMD, one tile per wave; the block reduction runs over four copies.
+template <bool IS_PI, int DT, bool DIRECT = false>
 __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
@@ -720,14 +722,18 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
 #endif
     // loss statistics first (their LDS scratch sits behind the staging area; the barriers inside flush_all_t publish it), the slab
     // stores last: nothing waits behind a global store
-    double *red = reinterpret_cast<double *>(smem + 8 * FL_HALF * 64);
+    double *red = reinterpret_cast<double *>(smem + (DIRECT ? 4 : 8) * FL_HALF * 64);  // statistics scratch behind the staging area
     double st[5] = {st_a, st_ent, st_kl, (double)st_clip, (double)st_n};
 #pragma unroll
     for (int q = 0; q < 5; q++)
         for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
     if (lane == 0)
         for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
-    flush_all_t<IS_PI>(smem, wave, lane, acc, L, D, NOUT, slab);  // (8 waves per block: tma_launch_grad_h64)
+    if constexpr (DIRECT) {
+        flush_all_t<IS_PI, 4>(smem, wave, lane, acc, L, D, NOUT, slab);  // 4-wave blocks of the small-minibatch kernel
+    } else {
+        flush_all_t<IS_PI>(smem, wave, lane, acc, L, D, NOUT, slab);  // (8 waves per block: tma_launch_grad_h64)
+    }
 #ifdef TMA_H64_TICKS
     if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][13] += __builtin_amdgcn_s_memtime() - loop_t1;
 #endif
@@ -757,6 +763,19 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
     }
 }
 
+// small minibatches (<= 128 tiles): 4-wave blocks, one wave per SIMD (no partner on the matrix pipe, 512 registers), one tile per wave
+template <int DT>
+__global__ __launch_bounds__(256, 1) void ppo_grad_h64_small_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+                                                                    const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
+                                                                    double *__restrict__ stat_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    float *slab = slabs + (int64_t)pair * L.P;
+    double *slot = stat_slots + (int64_t)pair * 8;
+    if ((blockIdx.x & 1) == 0) grad_h64t_body<true, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    else grad_h64t_body<false, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+}
+
 }  // namespace tma
 
 using namespace tma;
@@ -778,6 +797,20 @@ int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R,
     HParams hps = hpar;
     hps.debug = stagger;
     const int64_t tiles = ceil_div(M.count, 16);
+    if (ver == 2 && tiles <= H64_BLOCKS) {  // up to 2048 samples: one tile per wave, 4-wave blocks (a 256-sample minibatch: 4 + 4 blocks, 4 slabs)
+        const int64_t blocks = ceil_div(tiles, 4);
+        const int smem = (IMG_FLOATS + 4 * T_PER_WAVE) * 4;
+        auto launch_small = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            k<<<dim3((unsigned)(2 * blocks)), dim3(256), smem, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots);
+            return TMA_OK;
+        };
+        const int rc = L.D == 4 ? launch_small(ppo_grad_h64_small_kernel<4>) : (L.D == 6 ? launch_small(ppo_grad_h64_small_kernel<6>) : launch_small(ppo_grad_h64_small_kernel<0>));
+        if (rc) return rc;
+        TMA_LAUNCH_CHECK();
+        *n_slabs_out = (int)blocks;
+        return TMA_OK;
+    }
     const int wpb4 = 8, smem4 = grad_h64_smem_bytes(L, wpb4, ver);
     int64_t blocks4 = ceil_div(tiles, wpb4);
     if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;

@@ -2202,6 +2202,32 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     return TMA_OK;
 }
 
+int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch, int64_t batch_size,
+                              const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr, double beta1,
+                              double beta2, double eps, double max_grad_norm, void *workspace, void *stream) {
+    int rc = enter(d);
+    if (rc) return rc;
+    if (!params || !rb || !hp || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_local: null argument");
+    if (rb->T < 1 || rb->N < 1 || batch_size < 1 || first_step < 1) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_local: T, N, batch_size and first_step must be >= 1");
+    const int64_t total = (int64_t)rb->T * rb->N;
+    const bool prepared = total <= OFFS_CAP && batch_size >= 256;
+    if (prepared) {
+        const tma_minibatch ep{nullptr, perm_seed, perm_epoch, 0, total, 0, 0};
+        rc = tma_ppo_epoch_prepare(rb, &ep, batch_size, d, workspace, stream);
+        if (rc) return rc;
+    }
+    int64_t step = first_step;
+    for (int64_t start = 0; start < total; start += batch_size, step++) {
+        const int64_t count = start + batch_size <= total ? batch_size : total - start;
+        const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared ? batch_size : 0, 0};
+        rc = tma_ppo_minibatch_grad(params, d, rb, &mb, hp, grad, workspace, stream);
+        if (rc) return rc;
+        rc = tma_ppo_adam_step_local(params, grad, exp_avg, exp_avg_sq, d, step, lr, beta1, beta2, eps, max_grad_norm, workspace, stream, count);
+        if (rc) return rc;
+    }
+    return TMA_OK;
+}
+
 int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int64_t batch_size, const tma_policy_dims *d, void *workspace,
                           void *stream) {
     int rc = enter(d);

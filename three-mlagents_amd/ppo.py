@@ -290,7 +290,20 @@ class PPO:
             raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
         if global_stats and getattr(self, "_adv_sums", None) is None:
             self._adv_sums = torch.zeros(2 * ((total + self.batch_size - 1) // self.batch_size), dtype=torch.float64, device=self.device)
-        for _ in range(self.n_epochs):
+        if self.world_size == 1:
+            # one GPU: a whole epoch (prepare + every minibatch's gradient and optimizer step) is issued natively by ONE call -- at the
+            # reference's literal batch_size = 256 that is 16 384 optimizer steps without a host-language round trip in between
+            n_mb = (total + self.batch_size - 1) // self.batch_size
+            for _ in range(self.n_epochs):
+                _lib.check(L.tma_ppo_train_epoch_local(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view), perm_seed,
+                                                       self._epoch_counter & 0xFFFFFFFF, self.batch_size, C.byref(self._hp), _lib.ptr(self.grad),
+                                                       _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self._adam_step + 1, self.learning_rate, 0.9,
+                                                       0.999, 1e-5, self.max_grad_norm, _lib.ptr(self.workspace), self._stream()))
+                self._adam_step += n_mb
+                self._epoch_counter += 1
+            self._n_updates += self.n_epochs
+            return
+        for _ in range(self.n_epochs):  # data parallel: per-minibatch calls around the collectives
             if can_prepare:  # one launch per epoch: sample offsets of the permutation + advantage partials of every minibatch
                 ep = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, 0, total, 0)
                 _lib.check(L.tma_ppo_epoch_prepare(C.byref(self._rollout_view), C.byref(ep), self.batch_size, C.byref(self.policy.dims),
@@ -309,19 +322,13 @@ class PPO:
                                     count * self.world_size if global_stats else 0)
                 _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
                                                     C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
-                if self.world_size > 1:
-                    import torch.distributed as tdist
+                import torch.distributed as tdist
 
-                    tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
+                tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
                 self._adam_step += 1
-                if self.world_size == 1:  # grad is exactly the last minibatch's: norm partials + derived copies ride in one launch
-                    _lib.check(L.tma_ppo_adam_step_local(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
-                                                         _lib.ptr(self.exp_avg_sq), C.byref(self.policy.dims), self._adam_step, self.learning_rate,
-                                                         0.9, 0.999, 1e-5, self.max_grad_norm, _lib.ptr(self.workspace), self._stream(), mb.count))
-                else:
-                    _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                                   C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
-                                                   self.max_grad_norm, scale, _lib.ptr(self.workspace), self._stream()))
+                _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                               C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
+                                               self.max_grad_norm, scale, _lib.ptr(self.workspace), self._stream()))
             self._epoch_counter += 1
         self._n_updates += self.n_epochs
 

@@ -8,9 +8,9 @@ from three_mlagents_amd import _lib
 from three_mlagents_amd.ppo import PPO
 from three_mlagents_amd.harness import make_vector_env
 
-B = 131072
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 env = make_vector_env("gridworld", n_envs=4096, seed=1)
-m = PPO("MlpPolicy", env, n_steps=B // 4096, batch_size=B, n_epochs=1, seed=1, policy_kwargs={"net_arch": [64, 64]})
+m = PPO("MlpPolicy", env, n_steps=max(1, B // 4096), batch_size=B, n_epochs=1, seed=1, policy_kwargs={"net_arch": [64, 64]})
 m.collect_rollouts()
 mb = _lib.Minibatch(None, 1, 0, 0, B)
 L = _lib.lib()
@@ -27,7 +27,7 @@ for _ in range(reps):
     grad()
 L.tma_debug_h64_ticks(out, 0)
 names = ["L1+tanh1", "st h1+L2", "tanh2+st", "head", "loss", "st dz3+dW3", "dh2+dz2+st", "dW2", "dh1+dz1+st", "dW1", "", "", "", "", "", "loop top"]
-tiles = reps * (B // 16) // (128 * 8)
+tiles = max(1, reps * (B // 16) // (min(128, (B // 16 + 7) // 8) * 8))
 for net, o in (("pi", 0), ("vf", 16)):
     v = [out[o + i] / tiles for i in range(16)]
     print(net, "cycles per tile:", {n: round(x) for n, x in zip(names, v) if n}, "sum", round(sum(v[:10]) + v[15]))
