@@ -604,16 +604,16 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
             float ssum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                e[r] = ok[r] ? expf(x[r] - m) : 0.0f;
+                e[r] = ok[r] ? __expf(x[r] - m) : 0.0f;  // hardware exp2 / log2 / rcp (~1 ulp): the loss phase is the policy blocks' critical extra
                 ssum += e[r];
             }
             ssum = xg_sum(ssum);
-            const float lse = m + logf(ssum);
+            const float lse = m + __logf(ssum), rs = __builtin_amdgcn_rcpf(ssum);
             float lpa = 0.0f, ent = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 lp[r] = ok[r] ? x[r] - lse : 0.0f;
-                p[r] = e[r] / ssum;
+                p[r] = e[r] * rs;
                 lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
                 ent += p[r] * lp[r];
             }
@@ -621,7 +621,7 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
             ent = -xg_sum(ent);
             const float old = m0;
             const float advn = (m1 - amean) / (astd + 1e-8f);
-            const float ratio = expf(lpa - old);
+            const float ratio = __expf(lpa - old);
             const float pl1 = advn * ratio;
             const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
             const float pl2 = advn * rc;
