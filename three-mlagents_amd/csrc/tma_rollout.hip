@@ -418,38 +418,38 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
     __syncthreads();
     // X -> A1 -> A2 for this wave's 64 columns and both row tiles: the arithmetic of bf_hidden_layer with the fragments already in registers
     auto hidden = [&](const bf16_t *X) {
-        f32x4 acc[NTW][2];
-#pragma unroll
-        for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+        // (one row tile at a time: 16 accumulator registers live instead of 32 -- the 128 weight registers leave little room at 256 per wave;
+        //  the MFMA order per accumulator is unchanged)
 #pragma unroll
         for (int m2 = 0; m2 < 2; m2++) {
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
             const bf16x8 a = a_frag(X, ldx, 16 * m2 + r16, 0, g);
 #pragma unroll
-            for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W1l + (j * 64 + lane) * 8), acc[j][m2]);
+            for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W1l + (j * 64 + lane) * 8), acc[j]);
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
         }
-#pragma unroll
-        for (int j = 0; j < NTW; j++)
-#pragma unroll
-            for (int m2 = 0; m2 < 2; m2++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+        for (int m2 = 0; m2 < 2; m2++) {
+            f32x4 acc[NTW];
 #pragma unroll
-        for (int ks = 0; ks < KS2; ks++)
+            for (int j = 0; j < NTW; j++) acc[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
 #pragma unroll
-            for (int m2 = 0; m2 < 2; m2++) {
+            for (int ks = 0; ks < KS2; ks++) {
                 const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
 #pragma unroll
-                for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
+                for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(a, w2[j][ks], acc[j]);
             }
 #pragma unroll
-        for (int j = 0; j < NTW; j++)
+            for (int j = 0; j < NTW; j++)
 #pragma unroll
-            for (int m2 = 0; m2 < 2; m2++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
+        }
         __syncthreads();
     };
     // head of row tile mt in the summation order of bf_head (four partial sums over k-steps 2w', 2w' + 1, added to the bias in order)
