@@ -2066,7 +2066,7 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     hipStream_t s = (hipStream_t)stream;
     const PLayout L = layout_of(d);
     Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
-    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr, mbi->count};
+    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr, mbi->count, nullptr, 0};
     const bool prepared = mbi->prepared_batch > 0;
     if (mbi->stats_count != 0) {
         if (!prepared || mbi->stats_count < mbi->count)
@@ -2101,8 +2101,9 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         TMA_LAUNCH_CHECK();
         M.offs = offs;
     }
+    M.adv_part = adv_part, M.adv_n_part = nbk;
     if (hpar.normalize_advantage) {
-        if (!h64) {  // the H = 64 kernel folds the partials itself
+        if (!h64 && !L.bf16) {  // the H = 64 and bf16 wide kernels fold the partials themselves
             adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, M.stats_n, ws_adv);
             TMA_LAUNCH_CHECK();
         }
@@ -2245,7 +2246,7 @@ int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int
     if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
     const int64_t n_mb = ceil_div(total, batch_size);
     if (n_mb > 65535) return fail(TMA_ERR_INVALID, "too many minibatches per epoch (%lld)", (long long)n_mb);
-    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr, total};
+    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr, total, nullptr, 0};
     adv_partial_kernel<<<dim3(stride, (unsigned)n_mb), dim3(256), 0, (hipStream_t)stream>>>(
         rb->advantages, M, rb->T, rb->N, reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4), reinterpret_cast<int32_t *>(ws + offs_base), batch_size);
     TMA_LAUNCH_CHECK();

@@ -33,6 +33,8 @@ struct Minibatch {
     const int32_t *offs;          // optional: offs[j] = buffer offset of minibatch row j (written by adv_partial_kernel), saves the
                                   // permutation arithmetic in the gradient kernel
     int64_t stats_n;              // rows the advantage partials were summed over: count, or the global minibatch under data parallelism
+    const double *adv_part;       // (sum, sum of squares) partials of this minibatch's advantages, adv_n_part pairs: kernels that fold the
+    int adv_n_part;               // statistics themselves (H = 64, bf16 wide) read them; the others get (mean, std) from adv_final_kernel
 };
 
 __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {

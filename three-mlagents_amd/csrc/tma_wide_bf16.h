@@ -301,8 +301,28 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + 4 * 4 * 5), *row_off_next = row_off + M;
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
     const float invB = 1.0f / (float)mb.count;
-    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
-    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
+    // one-block launch in front of every minibatch
+    (void)ws_adv;
+    __shared__ float adv_ms[2];
+    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {
+        double a = 0.0, bsum = 0.0;
+        for (int k = threadIdx.x; k < mb.adv_n_part; k += 64) a += mb.adv_part[2 * k], bsum += mb.adv_part[2 * k + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            bsum += __shfl_down(bsum, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            const double n = (double)mb.stats_n, mean = a / n;
+            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            adv_ms[0] = (float)mean;
+            adv_ms[1] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
+    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
     const Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     BfNetPtr W = bf_net_ptr(params, L, IS_PI);
     const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
