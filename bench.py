@@ -440,6 +440,8 @@ def main():
                          f"`torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    if os.environ.get("TMA_BENCH_ONE_DEVICE"):  # test hook (with TMA_DIST_BACKEND=gloo): every rank on device 0 of a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -129,3 +129,25 @@ def test_bench_gpus_2_fails_cleanly_on_a_one_gpu_box():
         pytest.skip("multi-GPU box: `bench.py --gpus 2` would really run")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=280)
     assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The whole `bench.py --gpus 2` rank program (barriers, max-over-ranks timing, sharded envs, advantage-sum and gradient all-reduces,
+    rank-0-only roofline legs and JSON line) under torch.distributed.run with two ranks -- on this one-GPU box over gloo with both ranks on
+    device 0 (test hooks TMA_DIST_BACKEND / TMA_BENCH_ONE_DEVICE); on a multi-GPU node the same program runs one rank per GPU over RCCL."""
+    import json
+
+    env = dict(os.environ, TMA_DIST_BACKEND="gloo", TMA_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-envs", "512", "--n-steps", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512 and d["value"] > 0
+    assert d["value"] == pytest.approx(2 * 512 * 64 / (d["ms_per_step"] * 1e-3), rel=1e-6)  # whole-job env-steps of both ranks / max-over-ranks time
+    assert "roofline" in d and "cpu_baseline" not in d and "extra_configs" not in d  # CPU baseline and extras are N = 1 legs

@@ -42,8 +42,8 @@ def init_from_env(backend: str | None = None, single_rank_group: bool = False) -
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # (TMA_DIST_BACKEND=gloo: test hook -- several ranks on ONE GPU, which RCCL does not allow)
+            backend = os.environ.get("TMA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(lr)
             td.init_process_group(backend, rank=rk, world_size=ws, device_id=torch.device("cuda", lr))
