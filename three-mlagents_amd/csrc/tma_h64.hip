@@ -395,6 +395,15 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
     // the sums stay in registers until both halves are done: a barrier behind global stores would wait out their round trip
     // (__syncthreads drains vmcnt), so every store is issued after the last barrier
     float sums[2][QN];
+    // slab offsets of the registers this wave will sum: computed here, under the wait for the block's slowest wave, not behind the last barrier
+    int offs[2][QN];
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int q = 0; q < QN; q++) {
+            const int i = wave + NWV * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
+            offs[half][q] = i < cnt ? slab_offset_t<IS_PI>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
+        }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int base = half * FL_HALF, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
@@ -419,9 +428,7 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
     for (int half = 0; half < 2; half++)
 #pragma unroll
         for (int q = 0; q < QN; q++) {
-            const int i = wave + NWV * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
-            const int off = i < cnt ? slab_offset_t<IS_PI>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
-            if (off >= 0) slab[off] = sums[half][q];
+            if (offs[half][q] >= 0) slab[offs[half][q]] = sums[half][q];
         }
 }
 
