@@ -3,7 +3,7 @@
 // Replaces, for SB3's default-width MlpPolicy, what PPO.train computes per minibatch between RolloutBuffer.get and
 // optimizer.step (stable-baselines3 2.9.0, third party; constructed at /root/reference/backend/mlagents/training.py:150, driven by
 // model.learn() at training.py:166-170; formulas: SURVEY.md Appendix C.3 / C.5).  tma_policy.hip dispatches here.
-#include "tma_ppo_types.h"
+#include "tma_h64_tile.h"
 
 #include <cstdlib>
 
@@ -17,26 +17,6 @@ namespace tma {
 // (bitwise reproducible, no float atomics: the per-tile atomics of the generic kernel serialise on a 37 KB buffer).
 // Requirements: H == 64, D <= 16, Discrete head (A <= 16).
 // ------------------------------------------------------------------------------------------
-struct NetAcc {
-    f32x4 w1[1][4];
-    f32x4 w2[4][4];
-    f32x4 w3[4][1];
-    float b1[4], b2[4], b3[1];
-};
-
-__device__ __forceinline__ void zero_acc(NetAcc &a) {
-    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        a.w1[0][j] = z;
-        a.w3[j][0] = z;
-        a.b1[j] = 0.0f;
-        a.b2[j] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) a.w2[i][j] = z;
-    }
-    a.b3[0] = 0.0f;
-}
 
 template <int KT, int NT>
 __device__ __forceinline__ void bwd_weight_acc(const float *xin, int ldx, int K, const float *dz, int ldz, int N, f32x4 (&accW)[KT][NT],
@@ -293,99 +273,11 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
 // Activation tiles: [16][68] floats with the column index XOR-ed by 16 * (row & 1): the b128 stores of the chain (lane (g, s) holds
 // four consecutive features of sample s) and the transposed b32 reads of the weight-gradient operands are both conflict-free.
 // ------------------------------------------------------------------------------------------
-#ifdef TMA_H64_TICKS  // diagnostic build only (make CXXFLAGS+=-DTMA_H64_TICKS): per-phase issue-time stamps of wave 0 of blocks 0 / 1
-__device__ unsigned long long g_h64_ticks[2][16];
-#define H64_TICK(i)                                                                          \
-    do {                                                                                     \
-        const unsigned long long _t = __builtin_amdgcn_s_memtime();                          \
-        if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][i] += _t - tick_prev;          \
-        tick_prev = __builtin_amdgcn_s_memtime();                                            \
-    } while (0)
-#else
-#define H64_TICK(i) do {} while (0)
-#endif
-constexpr int LDT = 68;
-constexpr int T_PER_WAVE = 2 * 16 * LDT + 256 + 256;  // slot A, slot B, dz3 [16][16], X [16][16]
-__device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ ((row & 1) << 4)); }
-
-// all-reduce over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the lane groups holding one sample's 16 head outputs): VALU only
-template <class F>
-__device__ __forceinline__ float xg_reduce(float v, F op) {
-    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float xg_sum(float v) { return xg_reduce(v, [](float a, float b) { return a + b; }); }
-__device__ __forceinline__ float xg_max(float v) { return xg_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
-
-// lane (g, s) stores features 16mt + 4g .. + 3 of sample s: one b128 per output tile
-__device__ __forceinline__ void store_tile_t(float *tile, const f32x4 (&v)[4], int r16, int g) {
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4 *>(tile + tsw(r16, 16 * mt + 4 * g)) = v[mt];
-}
-
-// accW[kt][nt] += x[16 samples][16kt..]^T . dz[16 samples][16nt..]; accb[nt] += column sums of dz.  Operands are read transposed
-// (sample on the lane group / k index, feature on lane & 15) from [sample][feature] tiles: XS / ZS = swizzled [16][LDT] tile, else
-// a plain [16][16] tile.
-template <int KT, int NT, bool XS, bool ZS>
-__device__ __forceinline__ void bwd_weight_acc_t(const float *xin, const float *dz, f32x4 (&accW)[KT][NT], float (&accb)[NT], int lane) {
-    const int r16 = lane & 15, g = lane >> 4;
-    float bf[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-#pragma unroll
-        for (int s = 0; s < 4; s++) bf[nt][s] = ZS ? dz[tsw(4 * s + g, nt * 16 + r16)] : dz[(4 * s + g) * 16 + r16];
-        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
-        float a[4];
-        // (plain X tile: feature columns >= D hold stale LDS bytes; they only feed accumulator rows k >= D, which flush_segment never stores)
-#pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = XS ? xin[tsw(4 * s + g, kt * 16 + r16)] : xin[(4 * s + g) * 16 + r16];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
-    }
-}
 
 // ---- block reduction of the gradient accumulators (version 2): every wave stages its registers lane-for-lane (register-major:
 // conflict-free b32 stores at immediate offsets), then wave w sums registers w, w + 8, ... over the eight copies in wave order (the order
 // of flush_segment, so the bits match) and stores them to the slab.  Two halves of <= 56 registers keep the staging inside the tile
 // region's 112 KiB; all eight waves stay busy in both phases, against three store / barrier / strided-sum / barrier rounds before.
-constexpr int FL_HALF = 56, FL_REGS = 105;
-__device__ __forceinline__ float acc_reg(const NetAcc &a, int idx) {  // idx is a compile-time constant after unrolling
-    if (idx < 16) return a.w1[0][idx >> 2][idx & 3];
-    if (idx < 80) return a.w2[(idx - 16) >> 4][((idx - 16) >> 2) & 3][idx & 3];
-    if (idx < 96) return a.w3[(idx - 80) >> 2][0][idx & 3];
-    if (idx < 100) return a.b1[idx - 96];
-    if (idx < 104) return a.b2[idx - 100];
-    return a.b3[0];
-}
-// slab element of accumulator register idx in lane `lane` (-1: padding, nothing to store)
-template <bool IS_PI>
-__device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L, int D, int NOUT) {
-    const int r16 = lane & 15, g = lane >> 4;
-    const int perm = (r16 >> 2) + 4 * (r16 & 3);  // head: tile column m <-> output a(m)
-    if (idx < 16) {
-        const int k = 4 * g + (idx & 3), n = (idx >> 2) * 16 + r16;
-        return k < D ? (IS_PI ? L.pW1t : L.vW1t) + k * 64 + n : -1;
-    }
-    if (idx < 80) {
-        const int t = idx - 16, k = (t >> 4) * 16 + 4 * g + (t & 3), n = ((t >> 2) & 3) * 16 + r16;
-        return (IS_PI ? L.pW2t : L.vW2t) + k * 64 + n;
-    }
-    if (idx < 96) {
-        const int t = idx - 80, k = (t >> 2) * 16 + 4 * g + (t & 3);
-        return perm < NOUT ? (IS_PI ? L.pW3t : L.vW3t) + k * NOUT + perm : -1;
-    }
-    if (g != 0) return -1;  // bias sums are replicated over the lane groups
-    if (idx < 100) return (IS_PI ? L.pb1 : L.vb1) + (idx - 96) * 16 + r16;
-    if (idx < 104) return (IS_PI ? L.pb2 : L.vb2) + (idx - 100) * 16 + r16;
-    return perm < NOUT ? (IS_PI ? L.pb3 : L.vb3) + perm : -1;
-}
 template <bool IS_PI, int NWV = 8>  // NWV: waves per block (8; small-minibatch blocks: 4)
 __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, NetAcc &acc, const PLayout &L, int D, int NOUT, float *slab) {
     constexpr int QN = (FL_HALF + NWV - 1) / NWV;
@@ -432,24 +324,6 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
         }
 }
 
-// out[mt] += sum over the 16 k-steps (j, r) of  A = wrow[(16j + r) * 64 floats] (a lane's four output-tile operands: one b128)  x  B = in[j][r].
-// The weight reads do not depend on the chain: they are issued two k-steps ahead of the MFMAs that consume them and the scheduler is
-// fenced per k-step -- left alone, hipcc issues each pair of reads AFTER the previous eight MFMAs and waits out the LDS latency with
-// the matrix pipe drained.
-__device__ __forceinline__ void chain64(const float *wrow, const f32x4 (&in)[4], f32x4 (&out)[4]) {
-    f32x4 wq[3];
-    wq[0] = *reinterpret_cast<const f32x4 *>(wrow);
-    wq[1] = *reinterpret_cast<const f32x4 *>(wrow + 64);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i + 2 < 16) wq[(i + 2) % 3] = *reinterpret_cast<const f32x4 *>(wrow + (16 * ((i + 2) >> 2) + ((i + 2) & 3)) * 64);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 w = wq[i % 3];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) out[mt] = mfma16(w[mt], in[i >> 2][i & 3], out[mt]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // DIRECT (small minibatches): 4-wave blocks, one wave per SIMD, one tile per wave; the block reduction runs over four copies.
 template <bool IS_PI, int DT, bool DIRECT = false>
@@ -521,8 +395,8 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
     const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
     NetAcc acc;
     zero_acc(acc);
-    double st_a = 0.0, st_ent = 0.0, st_kl = 0.0;
-    float st_clip = 0.0f, st_n = 0.0f;  // counts: exact in float (a lane sees far fewer than 2^24 samples)
+    TileStats st;
+    TileTicks tk;
     // ---- gather, one tile ahead, straight into registers (offset_of / fetch above): the sample's buffer offset is fetched one stage
     // earlier still, so the dependent hop (offset -> rows) never waits.  Loads are issued from clamped addresses and masked when the tile
     // is consumed (a select on a value just loaded would make the compiler wait for it at the issue point).
@@ -532,8 +406,8 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
         for (int q = 0; q < hp.debug; q++) __builtin_amdgcn_s_sleep(100);
 #ifdef TMA_H64_TICKS
     const bool tick_on = block_net == 0 && wave == 0;
-    unsigned long long tick_prev = __builtin_amdgcn_s_memtime();
-    const unsigned long long loop_t0 = tick_prev, loop_r0 = __builtin_amdgcn_s_memrealtime();
+    tk.on = tick_on, tk.prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long loop_t0 = tk.prev, loop_r0 = __builtin_amdgcn_s_memrealtime();
     if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][12] += loop_t0 - kern_t0;
 #endif
     for (int64_t tile = (int64_t)block_net * wpb + wave; tile < n_tiles; tile += tile_stride) {
@@ -546,175 +420,7 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
         const float m0 = pf_m0, m1 = pf_m1;
         const int act = pf_act;
         fetch(tile + tile_stride);
-#pragma unroll
-        for (int ks = 0; ks < KS1C; ks++)
-            if (ks < KS1) Xt[r16 * 16 + 4 * ks + g] = xb[ks];
-        // ---- layer 1: h1^T = tanh(W1^T . x^T + b1) ----
-        f32x4 h1[4], h2[4];
-        {
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) h1[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B1 + 16 * mt + 4 * g);
-#pragma unroll
-            for (int ks = 0; ks < KS1C; ks++) {
-                if (ks < KS1) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W1 + (4 * ks + g) * 64 + r16 * 4);
-#pragma unroll
-                    for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(w[mt], xb[ks], h1[mt]);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) h1[mt][r] = tma_tanh(h1[mt][r]);
-        }
-        H64_TICK(0);
-        store_tile_t(slotA, h1, r16, g);
-        // ---- layer 2: the B operand of k-step (j, r) is register r of h1's tile j ----
-        {
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) h2[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B2 + 16 * mt + 4 * g);
-            chain64(wimg + IMG_W2F + 4 * g * 64 + r16 * 4, h1, h2);
-            H64_TICK(1);
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) h2[mt][r] = tma_tanh(h2[mt][r]);
-        }
-        store_tile_t(slotB, h2, r16, g);
-        H64_TICK(2);
-        // ---- head: the A operand's row m = lane & 15 carries output a(m) = (m >> 2) + 4 (m & 3), so register r of lane group g' is output
-        // g' + 4r: the n_out <= 8 real outputs sit in registers 0..1 and the head's input-gradient GEMM below needs ceil(n_out / 4) k-steps
-        // instead of 4.  Two accumulators halve the dependent MFMA chain.
-        const int acol = (r16 >> 2) + 4 * (r16 & 3);
-        f32x4 o0 = f32x4{wimg[IMG_B3 + g], wimg[IMG_B3 + g + 4], wimg[IMG_B3 + g + 8], wimg[IMG_B3 + g + 12]}, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float w = wimg[IMG_W3F + (16 * j + 4 * g + r) * 16 + acol];
-                if ((4 * j + r) & 1) o1 = mfma16(w, h2[j][r], o1);
-                else o0 = mfma16(w, h2[j][r], o0);
-            }
-        H64_TICK(3);
-        f32x4 dz3;
-        if constexpr (IS_PI) {
-            float x[4], e[4], lp[4], p[4];
-            bool ok[4];
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                ok[r] = g + 4 * r < A;
-                x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
-                m = fmaxf(m, x[r]);
-            }
-            m = xg_max(m);
-            float ssum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                e[r] = ok[r] ? __expf(x[r] - m) : 0.0f;  // hardware exp2 / log2 / rcp (~1 ulp): the loss phase is the policy blocks' critical extra
-                ssum += e[r];
-            }
-            ssum = xg_sum(ssum);
-            const float lse = m + __logf(ssum), rs = __builtin_amdgcn_rcpf(ssum);
-            float lpa = 0.0f, ent = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                lp[r] = ok[r] ? x[r] - lse : 0.0f;
-                p[r] = e[r] * rs;
-                lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
-                ent += p[r] * lp[r];
-            }
-            lpa = xg_sum(lpa);
-            ent = -xg_sum(ent);
-            const float old = m0;
-            const float advn = (m1 - amean) / (astd + 1e-8f);
-            const float ratio = __expf(lpa - old);
-            const float pl1 = advn * ratio;
-            const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
-            const float pl2 = advn * rc;
-            const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float dl = g_lp * (((g + 4 * r == act) ? 1.0f : 0.0f) - p[r]);
-                dl += valid ? (hp.ent_coef * invB) * (p[r] * (lp[r] + ent)) : 0.0f;
-                dz3[r] = ok[r] ? dl : 0.0f;
-            }
-            if (valid && g == 0) {
-                st_a += (double)(-fminf(pl1, pl2));
-                st_ent += (double)ent;
-                st_kl += (double)((ratio - 1.0f) - (lpa - old));
-                st_clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0f : 0.0f;
-                st_n += 1.0f;
-            }
-        } else {
-            const float diff = (o0[0] + o1[0]) - m0;
-            const bool mine = valid && g == 0;
-            dz3 = f32x4{mine ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f, 0.0f, 0.0f, 0.0f};
-            if (mine) st_a += (double)(diff * diff);
-        }
-        H64_TICK(4);
-        *reinterpret_cast<f32x4 *>(dz3t + r16 * 16 + 4 * g) = dz3;  // (column m = 4g + r of the tile <-> output a(m), undone by flush_segment)
-        H64_TICK(4);
-        // ---- dh2^T = W3 . dz3^T: k-step r contracts over the outputs {g' + 4r}; registers r >= ceil(n_out / 4) of dz3 are zero ----
-        f32x4 d[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) d[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (4 * r < NOUT) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W3B + (g + 4 * r) * 64 + r16 * 4);
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) d[mt] = mfma16(w[mt], dz3[r], d[mt]);
-            }
-        }
-        // dW3 (off the dependent path) right behind the chain's MFMAs: the pipe works on it while dh2 matures and dz2 is formed
-        bwd_weight_acc_t<4, 1, true, false>(slotB, dz3t, acc.w3, acc.b3, lane);
-        H64_TICK(5);
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) h2[mt][r] = d[mt][r] * (1.0f - h2[mt][r] * h2[mt][r]);
-        store_tile_t(slotB, h2, r16, g);  // dz2 over h2 (dW3 has read h2: LDS operations of one wave execute in order)
-        H64_TICK(6);
-        // ---- dh1^T = W2 . dz2^T (chain), then dW2 (64 MFMAs, off the path) with dz1 = dh1 * (1 - h1^2) formed between its k-tiles ----
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) d[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        chain64(wimg + IMG_W2B + 4 * g * 64 + r16 * 4, h2, d);
-        H64_TICK(7);
-        {
-            float bf[4][4];
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-#pragma unroll
-                for (int sk = 0; sk < 4; sk++) bf[nt][sk] = slotB[tsw(4 * sk + g, nt * 16 + r16)];
-                acc.b2[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
-            }
-            float av[4][4];
-#pragma unroll
-            for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-                for (int sk = 0; sk < 4; sk++) av[kt][sk] = slotA[tsw(4 * sk + g, kt * 16 + r16)];
-            // h1 is not kept in registers across the head / loss / layer-2 work: its LDS copy (slot A) is read back in the lane's own C-layout
-            // positions (the b128 pattern of the store: conflict-free); every read of slot A is issued before dz1 overwrites it below
-            f32x4 hh[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) hh[mt] = *reinterpret_cast<const f32x4 *>(slotA + tsw(r16, 16 * mt + 4 * g));
-#pragma unroll
-            for (int kt = 0; kt < 4; kt++) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sk = 0; sk < 4; sk++)
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++) acc.w2[kt][nt] = mfma16(av[kt][sk], bf[nt][sk], acc.w2[kt][nt]);
-#pragma unroll
-                for (int r = 0; r < 4; r++) h1[kt][r] = d[kt][r] * (1.0f - hh[kt][r] * hh[kt][r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        store_tile_t(slotA, h1, r16, g);  // dz1 over h1
-        H64_TICK(8);
-        bwd_weight_acc_t<1, 4, false, true>(Xt, slotA, acc.w1, acc.b1, lane);
-        H64_TICK(9);
+        h64t_tile<IS_PI, KS1C>(wimg, slotA, slotB, dz3t, Xt, xb, m0, m1, act, valid, KS1, A, invB, amean, astd, hp, acc, st, tk, lane);
     }
 #ifdef TMA_H64_TICKS
     const unsigned long long loop_t1 = __builtin_amdgcn_s_memtime();
@@ -730,12 +436,12 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
     // loss statistics first (their LDS scratch sits behind the staging area; the barriers inside flush_all_t publish it), the slab
     // stores last: nothing waits behind a global store
     double *red = reinterpret_cast<double *>(smem + (DIRECT ? 4 : 8) * FL_HALF * 64);  // statistics scratch behind the staging area
-    double st[5] = {st_a, st_ent, st_kl, (double)st_clip, (double)st_n};
+    double stv[5] = {st.a, st.ent, st.kl, (double)st.clip, (double)st.n};
 #pragma unroll
     for (int q = 0; q < 5; q++)
-        for (int o = 32; o > 0; o >>= 1) st[q] += __shfl_down(st[q], o, 64);
+        for (int o = 32; o > 0; o >>= 1) stv[q] += __shfl_down(stv[q], o, 64);
     if (lane == 0)
-        for (int q = 0; q < 5; q++) red[wave * 5 + q] = st[q];
+        for (int q = 0; q < 5; q++) red[wave * 5 + q] = stv[q];
     if constexpr (DIRECT) {
         flush_all_t<IS_PI, 4>(smem, wave, lane, acc, L, D, NOUT, slab);  // 4-wave blocks of the small-minibatch kernel
     } else {

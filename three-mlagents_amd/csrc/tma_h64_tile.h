@@ -1,0 +1,383 @@
+// tma_h64_tile.h -- one 16-sample tile of the H = 64 PPO minibatch gradient (forward, loss, backward) as a transposed register chain,
+// shared by the per-minibatch gradient kernels (tma_h64.hip) and the persistent small-minibatch epoch kernel (tma_h64p.hip).
+// Formulas: stable-baselines3 2.9.0 PPO.train / evaluate_actions, driven by model.learn() at
+// /root/reference/backend/mlagents/training.py:166-170.
+#pragma once
+#include "tma_ppo_types.h"
+
+namespace tma {
+
+// the whole parameter gradient of one net in MFMA accumulators (105 VGPRs): dW += X^T.dZ is accumulated through the MFMA C operand
+struct NetAcc {
+    f32x4 w1[1][4];
+    f32x4 w2[4][4];
+    f32x4 w3[4][1];
+    float b1[4], b2[4], b3[1];
+};
+
+__device__ __forceinline__ void zero_acc(NetAcc &a) {
+    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a.w1[0][j] = z;
+        a.w3[j][0] = z;
+        a.b1[j] = 0.0f;
+        a.b2[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a.w2[i][j] = z;
+    }
+    a.b3[0] = 0.0f;
+}
+
+#ifdef TMA_H64_TICKS  // diagnostic build only (make CXXFLAGS+=-DTMA_H64_TICKS): per-phase issue-time stamps of wave 0 of blocks 0 / 1
+static __device__ unsigned long long g_h64_ticks[2][16];
+struct TileTicks {
+    bool on;
+    unsigned long long prev;
+};
+#define H64_TICK(i)                                                                          \
+    do {                                                                                     \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                          \
+        if (tk.on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][i] += _t - tk.prev;              \
+        tk.prev = __builtin_amdgcn_s_memtime();                                              \
+    } while (0)
+#else
+struct TileTicks {};
+#define H64_TICK(i) do {} while (0)
+#endif
+constexpr int LDT = 68;
+constexpr int T_PER_WAVE = 2 * 16 * LDT + 256 + 256;  // slot A, slot B, dz3 [16][16], X [16][16]
+__device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ ((row & 1) << 4)); }
+
+// all-reduce over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the lane groups holding one sample's 16 head outputs): VALU only
+template <class F>
+__device__ __forceinline__ float xg_reduce(float v, F op) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xg_sum(float v) { return xg_reduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float xg_max(float v) { return xg_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+
+// lane (g, s) stores features 16mt + 4g .. + 3 of sample s: one b128 per output tile
+__device__ __forceinline__ void store_tile_t(float *tile, const f32x4 (&v)[4], int r16, int g) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) *reinterpret_cast<f32x4 *>(tile + tsw(r16, 16 * mt + 4 * g)) = v[mt];
+}
+
+// accW[kt][nt] += x[16 samples][16kt..]^T . dz[16 samples][16nt..]; accb[nt] += column sums of dz.  Operands are read transposed
+// (sample on the lane group / k index, feature on lane & 15) from [sample][feature] tiles: XS / ZS = swizzled [16][LDT] tile, else
+// a plain [16][16] tile.
+template <int KT, int NT, bool XS, bool ZS>
+__device__ __forceinline__ void bwd_weight_acc_t(const float *xin, const float *dz, f32x4 (&accW)[KT][NT], float (&accb)[NT], int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    float bf[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) bf[nt][s] = ZS ? dz[tsw(4 * s + g, nt * 16 + r16)] : dz[(4 * s + g) * 16 + r16];
+        accb[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        float a[4];
+        // (plain X tile: feature columns >= D hold stale LDS bytes; they only feed accumulator rows k >= D, which flush_segment never stores)
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[s] = XS ? xin[tsw(4 * s + g, kt * 16 + r16)] : xin[(4 * s + g) * 16 + r16];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) accW[kt][nt] = mfma16(a[s], bf[nt][s], accW[kt][nt]);
+    }
+}
+
+// out[mt] += sum over the 16 k-steps (j, r) of  A = wrow[(16j + r) * 64 floats] (a lane's four output-tile operands: one b128)  x  B = in[j][r].
+// The weight reads do not depend on the chain: they are issued two k-steps ahead of the MFMAs that consume them and the scheduler is
+// fenced per k-step -- left alone, hipcc issues each pair of reads AFTER the previous eight MFMAs and waits out the LDS latency with
+// the matrix pipe drained.
+__device__ __forceinline__ void chain64(const float *wrow, const f32x4 (&in)[4], f32x4 (&out)[4]) {
+    f32x4 wq[3];
+    wq[0] = *reinterpret_cast<const f32x4 *>(wrow);
+    wq[1] = *reinterpret_cast<const f32x4 *>(wrow + 64);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i + 2 < 16) wq[(i + 2) % 3] = *reinterpret_cast<const f32x4 *>(wrow + (16 * ((i + 2) >> 2) + ((i + 2) & 3)) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w = wq[i % 3];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) out[mt] = mfma16(w[mt], in[i >> 2][i & 3], out[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// chain64 with the B operands formed on the way: act(j, r) turns element r of input tile j into the operand of k-step (j, r) (tanh of
+// a pre-activation, or a delta from a back-propagated gradient) and is issued under the MFMAs of k-step (j - 1, r) -- only tile 0's four
+// elements are formed in front of the chain.  done(j) runs once tile j's four operands exist (the tile's LDS store).  Arithmetic and
+// accumulation order are chain64's: results are bit-identical, the matrix pipe just no longer idles through 16 activations.
+template <class ACT, class DONE>
+__device__ __forceinline__ void chain64_act(const float *wrow, f32x4 (&in)[4], f32x4 (&out)[4], ACT act, DONE done) {
+    f32x4 wq[3];
+    wq[0] = *reinterpret_cast<const f32x4 *>(wrow);
+    wq[1] = *reinterpret_cast<const f32x4 *>(wrow + 64);
+#pragma unroll
+    for (int r = 0; r < 4; r++) in[0][r] = act(0, r);
+    done(0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i + 2 < 16) wq[(i + 2) % 3] = *reinterpret_cast<const f32x4 *>(wrow + (16 * ((i + 2) >> 2) + ((i + 2) & 3)) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w = wq[i % 3];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) out[mt] = mfma16(w[mt], in[i >> 2][i & 3], out[mt]);
+        if (i + 4 < 16) {
+            in[(i + 4) >> 2][(i + 4) & 3] = act((i + 4) >> 2, (i + 4) & 3);
+            if (((i + 4) & 3) == 3) done((i + 4) >> 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#ifndef TMA_H64_PIPE
+#define TMA_H64_PIPE 1  // 0: activations / deltas formed in whole-tile passes between the chains (the round-2 first version; A/B builds)
+#endif
+
+struct TileStats {
+    double a = 0.0, ent = 0.0, kl = 0.0;
+    float clip = 0.0f, n = 0.0f;  // counts: exact in float (a lane sees far fewer than 2^24 samples)
+};
+
+// One tile.  Lane (g, r16) works for the tile's sample r16; xb[ks] = observation feature 4 ks + g of that sample (0 beyond D or for an
+// invalid row), m0 / m1 / act = (old log-prob, advantage, action) for the policy net, (return, -, -) for the value net.
+// wimg: this net's LDS weight image; slotA / slotB / dz3t / Xt: the wave's private [sample][feature] tiles (T_PER_WAVE floats in all).
+template <bool IS_PI, int KS1C>
+__device__ __forceinline__ void h64t_tile(const float *wimg, float *slotA, float *slotB, float *dz3t, float *Xt, const float (&xb)[KS1C], float m0,
+                                          float m1, int act, bool valid, int KS1, int A, float invB, float amean, float astd, const HParams &hp,
+                                          NetAcc &acc, TileStats &st, TileTicks &tk, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int NOUT = IS_PI ? A : 1;
+    (void)tk;
+#pragma unroll
+    for (int ks = 0; ks < KS1C; ks++)
+        if (ks < KS1) Xt[r16 * 16 + 4 * ks + g] = xb[ks];
+    // ---- layer 1: h1^T = tanh(W1^T . x^T + b1) ----
+    f32x4 h1[4], h2[4];
+    {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) h1[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B1 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ks++) {
+            if (ks < KS1) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W1 + (4 * ks + g) * 64 + r16 * 4);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(w[mt], xb[ks], h1[mt]);
+            }
+        }
+        if constexpr (!TMA_H64_PIPE) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h1[mt][r] = tma_tanh(h1[mt][r]);
+        }
+    }
+    H64_TICK(0);
+    if constexpr (!TMA_H64_PIPE) store_tile_t(slotA, h1, r16, g);
+    // ---- layer 2: the B operand of k-step (j, r) is register r of h1's tile j ----
+    {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) h2[mt] = *reinterpret_cast<const f32x4 *>(wimg + IMG_B2 + 16 * mt + 4 * g);
+        if constexpr (TMA_H64_PIPE) {
+            chain64_act(wimg + IMG_W2F + 4 * g * 64 + r16 * 4, h1, h2, [&](int j, int r) { return tma_tanh(h1[j][r]); },
+                        [&](int j) { *reinterpret_cast<f32x4 *>(slotA + tsw(r16, 16 * j + 4 * g)) = h1[j]; });
+        } else {
+            chain64(wimg + IMG_W2F + 4 * g * 64 + r16 * 4, h1, h2);
+        }
+        H64_TICK(1);
+        if constexpr (!TMA_H64_PIPE) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h2[mt][r] = tma_tanh(h2[mt][r]);
+        }
+    }
+    if constexpr (!TMA_H64_PIPE) store_tile_t(slotB, h2, r16, g);
+    H64_TICK(2);
+    // ---- head: the A operand's row m = lane & 15 carries output a(m) = (m >> 2) + 4 (m & 3), so register r of lane group g' is output
+    // g' + 4r: the n_out <= 8 real outputs sit in registers 0..1 and the head's input-gradient GEMM below needs ceil(n_out / 4) k-steps
+    // instead of 4.  Two accumulators halve the dependent MFMA chain.
+    const int acol = (r16 >> 2) + 4 * (r16 & 3);
+    f32x4 o0 = f32x4{wimg[IMG_B3 + g], wimg[IMG_B3 + g + 4], wimg[IMG_B3 + g + 8], wimg[IMG_B3 + g + 12]}, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float w = wimg[IMG_W3F + (16 * j + 4 * g + r) * 16 + acol];
+            if constexpr (TMA_H64_PIPE) h2[j][r] = tma_tanh(h2[j][r]);  // (the head's MFMAs of element (j, r) run under the next tanh)
+            if ((4 * j + r) & 1) o1 = mfma16(w, h2[j][r], o1);
+            else o0 = mfma16(w, h2[j][r], o0);
+        }
+    if constexpr (TMA_H64_PIPE) store_tile_t(slotB, h2, r16, g);
+    H64_TICK(3);
+    f32x4 dz3;
+    if constexpr (IS_PI) {
+        float x[4], e[4], lp[4], p[4];
+        bool ok[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            ok[r] = g + 4 * r < A;
+            x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
+            m = fmaxf(m, x[r]);
+        }
+        m = xg_max(m);
+        float ssum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            e[r] = ok[r] ? __expf(x[r] - m) : 0.0f;  // hardware exp2 / log2 / rcp (~1 ulp): the loss phase is the policy blocks' critical extra
+            ssum += e[r];
+        }
+        ssum = xg_sum(ssum);
+        const float lse = m + __logf(ssum), rs = __builtin_amdgcn_rcpf(ssum);
+        float lpa = 0.0f, ent = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            lp[r] = ok[r] ? x[r] - lse : 0.0f;
+            p[r] = e[r] * rs;
+            lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
+            ent += p[r] * lp[r];
+        }
+        lpa = xg_sum(lpa);
+        ent = -xg_sum(ent);
+        const float old = m0;
+        const float advn = (m1 - amean) / (astd + 1e-8f);
+        const float ratio = __expf(lpa - old);
+        const float pl1 = advn * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+        const float pl2 = advn * rc;
+        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float dl = g_lp * (((g + 4 * r == act) ? 1.0f : 0.0f) - p[r]);
+            dl += valid ? (hp.ent_coef * invB) * (p[r] * (lp[r] + ent)) : 0.0f;
+            dz3[r] = ok[r] ? dl : 0.0f;
+        }
+        if (valid && g == 0) {
+            st.a += (double)(-fminf(pl1, pl2));
+            st.ent += (double)ent;
+            st.kl += (double)((ratio - 1.0f) - (lpa - old));
+            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0f : 0.0f;
+            st.n += 1.0f;
+        }
+    } else {
+        const float diff = (o0[0] + o1[0]) - m0;
+        const bool mine = valid && g == 0;
+        dz3 = f32x4{mine ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f, 0.0f, 0.0f, 0.0f};
+        if (mine) st.a += (double)(diff * diff);
+    }
+    H64_TICK(4);
+    *reinterpret_cast<f32x4 *>(dz3t + r16 * 16 + 4 * g) = dz3;  // (column m = 4g + r of the tile <-> output a(m), undone by flush_segment)
+    H64_TICK(4);
+    // ---- dh2^T = W3 . dz3^T: k-step r contracts over the outputs {g' + 4r}; registers r >= ceil(n_out / 4) of dz3 are zero ----
+    f32x4 d[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) d[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (4 * r < NOUT) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W3B + (g + 4 * r) * 64 + r16 * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) d[mt] = mfma16(w[mt], dz3[r], d[mt]);
+        }
+    }
+    // dW3 (off the dependent path) right behind the chain's MFMAs: the pipe works on it while dh2 matures and dz2 is formed
+    bwd_weight_acc_t<4, 1, true, false>(slotB, dz3t, acc.w3, acc.b3, lane);
+    H64_TICK(5);
+    // ---- dz2 = dh2 * (1 - h2^2) over h2 (dW3 has read h2: LDS operations of one wave execute in order), dh1^T = W2 . dz2^T (chain),
+    // then dW2 (64 MFMAs, off the path) with dz1 = dh1 * (1 - h1^2) formed between its k-tiles ----
+    f32x4 e[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) e[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (TMA_H64_PIPE) {
+        chain64_act(wimg + IMG_W2B + 4 * g * 64 + r16 * 4, h2, e, [&](int j, int r) { return d[j][r] * (1.0f - h2[j][r] * h2[j][r]); },
+                    [&](int j) { *reinterpret_cast<f32x4 *>(slotB + tsw(r16, 16 * j + 4 * g)) = h2[j]; });
+        H64_TICK(6);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[mt][r] = d[mt][r] * (1.0f - h2[mt][r] * h2[mt][r]);
+        store_tile_t(slotB, h2, r16, g);
+        H64_TICK(6);
+        chain64(wimg + IMG_W2B + 4 * g * 64 + r16 * 4, h2, e);
+    }
+    H64_TICK(7);
+    {
+        float bf[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) bf[nt][sk] = slotB[tsw(4 * sk + g, nt * 16 + r16)];
+            acc.b2[nt] += (bf[nt][0] + bf[nt][1]) + (bf[nt][2] + bf[nt][3]);
+        }
+        float av[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) av[kt][sk] = slotA[tsw(4 * sk + g, kt * 16 + r16)];
+        // h1 is not kept in registers across the head / loss / layer-2 work: its LDS copy (slot A) is read back in the lane's own C-layout
+        // positions (the b128 pattern of the store: conflict-free); every read of slot A is issued before dz1 overwrites it below
+        f32x4 hh[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) hh[mt] = *reinterpret_cast<const f32x4 *>(slotA + tsw(r16, 16 * mt + 4 * g));
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc.w2[kt][nt] = mfma16(av[kt][sk], bf[nt][sk], acc.w2[kt][nt]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) h1[kt][r] = e[kt][r] * (1.0f - hh[kt][r] * hh[kt][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    store_tile_t(slotA, h1, r16, g);  // dz1 over h1
+    H64_TICK(8);
+    bwd_weight_acc_t<1, 4, false, true>(Xt, slotA, acc.w1, acc.b1, lane);
+    H64_TICK(9);
+}
+
+// accumulator register idx (0..104) of a NetAcc, and the flat parameter index it holds in lane `lane`
+constexpr int FL_HALF = 56, FL_REGS = 105;
+__device__ __forceinline__ float acc_reg(const NetAcc &a, int idx) {  // idx is a compile-time constant after unrolling
+    if (idx < 16) return a.w1[0][idx >> 2][idx & 3];
+    if (idx < 80) return a.w2[(idx - 16) >> 4][((idx - 16) >> 2) & 3][idx & 3];
+    if (idx < 96) return a.w3[(idx - 80) >> 2][0][idx & 3];
+    if (idx < 100) return a.b1[idx - 96];
+    if (idx < 104) return a.b2[idx - 100];
+    return a.b3[0];
+}
+// slab element of accumulator register idx in lane `lane` (-1: padding, nothing to store)
+template <bool IS_PI>
+__device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L, int D, int NOUT) {
+    const int r16 = lane & 15, g = lane >> 4;
+    const int perm = (r16 >> 2) + 4 * (r16 & 3);  // head: tile column m <-> output a(m)
+    if (idx < 16) {
+        const int k = 4 * g + (idx & 3), n = (idx >> 2) * 16 + r16;
+        return k < D ? (IS_PI ? L.pW1t : L.vW1t) + k * 64 + n : -1;
+    }
+    if (idx < 80) {
+        const int t = idx - 16, k = (t >> 4) * 16 + 4 * g + (t & 3), n = ((t >> 2) & 3) * 16 + r16;
+        return (IS_PI ? L.pW2t : L.vW2t) + k * 64 + n;
+    }
+    if (idx < 96) {
+        const int t = idx - 80, k = (t >> 2) * 16 + 4 * g + (t & 3);
+        return perm < NOUT ? (IS_PI ? L.pW3t : L.vW3t) + k * NOUT + perm : -1;
+    }
+    if (g != 0) return -1;  // bias sums are replicated over the lane groups
+    if (idx < 100) return (IS_PI ? L.pb1 : L.vb1) + (idx - 96) * 16 + r16;
+    if (idx < 104) return (IS_PI ? L.pb2 : L.vb2) + (idx - 100) * 16 + r16;
+    return perm < NOUT ? (IS_PI ? L.pb3 : L.vb3) + perm : -1;
+}
+
+}  // namespace tma

@@ -131,6 +131,55 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, in
     return L;
 }
 
+// One Adam step of parameter p with the clip-scaled gradient gv (torch.optim.Adam, no weight decay / amsgrad; SB3's optimizer, SURVEY.md
+// Appendix C.5) on the hardware sqrt / rcp units (1 ulp each; the update term carries ~3 ulp, i.e. ~1e-10 absolute at lr 3e-4) with
+// explicit FMAs: 11 VALU operations instead of the ~55 of two IEEE divisions and an IEEE sqrt.  Shared by adam_scatter_h64_kernel and the
+// persistent epoch kernel (tma_h64p.hip), which therefore stay bit-identical.  inv_bc2_sqrt = 1 / sqrt(1 - beta2^t).
+__device__ __forceinline__ float adam_update_h64(float p, float gv, float &mm, float &vv, float beta1, float beta2, float inv_bc2_sqrt, float eps,
+                                                 float lr_step) {
+    mm = __builtin_fmaf(gv - mm, 1.0f - beta1, mm);
+    vv = __builtin_fmaf(gv * gv, 1.0f - beta2, vv * beta2);
+    const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv), inv_bc2_sqrt, eps);
+    return __builtin_fmaf(-lr_step, mm * __builtin_amdgcn_rcpf(denom), p);
+}
+
+// Fast-path layouts (H == 64, LDS images): the derived locations of trainable parameter e -- its [out][in] copy and its slots in
+// the forward / input-gradient images of its net (inverse of build_image_elem).
+__device__ __forceinline__ void scatter_derived_h64(float *params, const PLayout &L, int e, float val) {
+    constexpr int H = 64;
+    const int D = L.D, A = L.A;
+    const bool vf = e >= L.vW1t && e < L.log_std;
+    const int base = vf ? L.vW1t : L.pW1t, img = vf ? L.img_vf : L.img_pi, n_out = vf ? 1 : A;
+    int x = e - base;
+    if (x < D * H) {  // W1t[k][n]
+        const int k = x >> 6, n = x & 63;
+        params[img + IMG_W1 + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        return;
+    }
+    x -= D * H;
+    if (x < H) { params[img + IMG_B1 + x] = val; return; }
+    x -= H;
+    if (x < H * H) {  // W2t[k][n]
+        const int k = x >> 6, n = x & 63;
+        params[(vf ? L.vW2 : L.pW2) + n * H + k] = val;
+        params[img + IMG_W2F + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        params[img + IMG_W2B + n * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * H;
+    if (x < H) { params[img + IMG_B2 + x] = val; return; }
+    x -= H;
+    if (x < H * n_out) {  // W3t[k][a]
+        const int k = x / n_out, a = x - k * n_out;
+        params[(vf ? L.vW3 : L.pW3) + a * H + k] = val;
+        params[img + IMG_W3F + k * 16 + a] = val;
+        params[img + IMG_W3B + a * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * n_out;
+    if (x < n_out) params[img + IMG_B3 + x] = val;
+}
+
 // value the optimiser must treat as new (not loop-invariant) but provably wave-uniform: keeps weight loads of a persistent loop
 // from being hoisted in front of it (and spilled), and keeps their address arithmetic scalar
 __device__ __forceinline__ const float *launder_uniform(const float *p) {

@@ -1212,42 +1212,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params, f
 }
 
 
-// Fast-path layouts (H == 64, LDS images): the derived locations of trainable parameter e -- its [out][in] copy and its slots in
-// the forward / input-gradient images of its net (inverse of build_image_elem).
-__device__ __forceinline__ void scatter_derived_h64(float *params, const PLayout &L, int e, float val) {
-    constexpr int H = 64;
-    const int D = L.D, A = L.A;
-    const bool vf = e >= L.vW1t && e < L.log_std;
-    const int base = vf ? L.vW1t : L.pW1t, img = vf ? L.img_vf : L.img_pi, n_out = vf ? 1 : A;
-    int x = e - base;
-    if (x < D * H) {  // W1t[k][n]
-        const int k = x >> 6, n = x & 63;
-        params[img + IMG_W1 + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
-        return;
-    }
-    x -= D * H;
-    if (x < H) { params[img + IMG_B1 + x] = val; return; }
-    x -= H;
-    if (x < H * H) {  // W2t[k][n]
-        const int k = x >> 6, n = x & 63;
-        params[(vf ? L.vW2 : L.pW2) + n * H + k] = val;
-        params[img + IMG_W2F + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
-        params[img + IMG_W2B + n * 64 + (k & 15) * 4 + (k >> 4)] = val;
-        return;
-    }
-    x -= H * H;
-    if (x < H) { params[img + IMG_B2 + x] = val; return; }
-    x -= H;
-    if (x < H * n_out) {  // W3t[k][a]
-        const int k = x / n_out, a = x - k * n_out;
-        params[(vf ? L.vW3 : L.pW3) + a * H + k] = val;
-        params[img + IMG_W3F + k * 16 + a] = val;
-        params[img + IMG_W3B + a * 64 + (k & 15) * 4 + (k >> 4)] = val;
-        return;
-    }
-    x -= H * n_out;
-    if (x < n_out) params[img + IMG_B3 + x] = val;
-}
 
 // sum-of-squares partials of the (scaled) gradient, one per 64 parameters -- the same values, in the same order, slab_reduce_kernel
 // leaves for an un-reduced gradient; used when the gradient was all-reduced (or accumulated) after the reduction kernel ran
@@ -1287,12 +1251,9 @@ __global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict
     const float gv = (grad[e] * scale) * coef_s;
     grad[e] = 0.0f;
     float mm = m[e], vv = v[e];
-    mm = mm + (gv - mm) * (1.0f - beta1);
-    vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+    const float pn = adam_update_h64(params[e], gv, mm, vv, beta1, beta2, 1.0f / bc2_sqrt, eps, lr_step);
     m[e] = mm;
     v[e] = vv;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    const float pn = params[e] - lr_step * (mm / denom);
     params[e] = pn;
     if (e < L.log_std) scatter_derived_h64(params, L, e, pn);
 }
@@ -2217,6 +2178,20 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         rc = tma_ppo_epoch_prepare(rb, &ep, batch_size, d, workspace, stream);
         if (rc) return rc;
     }
+    const PLayout L = layout_of(d);
+    if (prepared && total % batch_size == 0 && tma_epoch_h64p_eligible(L, batch_size, total)) {
+        // the reference's literal batch_size = 256 on an H = 64 policy: the whole epoch as one persistent launch (tma_h64p.hip)
+        if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
+        char *ws = static_cast<char *>(workspace);
+        const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
+        const Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N};
+        const HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, hp->normalize_advantage ? 1 : 0, 0};
+        int stride = (int)ceil_div(batch_size, 1024);
+        if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+        return tma_launch_epoch_h64p(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
+                                     reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size, exp_avg, exp_avg_sq,
+                                     first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
+    }
     int64_t step = first_step;
     for (int64_t start = 0; start < total; start += batch_size, step++) {
         const int64_t count = start + batch_size <= total ? batch_size : total - start;
@@ -2381,8 +2356,14 @@ int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {
     char *ws = static_cast<char *>(workspace);
     TMA_HIP(hipMemcpyAsync(tmp, ws + WS_STATS, sizeof(double) * MAX_GRAD_BLOCKS * 8, hipMemcpyDeviceToHost, s));
     TMA_HIP(hipMemcpyAsync(tmp + MAX_GRAD_BLOCKS * 8, ws + WS_NORM_OUT, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    int persist_err = 0;
+    TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), s));
     TMA_HIP(hipMemsetAsync(ws + WS_STATS, 0, sizeof(double) * MAX_GRAD_BLOCKS * 8, s));
     TMA_HIP(hipStreamSynchronize(s));
+    if (persist_err)
+        return fail(TMA_ERR_HIP, "the persistent epoch kernel could not place / synchronise its workgroups on one XCD; parameters of that epoch "
+                                      "were not updated (set TMA_NO_PERSIST=1 to use the per-minibatch launches)");
     for (int q = 0; q < 6; q++) out8_host[q] = 0.0;
     for (int b = 0; b < MAX_GRAD_BLOCKS; b++)
         for (int q = 0; q < 6; q++) out8_host[q] += tmp[b * 8 + q];

@@ -7,6 +7,7 @@ namespace tma {
 constexpr int WS_ADV = 0;             // float[2]: minibatch advantage mean, std
 constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-squares partials
 constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
+constexpr int WS_PERSIST_ERR = 2176;  // int32: set when the persistent epoch kernel (tma_h64p.hip) gave up on a wait; read + cleared by tma_ppo_pop_stats
 constexpr int WS_ADV_PART = 4096;     // byte offset of double[128][2] advantage (sum, sumsq) partials
 constexpr int WS_STATS = 8192;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
 constexpr int MAX_GRAD_BLOCKS = 2048;
@@ -154,6 +155,12 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
 // tma_h64.hip: the H = 64 persistent gradient kernel (internal, not part of the C ABI)
 int tma_launch_grad_h64(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
                         const double *adv_part, int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s);
+
+// tma_h64p.hip: one whole epoch at batch_size = 256 as a single persistent launch (H = 64 fast-path layouts)
+bool tma_epoch_h64p_eligible(const tma::PLayout &L, int64_t batch_size, int64_t total);
+int tma_launch_epoch_h64p(float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::HParams &hp, const int32_t *offs,
+                          const double *adv_part, int adv_stride, int64_t total, int64_t batch_size, float *exp_avg, float *exp_avg_sq,
+                          int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm, char *ws, hipStream_t s);
 
 // tma_bf16.hip: the column-parallel bf16-MFMA gradient kernel (hidden 128 / 192 / 256); `ws` is the update workspace (dz1 cache)
 int tma_launch_grad_wide_bf(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
