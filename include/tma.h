@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 200
+#define TMA_VERSION 201
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -198,10 +198,18 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
  * (perm_seed, perm_epoch) permutation: tma_ppo_minibatch_grad + tma_ppo_adam_step_local, issued natively with no host-language round trip
  * in between (at the reference's literal batch_size = 256 and 4096 envs an epoch is 16 384 optimizer steps: backend/mlagents/training.py:379).
  * first_step = Adam step index of the epoch's first minibatch (>= 1); grad must be zero on entry and is zero on return.  Bit-identical to the
- * per-minibatch calls. */
+ * per-minibatch calls -- except on H = 64 policies at batch_size = 256 with T*N a multiple of it, where the epoch runs as ONE persistent
+ * launch (csrc/tma_h64p.hip: weights in LDS, Adam moments in registers, eight workgroups of one XCD exchanging partial gradients through
+ * the L2): same gradient sums and Adam arithmetic, the clip norm's f64 sum in another fixed order (parameters agree to the last bit or
+ * two).  TMA_NO_PERSIST=1 in the environment selects the per-minibatch launches.  Should the kernel fail to place its workgroups it leaves
+ * the parameters untouched and the next tma_ppo_pop_stats returns TMA_ERR_HIP. */
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
+/* The minibatch order of the on-device permutation (the engine's stand-in for np.random.permutation in SB3's RolloutBuffer.get): writes, to
+ * HOST memory, the env-major flat indices f = i*T + t of permuted rows [0, total) for (perm_seed, perm_epoch).  Minibatch m of size B is
+ * rows [m*B, (m+1)*B).  Lets a caller reproduce or log the schedule; no GPU work. */
+int tma_ppo_permutation(uint32_t perm_seed, uint32_t perm_epoch, int64_t total, int64_t *indices_out_host);
 /* Profiling aid for bench.py's roofline object: when enabled, tma_ppo_minibatch_grad brackets its DOMINANT kernel (the persistent
  * forward+backward kernel; for two-pass shapes both passes; not the advantage pass, not the slab reduction) with HIP events recorded on
  * the stream it launches on; tma_debug_last_grad_kernel_us waits for the last bracketed launch and returns its duration. */

@@ -590,3 +590,65 @@ def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch
     assert torch.equal(c.policy.params.cpu(), pa)  # run-to-run bitwise reproducible
     for e in (env_a, env_b, env_c):
         e.close()
+
+
+@pytest.mark.parametrize("D,A", [(4, 5), (4, 12), (6, 5), (6, 14), (9, 7), (16, 16), (3, 2)])
+def test_persistent_epoch_kernel_equals_per_minibatch_launches(D, A, monkeypatch):
+    """The persistent epoch kernel (csrc/tma_h64p.hip: the reference's literal batch_size = 256 as one launch per epoch) against the same
+    epochs issued as per-minibatch launches (TMA_NO_PERSIST=1), both through tma_ppo_train_epoch_local on synthetic rollouts whose widths
+    select every instantiation of the kernel.  Gradient sums run in the same order in both paths, Adam is one shared routine and the clip
+    norm differs only in its f64 summation order: parameters, derived images and moments must agree to the last bit or two; statistics and
+    the reported norm to 1e-9 relative.  Then the first epoch against the torch restatement of SB3's loop (oracle), 1e-5."""
+    from three_mlagents_amd import _lib
+
+    T, N, B, H = 24, 64, 256, 64
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    res = []
+    for persist in (True, False):
+        if persist:
+            monkeypatch.delenv("TMA_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        pol, sd = _policy(D, H, A, False)
+        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+        d = {k: v.to(dev).contiguous() for k, v in dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret).items()}
+        rv = _lib.Rollout(_lib.ptr(d["obs"]), _lib.ptr(d["actions"]), _lib.ptr(d["old_lp"]), _lib.ptr(d["adv"]), _lib.ptr(d["ret"]), T, N)
+        hpar = _lib.PPOHParams(HP["clip_range"], HP["ent_coef"], HP["vf_coef"], 1)
+        grad = torch.zeros(pol.n_trainable, device=dev)
+        m, v = torch.zeros(pol.n_trainable, device=dev), torch.zeros(pol.n_trainable, device=dev)
+        ws = torch.zeros(int(L.tma_ppo_workspace_bytes(C.byref(pol.dims))), dtype=torch.uint8, device=dev)
+        n_mb, step, snaps = T * N // B, 1, []
+        for epoch in range(3):
+            _lib.check(L.tma_ppo_train_epoch_local(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), 77, epoch, B, C.byref(hpar), _lib.ptr(grad),
+                                                   _lib.ptr(m), _lib.ptr(v), step, 3e-4, 0.9, 0.999, 1e-5, 0.5, _lib.ptr(ws), _lib.stream_ptr()))
+            step += n_mb
+            if epoch == 0:
+                snaps.append({k: t.clone() for k, t in pol.state_dict().items()})
+        out = (C.c_double * 8)()
+        _lib.check(L.tma_ppo_pop_stats(_lib.ptr(ws), out, _lib.stream_ptr()))
+        after = pol.params.clone()
+        _lib.check(L.tma_policy_sync(_lib.ptr(pol.params), C.byref(pol.dims), _lib.stream_ptr()))
+        assert torch.equal(after, pol.params)  # every derived copy / image is what a full refresh of the trainable region rebuilds
+        assert float(grad.abs().max()) == 0.0
+        res.append((after.cpu(), m.cpu(), v.cpu(), list(out), snaps[0], sd, (obs, actions, old_lp, adv, ret)))
+    (p0, m0, v0, s0, snap0, sd0, roll), (p1, m1, v1, s1, _, _, _) = res
+    assert torch.isfinite(p0).all() and s0[5] == s1[5] == 3 * T * N
+    assert torch.allclose(p0, p1, rtol=0, atol=2e-7) and torch.allclose(m0, m1, rtol=1e-5, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-5, atol=1e-12)
+    for q in (0, 1, 2, 3, 4, 6, 7):
+        assert abs(s0[q] - s1[q]) <= 1e-6 * max(1.0, abs(s1[q])), (q, s0[q], s1[q])
+    # one epoch of SB3's loop on the CPU restatement (oracle/sb3_ref.RefTrainer: ppo_loss, clip_grad_norm_, torch.optim.Adam), minibatch by
+    # minibatch in the order of the on-device permutation (tma_ppo_permutation)
+    obs, actions, old_lp, adv, ret = roll
+    idx_np = np.zeros(T * N, dtype=np.int64)
+    _lib.check(L.tma_ppo_permutation(77, 0, T * N, idx_np.ctypes.data_as(C.c_void_p)))
+    assert sorted(idx_np.tolist()) == list(range(T * N))
+    perm = torch.from_numpy(idx_np)
+    tr = sb3_ref.RefTrainer(sd0, lr=3e-4, max_grad_norm=0.5)
+    flat = [_flatten_env_major(x, T, N) for x in (obs, actions, old_lp, adv, ret)]
+    for start in range(0, T * N, B):
+        rows = perm[start:start + B]
+        tr.step(*[x[rows] for x in flat], **HP)
+    for k in snap0:
+        ref = tr.sd[k].detach()
+        assert torch.allclose(snap0[k].cpu(), ref, rtol=0, atol=2e-5), (k, float((snap0[k].cpu() - ref).abs().max()))

@@ -2326,6 +2326,12 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
     return TMA_OK;
 }
 
+int tma_ppo_permutation(uint32_t perm_seed, uint32_t perm_epoch, int64_t total, int64_t *indices_out_host) {
+    if (!indices_out_host || total < 1 || total > 0x7fffffffLL) return fail(TMA_ERR_INVALID, "tma_ppo_permutation: null output or total outside [1, 2^31)");
+    for (int64_t j = 0; j < total; j++) indices_out_host[j] = (int64_t)perm_index(perm_seed, perm_epoch, (uint32_t)j, (uint32_t)total);
+    return TMA_OK;
+}
+
 int tma_debug_time_grad_kernel(int enable) {
     if (enable && !g_ev0) {
         TMA_HIP(hipEventCreate(&g_ev0));
