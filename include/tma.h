@@ -88,6 +88,14 @@ int tma_env_refill(tma_env *h, void *stream);
 int tma_env_get_state(tma_env *h, double *state_out, void *stream);
 int tma_env_set_state(tma_env *h, const double *state_in, void *stream);
 int tma_env_episode_index(tma_env *h, uint32_t *out, void *stream);
+/* Optional per-episode Monitor log (SB3 Monitor writes one `r,l,t` row per finished episode: reference training.py:85-86).  capacity > 0
+ * allocates a device log of that many records and turns logging on in every step / rollout kernel; 0 turns it off.  Synchronises the
+ * device.  tma_env_pop_episode_log copies up to max_records records (return, length, env index; in the order the kernels appended them)
+ * to HOST memory, reports how many were stored (*n_stored) and how many episodes ended since the last pop (*n_seen >= *n_stored when the
+ * log overflowed), and empties the log.  Synchronises `stream`. */
+int tma_env_episode_log(tma_env *env, int64_t capacity);
+int tma_env_pop_episode_log(tma_env *env, float *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored,
+                            int64_t *n_seen, void *stream);
 /* Monitor aggregate since the last call: out[0]=sum of episode returns, out[1]=sum of lengths, out[2]=count.
  * Synchronises `stream`. */
 int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream);

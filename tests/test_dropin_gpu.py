@@ -111,8 +111,16 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     assert os.path.exists(tmp_path / "runs" / "basic" / "t1" / "eval" / "evaluations.npz")
     prog = (tmp_path / "runs" / "basic" / "t1" / "tb" / "progress.csv").read_text().splitlines()
     assert "rollout/ep_rew_mean" in prog[0] and "train/approx_kl" in prog[0] and len(prog) >= 2
-    mon = (tmp_path / "runs" / "basic" / "t1" / "monitor" / "0.monitor.csv").read_text().splitlines()  # SB3 Monitor layout (aggregate rows)
-    assert mon[0].startswith("#{") and mon[1] == "r,l,t,n" and len(mon) >= 3 and len(mon[2].split(",")) == 4
+    mon = (tmp_path / "runs" / "basic" / "t1" / "monitor" / "0.monitor.csv").read_text().splitlines()  # SB3 Monitor layout: one row per episode
+    assert mon[0].startswith("#{") and "t_start" in json.loads(mon[0][1:]) and mon[1] == "r,l,t"
+    rows = [ln.split(",") for ln in mon[2:] if not ln.startswith("#")]
+    assert len(rows) >= 4096 // 50 and all(len(r) == 3 and 1 <= int(r[1]) <= 50 for r in rows)  # Basic: at most 50 steps per episode
+    assert [float(r[2]) for r in rows] == sorted(float(r[2]) for r in rows)
+    from three_mlagents_amd.tb_events import read_scalars
+
+    tb_dir = tmp_path / "runs" / "basic" / "t1" / "tb" / "PPO_1"
+    events = read_scalars(str(next(tb_dir.iterdir())))  # TensorBoard event file with the scalars SB3's logger writes
+    assert len(events) >= 1 and {"rollout/ep_rew_mean", "train/approx_kl", "time/fps"} <= set(events[0][1]) and events[-1][0] >= 4096
     cli.main(["evaluate", "basic", "basic_policy_t1.zip", "--episodes", "3"])
     ev = json.loads(capsys.readouterr().out)
     assert ev["episodes"] == 3 and len(ev["episode_lengths"]) == 3

@@ -243,3 +243,56 @@ def test_error_mapping_on_gpu():
         eng.step(torch.zeros(4, dtype=torch.float32, device="cuda"))  # wrong dtype for Discrete
     with pytest.raises(ValueError):
         eng.step(None, n_steps=5)  # exceeds steps until refill
+
+
+@pytest.mark.parametrize("task", ["gridworld", "basic", "walljump"])
+def test_episode_log_records_every_finished_episode(task):
+    """tma_env_episode_log / tma_env_pop_episode_log (the per-episode Monitor rows, reference training.py:85-86): the records the step
+    kernel appends equal the (return, length) pairs the same steps report through `infos[i]["episode"]`, env by env and in order; an
+    overflowing log keeps counting.  Then the same check against the fused rollout kernels through PPO.collect_rollouts."""
+    from three_mlagents_amd.vec_env import HipVecEnv
+
+    env = HipVecEnv(task, 96, seed=3)
+    env.engine.episode_log(4096)
+    env.reset()
+    rng = np.random.default_rng(0)
+    want = {i: [] for i in range(96)}
+    n_act = env.action_space.n
+    for _ in range(160):
+        _, _, dones, infos = env.step(rng.integers(0, n_act, 96))
+        for i in np.nonzero(dones)[0]:
+            want[int(i)].append((infos[i]["episode"]["r"], infos[i]["episode"]["l"]))
+    r, l, e, seen = env.engine.pop_episode_log()
+    assert seen == len(r) == sum(len(v) for v in want.values()) > 0
+    got = {i: [] for i in range(96)}
+    for rr, ll, ee in zip(r, l, e):
+        got[int(ee)].append((round(float(rr), 6), int(ll)))
+    for i in range(96):
+        assert len(got[i]) == len(want[i])
+        for (gr, gl), (wr, wl) in zip(got[i], want[i]):
+            assert gl == wl and abs(gr - wr) <= 1e-5 * max(1.0, abs(wr))
+    assert env.engine.pop_episode_log()[3] == 0  # emptied
+    env.engine.episode_log(8)  # overflow: 8 records kept, every episode counted
+    for _ in range(120):
+        env.step(rng.integers(0, n_act, 96))
+    r, l, e, seen = env.engine.pop_episode_log()
+    assert len(r) == 8 and seen > 8
+    env.close()
+
+
+def test_episode_log_from_the_fused_rollout():
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    for hidden, mfma in ((64, "f32"), (256, "bf16"), (256, "f32")):
+        env = make_vector_env("gridworld", n_envs=256, seed=2)
+        model = PPO("MlpPolicy", env, n_steps=128, batch_size=2048, n_epochs=1, seed=2, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
+        env.engine.episode_log(1 << 16)
+        model.collect_rollouts()
+        s_ret, s_len, cnt = env.engine.pop_episode_stats()
+        r, l, e, seen = env.engine.pop_episode_log()
+        done = (model.buf["terminated"] | model.buf["truncated"]).sum().item()
+        assert seen == len(r) == cnt == done > 0
+        assert abs(float(r.astype(np.float64).sum()) - s_ret) <= 1e-4 * max(1.0, abs(s_ret)) and int(l.sum()) == int(s_len)
+        assert 0 <= e.min() and e.max() < 256 and 1 <= l.min() and l.max() <= 100
+        env.close()

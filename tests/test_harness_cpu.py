@@ -94,3 +94,41 @@ def test_spaces_match_reference_declarations():  # envs.py:38-44,166-199
         assert act_space.contains(act_space.sample()) and not act_space.contains(n)
     obs_space, _ = task_spaces("gridworld")
     assert obs_space.contains(np.array([0.25, -0.75, 1, 0], np.float32)) and not obs_space.contains(np.array([2, 0, 0, 0], np.float32))
+
+
+def test_tensorboard_event_writer_round_trip_and_protobuf_schema(tmp_path):
+    """tb_events.py: CRC-32C known answer, writer -> reader round trip, and every record parses under the public Event / Summary schema
+    built with the protobuf runtime (an independent decoder of the bytes)."""
+    import struct
+
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    from three_mlagents_amd import tb_events as tb
+
+    assert tb.crc32c(b"123456789") == 0xE3069283
+    w = tb.EventWriter(str(tmp_path))
+    w.add_scalars({"train/approx_kl": 0.0125, "time/fps": 1.5e6, "skipped": float("nan")}, step=4096, wall_time=12.5)
+    w.add_scalars({"rollout/ep_rew_mean": -0.75}, step=8192)
+    got = tb.read_scalars(w.path)
+    assert got[0] == (4096, {"train/approx_kl": struct.unpack("<f", struct.pack("<f", 0.0125))[0], "time/fps": 1.5e6}) and got[1] == (8192, {"rollout/ep_rew_mean": -0.75})
+    fd = descriptor_pb2.FileDescriptorProto(name="ev.proto", package="t", syntax="proto3")
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=9, label=1)
+    val.field.add(name="simple_value", number=2, type=2, label=1)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=11, label=3, type_name=".t.Value")
+    ev = fd.message_type.add(name="Event")
+    ev.field.add(name="wall_time", number=1, type=1, label=1)
+    ev.field.add(name="step", number=2, type=3, label=1)
+    ev.field.add(name="file_version", number=3, type=9, label=1)
+    ev.field.add(name="summary", number=5, type=11, label=1, type_name=".t.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("t.Event"))
+    data, pos, events = open(w.path, "rb").read(), 0, []
+    while pos < len(data):
+        (n,) = struct.unpack("<Q", data[pos:pos + 8])
+        events.append(Event.FromString(data[pos + 12:pos + 12 + n]))
+        pos += 16 + n
+    assert events[0].file_version == "brain.Event:2" and events[1].step == 4096 and events[1].wall_time == 12.5
+    assert {v.tag: v.simple_value for v in events[1].summary.value}["time/fps"] == 1.5e6 and events[2].summary.value[0].tag == "rollout/ep_rew_mean"

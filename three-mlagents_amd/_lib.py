@@ -64,6 +64,8 @@ SIGNATURES = {
     "tma_env_get_state": (_i32, [_vp, _vp, _vp]),
     "tma_env_set_state": (_i32, [_vp, _vp, _vp]),
     "tma_env_episode_index": (_i32, [_vp, _vp, _vp]),
+    "tma_env_episode_log": (_i32, [_vp, _i64]),
+    "tma_env_pop_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
     "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
     "tma_gae_flags": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
                 if (ep_ret_out) ep_ret_out[off] = er;
                 if (ep_len_out) ep_len_out[off] = steps;
                 sret += er, slen += (double)steps, scnt += 1.0;
+                log_episode(v, i, er, steps);
                 er = 0.0;
                 ce += 1;
                 if constexpr (T::USES_MT) {
@@ -544,6 +545,10 @@ int tma_env_destroy(tma_env *h) {
     (void)hipFree(h->v.filled_hi);
     (void)hipFree(h->v.ep_ret);
     (void)hipFree(h->v.stats);
+    (void)hipFree(h->v.log_ret);
+    (void)hipFree(h->v.log_len);
+    (void)hipFree(h->v.log_env);
+    (void)hipFree(h->v.log_n);
     (void)hipFree(h->mt_scratch);
     (void)hipFree(h->rv.first_ep);
     (void)hipFree(h->rv.env_off);
@@ -681,6 +686,47 @@ int tma_env_episode_index(tma_env *h, uint32_t *out, void *stream) {
     TMA_HIP(hipSetDevice(h->device));
     copy_u32_kernel<<<dim3((unsigned)ceil_div(h->v.N, 256)), dim3(256), 0, (hipStream_t)stream>>>(h->v.cur_ep, out, h->v.N);
     TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+int tma_env_episode_log(tma_env *h, int64_t capacity) {
+    if (!h || capacity < 0) return fail(TMA_ERR_INVALID, "tma_env_episode_log: null handle or negative capacity");
+    TMA_HIP(hipSetDevice(h->device));
+    TMA_HIP(hipDeviceSynchronize());  // no step kernel may hold the old view
+    EnvView &v = h->v;
+    (void)hipFree(v.log_ret), (void)hipFree(v.log_len), (void)hipFree(v.log_env), (void)hipFree(v.log_n);
+    v.log_ret = nullptr, v.log_len = nullptr, v.log_env = nullptr, v.log_n = nullptr, v.log_cap = 0;
+    if (capacity == 0) return TMA_OK;
+    TMA_HIP(hipMalloc(&v.log_ret, sizeof(float) * (size_t)capacity));
+    TMA_HIP(hipMalloc(&v.log_len, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(hipMalloc(&v.log_env, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(hipMalloc(&v.log_n, sizeof(unsigned long long)));
+    TMA_HIP(hipMemset(v.log_n, 0, sizeof(unsigned long long)));
+    v.log_cap = capacity;
+    return TMA_OK;
+}
+
+int tma_env_pop_episode_log(tma_env *h, float *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored, int64_t *n_seen,
+                            void *stream) {
+    if (!h || !n_stored || !n_seen || max_records < 0 || (max_records > 0 && (!ret_host || !len_host || !env_host)))
+        return fail(TMA_ERR_INVALID, "tma_env_pop_episode_log: null argument");
+    const EnvView &v = h->v;
+    if (!v.log_n) return fail(TMA_ERR_INVALID, "tma_env_pop_episode_log: the episode log is off (tma_env_episode_log)");
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long seen = 0;
+    TMA_HIP(hipMemcpyAsync(&seen, v.log_n, sizeof(seen), hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipStreamSynchronize(s));
+    int64_t n = (int64_t)std::min<unsigned long long>(seen, (unsigned long long)v.log_cap);
+    if (n > max_records) n = max_records;
+    if (n > 0) {
+        TMA_HIP(hipMemcpyAsync(ret_host, v.log_ret, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+        TMA_HIP(hipMemcpyAsync(len_host, v.log_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+        TMA_HIP(hipMemcpyAsync(env_host, v.log_env, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    TMA_HIP(hipMemsetAsync(v.log_n, 0, sizeof(unsigned long long), s));
+    TMA_HIP(hipStreamSynchronize(s));
+    *n_stored = n, *n_seen = (int64_t)seen;
     return TMA_OK;
 }
 

@@ -33,7 +33,7 @@ constexpr int HP_GRID = 128;      // workgroups launched (16 per XCD under round
 constexpr int HP_SLAB_F = 6400;   // floats per slab / reduced-gradient array: >= one net's parameters for D <= 16, A <= 16 (6288)
 // byte offsets inside the persistent region (the workspace's partial-gradient slab area, which this path does not use otherwise)
 constexpr int HP_SYNC = 0;        // u32 words on lines of their own: [0] arrivals A policy net, [32] A value net, [64] arrivals B, [96] claimed XCD + 1, [128] roles taken, [160] abort
-constexpr int HP_SQ = 1024;       // double[HP_NB]: sum of squares of each block's reduced quarter
+constexpr int HP_SQ = 1024;       // HP_NB granules of 16 bytes {step tag, -, f64 sum of squares of the block's reduced quarter}
 constexpr int HP_TICKS = 2048;    // u64[16] phase ticks of role 0 (diagnostic, args.ticks)
 constexpr int HP_SLABS = 4096;
 constexpr int HP_G = HP_SLABS + HP_NB * HP_SLAB_F * 4;
@@ -176,6 +176,7 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
     __shared__ double red_sq[4];
     __shared__ double red_st[4 * 5];
     __shared__ int ok_s;
+    __shared__ double tot_s;
     const PLayout &L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int D = DT > 0 ? DT : L.D, A = L.A, KS1 = (D + 3) >> 2, NOUT = IS_PI ? A : 1;
@@ -263,6 +264,29 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
         pf_tb = reinterpret_cast<const float2 *>(a.region + HP_TABLE)[st];
     };
     fetch(0);
+    // the committed inputs of the minibatch about to run: formed one step ahead, under the wait of sync A (prepare)
+    float xb[KS1C], m0 = 0.0f, m1 = 0.0f, amean = 0.0f, astd = 1.0f, invB = 1.0f;
+    int act = 0;
+    bool valid = false;
+    float2 tb = make_float2(0.0f, 1.0f);
+    auto prepare = [&](int sn) {
+        const int count = count_of(sn < n_mb ? sn : n_mb - 1);
+        valid = local < count;
+        invB = 1.0f / (float)count;
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ks++) xb[ks] = (valid && 4 * ks + g < D) ? pf_x[ks] : 0.0f;
+        m0 = pf_m0, m1 = pf_m1, act = pf_act, tb = pf_tb;
+        amean = 0.0f, astd = 1.0f;
+        if (IS_PI && a.hp.normalize_advantage && count > 1) {  // (the fold of adv_final_kernel; one partial pair per minibatch at batch <= 1024)
+            const double n = (double)count, mean = pf_adv_a / n;
+            double var = n > 1.0 ? (pf_adv_b - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            amean = (float)mean;
+            astd = (float)sqrt(var);
+        }
+        fetch(sn + 1);
+    };
+    prepare(0);
     TileStats st;
     TileTicks tk;
 #ifdef TMA_H64_TICKS
@@ -273,26 +297,7 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
     HP_TICK(0);
 
     for (int s = 0; s < n_mb; s++) {
-        // ---- commit the prefetched minibatch rows ----
-        const int count = count_of(s);
-        const bool valid = local < count;
-        const float invB = 1.0f / (float)count;
-        float xb[KS1C];
-#pragma unroll
-        for (int ks = 0; ks < KS1C; ks++) xb[ks] = (valid && 4 * ks + g < D) ? pf_x[ks] : 0.0f;
-        const float m0 = pf_m0, m1 = pf_m1;
-        const int act = pf_act;
-        const float2 tb = pf_tb;
-        float amean = 0.0f, astd = 1.0f;
-        if (IS_PI && a.hp.normalize_advantage && count > 1) {  // (the fold of adv_final_kernel; one partial pair per minibatch at batch <= 1024)
-            const double n = (double)count, mean = pf_adv_a / n;
-            double var = n > 1.0 ? (pf_adv_b - n * mean * mean) / (n - 1.0) : 0.0;
-            if (var < 0.0) var = 0.0;
-            amean = (float)mean;
-            astd = (float)sqrt(var);
-        }
-        fetch(s + 1);
-        HP_TICK(8);
+        const float2 tbs = tb;  // (this step's Adam constants: prepare() below replaces tb with the next step's)
 #ifdef TMA_H64_TICKS
         tk.prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -332,10 +337,10 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
         __syncthreads();
         HP_TICK(2);
         // ---- sync A: the four blocks of this net ----
-        if (tid == 0) {
-            __hip_atomic_fetch_add(cntA, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_s = wait_ge(cntA, 4u * (unsigned)(s + 1), abortw) ? 1 : 0;
-        }
+        if (tid == 0) __hip_atomic_fetch_add(cntA, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prepare(s + 1);  // (the next minibatch's inputs, while the other blocks arrive)
+        HP_TICK(8);
+        if (tid == 0) ok_s = wait_ge(cntA, 4u * (unsigned)(s + 1), abortw) ? 1 : 0;
         __syncthreads();
         if (!ok_s) return;
         HP_TICK(3);
@@ -368,13 +373,39 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // ---- sync B: all eight blocks ----
-        if (tid == 0) {
-            sqp[role] = ((red_sq[0] + red_sq[1]) + red_sq[2]) + red_sq[3];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(cntB, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- sync B: all eight blocks.  Each block publishes ONE 16-byte granule {step tag, -, sum of squares}: the tag arrives with
+        // the value (a single aligned store), so there is no second drain and no counter; wave 0 polls the eight granules, one per lane ----
+        if (wave == 0) {
+            const unsigned tag = (unsigned)(s + 1);
+            if (lane == 0) {
+                const double sqb = ((red_sq[0] + red_sq[1]) + red_sq[2]) + red_sq[3];
+                const u32x2 h = __builtin_bit_cast(u32x2, sqb);
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(sqp) + 16 * role) = u32x4{tag, 0u, h[0], h[1]};
+            }
             HP_TICK(4);
-            ok_s = wait_ge(cntB, (unsigned)HP_NB * (unsigned)(s + 1), abortw) ? 1 : 0;
+            u32x4 gr;
+            int spins = 0;
+            bool fine = true;
+            for (;;) {
+                gr = __builtin_amdgcn_raw_buffer_load_b128(r_sq, 16 * (lane & (HP_NB - 1)), 0, SC1);
+                if (__builtin_amdgcn_ballot_w64(gr[0] != tag) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                spins++;
+                if ((spins & 1023) == 0 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) fine = false;
+                if (spins > (1 << 22)) {
+                    __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fine = false;
+                }
+                if (!fine) break;
+            }
+            double tot = 0.0;  // the blocks' sums in block order
+#pragma unroll
+            for (int b = 0; b < HP_NB; b++) {
+                const u32x2 h = {(unsigned)__builtin_amdgcn_readlane((int)gr[2], b), (unsigned)__builtin_amdgcn_readlane((int)gr[3], b)};
+                const double v = __builtin_bit_cast(double, h);
+                tot = b == 0 ? v : tot + v;
+            }
+            if (lane == 0) tot_s = tot, ok_s = fine ? 1 : 0;
         }
         __syncthreads();
         if (!ok_s) return;
@@ -386,15 +417,12 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
             for (int s4 = 0; s4 < 4; s4++) g_w2[s4] = ld_sc1_x4(r_G, 16 * (nm4 + tid + 256 * s4));
 #pragma unroll
             for (int u = 0; u < NM; u++) g_ms[u] = ld_sc1_x4(r_G, tid + 256 * u < nm4 ? 16 * (tid + 256 * u) : OOB);
-            double tot = ld_sc1_f64(r_sq, 0);
-#pragma unroll
-            for (int b = 1; b < HP_NB; b++) tot += ld_sc1_f64(r_sq, 8 * b);
-            const float total_norm = (float)sqrt(tot);
+            const float total_norm = (float)sqrt(tot_s);
             float coef = a.max_norm / (total_norm + 1e-6f);
             coef = coef > 1.0f ? 1.0f : coef;
             if (a.max_norm <= 0.0f) coef = 1.0f;
             last_norm = total_norm, last_coef = coef;
-            const float lr_step = tb.x, inv_bc2 = 1.0f / tb.y;
+            const float lr_step = tbs.x, inv_bc2 = 1.0f / tbs.y;
             HP_TICK(6);
             // W2t: both image slots follow from the thread index.  The forward image takes the new value directly (a wave's lanes cover
             // 64 consecutive words: conflict-free); the input-gradient image is [n][k]-major, where the same lanes would hit one bank

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
                     for (int c = 0; c < D; c++) XT[my_row * ldx + c] = o[c];
                 }
                 sret += er, slen += (double)steps, scnt += 1.0;
+                log_episode(v, i, er, steps);
                 er = 0.0;
                 ce += 1;
                 uint32_t rec[T::RW];
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
                         rw[p * 16 + my_row] = rew32;
                     }
                     sret += er, slen += (double)steps, scnt += 1.0;
+                    log_episode(v, i, er, steps);
                     er = 0.0;
                     ce += 1;
                     uint32_t rec[T::RW];
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
                             rw[my_row] = rew32;
                         }
                         sret += er, slen += (double)steps, scnt += 1.0;
+                        log_episode(v, i, er, steps);
                         er = 0.0;
                         ce += 1;
                         if constexpr (T::USES_MT) {

@@ -354,6 +354,9 @@ class PPO:
         cb.on_training_start(locals(), globals())
         t0 = time.time()
         iteration = 0
+        if getattr(self.env, "monitor_dir", None) and self.rank == 0 and getattr(self.env.engine, "_log_cap", 0) == 0:
+            self.env.engine.episode_log(self.monitor_log_capacity)  # per-episode Monitor rows (r, l, t)
+        t_prev = 0.0
         while self.num_timesteps < total_timesteps:
             cb.on_rollout_start()
             if not self.collect_rollouts(cb if callback is not None else None, chunk=getattr(cb, "chunk_steps", None)):
@@ -370,14 +373,16 @@ class PPO:
                               "rollout/episodes": cnt, "train/n_updates": self._n_updates})
                 self.logger_values = stats
                 self._write_progress(stats)
-                self._write_monitor(s_ret, s_len, cnt, time.time() - t0)
+                self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0)
+                t_prev = time.time() - t0
                 if self.verbose >= 1 and self.rank == 0:
                     print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
         cb.on_training_end()
         return self
 
     def _write_progress(self, stats: dict) -> None:
-        """Scalar log per iteration (the keys SB3's logger writes: rollout/*, train/*, time/*) as CSV under tensorboard_log."""
+        """Scalar log per iteration (the keys SB3's logger writes: rollout/*, train/*, time/*) under tensorboard_log: `progress.csv` and a
+        TensorBoard event file in `<tb_log_name>_1/` (tb_events.py; SB3 sends the same scalars through its TensorBoard output format)."""
         if not self.tensorboard_log or self.rank != 0:
             return
         os.makedirs(self.tensorboard_log, exist_ok=True)
@@ -388,22 +393,39 @@ class PPO:
             if new:
                 f.write(",".join(keys) + "\n")
             f.write(",".join(repr(float(stats[k])) for k in keys) + "\n")
+        if getattr(self, "_tb_writer", None) is None:
+            from .tb_events import EventWriter
 
-    def _write_monitor(self, sum_ret: float, sum_len: float, count: float, elapsed: float) -> None:
-        """SB3 Monitor file (`<monitor_dir>/0.monitor.csv`, the directory training.make_vector_env passes; reference
-        training.py:85-86): header line + `r,l,t` rows.  The device keeps Monitor SUMS, not one record per episode, so a row is the
-        mean return / mean length of the `n` episodes that finished since the previous row (documented deviation)."""
+            self._tb_writer = EventWriter(os.path.join(self.tensorboard_log, "PPO_1"))
+        self._tb_writer.add_scalars(stats, self.num_timesteps)
+
+    monitor_log_capacity = 1 << 20  # episode records the device keeps between two log intervals
+    monitor_max_rows = 100_000      # rows written per log interval (an evenly strided subsample beyond that)
+
+    def _write_monitor(self, sum_ret: float, sum_len: float, count: float, t_begin: float, t_end: float, t_start: float) -> None:
+        """SB3 Monitor file (`<monitor_dir>/0.monitor.csv`, the directory make_vector_env passes; reference training.py:85-86): the JSON
+        header line, then one `r,l,t` row per finished episode of ANY env of the vector, in the order the kernels logged them (one file for
+        the whole vector: `load_results` concatenates per-env files anyway).  `t` is interpolated over the log interval -- the device does
+        not stamp wall-clock time.  More than monitor_max_rows episodes in one interval are subsampled with an even stride and a `#` comment
+        line records how many finished; if the device log overflowed, the interval's mean is added as a comment as well."""
         mdir = getattr(self.env, "monitor_dir", None)
         if not mdir or self.rank != 0 or not count:
             return
         os.makedirs(mdir, exist_ok=True)
         path = os.path.join(str(mdir), "0.monitor.csv")
         new = not os.path.exists(path)
+        r, l, _, seen = self.env.engine.pop_episode_log()
+        n = len(r)
+        keep = np.arange(n) if n <= self.monitor_max_rows else np.linspace(0, n - 1, self.monitor_max_rows).astype(np.int64)
         with open(path, "a", encoding="utf-8") as f:
             if new:
-                f.write("#" + json.dumps({"t_start": time.time() - elapsed, "env_id": getattr(self.env, "task_id", None), "aggregate": True}) + "\n")
-                f.write("r,l,t,n\n")
-            f.write(f"{sum_ret / count:.6f},{sum_len / count:.3f},{elapsed:.6f},{int(count)}\n")
+                f.write("#" + json.dumps({"t_start": t_start, "env_id": getattr(self.env, "task_id", None)}) + "\n")
+                f.write("r,l,t\n")
+            if len(keep) < seen:
+                f.write(f"# {seen} episodes finished in this interval, {len(keep)} rows kept; interval mean r={sum_ret / count:.6f} l={sum_len / count:.3f}\n")
+            for q, k in enumerate(keep):
+                t = t_begin + (t_end - t_begin) * (q + 1) / len(keep)
+                f.write(f"{round(float(r[k]), 6)},{int(l[k])},{round(t, 6)}\n")
 
     # -- inference ------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):

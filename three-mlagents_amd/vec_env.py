@@ -169,6 +169,22 @@ class HipEnvEngine:
         _lib.check(_lib.lib().tma_env_episode_index(self._h, _lib.ptr(out), self._stream()))
         return out
 
+    def episode_log(self, capacity: int) -> None:
+        """Turn the per-episode Monitor log on (capacity records kept between pops) or off (0)."""
+        _lib.check(_lib.lib().tma_env_episode_log(self._h, int(capacity)))
+        self._log_cap = int(capacity)
+
+    def pop_episode_log(self) -> tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+        """(returns f32[n], lengths i32[n], env index i32[n], episodes seen) since the last pop, in the order the kernels logged them."""
+        cap = getattr(self, "_log_cap", 0)
+        if cap <= 0:
+            raise RuntimeError("episode log is off: call episode_log(capacity) first")
+        r, l, e = np.empty(cap, np.float32), np.empty(cap, np.int32), np.empty(cap, np.int32)
+        n, seen = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().tma_env_pop_episode_log(self._h, r.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                                      cap, C.byref(n), C.byref(seen), self._stream()))
+        return r[:n.value].copy(), l[:n.value].copy(), e[:n.value].copy(), int(seen.value)
+
     def pop_episode_stats(self) -> tuple[float, float, int]:
         out = (C.c_double * 3)()
         _lib.check(_lib.lib().tma_env_pop_episode_stats(self._h, out, self._stream()))
