@@ -187,3 +187,30 @@ def test_engine_runs_from_a_worker_thread():
     is_main, p_main, a_main = work()
     assert not was_main and is_main
     assert torch.equal(p_thread, p_main) and np.array_equal(a_thread, a_main) and torch.isfinite(p_main).all()
+
+
+def test_bridge_streams_run_steps_with_device_state(tmp_path, monkeypatch):
+    """bridge.run_for_websocket (reference websocket_training.py:141-185): a saved policy drives one device env and every `run_step` frame
+    carries that env's state read back from the GPU; the Crawler-shape readback has the reference wrapper's three keys."""
+    import asyncio
+
+    monkeypatch.chdir(tmp_path)
+    from three_mlagents_amd import bridge, harness
+
+    harness.train_task(harness.TrainConfig("gridworld", 2048, "ppo", 1, 8, 2, 100_000, run_name="b1", verbose=0))
+    frames = []
+
+    class Sock:
+        async def send_json(self, payload):
+            frames.append(payload)
+
+    episodes = asyncio.run(bridge.run_for_websocket(Sock(), "gridworld", model_filename="gridworld_policy_b1.zip", sleep_seconds=0.0, max_steps=130))
+    assert len(frames) == 130 and all(f["type"] == "run_step" and set(f["state"]) == set(bridge.STATE_FIELDS["gridworld"]) for f in frames)
+    assert episodes >= 1 and frames[-1]["episode"] >= episodes and all(0 <= f["state"]["agentX"] < 5 and 1 <= f["state"]["steps"] <= 100 or f["state"]["steps"] == 0 for f in frames)
+    from three_mlagents_amd.vec_env import HipVecEnv
+
+    env = HipVecEnv("crawler", 4, seed=1)
+    env.reset()
+    st = bridge.state_for_viz(env, 2)
+    assert set(st) == {"basePos", "baseOri", "jointAngles", "steps"} and len(st["basePos"]) == 3 and len(st["baseOri"]) == 4 and len(st["jointAngles"]) == 8
+    env.close()

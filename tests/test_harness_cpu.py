@@ -132,3 +132,43 @@ def test_tensorboard_event_writer_round_trip_and_protobuf_schema(tmp_path):
         pos += 16 + n
     assert events[0].file_version == "brain.Event:2" and events[1].step == 4096 and events[1].wall_time == 12.5
     assert {v.tag: v.simple_value for v in events[1].summary.value}["time/fps"] == 1.5e6 and events[2].summary.value[0].tag == "rollout/ep_rew_mean"
+
+
+def test_bridge_message_shapes_without_a_gpu():
+    """bridge.py: the `progress` / `trained` frames of the reference's WebSocket protocol (websocket_training.py:19-51,98-112) from the
+    engine's callback protocol, with a stand-in trainer (no GPU) and a stand-in socket."""
+    import asyncio
+
+    from three_mlagents_amd import bridge, harness
+
+    sent = []
+
+    class Sock:
+        async def send_json(self, payload):
+            sent.append(payload)
+
+    class Model:
+        num_timesteps = 0
+
+        def get_env(self):
+            return None
+
+    def fake_train(cfg, *, callback):
+        m = Model()
+        callback.init_callback(m)
+        callback.on_training_start()
+        for _ in range(5):
+            m.num_timesteps += 1500
+            assert callback.on_step()
+        return harness.TrainResult(cfg.task_id, "ppo", "gridworld_ppo_20260101_000000_ab12cd34", "gridworld_policy_x.zip", "policies/gridworld_policy_x.zip",
+                                   "runs/gridworld/x", 0.5, 0.1, 7, 7500, "runs/gridworld/x/metadata.json")
+
+    out = asyncio.run(bridge.train_for_websocket(Sock(), "gridworld", total_timesteps=7500, progress_freq=2000, train=fake_train))
+    kinds = [p["type"] for p in sent]
+    assert kinds[0] == "progress" and sent[0]["timesteps"] == 0 and sent[0]["task_id"] == "gridworld" and kinds[-1] == "trained"
+    prog = [p for p in sent[1:] if p["type"] == "progress"]
+    assert [p["timesteps"] for p in prog] == [3000, 6000] and prog[-1]["progress"] == 0.8 and prog[0]["algorithm"] == "Model"
+    assert set(prog[0]) == {"type", "episode", "reward", "loss", "timesteps", "progress", "algorithm"}
+    t = sent[-1]
+    assert t["file_url"] == "/policies/gridworld_policy_x.zip" and t["session_uuid"] == "ab12cd34" and t["eval_episodes"] == 7 and out["mean_reward"] == 0.5
+    assert set(bridge.STATE_FIELDS) == {"basic", "gridworld", "push", "ball3d", "walljump"}
