@@ -214,3 +214,50 @@ def test_bridge_streams_run_steps_with_device_state(tmp_path, monkeypatch):
     st = bridge.state_for_viz(env, 2)
     assert set(st) == {"basePos", "baseOri", "jointAngles", "steps"} and len(st["basePos"]) == 3 and len(st["baseOri"]) == 4 and len(st["jointAngles"]) == 8
     env.close()
+
+
+def test_saved_zip_follows_the_sb3_layout(tmp_path):
+    """PPO.save (training.py:172-175 `model.save`): the zip members SB3's load_from_zip_file reads; `policy.pth` loads strictly into a torch
+    module laid out like SB3's ActorCriticPolicy and reproduces the engine's values; `policy.optimizer.pth` is a torch.optim.Adam
+    state_dict for that module; PPO.load(env=...) restores parameters AND moments bit for bit."""
+    import io
+    import zipfile
+
+    import torch
+
+    from test_harness_cpu import _sb3_like_policy
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    for task, cont in (("gridworld", False), ("crawler", True)):
+        env = make_vector_env(task, n_envs=64, seed=1)
+        model = PPO("MlpPolicy", env, n_steps=32, batch_size=512, n_epochs=2, seed=1, policy_kwargs={"net_arch": [64, 64]})
+        model.learn(2 * 64 * 32)
+        path = tmp_path / f"{task}_policy.zip"
+        model.save(str(path))
+        with zipfile.ZipFile(path) as z:
+            assert {"data", "policy.pth", "policy.optimizer.pth", "pytorch_variables.pth", "_stable_baselines3_version", "system_info.txt"} <= set(z.namelist())
+            data = json.loads(z.read("data"))
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True)
+            opt_sd = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), weights_only=True)
+        for key in ("policy_class", "observation_space", "action_space"):
+            assert set(data[key]) >= {":type:", ":serialized:"}
+        for key in ("learning_rate", "n_steps", "gamma", "gae_lambda", "n_envs", "clip_range", "use_sde", "policy_kwargs", "seed", "num_timesteps"):
+            assert key in data and not isinstance(data[key], dict) or key == "policy_kwargs"
+        assert data["policy_kwargs"] == {"net_arch": [64, 64]} and data["n_envs"] == 64 and data["num_timesteps"] == 2 * 64 * 32
+        D, A = model.policy.obs_dim, model.policy.act_dim
+        net = _sb3_like_policy(D, 64, A, cont)
+        assert list(sd) == [n for n, _ in net.named_parameters()]
+        net.load_state_dict(sd, strict=True)
+        obs = torch.randn(17, D)
+        v_torch = net.value_net(net.mlp_extractor.value_net(obs)).squeeze(1)
+        assert torch.allclose(model.policy.predict_values(obs.cuda()).cpu(), v_torch, rtol=1e-5, atol=1e-5)
+        opt = torch.optim.Adam(net.parameters(), lr=1.0, eps=1e-5)
+        opt.load_state_dict(opt_sd)
+        assert float(opt.state[net.action_net.weight]["step"]) == model._adam_step > 0
+        assert torch.equal(opt.state[net.value_net.bias]["exp_avg"], model.policy.named_from_flat(model.exp_avg)["value_net.bias"])
+        env2 = make_vector_env(task, n_envs=64, seed=1)
+        again = PPO.load(str(path), env=env2)
+        assert torch.equal(again.policy.params, model.policy.params) and torch.equal(again.exp_avg, model.exp_avg) and torch.equal(again.exp_avg_sq, model.exp_avg_sq)
+        assert again._adam_step == model._adam_step and again.num_timesteps == model.num_timesteps and again.n_steps == 32
+        env.close(), env2.close()

@@ -172,3 +172,89 @@ def test_bridge_message_shapes_without_a_gpu():
     t = sent[-1]
     assert t["file_url"] == "/policies/gridworld_policy_x.zip" and t["session_uuid"] == "ab12cd34" and t["eval_episodes"] == 7 and out["mean_reward"] == 0.5
     assert set(bridge.STATE_FIELDS) == {"basic", "gridworld", "push", "ball3d", "walljump"}
+
+
+def _sb3_like_policy(D, H, A, continuous):
+    """A torch module with the parameter names and registration order of SB3's ActorCriticPolicy (MlpExtractor with separate 2-layer
+    pi / vf nets; `log_std` a direct parameter of the policy)."""
+    import torch
+    from torch import nn
+
+    class Extractor(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.policy_net = nn.Sequential(nn.Linear(D, H), nn.Tanh(), nn.Linear(H, H), nn.Tanh())
+            self.value_net = nn.Sequential(nn.Linear(D, H), nn.Tanh(), nn.Linear(H, H), nn.Tanh())
+
+    class Policy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp_extractor = Extractor()
+            self.action_net = nn.Linear(H, A)
+            if continuous:
+                self.log_std = nn.Parameter(torch.zeros(A))
+            self.value_net = nn.Linear(H, 1)
+
+    return Policy()
+
+
+def test_sb3_zip_members_without_sb3(monkeypatch):
+    """sb3_format.py: the three pickled members of `data` restore through a re-statement of SB3's json_to_data (base64 -> cloudpickle.loads)
+    into classes that restore state the way gymnasium's spaces do (`__dict__.update`), the parameter order is torch's registration order of
+    an ActorCriticPolicy, and the Adam state_dict loads into a real torch.optim.Adam over such a module and steps."""
+    import base64
+    import sys
+    import types
+
+    import cloudpickle
+    import numpy as np
+    import torch
+
+    from three_mlagents_amd import sb3_format as sf
+    from three_mlagents_amd.spaces import Box, Discrete
+
+    assert "gymnasium" not in sys.modules and "stable_baselines3" not in sys.modules  # (the image has neither; stand-ins below)
+    members = sf.data_members(Box(-1.0, 1.0, (4,), np.float32), Discrete(5))
+    assert "gymnasium" not in sys.modules  # the writer leaves no stub module behind
+
+    class Space:  # gymnasium.spaces.Space.__setstate__: legacy key renames, then __dict__.update
+        def __setstate__(self, state):
+            state = dict(state)
+            for old, new in (("shape", "_shape"), ("np_random", "_np_random")):
+                if old in state:
+                    state[new] = state.pop(old)
+            self.__dict__.update(state)
+
+        shape = property(lambda self: self._shape)
+
+    for name, attrs in (("gymnasium", {}), ("gymnasium.spaces", {}), ("gymnasium.spaces.box", {"Box": type("Box", (Space,), {})}),
+                        ("gymnasium.spaces.discrete", {"Discrete": type("Discrete", (Space,), {})}), ("stable_baselines3", {}),
+                        ("stable_baselines3.common", {}), ("stable_baselines3.common.policies", {"ActorCriticPolicy": type("ActorCriticPolicy", (), {})})):
+        mod = types.ModuleType(name)
+        for k, v in attrs.items():
+            v.__module__, v.__qualname__ = name, k
+            setattr(mod, k, v)
+        monkeypatch.setitem(sys.modules, name, mod)
+    got = {k: cloudpickle.loads(base64.b64decode(v[":serialized:"].encode())) for k, v in members.items()}  # SB3's json_to_data, per member
+    assert got["policy_class"] is sys.modules["stable_baselines3.common.policies"].ActorCriticPolicy
+    ob, ac = got["observation_space"], got["action_space"]
+    assert type(ob).__name__ == "Box" and ob.shape == (4,) and ob.dtype == np.float32 and np.array_equal(ob.low, -np.ones(4, np.float32))
+    assert np.array_equal(ob.high, np.ones(4, np.float32)) and ob.bounded_below.all() and ob.low_repr == "-1.0" and ob._np_random is None
+    assert type(ac).__name__ == "Discrete" and int(ac.n) == 5 and int(ac.start) == 0 and ac.shape == () and ac.dtype == np.int64
+
+    for cont in (False, True):
+        D, H, A = 4, 64, 5
+        net = _sb3_like_policy(D, H, A, cont)
+        order = sf.parameter_order(cont)
+        assert [n for n, _ in net.named_parameters()] == order
+        moments = {n: torch.rand_like(p) for n, p in net.named_parameters()}
+        sd = sf.adam_state_dict(order, moments, {k: v * v for k, v in moments.items()}, step=7, lr=3e-4)
+        opt = torch.optim.Adam(net.parameters(), lr=1.0, eps=1e-5)
+        opt.load_state_dict(sd)
+        assert opt.param_groups[0]["lr"] == 3e-4 and float(opt.state[next(iter(net.parameters()))]["step"]) == 7.0
+        for p in net.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()
+        assert float(opt.state[next(iter(net.parameters()))]["step"]) == 8.0
+        fresh = sf.adam_state_dict(order, {}, {}, step=0, lr=3e-4)  # an untrained model: empty state, still loadable
+        torch.optim.Adam(net.parameters()).load_state_dict(fresh)

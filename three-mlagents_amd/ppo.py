@@ -102,18 +102,26 @@ class HipActorCriticPolicy:
         return list(zip(SB3_KEYS, self.offsets[:12], shapes))
 
     def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
-        flat = torch.zeros(self.n_trainable, dtype=torch.float32)
-        for key, off, shape in self._segments():
-            w = sd[key].detach().to(torch.float32).cpu().reshape(shape)
-            w = w.t().contiguous() if len(shape) == 2 else w  # kernels use the [in][out] layout
-            flat[off:off + w.numel()] = w.reshape(-1)
-        if self.continuous:
-            flat[self.offsets[12]:self.offsets[12] + self.act_dim] = sd["log_std"].detach().float().cpu()
-        self.params[: self.n_trainable].copy_(flat.to(self.device))
+        self.params[: self.n_trainable].copy_(self.flat_from_named(sd).to(self.device))
         _lib.check(_lib.lib().tma_policy_sync(_lib.ptr(self.params), C.byref(self.dims), _lib.stream_ptr(self.device)))
 
     def state_dict(self) -> dict[str, torch.Tensor]:
-        flat = self.params[: self.n_trainable].detach().cpu()
+        return self.named_from_flat(self.params[: self.n_trainable])
+
+    def flat_from_named(self, sd: dict[str, torch.Tensor]) -> torch.Tensor:
+        """SB3-named tensors ([out][in] matrices) -> one vector in the engine's trainable layout (CPU)."""
+        flat = torch.zeros(self.n_trainable, dtype=torch.float32)
+        for key, off, shape in self._segments():
+            w = sd[key].detach().to(torch.float32).cpu().reshape(shape)
+            w = w.t().contiguous() if len(shape) == 2 else w
+            flat[off:off + w.numel()] = w.reshape(-1)
+        if self.continuous:
+            flat[self.offsets[12]:self.offsets[12] + self.act_dim] = sd["log_std"].detach().float().cpu()
+        return flat
+
+    def named_from_flat(self, vec: torch.Tensor) -> dict[str, torch.Tensor]:
+        """A vector in the engine's trainable layout (parameters, or an optimizer moment) -> SB3-named tensors."""
+        flat = vec.detach().cpu()
         sd = {}
         for key, off, shape in self._segments():
             n = int(np.prod(shape))
@@ -447,15 +455,29 @@ class PPO:
 
     # -- artefacts (SB3 zip member names) ---------------------------------------
     def _data(self) -> dict[str, Any]:
-        return {
-            "policy_class": self.policy_class, "engine": "three-mlagents_amd", "task_id": getattr(self.env, "task_id", None),
-            "obs_dim": self.policy.obs_dim, "act_dim": self.policy.act_dim, "continuous": self.policy.continuous, "hidden": self.policy.hidden,
-            "learning_rate": self.learning_rate, "n_steps": self.n_steps, "batch_size": self.batch_size, "n_epochs": self.n_epochs,
-            "gamma": self.gamma, "gae_lambda": self.gae_lambda, "clip_range": self.clip_range, "normalize_advantage": self.normalize_advantage,
-            "ent_coef": self.ent_coef, "vf_coef": self.vf_coef, "max_grad_norm": self.max_grad_norm, "policy_kwargs": self.policy_kwargs,
-            "seed": self.seed, "num_timesteps": self.num_timesteps, "_n_updates": self._n_updates, "_adam_step": self._adam_step,
-            "n_envs": getattr(self, "n_envs", None),
+        """The `data` member of the zip in stable-baselines3's vocabulary: what BaseAlgorithm.load puts into `model.__dict__` before
+        `_setup_model` (sb3_format.py builds the three members that must be live objects).  Engine-only values sit under "tma"."""
+        from . import sb3_format
+        from .spaces import Box, Discrete
+
+        pol = self.policy
+        env = self.env
+        obs_space = getattr(env, "observation_space", None) or Box(-np.inf, np.inf, (pol.obs_dim,), np.float32)
+        act_space = getattr(env, "action_space", None) or (Box(-1.0, 1.0, (pol.act_dim,), np.float32) if pol.continuous else Discrete(pol.act_dim))
+        data = {
+            "policy_kwargs": {"net_arch": [pol.hidden, pol.hidden]}, "num_timesteps": self.num_timesteps, "_total_timesteps": getattr(self, "_total_timesteps", 0),
+            "_num_timesteps_at_start": 0, "seed": self.seed, "action_noise": None, "start_time": time.time_ns(), "learning_rate": self.learning_rate,
+            "tensorboard_log": self.tensorboard_log, "_last_obs": None, "_last_episode_starts": None, "_last_original_obs": None, "_episode_num": 0,
+            "use_sde": False, "sde_sample_freq": -1, "_current_progress_remaining": 0.0, "_stats_window_size": 100, "ep_info_buffer": None,
+            "ep_success_buffer": None, "_n_updates": self._n_updates, "n_envs": getattr(self, "n_envs", 1), "n_steps": self.n_steps, "gamma": self.gamma,
+            "gae_lambda": self.gae_lambda, "ent_coef": self.ent_coef, "vf_coef": self.vf_coef, "max_grad_norm": self.max_grad_norm,
+            "rollout_buffer_class": None, "rollout_buffer_kwargs": {}, "batch_size": self.batch_size, "n_epochs": self.n_epochs, "clip_range": self.clip_range,
+            "clip_range_vf": None, "normalize_advantage": self.normalize_advantage, "target_kl": None, "verbose": self.verbose, "_custom_logger": False,
+            "tma": {"engine": "three-mlagents_amd", "task_id": getattr(env, "task_id", None), "mfma_dtype": self.policy_kwargs.get("mfma_dtype", "f32"),
+                    "adam_step": self._adam_step, "obs_dim": pol.obs_dim, "act_dim": pol.act_dim, "continuous": pol.continuous, "hidden": pol.hidden},
         }
+        data.update(sb3_format.data_members(obs_space, act_space))
+        return data
 
     def save(self, path, exclude=None, include=None) -> None:
         path = str(path)
@@ -468,11 +490,15 @@ class PPO:
             torch.save(obj, bio)
             return bio.getvalue()
 
+        from . import sb3_format
+
         sd = self.policy.state_dict()
-        opt = {"state": {}, "param_groups": [{"lr": self.learning_rate, "betas": (0.9, 0.999), "eps": 1e-5, "weight_decay": 0,
-                                               "amsgrad": False, "params": list(range(len(sd)))}]}
-        if getattr(self, "exp_avg", None) is not None:  # (a model loaded without an env has a policy but no optimizer state)
-            opt["tma_flat"] = {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self._adam_step}
+        order = sb3_format.parameter_order(self.policy.continuous)
+        sd = {k: sd[k] for k in order}  # torch's registration order of an ActorCriticPolicy: also the optimizer's parameter indices
+        has_moments = getattr(self, "exp_avg", None) is not None  # (a model loaded without an env has a policy but no optimizer state)
+        opt = sb3_format.adam_state_dict(order, self.policy.named_from_flat(self.exp_avg) if has_moments else {},
+                                         self.policy.named_from_flat(self.exp_avg_sq) if has_moments else {}, self._adam_step if has_moments else 0,
+                                         self.learning_rate)
         with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
             z.writestr("data", json.dumps(self._data(), indent=2, default=str))
             z.writestr("policy.pth", _pth(sd))
@@ -502,6 +528,7 @@ class PPO:
         # zips written by stable-baselines3 carry their own `data` schema: recover the policy shape from the state_dict,
         # whose keys/shapes are SB3's (mlp_extractor.policy_net.{0,2}, mlp_extractor.value_net.{0,2}, action_net, value_net, log_std)
         w1, wa = sd["mlp_extractor.policy_net.0.weight"], sd["action_net.weight"]
+        tma_extra = data.get("tma") if isinstance(data.get("tma"), dict) else {}
         data.setdefault("obs_dim", int(w1.shape[1]))
         data.setdefault("hidden", int(w1.shape[0]))
         data.setdefault("act_dim", int(wa.shape[0]))
@@ -510,7 +537,7 @@ class PPO:
             raise ValueError("unsupported net_arch in policy zip: the engine needs two equal hidden layers for pi and vf")
 
         pk = data.get("policy_kwargs")
-        mfma = pk.get("mfma_dtype", "f32") if isinstance(pk, dict) else "f32"
+        mfma = tma_extra.get("mfma_dtype") or (pk.get("mfma_dtype", "f32") if isinstance(pk, dict) else "f32")
 
         def _num(key, default):
             v = data.get(key, default)
@@ -522,15 +549,20 @@ class PPO:
                     normalize_advantage=_num("normalize_advantage", True), ent_coef=_num("ent_coef", 0.0), vf_coef=_num("vf_coef", 0.5),
                     max_grad_norm=_num("max_grad_norm", 0.5),
                     policy_kwargs={"net_arch": [data["hidden"], data["hidden"]], "mfma_dtype": mfma}, seed=_num("seed", 0), _init_setup_model=False)
-        model.num_timesteps, model._n_updates, model._adam_step = data.get("num_timesteps", 0), data.get("_n_updates", 0), data.get("_adam_step", 0)
+        model.num_timesteps, model._n_updates = data.get("num_timesteps", 0), data.get("_n_updates", 0)
+        model._adam_step = int(tma_extra.get("adam_step", data.get("_adam_step", 0)))
         if env is not None:
             model.env = env
             model._setup_model()
             model.policy.load_state_dict(sd)
-            flat = opt.get("tma_flat")
-            if flat is not None:
-                model.exp_avg.copy_(flat["exp_avg"].to(model.device))
-                model.exp_avg_sq.copy_(flat["exp_avg_sq"].to(model.device))
+            state = opt.get("state") or {}
+            from . import sb3_format
+
+            order = sb3_format.parameter_order(model.policy.continuous)
+            if len(state) == len(order):  # torch.optim.Adam state, indexed in the policy's parameter order (SB3's own zips included)
+                model.exp_avg.copy_(model.policy.flat_from_named({k: state[i]["exp_avg"] for i, k in enumerate(order)}).to(model.device))
+                model.exp_avg_sq.copy_(model.policy.flat_from_named({k: state[i]["exp_avg_sq"] for i, k in enumerate(order)}).to(model.device))
+                model._adam_step = int(float(state[0]["step"]))
         else:
             from .vec_env import _require_gpu
 
