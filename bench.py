@@ -343,7 +343,10 @@ def literal_batch_256(args, dev):
         st = model.pop_train_stats()
         return {"batch_size": 256, "optimizer_steps_per_epoch": n_mb, "epoch_ms": t_epoch * 1e3, "rollout_ms": t_roll * 1e3,
                 "ppo_updates_per_sec": n_mb / t_epoch, "env_steps_per_sec_10_epochs_composed": total / (t_roll + args.n_epochs * t_epoch),
-                "approx_kl": round(st["train/approx_kl"], 6),
+                "approx_kl": round(st["train/approx_kl"], 6), "us_per_optimizer_step": t_epoch / n_mb * 1e6,
+                "update_path": ("per-minibatch launches (TMA_NO_PERSIST set)" if os.environ.get("TMA_NO_PERSIST") else
+                                "persistent epoch kernel ppo_epoch_h64p_kernel (csrc/tma_h64p.hip): one launch per epoch")
+                if args.hidden == 64 and args.mfma_dtype == "f32" else "per-minibatch launches",
                 "workload": f"{args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, batch_size 256 "
                             "(reference training.py:379), one epoch timed"}
     finally:
