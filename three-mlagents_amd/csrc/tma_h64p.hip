@@ -32,7 +32,7 @@ constexpr int HP_NB = 8;          // roles: 4 workgroups per net
 constexpr int HP_GRID = 128;      // workgroups launched (16 per XCD under round-robin placement)
 constexpr int HP_SLAB_F = 6400;   // floats per slab / reduced-gradient array: >= one net's parameters for D <= 16, A <= 16 (6288)
 // byte offsets inside the persistent region (the workspace's partial-gradient slab area, which this path does not use otherwise)
-constexpr int HP_SYNC = 0;        // u32 words on lines of their own: [0] arrivals A policy net, [32] A value net, [64] arrivals B, [96] claimed XCD + 1, [128] roles taken, [160] abort
+constexpr int HP_SYNC = 0;        // u32 words on lines of their own: [0] arrivals A policy net, [32] A value net, [96] claimed XCD + 1, [128] roles taken, [160] abort
 constexpr int HP_SQ = 1024;       // HP_NB granules of 16 bytes {step tag, -, f64 sum of squares of the block's reduced quarter}
 constexpr int HP_TICKS = 2048;    // u64[16] phase ticks of role 0 (diagnostic, args.ticks)
 constexpr int HP_SLABS = 4096;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
     float *slotA = region, *slotB = slotA + 16 * LDT, *dz3t = slotB + 16 * LDT, *Xt = dz3t + 256;
     float *copies = smem + IMG_FLOATS;
     unsigned *sync = reinterpret_cast<unsigned *>(a.region + HP_SYNC);
-    unsigned *cntA = sync + 32 * net, *cntB = sync + 64, *abortw = sync + 160;
+    unsigned *cntA = sync + 32 * net, *abortw = sync + 160;
     float *slab_mine = reinterpret_cast<float *>(a.region + HP_SLABS) + role * HP_SLAB_F;
     float *Gnet = reinterpret_cast<float *>(a.region + HP_G) + net * HP_SLAB_F;
     double *sqp = reinterpret_cast<double *>(a.region + HP_SQ);
