@@ -652,3 +652,36 @@ def test_persistent_epoch_kernel_equals_per_minibatch_launches(D, A, monkeypatch
     for k in snap0:
         ref = tr.sd[k].detach()
         assert torch.allclose(snap0[k].cpu(), ref, rtol=0, atol=2e-5), (k, float((snap0[k].cpu() - ref).abs().max()))
+
+
+def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
+    """1024 optimizer steps in one persistent launch (GridWorld rollout of 1024 envs x 256 steps, the reference's batch_size = 256) against
+    the same epoch as per-minibatch launches: the two paths differ only in the f64 summation order of the clip norm, so after a thousand
+    dependent Adam steps the parameters still agree to 1e-6 and the loss statistics to 1e-6 relative; the persistent path is run-to-run
+    bit-identical."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(persist):
+        if persist:
+            monkeypatch.delenv("TMA_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        env = make_vector_env("gridworld", n_envs=1024, seed=9)
+        m = PPO("MlpPolicy", env, n_steps=256, batch_size=256, n_epochs=1, seed=9, policy_kwargs={"net_arch": [64, 64]})
+        m.collect_rollouts()
+        m.train()
+        st = m.pop_train_stats()
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, m._adam_step)
+        env.close()
+        return out
+
+    p0, m0, v0, s0, n0 = run(True)
+    p1, m1, v1, s1, n1 = run(False)
+    p2, m2, v2, s2, n2 = run(True)
+    assert n0 == n1 == 1024 and torch.isfinite(p0).all()
+    assert torch.equal(p0, p2) and torch.equal(m0, m2) and torch.equal(v0, v2)
+    assert torch.allclose(p0, p1, rtol=0, atol=1e-6), float((p0 - p1).abs().max())
+    assert torch.allclose(m0, m1, rtol=1e-4, atol=1e-8) and torch.allclose(v0, v1, rtol=1e-4, atol=1e-10)
+    for k in ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/approx_kl", "train/clip_fraction", "train/n_samples"):
+        assert abs(s0[k] - s1[k]) <= 1e-6 * max(1.0, abs(s1[k])), (k, s0[k], s1[k])
