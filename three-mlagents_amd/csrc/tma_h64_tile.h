@@ -147,6 +147,72 @@ struct TileStats {
     float clip = 0.0f, n = 0.0f;  // counts: exact in float (a lane sees far fewer than 2^24 samples)
 };
 
+// Loss of one tile from the head outputs (C layout: register r of lane group g is output g + 4r of sample r16): the clipped
+// surrogate + entropy bonus for the policy net, the squared error for the value net.  Returns d loss / d head output, adds the
+// tile's statistics.  (SB3 PPO.train)
+template <bool IS_PI>
+__device__ __forceinline__ f32x4 h64t_loss(const f32x4 &o0, const f32x4 &o1, float m0, float m1, int act, bool valid, int A, float invB, float amean,
+                                           float astd, const HParams &hp, TileStats &st, int lane) {
+    const int g = lane >> 4;
+    f32x4 dz3;
+    if constexpr (IS_PI) {
+        float x[4], e[4], lp[4], p[4];
+        bool ok[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            ok[r] = g + 4 * r < A;
+            x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
+            m = fmaxf(m, x[r]);
+        }
+        m = xg_max(m);
+        float ssum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            e[r] = ok[r] ? __expf(x[r] - m) : 0.0f;  // hardware exp2 / log2 / rcp (~1 ulp): the loss phase is the policy blocks' critical extra
+            ssum += e[r];
+        }
+        ssum = xg_sum(ssum);
+        const float lse = m + __logf(ssum), rs = __builtin_amdgcn_rcpf(ssum);
+        float lpa = 0.0f, ent = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            lp[r] = ok[r] ? x[r] - lse : 0.0f;
+            p[r] = e[r] * rs;
+            lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
+            ent += p[r] * lp[r];
+        }
+        lpa = xg_sum(lpa);
+        ent = -xg_sum(ent);
+        const float old = m0;
+        const float advn = (m1 - amean) / (astd + 1e-8f);
+        const float ratio = __expf(lpa - old);
+        const float pl1 = advn * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+        const float pl2 = advn * rc;
+        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float dl = g_lp * (((g + 4 * r == act) ? 1.0f : 0.0f) - p[r]);
+            dl += valid ? (hp.ent_coef * invB) * (p[r] * (lp[r] + ent)) : 0.0f;
+            dz3[r] = ok[r] ? dl : 0.0f;
+        }
+        if (valid && g == 0) {
+            st.a += (double)(-fminf(pl1, pl2));
+            st.ent += (double)ent;
+            st.kl += (double)((ratio - 1.0f) - (lpa - old));
+            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0f : 0.0f;
+            st.n += 1.0f;
+        }
+    } else {
+        const float diff = (o0[0] + o1[0]) - m0;
+        const bool mine = valid && g == 0;
+        dz3 = f32x4{mine ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f, 0.0f, 0.0f, 0.0f};
+        if (mine) st.a += (double)(diff * diff);
+    }
+    return dz3;
+}
+
 // One tile.  Lane (g, r16) works for the tile's sample r16; xb[ks] = observation feature 4 ks + g of that sample (0 beyond D or for an
 // invalid row), m0 / m1 / act = (old log-prob, advantage, action) for the policy net, (return, -, -) for the value net.
 // wimg: this net's LDS weight image; slotA / slotB / dz3t / Xt: the wave's private [sample][feature] tiles (T_PER_WAVE floats in all).
@@ -218,62 +284,7 @@ __device__ __forceinline__ void h64t_tile(const float *wimg, float *slotA, float
         }
     if constexpr (TMA_H64_PIPE) store_tile_t(slotB, h2, r16, g);
     H64_TICK(3);
-    f32x4 dz3;
-    if constexpr (IS_PI) {
-        float x[4], e[4], lp[4], p[4];
-        bool ok[4];
-        float m = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            ok[r] = g + 4 * r < A;
-            x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
-            m = fmaxf(m, x[r]);
-        }
-        m = xg_max(m);
-        float ssum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            e[r] = ok[r] ? __expf(x[r] - m) : 0.0f;  // hardware exp2 / log2 / rcp (~1 ulp): the loss phase is the policy blocks' critical extra
-            ssum += e[r];
-        }
-        ssum = xg_sum(ssum);
-        const float lse = m + __logf(ssum), rs = __builtin_amdgcn_rcpf(ssum);
-        float lpa = 0.0f, ent = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            lp[r] = ok[r] ? x[r] - lse : 0.0f;
-            p[r] = e[r] * rs;
-            lpa += (g + 4 * r == act) ? lp[r] : 0.0f;
-            ent += p[r] * lp[r];
-        }
-        lpa = xg_sum(lpa);
-        ent = -xg_sum(ent);
-        const float old = m0;
-        const float advn = (m1 - amean) / (astd + 1e-8f);
-        const float ratio = __expf(lpa - old);
-        const float pl1 = advn * ratio;
-        const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
-        const float pl2 = advn * rc;
-        const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float dl = g_lp * (((g + 4 * r == act) ? 1.0f : 0.0f) - p[r]);
-            dl += valid ? (hp.ent_coef * invB) * (p[r] * (lp[r] + ent)) : 0.0f;
-            dz3[r] = ok[r] ? dl : 0.0f;
-        }
-        if (valid && g == 0) {
-            st.a += (double)(-fminf(pl1, pl2));
-            st.ent += (double)ent;
-            st.kl += (double)((ratio - 1.0f) - (lpa - old));
-            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0f : 0.0f;
-            st.n += 1.0f;
-        }
-    } else {
-        const float diff = (o0[0] + o1[0]) - m0;
-        const bool mine = valid && g == 0;
-        dz3 = f32x4{mine ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f, 0.0f, 0.0f, 0.0f};
-        if (mine) st.a += (double)(diff * diff);
-    }
+    const f32x4 dz3 = h64t_loss<IS_PI>(o0, o1, m0, m1, act, valid, A, invB, amean, astd, hp, st, lane);
     H64_TICK(4);
     *reinterpret_cast<f32x4 *>(dz3t + r16 * 16 + 4 * g) = dz3;  // (column m = 4g + r of the tile <-> output a(m), undone by flush_segment)
     H64_TICK(4);

@@ -158,11 +158,12 @@ __device__ __forceinline__ bool wait_ge(unsigned *ctr, unsigned want, unsigned *
     return true;
 }
 
+// phase ticks of role 0's thread 0, accumulated in the region itself (a register array would stay live across the whole step loop)
 #define HP_TICK(i)                                                                      \
     do {                                                                                \
         if (tick_on) {                                                                  \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
-            tick_acc[i] += t_ - tick_prev;                                              \
+            tick_out[i] += t_ - tick_prev;                                              \
             tick_prev = __builtin_amdgcn_s_memtime();                                   \
         }                                                                               \
     } while (0)
@@ -195,7 +196,8 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
     const __amdgpu_buffer_rsrc_t r_slabs = rsrc_of(reinterpret_cast<float *>(a.region + HP_SLABS) + net * 4 * HP_SLAB_F);
     const __amdgpu_buffer_rsrc_t r_G = rsrc_of(Gnet), r_sq = rsrc_of(sqp);
     const bool tick_on = a.ticks != 0 && role == 0 && tid == 0;
-    unsigned long long tick_acc[10] = {}, tick_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long tick_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long *tick_out = reinterpret_cast<unsigned long long *>(a.region + HP_TICKS);
 
     // ---- resident state: the net's LDS image; per thread, in registers for the whole epoch (every trip to memory -- the L2 included, and
     // scratch above all -- costs about a microsecond here), the Adam moments of the float4s it owns and the image-slot words of the small ones
@@ -513,10 +515,6 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
                 if (pos < q.nmisc) put(misc_natural(pos, D), wimg[io_ms[u][c] & 0xFFFFu], m_ms[u][c], v_ms[u][c]);
             }
         if (IS_PI && tid == 0) a.norm_out[0] = (double)last_norm, a.norm_out[1] = (double)last_coef;
-    }
-    if (tick_on) {
-        unsigned long long *out = reinterpret_cast<unsigned long long *>(a.region + HP_TICKS);
-        for (int qi = 0; qi < 10; qi++) out[qi] = tick_acc[qi];
     }
 }
 
