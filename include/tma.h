@@ -222,6 +222,8 @@ int tma_ppo_permutation(uint32_t perm_seed, uint32_t perm_epoch, int64_t total, 
  * forward+backward kernel; for two-pass shapes both passes; not the advantage pass, not the slab reduction) with HIP events recorded on
  * the stream it launches on; tma_debug_last_grad_kernel_us waits for the last bracketed launch and returns its duration. */
 int tma_debug_time_grad_kernel(int enable);
+/* Test aid: fills the LDS of every CU with `pattern` (0: quiet NaNs) so that a kernel reading LDS it never wrote shows it in its outputs. */
+int tma_debug_poison_lds(unsigned pattern, void *stream);
 int tma_debug_last_grad_kernel_us(float *us_out);
 /* out8: sums since the last call of {policy_loss, value_sq_err, entropy, approx_kl, clipped, n_samples}, then the last
  * total grad norm and clip coefficient.  Synchronises `stream`. */

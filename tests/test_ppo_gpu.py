@@ -342,8 +342,10 @@ def test_native_rollout_equals_stepwise_composition(task, hidden, N, mfma):
     T = {"ball3d": 230, "gridworld": 130, "walljump": 170, "basic": 60}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
     env = HipVecEnv(task, N, seed=3, ring_depth=16)
     model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
+    _lib.check(_lib.lib().tma_debug_poison_lds(0, _lib.stream_ptr()))  # NaNs in every LDS word the rollout kernels do not write themselves
     assert model.collect_rollouts()
     b = {k: v.clone() for k, v in model.buf.items()}
+    assert all(torch.isfinite(b[k]).all() for k in ("values", "log_probs", "rewards", "obs"))
     env2 = HipVecEnv(task, N, seed=3, ring_depth=16)
     eng = env2.engine
     obs = eng.reset()

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tma_ppo_workspace_bytes": (_i64, [_pd]),
     "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
     "tma_debug_time_grad_kernel": (_i32, [_i32]),
+    "tma_debug_poison_lds": (_i32, [_u32, _vp]),
     "tma_debug_last_grad_kernel_us": (_i32, [C.POINTER(C.c_float)]),
     "tma_ppo_epoch_prepare": (_i32, [C.POINTER(Rollout), C.POINTER(Minibatch), _i64, _pd, _vp, _vp]),
     "tma_ppo_epoch_adv_sums": (_i32, [_vp, _pd, _i64, _i64, _vp, _i32, _vp]),

@@ -1650,23 +1650,62 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *A1 = Xa + M * ldxb, *A2 = A1 + M * lda;
     const int n_base = wave * 16 * NTW;
     const int64_t n_groups = (n + M - 1) / M;
+    // bf16 mode: the net of a block never changes (MODE 0: value net on even, policy net on odd blocks; MODES 1 / 2: value net), so EVERY
+    // weight fragment and bias of this wave -- up to six layer-1 k-steps (observations of up to 192 floats) and the whole layer 2 -- is
+    // requested once, at kernel start, in front of the observation loads: one L2 round trip under the observation staging instead of one
+    // per layer-1 k-step behind it.  Same k order per accumulator as bf_hidden_layer, hence the same bits (the update kernel's
+    // forward pass must reproduce these log-probabilities).
+    constexpr int KS2B = H / 32, KS1R = 6;
+    const int KS1b = Kp1 >> 5;
+    const bool blk_pi = MODE == 0 && (blockIdx.x & 1) == 1;
+    bf16x8 w1r[BF ? NTW : 1][BF ? KS1R : 1], w2r[BF ? NTW : 1][BF ? KS2B : 1];
+    float b1r[NTW], b2r[NTW];
+    if constexpr (BF) {
+        const BfNetPtr Wb = bf_net_ptr(params, L, blk_pi);
+        const Net Qb = blk_pi ? pi_net(params, L) : vf_net(params, L);
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+#pragma unroll
+            for (int ks = 0; ks < KS1R; ks++)
+                if (ks < KS1b && KS1b <= KS1R) w1r[j][ks] = bf_frag(Wb.fW1, (wave * NTW + j) * KS1b + ks, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+#pragma unroll
+            for (int ks = 0; ks < KS2B; ks++) w2r[j][ks] = bf_frag(Wb.fW2, (wave * NTW + j) * KS2B + ks, lane);
+            b1r[j] = Qb.b1[n_base + 16 * j + r16];
+            b2r[j] = Qb.b2[n_base + 16 * j + r16];
+        }
+    }
     auto hidden = [&](const Net &Q, bool is_pi) {  // X -> h1 -> h2 for this wave's columns, both row tiles
         if constexpr (BF) {
-            const BfNetPtr W = bf_net_ptr(params, L, is_pi);
-            // every layer-2 weight fragment and bias of this wave is requested BEFORE layer 1 runs (the net of a block never changes, so
-            // the loads are also loop-invariant for the grid-stride modes): the 32 KiB stream's L2 round trips sit under the observation
-            // staging, layer 1 and its barrier instead of in front of every other k-step.  Same k order per accumulator as
-            // bf_hidden_layer, hence the same bits (the update kernel's forward pass must reproduce these log-probabilities).
-            constexpr int KS2 = H / 32;
-            bf16x8 w2[NTW][KS2];
-            float b2v[NTW];
+            constexpr int KS2 = KS2B;
+            auto &w2 = w2r;
+            auto &b2v = b2r;
+            if (KS1b <= KS1R) {  // (uniform) layer 1 from the register fragments: bf_hidden_layer's loop order and epilogue
+                f32x4 acc1[NTW][2];
 #pragma unroll
-            for (int j = 0; j < NTW; j++) {
+                for (int j = 0; j < NTW; j++) acc1[j][0] = acc1[j][1] = f32x4{b1r[j], b1r[j], b1r[j], b1r[j]};
 #pragma unroll
-                for (int ks = 0; ks < KS2; ks++) w2[j][ks] = bf_frag(W.fW2, (wave * NTW + j) * KS2 + ks, lane);
-                b2v[j] = Q.b2[n_base + 16 * j + r16];
+                for (int ks = 0; ks < KS1R; ks++) {
+                    if (ks < KS1b) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; mt++) {
+                            const bf16x8 a = a_frag(Xa, ldxb, 16 * mt + r16, ks, g);
+#pragma unroll
+                            for (int j = 0; j < NTW; j++) acc1[j][mt] = mfma_bf(a, w1r[j][ks], acc1[j][mt]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; j++)
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) A1[(16 * mt + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc1[j][mt][r]);
+            } else {
+                bf_hidden_layer<NTW, 2, false>(Xa, ldxb, KS1b, bf_net_ptr(params, L, is_pi).fW1, Q.b1, A1, lda, nullptr, n_base, lane);
             }
-            bf_hidden_layer<NTW, 2, false>(Xa, ldxb, Kp1 >> 5, W.fW1, Q.b1, A1, lda, nullptr, n_base, lane);
             __syncthreads();
             f32x4 acc[NTW][2];
 #pragma unroll
@@ -1738,16 +1777,29 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
             const int any = __syncthreads_or((threadIdx.x < M && rr < n && trunc[rr] != 0) ? 1 : 0);
             if (!any) continue;
         }
-        if constexpr (BF) {
-            for (int e = threadIdx.x; e < M * Kp1; e += blockDim.x) {
-                const int row = e / Kp1, c = e - row * Kp1;
-                Xa[row * ldxb + c] = (bf16_t)((row0 + row < n && c < D) ? obs[(row0 + row) * D + c] : 0.0f);
-            }
-        } else {
-            const int Dp = (D + 3) & ~3, tot = M * Dp;
-            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-                const int row = e / Dp, c = e - row * Dp;
-                X[row * ldx + c] = (row0 + row < n && c < D) ? obs[(row0 + row) * D + c] : 0.0f;
+        // observation rows -> LDS, twelve loads in flight per thread: the element-by-element form of this loop waited out one memory round
+        // trip per element (24 in a row at the Crawler width, more than the rest of the kernel together)
+        {
+            const int width = BF ? Kp1 : ((D + 3) & ~3), tot = M * width;
+            for (int e0 = threadIdx.x; e0 < tot; e0 += 12 * blockDim.x) {
+                float val[12];
+#pragma unroll
+                for (int u = 0; u < 12; u++) {
+                    const int e = e0 + u * blockDim.x, ec = e < tot ? e : 0;
+                    const int row = ec / width, c = ec - row * width;
+                    const bool ok = e < tot && row0 + row < n && c < D;
+                    val[u] = obs[ok ? (row0 + row) * D + c : 0];  // (clamped address; masked when it is consumed below)
+                }
+#pragma unroll
+                for (int u = 0; u < 12; u++) {
+                    const int e = e0 + u * blockDim.x;
+                    if (e < tot) {
+                        const int row = e / width, c = e - row * width;
+                        const float x = (row0 + row < n && c < D) ? val[u] : 0.0f;
+                        if constexpr (BF) Xa[row * ldxb + c] = (bf16_t)x;
+                        else X[row * ldx + c] = x;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1834,7 +1886,8 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
                                 if (!deterministic) {
                                     const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rng_step)), 5.9604645e-08f);
                                     const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rng_step));
-                                    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+                                    // Box-Muller on the hardware units: v_log (base 2, scaled), v_sqrt, and v_cos, whose argument is in revolutions
+                                    const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
                                     a = mu + sd * z;
                                 }
                                 const float d = a - mu;

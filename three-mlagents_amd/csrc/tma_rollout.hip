@@ -209,6 +209,9 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     if (wave == 0) {
         if (lane < 16) row_off[lane] = (row0 + lane < N) ? (int64_t)t0 * N + row0 + lane : -1;
         load_obs_tile(b.obs, row_off, D, X0, ldx, lane);
+        // the other parity's tile too: the owner lanes only ever write columns < D of it, and the last layer-1 k-step reads its padding
+        // columns (D = 6: columns 6, 7) -- uninitialised LDS there is harmless only while it is finite (0 x NaN = NaN)
+        for (int e = lane; e < 16 * ldx; e += 64) X0[16 * ldx + e] = 0.0f;
         for (int e = lane; e < 2 * 16 * ldx; e += 64) XT0[e] = 0.0f;
         if (lane < 2) flag[lane] = 0;
     }
@@ -646,6 +649,25 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
 }
 
 }  // namespace tma
+
+// Test aid: fill the LDS of every CU with a bit pattern (default: quiet NaNs).  LDS is not cleared between workgroups, so a kernel that reads
+// a word it never wrote sees whatever ran before it on that CU -- usually something finite, which hides the bug.  Poisoning first makes such
+// reads show up as NaNs in the outputs (tests/test_ppo_gpu.py runs the fused rollout kernels behind it).
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_words[];
+    constexpr int WORDS = 160 * 1024 / 4;
+    for (int e = threadIdx.x; e < WORDS; e += blockDim.x) lds_words[e] = pattern;
+    __syncthreads();
+    if (sink && lds_words[(threadIdx.x * 97) % WORDS] != pattern) sink[0] = 1;  // (keeps the stores alive)
+}
+
+extern "C" int tma_debug_poison_lds(unsigned pattern, void *stream) {
+    auto k = poison_lds_kernel;
+    TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    k<<<dim3(1024), dim3(256), 160 * 1024, (hipStream_t)stream>>>(pattern ? pattern : 0x7FC00000u, nullptr);  // four rounds over the 256 CUs
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
 
 extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin,
                                    int t_end, int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma,
