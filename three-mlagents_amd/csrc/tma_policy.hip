@@ -1677,6 +1677,7 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
             b2r[j] = Qb.b2[n_base + 16 * j + r16];
         }
     }
+    bool two_rt = true;  // (block-uniform) the row group has more than 16 valid rows
     auto hidden = [&](const Net &Q, bool is_pi) {  // X -> h1 -> h2 for this wave's columns, both row tiles
         if constexpr (BF) {
             constexpr int KS2 = KS2B;
@@ -1727,41 +1728,64 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
             __syncthreads();
             return;
         }
+        // f32 mode.  A row group with at most 16 valid rows (the reference's own 8-env runs) skips its second row tile: half the MFMAs of a
+        // latency chain that is all there is at that size.  Weights: the whole k range of a column tile is fetched before it is used, and
+        // tile j + 1's layer-2 column slice is requested before tile j multiplies (one exposed L2 latency per layer, not one per tile).
 #pragma unroll 1
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b1[n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
-            for (int ks = 0; ks < KS1; ks++) {
-                const int k = 4 * ks + g;
-                const float w = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
-                c0 = mfma16(X[r16 * ldx + k], w, c0);
-                c1 = mfma16(X[(16 + r16) * ldx + k], w, c1);
+            for (int ks0 = 0; ks0 < KS1; ks0 += 16) {
+                float wv1[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int k = 4 * (ks0 + u) + g;
+                    wv1[u] = Q.W1t[(int64_t)((ks0 + u < KS1 && k < D) ? k : 0) * H + n_base + 16 * j + r16];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (ks0 + u < KS1) {  // (uniform)
+                        const int k = 4 * (ks0 + u) + g;
+                        const float w = k < D ? wv1[u] : 0.0f;
+                        c0 = mfma16(X[r16 * ldx + k], w, c0);
+                        if (two_rt) c1 = mfma16(X[(16 + r16) * ldx + k], w, c1);
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 h1[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
-                h1[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+                if (two_rt) h1[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
             }
         }
         __syncthreads();
-#pragma unroll 1
+        float wv[2][H / 4];
+        auto fetch2 = [&](int j, float (&dst)[H / 4]) {
+            const float *wcol = Q.W2t + n_base + 16 * j + r16;
+#pragma unroll
+            for (int ks = 0; ks < H / 4; ks++) dst[ks] = wcol[(int64_t)(4 * ks + g) * H];
+        };
+        fetch2(0, wv[0]);
+#pragma unroll
         for (int j = 0; j < NTW; j++) {
             const float bias = Q.b2[n_base + 16 * j + r16];
             f32x4 c0 = f32x4{bias, bias, bias, bias}, c1 = c0;
-            const float *wcol = Q.W2t + n_base + 16 * j + r16;
-            float wv[H / 4];  // the whole weight column slice of this tile is fetched first: one L2 latency per tile, not per k-step
+            if (j + 1 < NTW) fetch2(j + 1, wv[(j + 1) & 1]);
+            if (two_rt) {
 #pragma unroll
-            for (int ks = 0; ks < H / 4; ks++) wv[ks] = wcol[(int64_t)(4 * ks + g) * H];
+                for (int ks = 0; ks < H / 4; ks++) {
+                    const int k = 4 * ks + g;
+                    c0 = mfma16(h1[r16 * ld + k], wv[j & 1][ks], c0);
+                    c1 = mfma16(h1[(16 + r16) * ld + k], wv[j & 1][ks], c1);
+                }
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < H / 4; ks++) {
-                const int k = 4 * ks + g;
-                c0 = mfma16(h1[r16 * ld + k], wv[ks], c0);
-                c1 = mfma16(h1[(16 + r16) * ld + k], wv[ks], c1);
+                for (int ks = 0; ks < H / 4; ks++) c0 = mfma16(h1[r16 * ld + 4 * ks + g], wv[j & 1][ks], c0);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
-                h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+                if (two_rt) h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
             }
         }
         __syncthreads();
@@ -1772,6 +1796,7 @@ __global__ __launch_bounds__(256) void policy_fwd_wide_kernel(const float *__res
     const int role = MODE == 0 ? (int)(blockIdx.x & 1) : 0;
     for (int64_t grp = blockIdx.x / NR; grp < n_groups; grp += gridDim.x / NR) {
         const int64_t row0 = grp * M;
+        two_rt = row0 + 16 < n;
         if constexpr (MODE == 2) {  // skip row groups without a truncated env (block-uniform vote)
             const int64_t rr = row0 + threadIdx.x;
             const int any = __syncthreads_or((threadIdx.x < M && rr < n && trunc[rr] != 0) ? 1 : 0);
