@@ -381,10 +381,25 @@ __device__ __forceinline__ void dense64_bwd_input_lds(const float *dzin, int ldz
 }
 
 // cooperative float4 copy global -> LDS (n_floats % 4 == 0, both 16-byte aligned)
+// (eight loads per thread in flight: the one-element-per-iteration form waits out a memory round trip per iteration -- six in a row for
+// a 45 KiB weight image on 512 threads, at the head of every launch that stages one)
 __device__ __forceinline__ void stage_copy(const float *__restrict__ src, float *dst, int n_floats) {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    for (int e = threadIdx.x; e < (n_floats >> 2); e += blockDim.x) d4[e] = s4[e];
+    const int n4 = n_floats >> 2, stride = blockDim.x;
+    for (int e0 = threadIdx.x; e0 < n4; e0 += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * stride;
+            v[u] = s4[e < n4 ? e : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * stride;
+            if (e < n4) d4[e] = v[u];
+        }
+    }
 }
 
 // stage a [16][D] tile of rows (gathered through row_off[]) into LDS, zero rows that are out of range
