@@ -75,6 +75,38 @@ __device__ __forceinline__ bf16x4 *t_quad(bf16_t *T, int n, int mt, int g) {
 __device__ __forceinline__ bf16x8 a_frag(const bf16_t *A, int ld, int row, int ks, int g) {
     return *reinterpret_cast<const bf16x8 *>(A + row * ld + 32 * ks + 8 * g);
 }
+// The same A fragment (rows = samples 16 mt .. + 15, k = 32 ks + 8 g + j) read from the TRANSPOSED image T[k][m] with the hardware
+// transposing read: per 16-lane group, ds_read_b64_tr_b16 takes a block of 4 image rows (k) x 16 columns (samples) -- lane 4q + p supplies
+// the address of row q, columns 4p .. 4p + 3 -- and hands lane i column i of the four rows.  Two reads (k rows 8g .. + 3 and + 4 .. + 7)
+// make the eight elements.  With it the activations and deltas need no row-major copy: an epilogue writes one 8-byte quad per four
+// elements into the T image instead of that plus four 2-byte stores (whose addresses and LDS issue slots were a quarter of the epilogue).
+// EXEC must be all ones (the gather crosses lanes): only called from wave-uniform code.  Measured (one box, 131 072 samples): Crawler width
+// 515.7 -> 494.6 us, H = 128 159.8 -> 157.0, H = 192 264.5 -> 262.4.
+#ifndef TMA_BF_TR_READS
+#define TMA_BF_TR_READS 1  // 0: row-major A images + ds_read_b128 everywhere (A/B builds).  Used for 32-row groups only: at 64-row groups the
+                           // eight per-row-tile address registers of the transposed reads push the 510-register variant into spills (+3 %)
+#endif
+template <int MT>
+__device__ __forceinline__ bf16x8 a_frag_t(const bf16_t *T, int mt, int ks, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) *lds_s16x4;
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3, g = lane >> 4;
+    const int k0 = 32 * ks + 8 * g + q, k1 = k0 + 4;
+    const int ch = 2 * mt + (p >> 1), sub = 4 * (p & 1);
+    const bf16_t *a0 = T + k0 * (16 * MT) + 8 * (ch ^ t_swz<MT>(k0)) + sub;
+    const bf16_t *a1 = T + k1 * (16 * MT) + 8 * (ch ^ t_swz<MT>(k1)) + sub;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// A fragment of activations / deltas held in both images (A image + T image): the transposed read, or the row-major one
+template <int MT>
+__device__ __forceinline__ bf16x8 act_frag(const bf16_t *A, int ld, const bf16_t *T, int mt, int ks, int lane) {
+    if constexpr (TMA_BF_TR_READS && MT == 2) return a_frag_t<MT>(T, mt, ks, lane);
+    else return a_frag(A, ld, 16 * mt + (lane & 15), ks, lane >> 4);
+}
 
 // rebuilds the fragment-major bf16 images of both nets from the f32 master weights ([in][out] flat layout)
 static __global__ void build_bf16_images_kernel(float *params, PLayout L) {
@@ -575,7 +607,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
-                        A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
                     }
                     *t_quad<MT>(T1, n, mt, g) = q;
                 }
@@ -601,7 +633,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int i = 0; i < HK; i++) {
                     const int ks = head_ks(i);
                     if (ks < KS2) {
-                        const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+                        const bf16x8 a = act_frag<MT>(A2, lda, T2, mt, ks, lane);
 #pragma unroll
                         for (int q = 0; q < NT3; q++) part[q] = mfma_bf(a, w3f[i * NT3 + q], part[q]);
                     }
@@ -637,7 +669,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     }
                     bf16x8 a[2][2];  // A fragments of two row tiles, half a k-step ahead
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = act_frag<MT>(A1, lda, T1, mt, 0, lane);
 #pragma unroll
                     for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
@@ -645,7 +677,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             const int cur = hb, nb_ks = hb ? ks + 1 : ks, nb_h = hb ? 0 : 1;
                             if (nb_ks < KS2) {
 #pragma unroll
-                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = a_frag(A1, lda, 16 * (nb_h * 2 + mt) + r16, nb_ks, g);
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = act_frag<MT>(A1, lda, T1, (nb_h * 2 + mt), nb_ks, lane);
                             }
 #pragma unroll
                             for (int jj = 0; jj < NH; jj++) {
@@ -666,7 +698,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 q[r] = (bf16_t)tma_tanh(acc[jj][mt][r]);
-                                A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                                if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                             }
                             *t_quad<MT>(T2, n, mt, g) = q;
                         }
@@ -685,7 +717,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             constexpr int AH = MT == 4 ? 2 : MT;  // row tiles per A-fragment batch
             bf16x8 a[2][AH];
 #pragma unroll
-            for (int mt = 0; mt < AH; mt++) a[0][mt] = a_frag(A1, lda, 16 * mt + r16, 0, g);
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = act_frag<MT>(A1, lda, T1, mt, 0, lane);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
 #pragma unroll
@@ -693,7 +725,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const int cur = (ks * (MT / AH) + hb) & 1, nb_ks = hb + 1 < MT / AH ? ks : ks + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
                     if (nb_ks < KS2) {
 #pragma unroll
-                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = a_frag(A1, lda, 16 * (nb_h * AH + mt) + r16, nb_ks, g);
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = act_frag<MT>(A1, lda, T1, (nb_h * AH + mt), nb_ks, lane);
                     }
 #pragma unroll
                     for (int j = 0; j < NTW; j++) {
@@ -718,7 +750,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
-                        A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                     }
                     *t_quad<MT>(T2, n, mt, g) = q;
                 }
@@ -755,7 +787,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     for (int w = 0; w < 4; w++) {
                         const int ks = OWNK ? w * HK + i : w + 4 * i;
                         if (ks < KS2) {
-                            const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+                            const bf16x8 a = act_frag<MT>(A2, lda, T2, mt, ks, lane);
 #pragma unroll
                             for (int q = 0; q < NT3; q++) part[w][q] = mfma_bf(a, w3all[ks * NT3 + q], part[w][q]);
                         }
@@ -915,7 +947,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         const float h = (float)h4[r];
                         const float dz = dh[r] * (1.0f - h * h);
                         q[r] = (bf16_t)dz;
-                        A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                     }
                     *tq = q;
                 }
@@ -987,7 +1019,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         for (int mt = 0; mt < MT; mt++) dh[jj][mt] = z4;
                     bf16x8 a[2][2];
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = act_frag<MT>(A2, lda, T2, mt, 0, lane);
 #pragma unroll
                     for (int ns = 0; ns < KS2; ns++)
 #pragma unroll
@@ -995,7 +1027,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             const int cur = hb, nb_ns = hb ? ns + 1 : ns, nb_h = hb ? 0 : 1;
                             if (nb_ns < KS2) {
 #pragma unroll
-                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = a_frag(A2, lda, 16 * (nb_h * 2 + mt) + r16, nb_ns, g);
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = act_frag<MT>(A2, lda, T2, (nb_h * 2 + mt), nb_ns, lane);
                             }
 #pragma unroll
                             for (int jj = 0; jj < NH; jj++) {
@@ -1031,7 +1063,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             constexpr int AH = MT == 4 ? 2 : MT;
             bf16x8 a[2][AH];
 #pragma unroll
-            for (int mt = 0; mt < AH; mt++) a[0][mt] = a_frag(A2, lda, 16 * mt + r16, 0, g);
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = act_frag<MT>(A2, lda, T2, mt, 0, lane);
 #pragma unroll
             for (int ns = 0; ns < KS2; ns++) {
 #pragma unroll
@@ -1039,7 +1071,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const int cur = (ns * (MT / AH) + hb) & 1, nb_ns = hb + 1 < MT / AH ? ns : ns + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
                     if (nb_ns < KS2) {
 #pragma unroll
-                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = a_frag(A2, lda, 16 * (nb_h * AH + mt) + r16, nb_ns, g);
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = act_frag<MT>(A2, lda, T2, (nb_h * AH + mt), nb_ns, lane);
                     }
 #pragma unroll
                     for (int j = 0; j < NTW; j++) {
