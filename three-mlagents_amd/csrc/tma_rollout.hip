@@ -611,12 +611,334 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same fused chunk for a Box action space and wide observations (the Crawler shape: 172 observations, 20 actions; BASELINE
+// configs[4]): one launch advances every env by n_steps vector steps, a block of 8 waves owns 32 envs, waves 0..3 the policy net and 4..7 the
+// value net, 64 hidden columns each.  The 32 layer-2 fragments of a wave stay in registers for the whole launch; the layer-1 fragments
+// (6 k-steps x 4 column tiles: 24 KiB a wave, too many to keep) are streamed from the L2 every step, two k-steps at a time; head fragments, the sampled actions and the ENV STATE (69 words an env) live in LDS.  Per step: layer 1 -> barrier -> layer 2 ->
+// barrier -> {mean head, Gaussian sample (policy_fwd_wide_kernel's streams and Box-Muller), log-prob, env step of the 32 owner lanes from
+// LDS state, next observation to the buffer AND as bf16 into the LDS image | value head} -> barrier; timeout bootstrap as in the Discrete
+// kernel.  Forward arithmetic = policy_fwd_wide_kernel<true, 0, 4, true> (same k order per accumulator, same split-K head order): the
+// chunk is bit-identical to the per-step composition, which it replaces at 16 + 16 us per vector step (forward launch + env-step launch).
+// ------------------------------------------------------------------------------------------
+template <class T>
+struct WideContLds {
+    static constexpr int M = 32, H = 256, NTW = 4, KS2 = H / 32, LDA = H + 16, KP1 = (T::OBS + 31) & ~31, KS1 = KP1 / 32, LDX = KP1 + 16, NT3 = 2;
+    // observation + terminal-observation images, two activation images per net, head fragments (policy NT3 x KS2, value KS2), sampled
+    // actions [M][32] f32, env state [SW][M], bootstrap scratch
+    static constexpr int bytes() { return (2 * M * LDX + 4 * M * LDA + (NT3 + 1) * KS2 * 512) * 2 + (M * 32 + T::SW * M + 32 + 32 + 4) * 4; }
+};
+
+// one observation element to its global row and, as bf16, to its LDS image row (CrawlerTask::obs writes through operator[] / operator+)
+struct ObsDual {
+    float *gl;
+    bf16_t *img;
+    struct Ref {
+        float *gl;
+        bf16_t *img;
+        __device__ __forceinline__ void operator=(float x) const {
+            *gl = x;
+            *img = (bf16_t)x;
+        }
+    };
+    __device__ __forceinline__ Ref operator[](int k) const { return Ref{gl + k, img + k}; }
+    __device__ __forceinline__ ObsDual operator+(int k) const { return ObsDual{gl + k, img + k}; }
+};
+struct ObsImage {  // bf16 image row only (terminal observations: only the bootstrap reads them)
+    bf16_t *img;
+    struct Ref {
+        bf16_t *img;
+        __device__ __forceinline__ void operator=(float x) const { *img = (bf16_t)x; }
+    };
+    __device__ __forceinline__ Ref operator[](int k) const { return Ref{img + k}; }
+    __device__ __forceinline__ ObsImage operator+(int k) const { return ObsImage{img + k}; }
+};
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0,
+                                                                         int n_steps, uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    using W = WideContLds<T>;
+    constexpr int M = W::M, H = W::H, NTW = W::NTW, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
+    static_assert(T::NACT == 0 && AD <= 32 && KS1 % 2 == 0 && !T::USES_MT, "fused wide rollout, Box actions: <= 32 action dims, inline resets");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool is_pi = wave < 4;
+    const int w4 = wave & 3, n_base = w4 * 16 * NTW, mt = w4 & 1;  // mt: the row tile the two head waves of a net (w4 < 2) finish
+    bf16_t *Xa = reinterpret_cast<bf16_t *>(smem_w), *XTa = Xa + M * ldx;
+    bf16_t *A1 = XTa + M * ldx + (is_pi ? 0 : 2 * M * lda), *A2 = A1 + M * lda;  // per-net activation images
+    bf16_t *W3pi = XTa + M * ldx + 4 * M * lda, *W3vf = W3pi + NT3 * KS2 * 512;
+    const bf16_t *W3l = is_pi ? W3pi : W3vf;
+    float *actl = reinterpret_cast<float *>(W3vf + KS2 * 512);         // [M][32] sampled actions of this step
+    uint32_t *stl = reinterpret_cast<uint32_t *>(actl + M * 32);        // [SW][M] env state words
+    float *rw = reinterpret_cast<float *>(stl + T::SW * M);             // [32] reward of a truncated row before the bootstrap
+    int *trf = reinterpret_cast<int *>(rw + 32), *flag = trf + 32;      // [32] row truncated in this step; [1] any of them
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x * M;
+    float *act_out = reinterpret_cast<float *>(b.actions);
+    // ---- this wave's weights ----
+    const Net Q = is_pi ? pi_net(params, L) : vf_net(params, L);
+    const BfNetPtr Wn = bf_net_ptr(params, L, is_pi);
+    bf16x8 w2[NTW][KS2];
+    float b1v[NTW], b2v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) w2[j][ks] = bf_frag(Wn.fW2, (w4 * NTW + j) * KS2 + ks, lane);
+        b1v[j] = Q.b1[n_base + 16 * j + r16];
+        b2v[j] = Q.b2[n_base + 16 * j + r16];
+    }
+    if (w4 == 0) {  // head fragments of this net -> LDS (fragment q * KS2 + ks, 1 KiB each)
+        const int nfr = (is_pi ? NT3 : 1) * KS2;
+        for (int f = 0; f < nfr; f++) *reinterpret_cast<bf16x8 *>((is_pi ? W3pi : W3vf) + (f * 64 + lane) * 8) = bf_frag(Wn.fW3, f, lane);
+    }
+    const int n_out = is_pi ? L.A : 1;
+    float b3v[NT3];
+#pragma unroll
+    for (int q = 0; q < NT3; q++) b3v[q] = (16 * q + r16 < n_out) ? Q.b3[16 * q + r16] : 0.0f;
+    // ---- env state of the 32 owner lanes (policy head waves 0 / 1, lanes r16 < 4: row = 16 mt + 4 g + r16) -> LDS ----
+    const int my_row = mt * 16 + g * 4 + r16;
+    const int64_t i = row0 + my_row;
+    const bool owner = wave < 2 && r16 < 4 && i < N;
+    double er = 0.0;
+    uint32_t ce = 0;
+    // (the state struct lives in LDS for the whole launch and T::step / T::obs work on it in place: next to the 128 weight registers a wave
+    //  has no room for 69 state words plus the step's temporaries)
+    static_assert(sizeof(typename T::S) <= T::SW * 4, "state struct fits its LDS slot");
+    typename T::S *sl = reinterpret_cast<typename T::S *>(stl);
+    if (owner) {
+        T::unpack(v.st, N, i, sl[my_row]);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int e = threadIdx.x; e < M * ldx; e += blockDim.x) {  // observation image of step t0 (columns >= D stay zero for the whole launch)
+        const int row = e / ldx, c = e - row * ldx;
+        Xa[e] = (bf16_t)((row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f);
+        XTa[e] = (bf16_t)0.0f;
+    }
+    if (threadIdx.x == 0) flag[0] = 0;
+    if (threadIdx.x < 32) trf[threadIdx.x] = 0;
+    __syncthreads();
+    // X -> A1 -> A2 for this wave's 64 columns and both row tiles: bf_hidden_layer's loop order (k-step outer, row tile, column tile) with
+    // the layer-1 fragments streamed two k-steps per batch
+    auto hidden = [&](const bf16_t *X) {
+        {
+            // (the tile index goes through an opaque scalar copy: otherwise the 24 loop-invariant 64-bit fragment addresses are hoisted out of the
+            //  step loop, do not fit next to the weights and come back as scratch reloads in front of every load)
+            const int w4l = launder_uniform(w4);
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+#pragma unroll
+            for (int bt = 0; bt < KS1 / 2; bt++) {  // (one batch of eight fragments in registers at a time: 32 of the 128 a wave has left)
+                bf16x8 wb[2][NTW];
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) wb[kk][j] = bf_frag(Wn.fW1, (w4l * NTW + j) * KS1 + 2 * bt + kk, lane);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; m2++) {
+                        const bf16x8 a = a_frag(X, ldx, 16 * m2 + r16, 2 * bt + kk, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, wb[kk][j], acc[j][m2]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; m2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m2 = 0; m2 < 2; m2++) {  // (one row tile at a time: the MFMA order per accumulator is policy_fwd_wide_kernel's)
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+#pragma unroll
+                for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(a, w2[j][ks], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
+        }
+        __syncthreads();
+    };
+    // head of row tile mt, NQ column tiles, in the summation order of bf_head (four partial sums over k-steps 2w', 2w' + 1, added to the bias)
+    auto head = [&](f32x4 (&out)[NT3], int nq) {
+        f32x4 part[4][NT3];
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++)
+#pragma unroll
+            for (int q = 0; q < NT3; q++) part[wq][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++) {
+                const int ks = wq * 2 + i2;
+                const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                for (int q = 0; q < NT3; q++)
+                    if (q < nq) part[wq][q] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W3l + ((q * KS2 + ks) * 64 + lane) * 8), part[wq][q]);
+            }
+#pragma unroll
+        for (int q = 0; q < NT3; q++) {
+            out[q] = f32x4{b3v[q], b3v[q], b3v[q], b3v[q]};
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++) out[q] += part[wq][q];
+        }
+    };
+    const float *ls = params + L.log_std;
+    float lsd_v[2], sd_v[2];  // log_std and exp(log_std) of this lane's two action columns: constant over the launch
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        lsd_v[j] = (is_pi && 16 * j + r16 < AD) ? ls[16 * j + r16] : 0.0f;
+        sd_v[j] = expf(lsd_v[j]);
+    }
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        hidden(Xa);  // (two barriers inside: every wave of the block takes part)
+        if (w4 < 2) {
+            f32x4 acc[NT3];
+            head(acc, is_pi ? NT3 : 1);
+            if (!is_pi) {
+                if (r16 == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t row = row0 + mt * 16 + g * 4 + r;
+                        if (row < N) b.values[(int64_t)t * N + row] = acc[0][r];
+                    }
+            } else {
+                // DiagGaussian sample + log-prob: policy_fwd_wide_kernel<CONT>'s streams and arithmetic
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int lrow = mt * 16 + g * 4 + r;
+                    const int64_t row = row0 + lrow;
+                    const uint32_t gi = v.env_offset + (uint32_t)row;
+                    const uint32_t rstep = rng_step0 + (uint32_t)t;
+                    float lpsum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int col = 16 * j + r16;
+                        if (col < AD) {
+                            const float mu = acc[j][r], lsd = lsd_v[j], sd = sd_v[j];
+                            const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
+                            const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
+                            const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+                            const float a = mu + sd * z;
+                            const float d = a - mu;
+                            lpsum += -(d * d) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                            actl[lrow * 32 + col] = a;
+                            if (row < N) act_out[((int64_t)t * N + row) * AD + col] = a;
+                        }
+                    }
+                    lpsum = gsum16(lpsum);
+                    if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
+                }
+                bool tr_flag = false;
+                if (owner) {  // (the actions of row tile mt were written by this wave: LDS operations of one wave execute in order)
+                    const int64_t off = (int64_t)t * N + i;
+                    typename T::S &s = sl[my_row];
+                    double r;
+                    bool done;
+                    T::step(s, 0, actl + my_row * 32, r, done);
+                    const int steps = T::steps(s);
+                    const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+                    const bool te = done && !hit, tr = hit;
+                    er += r;
+                    const float rew32 = (float)r;
+                    b.terminated[off] = (uint8_t)te;
+                    b.truncated[off] = (uint8_t)tr;
+                    if (te || tr) {
+                        if (tr) {
+                            T::obs(s, ObsImage{XTa + my_row * ldx});
+                            rw[my_row] = rew32;
+                        }
+                        sret += er, slen += (double)steps, scnt += 1.0;
+                        log_episode(v, i, er, steps);
+                        er = 0.0;
+                        ce += 1;
+                        T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+                    }
+                    // next observation: buffer slot t + 1 and, as bf16, this row of the LDS image (every layer-1 read of this step's image is
+                    // behind hidden()'s barriers)
+                    T::obs(s, ObsDual{b.obs + ((int64_t)(t + 1) * N + i) * D, Xa + my_row * ldx});
+                    if (!tr) b.rewards[off] = rew32;  // truncated rows: the value head waves write reward + bootstrap below
+                    trf[my_row] = tr ? 1 : 0;
+                    tr_flag = tr;
+                }
+                if (__ballot(tr_flag) != 0ull && lane == 0) atomicOr(flag, 1);
+            }
+        }
+        __syncthreads();
+        if (flag[0]) {  // (block-uniform) timeout bootstrap of this step: rewards = reward + gamma * V(terminal observation) where truncated
+            if (!is_pi) {
+                hidden(XTa);
+                if (w4 < 2) {
+                    f32x4 vt[NT3];
+                    head(vt, 1);
+                    if (r16 == 0)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = mt * 16 + g * 4 + r;
+                            if (row0 + row < N && trf[row]) {
+                                const float gv = gamma * vt[0][r];
+                                b.rewards[(int64_t)t * N + row0 + row] = rw[row] + gv;
+                            }
+                        }
+                }
+            } else {
+                __syncthreads();  // the policy waves keep the value waves' two barriers company
+                __syncthreads();
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) flag[0] = 0;
+            if (threadIdx.x < 32) trf[threadIdx.x] = 0;
+            __syncthreads();
+        }
+    }
+    if (owner) {
+        T::pack(v.st, N, i, sl[my_row]);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    if (wave < 2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sret += __shfl_down(sret, o, 64);
+            slen += __shfl_down(slen, o, 64);
+            scnt += __shfl_down(scnt, o, 64);
+        }
+        if (lane == 0 && scnt > 0.0) {
+            double *slot = v.stats + (row0 >> 8) * 3;
+            atomicAdd(slot + 0, sret);
+            atomicAdd(slot + 1, slen);
+            atomicAdd(slot + 2, scnt);
+        }
+    }
+}
+
 template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
                              uint32_t rng_step0, float gamma, hipStream_t s) {
     if constexpr (T::OBS <= 32 && T::NACT > 0) {
         auto k = rollout_chunk_wide_bf_kernel<T>;
         const int smem = WideLds::bytes();
+        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    } else if constexpr (T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && ((T::OBS + 31) / 32) % 2 == 0) {
+        auto k = rollout_chunk_wide_cont_kernel<T>;
+        const int smem = WideContLds<T>::bytes();
         TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
         TMA_LAUNCH_CHECK();
@@ -685,8 +1007,10 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
     // 256-wide bf16 policies on the Discrete tasks with observations of up to 32 floats: fused chunk with register-resident weights
     static const bool no_wide_fused = getenv("TMA_NO_WIDE_FUSED") != nullptr;  // test hook: the per-step composition
-    const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && !d->continuous && env->is_reset && env->task != TMA_TASK_CRAWLER &&
-                            d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
+    const bool fused_disc = !d->continuous && env->task != TMA_TASK_CRAWLER && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
+    // ... and on the Crawler shape (Box actions, 172 observations): layer-1 fragments streamed per step, env state in LDS
+    const bool fused_cont = d->continuous && env->task == TMA_TASK_CRAWLER && d->act_dim == tma_task_act_dim(env->task);
+    const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && env->is_reset && d->obs_dim == tma_task_obs_dim(env->task) && (fused_disc || fused_cont);
     if (fused_wide) {
         TMA_HIP(hipSetDevice(env->device));
         ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};

@@ -707,20 +707,23 @@ struct CrawlerTask {
     __device__ static float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
     __device__ static void step(S &s, int, const float *act, double &r, bool &done) {
         const float dt = 0.05f, gear = 8.0f, kq = 4.0f, cq = 1.5f, kc = 1.0f;
-        float a[NJ], nq[NJ], nqd[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) a[j] = clipf(act[j], -1.0f, 1.0f);
+        // joints are updated in place: every joint reads its neighbours' OLD angles (the previous joint's is carried in q_prev, joint 0's
+        // in q_first), so no second copy of the 60 joint words is held -- the fused rollout runs this next to 128 weight registers
         float thrust_x = 0.0f, thrust_y = 0.0f, asym = 0.0f, ctrl = 0.0f, lift = 0.0f;
+        const float q_first = s.q[0];
+        float q_prev = s.q[NJ - 1];
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            float ql = s.q[(j + NJ - 1) % NJ], qr = s.q[(j + 1) % NJ];
-            float lap = (ql + qr) - 2.0f * s.q[j];
-            float acc = gear * a[j];
-            acc = acc - kq * s.q[j];
+            const float aj = clipf(act[j], -1.0f, 1.0f);
+            const float qj = s.q[j];
+            const float ql = q_prev, qr = (j + 1 < NJ) ? s.q[j + 1] : q_first;
+            float lap = (ql + qr) - 2.0f * qj;
+            float acc = gear * aj;
+            acc = acc - kq * qj;
             acc = acc - cq * s.qd[j];
             acc = acc + kc * lap;
             float v = s.qd[j] + dt * acc;
-            float p = s.q[j] + dt * v;
+            float p = qj + dt * v;
             if (p > 1.2f) {
                 p = 1.2f;
                 v = 0.0f;
@@ -729,8 +732,10 @@ struct CrawlerTask {
                 p = -1.2f;
                 v = 0.0f;
             }
-            nq[j] = p;
-            nqd[j] = v;
+            q_prev = qj;
+            s.q[j] = p;
+            s.qd[j] = v;
+            s.pa[j] = aj;
             float c = ccos(p), sn = csin(p);
             float side = (j & 1) ? -1.0f : 1.0f;
             float w = (j < NJ / 2) ? 1.0f : -1.0f;
@@ -738,7 +743,7 @@ struct CrawlerTask {
             thrust_y = thrust_y + (w * v) * c;
             asym = asym + side * sn;
             lift = lift + c;
-            ctrl = ctrl + a[j] * a[j];
+            ctrl = ctrl + aj * aj;
         }
         float z = s.root[0], vx = s.root[1], vy = s.root[2], pitch = s.root[3], roll = s.root[4], pr = s.root[5], rr = s.root[6], x = s.root[7];
         vx = vx + dt * (0.15f * thrust_x - 0.8f * vx);
@@ -749,12 +754,6 @@ struct CrawlerTask {
         roll = roll + dt * rr;
         z = 0.25f + 0.015f * lift;
         x = x + dt * vx;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            s.q[j] = nq[j];
-            s.qd[j] = nqd[j];
-            s.pa[j] = a[j];
-        }
         s.root[0] = z, s.root[1] = vx, s.root[2] = vy, s.root[3] = pitch, s.root[4] = roll, s.root[5] = pr, s.root[6] = rr, s.root[7] = x;
         s.steps += 1;
         bool unhealthy = (z < 0.38f) || (fabsf(pitch) > 1.0f) || (fabsf(roll) > 1.0f);
@@ -763,8 +762,10 @@ struct CrawlerTask {
         r = (double)rew;
         done = unhealthy || s.steps >= 1000;
     }
-    // writes straight to the destination row (172 floats) -- too wide to stage in registers
-    __device__ static void obs(const S &s, float *o) {
+    // writes straight to the destination row (172 floats) -- too wide to stage in registers.  `o` is a float pointer or anything with
+    // operator[] / operator+ (the fused rollout writes the global row and the bf16 LDS image in one pass)
+    template <class O>
+    __device__ static void obs(const S &s, O o) {
         float pitch = s.root[3], roll = s.root[4];
         o[0] = s.root[0], o[1] = s.root[1], o[2] = s.root[2], o[3] = pitch, o[4] = roll, o[5] = s.root[5], o[6] = s.root[6];
         o[7] = csin(pitch), o[8] = ccos(pitch), o[9] = csin(roll), o[10] = ccos(roll), o[11] = s.root[0] - 0.55f;
@@ -774,7 +775,7 @@ struct CrawlerTask {
             float sn = csin(qj), c = ccos(qj);
             float side = (j & 1) ? -1.0f : 1.0f;
             float contact = -(sn + side * pitch * 0.5f);
-            float *p = o + 12 + 8 * j;
+            auto p = o + (12 + 8 * j);
             p[0] = qj, p[1] = s.qd[j] * 0.1f, p[2] = sn, p[3] = c, p[4] = s.pa[j], p[5] = qn - qj, p[6] = contact > 0.0f ? contact : 0.0f, p[7] = qj * qj;
         }
     }
