@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtma_oracle.so")
 
-TASK_IDS = {"basic": 0, "gridworld": 1, "ball3d": 2, "push": 3, "crawler": 4, "walljump": 5}
+TASK_IDS = {"basic": 0, "gridworld": 1, "ball3d": 2, "push": 3, "crawler": 4, "walljump": 5, "bicycle": 6, "brickbreak": 7, "glider": 8}
 EP_STRIDE = 1 << 20
 
 

@@ -109,20 +109,26 @@ void orc_mt_uniform(uint32_t seed, double lo, double hi, double *out, int n) {
 #define CRAWLER_STATE (2 * CRAWLER_NJ + CRAWLER_NJ + 8 + 1) /* q, qd, prev action, root(8), steps */
 
 int orc_obs_dim(int task) {
-    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS, 4};
+    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS, 4, 7, 45, 16};
     return d[task];
 }
 int orc_num_actions(int task) {
-    static const int d[] = {3, 5, 5, 5, 0, 4};
+    static const int d[] = {3, 5, 5, 5, 0, 4, 3, 3, 5};
     return d[task];
 }
 int orc_act_dim(int task) { return task == ORC_CRAWLER ? CRAWLER_NJ : 1; }
 int orc_state_dim(int task) {
-    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE, 4};
+    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE, 4, 10, 46, 14};
     return d[task];
 }
 int orc_max_episode_steps(int task) {
-    static const int d[] = {50, 100, 200, 120, 1000, 150};
+    static const int d[] = {50, 100, 200, 120, 1000, 150, 2000, 2000, 4000};
+    return d[task];
+}
+
+/* position of the step counter in the flat state vector */
+static int orc_steps_index(int task) {
+    static const int d[] = {1, 7, 6, 5, 3 * CRAWLER_NJ + 8, 3, 9, 5, 13};
     return d[task];
 }
 
@@ -547,6 +553,263 @@ static void crawler_step(double *st, const float *act, float *obs, double *rewar
 }
 
 /* =========================================================================================
+ * numpy / OpenBLAS summation orders the three float tasks below depend on (probed against numpy 2.2.6 + its bundled
+ * OpenBLAS in the build container; the fixtures pin them): np.dot / np.linalg.norm / `@` of 2- and 3-element float64
+ * operands are one FMA chain from the left, s = a0 b0; s = fma(a1, b1, s); s = fma(a2, b2, s); the 3x3 matrix-vector
+ * product starts from the middle column, s = a1 b1; s = fma(a0, b0, s); s = fma(a2, b2, s).
+ * ======================================================================================= */
+static double dot2(double a0, double b0, double a1, double b1) { return fma(a1, b1, a0 * b0); }
+static double dot3(const double *a, const double *b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+static double matvec3_row(const double *a, const double *v) { return fma(a[2], v[2], fma(a[0], v[0], a[1] * v[1])); }
+static double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* `x ** y` on a numpy float64 scalar is libm pow(x, y) (scalarmath): within 1 ulp of, not always equal to, x * x or sqrt(x).  Called through
+ * a volatile pointer so that gcc does not rewrite pow(x, 2.0) as x * x. */
+static double (*volatile libm_pow)(double, double) = pow;
+
+/* =========================================================================================
+ * Bicycle -- backend/examples/bicycle.py:14-37 (constants), :40-58 (reset), :60-125 (step), :127-141 (obs); adapter
+ * backend/mlagents/envs.py:228-239 (Discrete(3), 2000-step limit).  SURVEY.md 8f rank N3.
+ * state = [x, z, theta, phi, phi_dot, delta, goal_x, goal_z, dist_to_goal, steps]
+ * ======================================================================================= */
+#define BK_MAX_PHI 0.78539816339744828   /* np.pi / 4 */
+#define BK_MAX_DELTA 0.52359877559829882 /* np.pi / 6 */
+static void bike_obs(const double *st, float *obs) { /* bicycle.py:127-141 */
+    double dx = st[6] - st[0], dz = st[7] - st[1];
+    double dist = sqrt(dot2(dx, dx, dz, dz));
+    double nx = 0.0, nz = 0.0;
+    if (dist > 0) nx = dx / dist, nz = dz / dist;
+    obs[0] = (float)st[3];
+    obs[1] = (float)st[4];
+    obs[2] = (float)st[5];
+    obs[3] = (float)cos(st[2]);
+    obs[4] = (float)sin(st[2]);
+    obs[5] = (float)nx;
+    obs[6] = (float)nz;
+}
+static void bike_reset(orc_mt *rng, double *st) { /* bicycle.py:40-58 */
+    st[0] = st[1] = st[2] = 0.0;
+    st[3] = mt_uniform(rng, -0.1, 0.1);
+    st[4] = mt_uniform(rng, -0.1, 0.1);
+    st[5] = 0.0;
+    double radius = mt_uniform(rng, 15, 25);
+    double angle = mt_uniform(rng, -BK_MAX_PHI, BK_MAX_PHI);
+    st[6] = radius * cos(angle);
+    st[7] = radius * sin(angle);
+    st[8] = sqrt(dot2(st[6], st[6], st[7], st[7])); /* goal - [0, 0] */
+    st[9] = 0;
+}
+static void bike_step(double *st, int a, float *obs, double *reward, int *done) { /* bicycle.py:60-125 */
+    const double g = 9.8, h = 0.8, L = 1.0, v = 5.0, dt = 0.02;
+    st[9] += 1;
+    double delta = st[5] + (a == 0 ? -0.05 : (a == 2 ? 0.05 : 0.0));
+    delta = clipd(delta, -BK_MAX_DELTA, BK_MAX_DELTA);
+    double grav = (g / h) * sin(st[3]);
+    double cen = (v * v / (L * h)) * tan(delta);
+    cen = cen * cos(st[3]);
+    double phi_ddot = grav - cen;
+    st[4] = st[4] + phi_ddot * dt;
+    st[3] = st[3] + st[4] * dt;
+    delta = delta * 0.95;
+    st[5] = delta;
+    double th = (v / L) * tan(delta);
+    st[2] = st[2] + th * dt;
+    double cx = v * cos(st[2]);
+    st[0] = st[0] + cx * dt;
+    double cz = v * sin(st[2]);
+    st[1] = st[1] + cz * dt;
+    double dx = st[6] - st[0], dz = st[7] - st[1];
+    double nd = sqrt(dot2(dx, dx, dz, dz));
+    double progress = (st[8] - nd) * 10.0;
+    st[8] = nd;
+    double upright = (1.0 - libm_pow(fabs(st[3]) / BK_MAX_PHI, 0.5)) * 0.2;
+    double den = nd > 0 ? nd : 1.0;
+    double heading = dot2(cos(st[2]), dx / den, sin(st[2]), dz / den) * 0.3;
+    double steer = -(fabs(delta) / BK_MAX_DELTA) * 0.1;
+    double r = progress + upright;
+    r = r + heading;
+    r = r + steer;
+    int d = 0;
+    if (fabs(st[3]) > BK_MAX_PHI) r = -10.0, d = 1;
+    if (st[9] > 2000) d = 1;
+    if (nd < 2.0) r = 50.0, d = 1;
+    *reward = r;
+    *done = d;
+    bike_obs(st, obs);
+}
+
+/* =========================================================================================
+ * BrickBreak -- backend/examples/brick_break.py:14-37 (constants), :39-47 (reset), :49-121 (step), :123-131 (obs); adapter
+ * backend/mlagents/envs.py:214-225 (Discrete(3), 2000-step limit).
+ * state = [paddle_x, ball_x, ball_y, vel_x, vel_y, steps, bricks[5][8]]
+ * ======================================================================================= */
+#define BB_OBS 45
+static void brick_obs(const double *st, float *obs) { /* brick_break.py:123-131 */
+    obs[0] = (float)(st[1] / 40.0);
+    obs[1] = (float)(st[2] / 40.0);
+    obs[2] = (float)st[3];
+    obs[3] = (float)st[4];
+    obs[4] = (float)(st[0] / 40.0);
+    for (int k = 0; k < 40; k++) obs[5 + k] = (float)st[6 + k];
+}
+static void brick_reset(orc_mt *rng, double *st) { /* brick_break.py:39-47 */
+    st[0] = 20.0;
+    st[1] = 20.0;
+    st[2] = 10.0;
+    double angle = mt_uniform(rng, 0.78539816339744828, 2.3561944901923448); /* np.pi / 4, 3 * np.pi / 4 */
+    st[3] = cos(angle) * 1.5;
+    st[4] = sin(angle) * 1.5;
+    st[5] = 0;
+    for (int k = 0; k < 40; k++) st[6 + k] = 1.0;
+}
+static void brick_step(double *st, int a, float *obs, double *reward, int *done) { /* brick_break.py:49-121 */
+    st[5] += 1;
+    if (a == 0) st[0] -= 3;
+    else if (a == 2) st[0] += 3;
+    st[0] = clipd(st[0], 4.0, 36.0);
+    st[1] += st[3];
+    st[2] += st[4];
+    double r = 0.0;
+    if (st[1] <= 1 || st[1] >= 39) st[3] *= -1;
+    if (st[2] >= 39) st[4] *= -1;
+    if (st[4] < 0 && st[2] - 1 <= 2 && st[1] >= st[0] - 4.0 && st[1] <= st[0] + 4.0) {
+        st[4] *= -1;
+        double offset = (st[1] - st[0]) / 4.0;
+        st[3] += offset * 0.5;
+        r = 0.1;
+    }
+    const double y0 = 40 - 5 * 2 - 10; /* brick_y_start */
+    int hit = 0;
+    for (int row = 0; row < 5 && !hit; row++)
+        for (int c = 0; c < 8; c++)
+            if (st[6 + row * 8 + c] == 1) {
+                double bx = c * 5.0, by = y0 + row * 2;
+                if (st[1] >= bx && st[1] <= bx + 5.0 && st[2] >= by && st[2] <= by + 2) {
+                    st[6 + row * 8 + c] = 0;
+                    st[4] *= -1;
+                    r = 1.0;
+                    hit = 1;
+                    break;
+                }
+            }
+    int d = 0;
+    if (st[2] < 1) r = -1.0, d = 1;
+    double left = 0;
+    for (int k = 0; k < 40; k++) left += st[6 + k];
+    if (left == 0) r = 10.0, d = 1;
+    if (st[5] > 2000) d = 1;
+    *reward = r;
+    *done = d;
+    brick_obs(st, obs);
+}
+
+/* =========================================================================================
+ * Glider -- backend/examples/glider.py:14-53 (constants), :55-79 (wind), :81-88 (reset), :90-237 (step), :239-265 (obs);
+ * adapter backend/mlagents/envs.py:242-253 (Discrete(5), 4000-step limit).
+ * state = [pos(3), vel(3), rot(3), ang_vel(3), waypoint index, steps]
+ * ======================================================================================= */
+#define GL_OBS 16
+static const double GL_WP[2][3] = {{-160.0, 0.0, 70.0}, {160.0, 0.0, 70.0}};
+static void glider_obs(const double *st, float *obs) { /* glider.py:239-265 */
+    const double *wp = GL_WP[(int)st[12]];
+    double vec[3] = {wp[0] - st[0], wp[1] - st[1], wp[2] - st[2]};
+    double dist = sqrt(dot3(vec, vec));
+    obs[0] = (float)(st[5] / 10.0);
+    obs[1] = (float)((st[2] - 50.0) / 50.0);
+    obs[2] = (float)st[6];
+    obs[3] = (float)st[7];
+    obs[4] = (float)sin(st[8]);
+    obs[5] = (float)cos(st[8]);
+    for (int k = 0; k < 3; k++) obs[6 + k] = (float)st[9 + k];
+    for (int k = 0; k < 3; k++) obs[9 + k] = (float)(st[3 + k] / 20.0);
+    for (int k = 0; k < 3; k++) obs[12 + k] = (float)(vec[k] / (dist + 1e-8));
+    obs[15] = (float)(dist / 100.0);
+}
+static void glider_reset(orc_mt *rng, double *st) { /* glider.py:81-88 */
+    st[0] = 0.0, st[1] = 0.0, st[2] = 60.0;
+    st[3] = 15.0, st[4] = 0.0, st[5] = -1.0;
+    st[6] = st[7] = st[8] = 0.0;
+    for (int k = 0; k < 3; k++) st[9 + k] = mt_uniform(rng, -0.1, 0.1);
+    st[12] = (double)orc_mt_interval(rng, 1); /* np.random.randint(0, 2): one masked 32-bit draw */
+    st[13] = 0;
+}
+static void matmul3(const double A[3][3], const double B[3][3], double C[3][3]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C[i][j] = fma(A[i][2], B[2][j], fma(A[i][1], B[1][j], A[i][0] * B[0][j]));
+}
+static void glider_step(double *st, int a, float *obs, double *reward, int *done) { /* glider.py:90-237 */
+    const double dt = 0.02, two_pi = 6.283185307179586, pi = 3.141592653589793;
+    double *pos = st, *vel = st + 3, *rot = st + 6, *av = st + 9;
+    st[13] += 1;
+    double tq[3] = {0.0, 0.0, 0.0}; /* roll, pitch, yaw */
+    if (a == 1) tq[0] = -15.0, tq[2] = 4.0;
+    else if (a == 2) tq[0] = 15.0, tq[2] = -4.0;
+    else if (a == 3) tq[1] = 10.0;
+    else if (a == 4) tq[1] = -10.0;
+    for (int k = 0; k < 3; k++) av[k] = av[k] + tq[k] * dt;
+    for (int k = 0; k < 3; k++) av[k] = av[k] * 0.95;
+    for (int k = 0; k < 3; k++) rot[k] = rot[k] + av[k] * dt;
+    rot[0] = clipd(rot[0], -pi / 2, pi / 2);
+    rot[1] = clipd(rot[1], -pi / 4, pi / 4);
+    /* wind (glider.py:55-79) */
+    const double f1 = 1.0 / 250.0, f2 = 1.0 / 400.0;
+    double u1 = sin(pos[0] * f1 * 2 * pi) * cos(pos[1] * f1 * 2 * pi) * 8.0 * 1.0;
+    double u2 = sin(pos[0] * f2 * 2 * pi / 1.5) * cos(pos[1] * f1 * 2 * pi / 1.5) * 8.0 * 0.7;
+    double wind[3] = {1.0, 0.5, u1 + u2};
+    double va[3] = {vel[0] - wind[0], vel[1] - wind[1], vel[2] - wind[2]};
+    double vam = sqrt(dot3(va, va));
+    double aoa = va[0] != 0 ? atan2(-va[2], va[0]) : 0.0;
+    double aero[3] = {0.0, 0.0, 0.0};
+    if (vam > 0.1) {
+        double CL = two_pi * aoa;
+        double CD = 0.02 + 0.05 * libm_pow(CL, 2.0);
+        double q = 0.5 * 1.225 * libm_pow(vam, 2.0) * 0.5;
+        double lift = q * CL, drag = q * CD;
+        double F[3] = {0 + -drag, 0.0, lift + 0};
+        double cr = cos(rot[0]), sr = sin(rot[0]), cp = cos(rot[1]), sp = sin(rot[1]), cy = cos(rot[2]), sy = sin(rot[2]);
+        const double Rr[3][3] = {{1, 0, 0}, {0, cr, -sr}, {0, sr, cr}};
+        const double Rp[3][3] = {{cp, 0, sp}, {0, 1, 0}, {-sp, 0, cp}};
+        const double Ry[3][3] = {{cy, -sy, 0}, {sy, cy, 0}, {0, 0, 1}};
+        double T[3][3], R[3][3];
+        matmul3(Ry, Rp, T);
+        matmul3(T, Rr, R);
+        for (int i = 0; i < 3; i++) aero[i] = matvec3_row(R[i], F);
+    } else {
+        aoa = 0;
+    }
+    double total[3] = {aero[0] + 0, aero[1] + 0, aero[2] + -(1.5 * 9.81)};
+    for (int k = 0; k < 3; k++) vel[k] = vel[k] + (total[k] / 1.5) * dt;
+    for (int k = 0; k < 3; k++) pos[k] = pos[k] + vel[k] * dt;
+    int d = 0, wi = (int)st[12];
+    double vec[3] = {GL_WP[wi][0] - pos[0], GL_WP[wi][1] - pos[1], GL_WP[wi][2] - pos[2]};
+    double dist = sqrt(dot3(vec, vec));
+    if (dist < 15.0) st[12] = (double)((wi + 1) % 2);
+    double vn = sqrt(dot3(vel, vel));
+    double vd[3], td[3];
+    for (int k = 0; k < 3; k++) vd[k] = vel[k] / (vn + 1e-8), td[k] = vec[k] / (dist + 1e-8);
+    double H = (dot3(vd, td) + 1) / 2;
+    double E = clipd(vn / 30.0, 0, 2.0);
+    double r = E * (H - E + 1);
+    double lateral = fabs(pos[1]);
+    if (lateral > 250.0) {
+        double pr = (lateral - 250.0) / 100.0;
+        r -= 2.0 * libm_pow(pr, 2.0);
+    }
+    if (pos[2] > 250.0) {
+        double pr = (pos[2] - 250.0) / 50.0;
+        r -= 2.0 * libm_pow(pr, 2.0);
+    } else if (pos[2] < 25.0) {
+        r -= 0.5;
+    }
+    if (pos[2] < 5.0) r = -50.0, d = 1;
+    if (fabs(aoa) > 0.26179938779914941) r = -50.0, d = 1; /* np.deg2rad(15) */
+    if (dist > 500) r = -50.0, d = 1;
+    if (st[13] > 4000) d = 1;
+    *reward = r;
+    *done = d;
+    glider_obs(st, obs);
+}
+
+/* =========================================================================================
  * adapter + vec env
  * ======================================================================================= */
 static void task_obs(int task, const double *st, float *obs) {
@@ -557,6 +820,9 @@ static void task_obs(int task, const double *st, float *obs) {
     case ORC_PUSH: push_obs(st, obs); break;
     case ORC_CRAWLER: crawler_obs(st, obs); break;
     case ORC_WALLJUMP: wj_obs(st, obs); break;
+    case ORC_BICYCLE: bike_obs(st, obs); break;
+    case ORC_BRICKBREAK: brick_obs(st, obs); break;
+    case ORC_GLIDER: glider_obs(st, obs); break;
     }
 }
 
@@ -587,6 +853,21 @@ void orc_reset_from_seed(int task, uint32_t seed, double *st, float *obs) {
         wj_reset(&rng, st);
         wj_reset(&rng, st);
         break;
+    case ORC_BICYCLE:
+        orc_mt_seed(&rng, seed);
+        bike_reset(&rng, st);
+        bike_reset(&rng, st);
+        break;
+    case ORC_BRICKBREAK:
+        orc_mt_seed(&rng, seed);
+        brick_reset(&rng, st);
+        brick_reset(&rng, st);
+        break;
+    case ORC_GLIDER:
+        orc_mt_seed(&rng, seed);
+        glider_reset(&rng, st);
+        glider_reset(&rng, st);
+        break;
     }
     if (obs) task_obs(task, st, obs);
 }
@@ -601,6 +882,9 @@ void orc_legacy_step(int task, double *st, const void *action, float *obs, doubl
     case ORC_PUSH: push_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_CRAWLER: crawler_step(st, (const float *)action, obs, reward, done); break;
     case ORC_WALLJUMP: wj_step(st, *(const int32_t *)action, obs, reward, done); break;
+    case ORC_BICYCLE: bike_step(st, *(const int32_t *)action, obs, reward, done); break;
+    case ORC_BRICKBREAK: brick_step(st, *(const int32_t *)action, obs, reward, done); break;
+    case ORC_GLIDER: glider_step(st, *(const int32_t *)action, obs, reward, done); break;
     }
 }
 
@@ -665,7 +949,7 @@ void orc_vec_step(orc_vec *v, const void *actions, float *obs_out, float *rew32_
         const void *act = task == ORC_CRAWLER ? (const void *)((const float *)actions + (size_t)i * v->A)
                                               : (const void *)((const int32_t *)actions + i);
         orc_legacy_step(task, st, act, obs, &r, &done);
-        int steps = (int)st[task == ORC_CRAWLER ? 3 * CRAWLER_NJ + 8 : (task == ORC_BASIC ? 1 : (task == ORC_PUSH ? 5 : (task == ORC_GRIDWORLD ? 7 : (task == ORC_WALLJUMP ? 3 : 6))))];
+        int steps = (int)st[orc_steps_index(task)];
         if (task == ORC_BASIC) { /* envs.py:76 */
             terminated = done;
             truncated = (steps >= max_steps) && !terminated;

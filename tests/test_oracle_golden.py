@@ -10,7 +10,8 @@ import pytest
 
 from oracle import oracle as orc
 
-TASKS = ["basic", "gridworld", "push", "ball3d", "walljump"]
+FLOAT_TASKS = ["bicycle", "brickbreak", "glider"]  # f64 physics, fixtures generated with numpy's libm paths (tools/gen_golden.py)
+TASKS = ["basic", "gridworld", "push", "ball3d", "walljump"] + FLOAT_TASKS
 
 
 def test_known_answer_basic_reference_unit_test():
@@ -62,6 +63,11 @@ def test_single_transitions(golden, task):
         elif task == "walljump":
             st, obs, r, done = orc.legacy_step(task, row_in[:4].astype(np.float64), int(row_in[4]))
             assert [st[0], st[1], st[2], st[3], r, float(done)] == list(row_out)
+        elif task in FLOAT_TASKS:
+            st, obs, r, done = orc.legacy_step(task, row_in[:-1], int(row_in[-1]))
+            got = [*st[: len(row_out) - 2], r, float(done)]
+            assert got == list(row_out), (row_in, got, row_out)
+            o_ref = o_ref.astype(np.float32)  # the legacy env returns float64; the adapter casts (backend/mlagents/envs.py:147)
         else:
             st, obs, r, done = orc.legacy_step(task, row_in[:8], int(row_in[8]))
             got = [*st[:7], r, float(done)]

@@ -10,6 +10,7 @@ What is imported, unmodified, from the reference:
   backend/examples/ball3d.py      (Ball3DEnv)
   backend/examples/push.py        (PushEnv)
   backend/examples/walljump.py    (WallJumpEnv)
+  backend/examples/bicycle.py, brick_break.py, glider.py   (BicycleEnv, BrickBreakEnv, GliderEnv: SURVEY.md 8f rank N3)
 `gymnasium` is not installed here, so a ~20-line stand-in (Env with a no-op reset, Box/Discrete
 holders) is placed in sys.modules first; it carries no arithmetic.
 
@@ -19,12 +20,19 @@ The driver below restates what SB3's DummyVecEnv + Monitor do around those envs
 (k = 0 coincides with the reference's own `seed + rank`, backend/mlagents/training.py:80).
 Actions come from a counter-based tape  a(i,t) = mix32(tape_seed, i, t) % n_actions.
 
-Usage:  python tools/gen_golden.py   (writes tests/golden/*.npz)
+The three float tasks (bicycle, brickbreak, glider) are generated in a child process that runs with
+NPY_DISABLE_CPU_FEATURES set to the AVX-512 groups: numpy then takes np.tan / np.arctan2 of a float64 from libm instead of its
+AVX-512 SVML kernels (which differ from libm in the last bit for ~0.5 % of the arguments), i.e. the fixtures are the reference as it
+runs on a host without AVX-512 -- the configuration a plain-C restatement can match bit for bit.  The five earlier fixtures are
+generated with numpy's default dispatch, as before.
+
+Usage:  python tools/gen_golden.py [task ...]   (writes tests/golden/<task>.npz; no arguments = every task + the RNG fixture)
 """
 from __future__ import annotations
 
 import importlib.util
 import os
+import subprocess
 import sys
 import types
 
@@ -119,11 +127,24 @@ def get_state(task: str, env) -> np.ndarray:
     if task == "ball3d":
         first = 1.0 if e.rot.dtype == np.float32 else 0.0
         return np.array([*e.rot, *e.pos, *e.vel, e.steps, first], dtype=np.float64)
+    if task == "bicycle":
+        return np.array([e.x, e.z, e.theta, e.phi, e.phi_dot, e.delta, *e.goal_pos, e.dist_to_goal, e.steps], dtype=np.float64)
+    if task == "brickbreak":
+        return np.array([e.paddle_x, *e.ball_pos, *e.ball_vel, e.steps, *e.bricks.flatten()], dtype=np.float64)
+    if task == "glider":
+        return np.array([*e.pos, *e.vel, *e.rot, *e.ang_vel, e.current_waypoint_index, e.steps], dtype=np.float64)
     raise KeyError(task)
 
 
+FACTORY = {"brickbreak": "make_brick_break_env"}  # registry id -> factory name where they differ (backend/mlagents/registry.py:133-146)
+
+
+def factory(mod, task):
+    return getattr(mod, FACTORY.get(task, f"make_{task}_env"))
+
+
 def vec_rollout(mod, task: str, n_envs: int, T: int, base_seed: int, tape_seed: int):
-    make = getattr(mod, f"make_{task}_env")
+    make = factory(mod, task)
     envs = [make() for _ in range(n_envs)]
     n_act = envs[0].action_space.n
     D = envs[0].observation_space.shape[0]
@@ -182,7 +203,7 @@ def vec_rollout(mod, task: str, n_envs: int, T: int, base_seed: int, tape_seed: 
 
 
 def seeded_resets(mod, task: str, seeds: np.ndarray):
-    make = getattr(mod, f"make_{task}_env")
+    make = factory(mod, task)
     env = make()
     D = env.observation_space.shape[0]
     obs = np.zeros((len(seeds), D), np.float32)
@@ -279,6 +300,26 @@ def walljump_transitions(mod, rng):
     return dict(tr_in=np.array(rows_in, np.int32), tr_out=np.array(rows_out, np.float64), tr_obs=np.stack(obs_out))
 
 
+def float_task_transitions(mod, task, rng):
+    """Single legacy steps (below the adapter) from states visited by seeded random-action episodes: state in, action -> state out,
+    reward, done, observation.  The injected state is the flat vector of get_state()."""
+    env = factory(mod, task)()
+    n_act = env.action_space.n
+    rows_in, rows_out, obs_out = [], [], []
+    for ep in range(40):
+        env.reset(seed=1000 + ep)
+        e = env.env
+        for t in range(100):
+            act = int(rng.integers(0, n_act))
+            rows_in.append([*get_state(task, env), act])
+            o, rew, done = e.step(act)
+            rows_out.append([*get_state(task, env), float(rew), float(done)])
+            obs_out.append(np.asarray(o, np.float64))
+            if done:
+                break
+    return dict(tr_in=np.array(rows_in, np.float64), tr_out=np.array(rows_out, np.float64), tr_obs=np.stack(obs_out))
+
+
 def basic_transitions(mod):
     env = mod.make_basic_env()
     rows_in, rows_out, obs_out = [], [], []
@@ -324,10 +365,13 @@ def rng_fixture():
     )
 
 
+FLOAT_TASKS = ("bicycle", "brickbreak", "glider")
+NO_AVX512 = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR"
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    mod = load_reference_envs()
-    rng = np.random.default_rng(20261002)
+    want = sys.argv[1:]
     cfg = {
         # task: (n_envs, T, base_seed, tape_seed)
         "basic": (8, 400, 1, 11),
@@ -335,29 +379,53 @@ def main():
         "push": (16, 900, 1, 13),
         "ball3d": (16, 900, 1, 14),
         "walljump": (16, 700, 1, 15),
+        "bicycle": (16, 500, 1, 16),
+        "brickbreak": (16, 900, 1, 17),
+        "glider": (8, 700, 1, 18),
     }
+    floats = [t for t in FLOAT_TASKS if not want or t in want]
+    if floats and os.environ.get("NPY_DISABLE_CPU_FEATURES") != NO_AVX512:
+        # the float tasks: a child with the AVX-512 dispatch of numpy disabled (see the module docstring)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), *floats], env={**os.environ, "NPY_DISABLE_CPU_FEATURES": NO_AVX512})
+        want = [t for t in (want or [*cfg, "rng"]) if t not in FLOAT_TASKS]
+        if not want:
+            return
+    mod = load_reference_envs()
+    rng = np.random.default_rng(20261002)
     for task, (n, T, base, tape) in cfg.items():
-        d = vec_rollout(mod, task, n, T, base, tape)
-        # a second rollout at the reference test-suite's seed (tests/test_mlagents.py:86 uses 321)
-        d2 = vec_rollout(mod, task, 4, 300, 321, tape + 100)
-        d.update({f"b_{k}": v for k, v in d2.items()})
-        d.update(seeded_resets(mod, task, np.concatenate([np.arange(0, 200), [321, 10_001, 2**20 + 1, 2**32 - 1]])))
+        if task in FLOAT_TASKS and os.environ.get("NPY_DISABLE_CPU_FEATURES") != NO_AVX512:
+            continue
+        # (the shared generator advances per task in table order whether or not the task is written, so a partial run reproduces the files)
+        if task in FLOAT_TASKS:
+            rng_t = np.random.default_rng(20261002 + tape)
+        d = vec_rollout(mod, task, n, T, base, tape) if (not want or task in want) else None
+        if d is not None:
+            # a second rollout at the reference test-suite's seed (tests/test_mlagents.py:86 uses 321)
+            d2 = vec_rollout(mod, task, 4, 300, 321, tape + 100)
+            d.update({f"b_{k}": v for k, v in d2.items()})
+            d.update(seeded_resets(mod, task, np.concatenate([np.arange(0, 200), [321, 10_001, 2**20 + 1, 2**32 - 1]])))
         if task == "gridworld":
-            d.update(grid_transitions(mod, rng))
+            tr = grid_transitions(mod, rng)
         elif task == "push":
-            d.update(push_transitions(mod, rng))
+            tr = push_transitions(mod, rng)
         elif task == "ball3d":
-            d.update(ball3d_transitions(mod, rng))
+            tr = ball3d_transitions(mod, rng)
         elif task == "walljump":
-            d.update(walljump_transitions(mod, rng))
+            tr = walljump_transitions(mod, rng)
+        elif task in FLOAT_TASKS:
+            tr = float_task_transitions(mod, task, rng_t)
         else:
-            d.update(basic_transitions(mod))
+            tr = basic_transitions(mod)
+        if d is None:
+            continue
+        d.update(tr)
         path = os.path.join(OUT, f"{task}.npz")
         np.savez_compressed(path, **d)
         print(task, "episodes/env:", d["episodes_per_env"].tolist(), "->", path, os.path.getsize(path), "B")
-    path = os.path.join(OUT, "numpy_legacy_rng.npz")
-    np.savez_compressed(path, **rng_fixture())
-    print("rng ->", path, os.path.getsize(path), "B")
+    if not want or "rng" in want:
+        path = os.path.join(OUT, "numpy_legacy_rng.npz")
+        np.savez_compressed(path, **rng_fixture())
+        print("rng ->", path, os.path.getsize(path), "B")
 
 
 if __name__ == "__main__":
