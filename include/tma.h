@@ -26,7 +26,8 @@ extern "C" {
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
 /* task ids (backend/mlagents/registry.py:52-116,225-240) */
-enum { TMA_TASK_BASIC = 0, TMA_TASK_GRIDWORLD = 1, TMA_TASK_BALL3D = 2, TMA_TASK_PUSH = 3, TMA_TASK_CRAWLER = 4, TMA_TASK_WALLJUMP = 5, TMA_NUM_TASKS = 6 };
+enum { TMA_TASK_BASIC = 0, TMA_TASK_GRIDWORLD = 1, TMA_TASK_BALL3D = 2, TMA_TASK_PUSH = 3, TMA_TASK_CRAWLER = 4, TMA_TASK_WALLJUMP = 5, TMA_TASK_BICYCLE = 6, TMA_TASK_BRICKBREAK = 7, TMA_TASK_GLIDER = 8,
+       TMA_NUM_TASKS = 9 };
 
 /* dtype of the `actions` buffer handed to tma_env_step */
 enum { TMA_ACT_I32 = 0, TMA_ACT_I64 = 1, TMA_ACT_F32 = 2 };
@@ -44,11 +45,12 @@ int tma_task_obs_dim(int task);           /* 21 / 4 / 6 / 4 / 172 / 4 */
 int tma_task_num_actions(int task);       /* Discrete(n); 0 for a Box action space */
 int tma_task_act_dim(int task);           /* Box action dim (crawler: 20), else 1 */
 int tma_task_state_dim(int task);         /* doubles per env in the flat get/set_state layout */
-int tma_task_max_episode_steps(int task); /* 50 / 100 / 200 / 120 / 1000 / 150 */
+int tma_task_max_episode_steps(int task); /* 50 / 100 / 200 / 120 / 1000 / 150 / 2000 / 2000 / 4000 */
 
 /* ---- vector env: replaces make_vector_env + DummyVecEnv + Monitor + LegacySingleAgentGymAdapter +
  *      the task step()/reset() (backend/mlagents/training.py:71-89; backend/mlagents/envs.py:30-159;
- *      backend/examples/{gridworld.py:40-95, ball3d.py:47-113, push.py:39-125, walljump.py:40-98}) ---- */
+ *      backend/examples/{gridworld.py:40-95, ball3d.py:47-113, push.py:39-125, walljump.py:40-98, bicycle.py:40-141,
+ *      brick_break.py:39-131, glider.py:55-265}) ---- */
 typedef struct tma_env tma_env;
 
 /* env_offset = global index of this shard's env 0 (data-parallel sharding); ring_depth = look-ahead of

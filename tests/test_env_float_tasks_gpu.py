@@ -1,0 +1,139 @@
+"""GPU parity of the three float64-physics tasks of SURVEY.md 8f N3 -- Bicycle, BrickBreak, Glider (backend/examples/bicycle.py,
+brick_break.py, glider.py behind LegacySingleAgentGymAdapter, backend/mlagents/envs.py:214-253) -- through the C ABI, against the
+fixtures generated from the reference and against the C oracle (which is bit-exact against those fixtures, tests/test_oracle_golden.py).
+The device math library's sin / cos / tan / atan2 may differ from the generating host's libm in the last bit, so floats are held to the
+north_star tolerance (1e-5) and the number of elements that are not bit-identical is bounded; flags, episode lengths and episode
+indices must be exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TASKS = ["bicycle", "brickbreak", "glider"]
+SDIM = {"bicycle": 10, "brickbreak": 46, "glider": 14}
+TOL = 1e-5
+
+
+def _engine(task, n, **kw):
+    from three_mlagents_amd.vec_env import HipEnvEngine
+
+    return HipEnvEngine(task, n, **kw)
+
+
+def _close(name, got, ref, ctx):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert np.allclose(got, ref, rtol=1e-9, atol=TOL), (name, ctx, np.abs(got - ref).max())
+    return int((got != ref).sum())
+
+
+def _run_golden(task, g, prefix, ring_depth):
+    n, T, base, tape, n_act, D = [int(x) for x in g[prefix + "meta"]]
+    eng = _engine(task, n, seed=base, ring_depth=ring_depth)
+    inexact = _close("reset_obs", eng.reset().cpu().numpy(), g[prefix + "reset_obs"], 0)
+    actions = torch.from_numpy(g[prefix + "actions"]).cuda()
+    for t in range(T):
+        o = eng.step(actions[t])
+        inexact += _close("obs", o["obs"][0].cpu(), g[prefix + "obs"][t], t)
+        inexact += _close("rew", o["rew"][0].cpu(), g[prefix + "rewards_f32"][t], t)
+        assert np.array_equal(o["term"][0].cpu().numpy().astype(bool), g[prefix + "terminated"][t]), (task, t)
+        assert np.array_equal(o["trunc"][0].cpu().numpy().astype(bool), g[prefix + "truncated"][t]), (task, t)
+        done = g[prefix + "terminated"][t] | g[prefix + "truncated"][t]
+        inexact += _close("term_obs", o["term_obs"][0].cpu().numpy()[done], g[prefix + "terminal_obs"][t][done], t)
+        inexact += _close("ep_ret", o["ep_ret"][0].cpu(), g[prefix + "ep_ret"][t], t)
+        assert np.array_equal(o["ep_len"][0].cpu().numpy(), g[prefix + "ep_len"][t]), (task, t)
+    assert np.array_equal(eng.episode_index().cpu().numpy(), g[prefix + "episodes_per_env"])
+    eng.close()
+    return inexact
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_rollouts_from_reference(golden, task):
+    g = golden(task)
+    inexact = _run_golden(task, g, "", ring_depth=8) + _run_golden(task, g, "b_", ring_depth=2)
+    total = sum(int(np.prod(g[p + k].shape)) for p in ("", "b_") for k in ("obs", "rewards_f32"))
+    print(f"[{task}] elements not bit-identical to the reference: {inexact} of ~{total}")
+    # observed on MI355X: bicycle 15 of 73 600, brickbreak 0 of 717 600, glider 9 of 115 600; bounded so that a
+    # regression to "a visible fraction of the elements differs" cannot pass
+    assert inexact <= 64 + total // 2000, (inexact, total)
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_seeded_resets(golden, task):
+    g = golden(task)
+    for s, obs_ref, st_ref in list(zip(g["reset_seeds"], g["reset_seed_obs"], g["reset_seed_state"]))[::9]:
+        eng = _engine(task, 1, seed=int(s), ring_depth=2)
+        obs = eng.reset().cpu().numpy()[0]
+        st = eng.get_state().cpu().numpy()[0]
+        assert np.allclose(obs, obs_ref, rtol=0, atol=1e-6), (task, s)
+        assert np.allclose(st[: len(st_ref)], st_ref, rtol=1e-13, atol=1e-13), (task, s, st, st_ref)
+        eng.close()
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_golden_transitions_state_injection(golden, task):
+    g = golden(task)
+    tin, tout, tobs = g["tr_in"], g["tr_out"], g["tr_obs"]
+    n, sdim = len(tin), SDIM[task]
+    eng = _engine(task, n, seed=1, ring_depth=2)
+    eng.reset()
+    eng.set_state(tin[:, :sdim].astype(np.float64))
+    act = torch.from_numpy(tin[:, sdim].astype(np.int32)).cuda()
+    o = eng.step(act, want_terminal_obs=True)
+    done = (o["term"][0] | o["trunc"][0]).cpu().numpy().astype(bool)
+    obs = np.where(done[:, None], o["term_obs"][0].cpu().numpy(), o["obs"][0].cpu().numpy())
+    assert np.allclose(obs, tobs.astype(np.float32), rtol=0, atol=TOL)
+    assert np.allclose(o["rew"][0].cpu().numpy(), tout[:, sdim].astype(np.float32), rtol=1e-6, atol=TOL)
+    # the legacy env's own `done`, or the adapter's step limit (none of the injected states sits at it)
+    assert np.array_equal(done, tout[:, sdim + 1].astype(bool))
+    eng.close()
+
+
+@pytest.mark.parametrize("task", TASKS)
+@pytest.mark.parametrize("mode", ["actions", "tape_multi"])
+def test_against_oracle_many_envs(task, mode):
+    n, T, base, tape_seed, offset, depth = 1000, 192, 7, 99, 5000, 16
+    eng = _engine(task, n, seed=base, env_offset=offset, ring_depth=depth)
+    ref = orc.OracleVecEnv(task, n, seed=base, env_offset=offset)
+    inexact = _close("reset", eng.reset().cpu().numpy(), ref.reset(), 0)
+    actions = orc.action_tape(tape_seed, n, T, orc.num_actions(task), env_offset=offset)
+    outs = []
+    if mode == "actions":
+        dev_actions = torch.from_numpy(actions).cuda()
+        for t in range(T):
+            o = eng.step(dev_actions[t])
+            outs.append({k: v[0].cpu().numpy() for k, v in o.items()})
+    else:  # device-generated tape, `depth` steps per launch
+        for t0 in range(0, T, depth):
+            o = eng.step(None, n_steps=depth, tape_seed=tape_seed, tape_t0=t0)
+            for s in range(depth):
+                outs.append({k: v[s].cpu().numpy() for k, v in o.items()})
+    for t in range(T):
+        r = ref.step(actions[t])
+        o = outs[t]
+        done = (r["term"] | r["trunc"]).astype(bool)
+        inexact += _close("obs", o["obs"], r["obs"], t)
+        inexact += _close("rew", o["rew"], r["rew32"], t)
+        assert np.array_equal(o["term"], r["term"]) and np.array_equal(o["trunc"], r["trunc"]), (task, t)
+        inexact += _close("term_obs", o["term_obs"][done], r["term_obs"][done], t)
+        inexact += _close("ep_ret", o["ep_ret"], r["ep_ret"], t)
+        assert np.array_equal(o["ep_len"], r["ep_len"]), (task, t)
+    assert np.array_equal(eng.episode_index().cpu().numpy().astype(np.uint32), ref.episode_index())
+    inexact += _close("state", eng.get_state().cpu().numpy(), ref.get_state(), "final")
+    print(f"[{task}/{mode}] elements not bit-identical to the oracle: {inexact}")
+    eng.close()
+
+
+def test_train_a_few_iterations_on_a_float_task():
+    """The new tasks run through the whole path (per-step rollout, GAE, PPO update) like the others."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    env = make_vector_env("bicycle", n_envs=64, seed=3)
+    m = PPO("MlpPolicy", env, n_steps=64, batch_size=1024, n_epochs=2, seed=3, policy_kwargs={"net_arch": [64, 64]})
+    m.learn(total_timesteps=3 * 64 * 64)
+    obs = env.reset()
+    a, _ = m.predict(obs if isinstance(obs, np.ndarray) else obs.cpu().numpy(), deterministic=True)
+    assert a.shape[0] == 64 and set(np.unique(a)).issubset({0, 1, 2})

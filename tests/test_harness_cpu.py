@@ -10,7 +10,7 @@ from three_mlagents_amd import harness, tasks
 
 
 def test_engine_task_table():
-    assert set(tasks.ENGINE_TASKS) == {"basic", "gridworld", "ball3d", "push", "ant", "walljump"}
+    assert set(tasks.ENGINE_TASKS) == {"basic", "gridworld", "ball3d", "push", "ant", "walljump", "brickbreak", "bicycle", "glider"}
     for t in tasks.ENGINE_TASKS.values():
         card = t.card()
         assert card["trainable"] is True and card["id"] == t.id and card["policy_prefix"].endswith("_policy")
@@ -24,11 +24,12 @@ def test_name_resolution_and_error_types():  # test_mlagents.py:47-49 + registry
     assert tasks.resolve("Crawler").id == "ant" and tasks.resolve("GRIDWORLD").kernel == "gridworld"
     with pytest.raises(KeyError):
         tasks.resolve("not-a-task")
-    for ref_only in ("bicycle", "brick-break", "self_driving_car", "fish"):
+    assert tasks.resolve("brick-break").kernel == "brickbreak" and tasks.resolve("Bicycle").id == "bicycle"  # registry.py:354 spelling
+    for ref_only in ("labyrinth", "self_driving_car", "fish"):
         with pytest.raises(ValueError):
             tasks.resolve(ref_only)
     with pytest.raises(ValueError):
-        tasks.make_env("bicycle")
+        tasks.make_env("kraken")
 
 
 def test_predict_requires_model_file(tmp_path, monkeypatch):  # test_mlagents.py:105-108
@@ -88,7 +89,8 @@ def test_runner_grammar():  # cli.py:14-41
 def test_spaces_match_reference_declarations():  # envs.py:38-44,166-199
     from three_mlagents_amd.spaces import task_spaces
 
-    for name, (d, n) in {"basic": (21, 3), "gridworld": (4, 5), "ball3d": (6, 5), "push": (4, 5), "walljump": (4, 4)}.items():
+    for name, (d, n) in {"basic": (21, 3), "gridworld": (4, 5), "ball3d": (6, 5), "push": (4, 5), "walljump": (4, 4), "bicycle": (7, 3), "brickbreak": (45, 3),
+                         "glider": (16, 5)}.items():
         obs_space, act_space = task_spaces(name)
         assert obs_space.shape == (d,) and obs_space.dtype == np.float32 and act_space.n == n
         assert act_space.contains(act_space.sample()) and not act_space.contains(n)
@@ -171,7 +173,7 @@ def test_bridge_message_shapes_without_a_gpu():
     assert set(prog[0]) == {"type", "episode", "reward", "loss", "timesteps", "progress", "algorithm"}
     t = sent[-1]
     assert t["file_url"] == "/policies/gridworld_policy_x.zip" and t["session_uuid"] == "ab12cd34" and t["eval_episodes"] == 7 and out["mean_reward"] == 0.5
-    assert set(bridge.STATE_FIELDS) == {"basic", "gridworld", "push", "ball3d", "walljump"}
+    assert set(bridge.STATE_FIELDS) == {"basic", "gridworld", "push", "ball3d", "walljump", "bicycle", "brickbreak", "glider"}
 
 
 def _sb3_like_policy(D, H, A, continuous):

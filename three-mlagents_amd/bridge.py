@@ -25,6 +25,9 @@ STATE_FIELDS = {
     "push": ("agentX", "agentY", "boxX", "boxY", "goalX", "steps"),
     "ball3d": ("rotX", "rotZ", "ballX", "ballZ", "velX", "velZ", "steps", "first"),
     "walljump": ("x", "inAir", "wall", "steps"),
+    "bicycle": ("x", "z", "theta", "phi", "phiDot", "delta", "goalX", "goalZ", "distToGoal", "steps"),
+    "brickbreak": ("paddleX", "ballX", "ballY", "velX", "velY", "steps") + tuple(f"brick{k}" for k in range(40)),
+    "glider": ("posX", "posY", "posZ", "velX", "velY", "velZ", "roll", "pitch", "yaw", "rollRate", "pitchRate", "yawRate", "waypoint", "steps"),
 }
 
 

@@ -364,7 +364,8 @@ constexpr TaskMeta meta_of(const char *n) {
     return TaskMeta{n, T::OBS, T::NACT, T::ADIM, T::SDIM, T::MAXSTEPS, T::SW, T::RW, T::USES_MT};
 }
 static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_of<GridTask>("gridworld"), meta_of<BallTask>("ball3d"),
-                                              meta_of<PushTask>("push"), meta_of<CrawlerTask>("crawler"), meta_of<WallJumpTask>("walljump")};
+                                              meta_of<PushTask>("push"), meta_of<CrawlerTask>("crawler"), meta_of<WallJumpTask>("walljump"),
+                                              meta_of<BicycleTask>("bicycle"), meta_of<BrickBreakTask>("brickbreak"), meta_of<GliderTask>("glider")};
 
 }  // namespace tma
 
@@ -458,7 +459,7 @@ int tma_task_id(const char *name, int *task_out) {
         *task_out = TMA_TASK_CRAWLER;
         return TMA_OK;
     }
-    return fail(TMA_ERR_UNKNOWN_TASK, "Unknown task '%s'. Available: ball3d, basic, crawler, gridworld, push, walljump", name);
+    return fail(TMA_ERR_UNKNOWN_TASK, "Unknown task '%s'. Available: ball3d, basic, bicycle, brickbreak, crawler, glider, gridworld, push, walljump", name);
 }
 #define META_GETTER(fn, field)                                 \
     int fn(int task) {                                         \

@@ -87,6 +87,9 @@ static int dispatch_task(int task, F &&f) {
     case TMA_TASK_PUSH: return f(tma::PushTask{});
     case TMA_TASK_CRAWLER: return f(tma::CrawlerTask{});
     case TMA_TASK_WALLJUMP: return f(tma::WallJumpTask{});
+    case TMA_TASK_BICYCLE: return f(tma::BicycleTask{});
+    case TMA_TASK_BRICKBREAK: return f(tma::BrickBreakTask{});
+    case TMA_TASK_GLIDER: return f(tma::GliderTask{});
     }
     return tma::fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
 }

@@ -929,14 +929,14 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
 template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
                              uint32_t rng_step0, float gamma, hipStream_t s) {
-    if constexpr (T::OBS <= 32 && T::NACT > 0) {
+    if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
         auto k = rollout_chunk_wide_bf_kernel<T>;
         const int smem = WideLds::bytes();
         TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
-    } else if constexpr (T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && ((T::OBS + 31) / 32) % 2 == 0) {
+    } else if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && ((T::OBS + 31) / 32) % 2 == 0) {
         auto k = rollout_chunk_wide_cont_kernel<T>;
         const int smem = WideContLds<T>::bytes();
         TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1007,7 +1007,8 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
     // 256-wide bf16 policies on the Discrete tasks with observations of up to 32 floats: fused chunk with register-resident weights
     static const bool no_wide_fused = getenv("TMA_NO_WIDE_FUSED") != nullptr;  // test hook: the per-step composition
-    const bool fused_disc = !d->continuous && env->task != TMA_TASK_CRAWLER && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
+    const bool task_fused = dispatch_task(env->task, [](auto t) { return decltype(t)::FUSED_ROLLOUT ? 1 : 0; }) == 1;
+    const bool fused_disc = task_fused && !d->continuous && env->task != TMA_TASK_CRAWLER && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
     // ... and on the Crawler shape (Box actions, 172 observations): layer-1 fragments streamed per step, env state in LDS
     const bool fused_cont = d->continuous && env->task == TMA_TASK_CRAWLER && d->act_dim == tma_task_act_dim(env->task);
     const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && env->is_reset && d->obs_dim == tma_task_obs_dim(env->task) && (fused_disc || fused_cont);

@@ -142,6 +142,7 @@ __device__ __forceinline__ uint32_t interval_mask(uint32_t m) {
 struct BasicTask {
     static constexpr int ID = TMA_TASK_BASIC, OBS = 21, NACT = 3, ADIM = 1, MAXSTEPS = 50, SW = 1, RW = 0, SDIM = 2;
     static constexpr bool USES_MT = false, NATIVE_TRUNC_RULE = true;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
         int pos, steps;
     };
@@ -192,6 +193,7 @@ struct BasicTask {
 struct GridTask {
     static constexpr int ID = TMA_TASK_GRIDWORLD, OBS = 4, NACT = 5, ADIM = 1, MAXSTEPS = 100, SW = 1, RW = 1, SDIM = 8;
     static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
         int ax, ay, gx, gy, rx, ry, gt, steps;
     };
@@ -299,6 +301,7 @@ struct GridTask {
 struct PushTask {
     static constexpr int ID = TMA_TASK_PUSH, OBS = 4, NACT = 5, ADIM = 1, MAXSTEPS = 120, SW = 1, RW = 1, SDIM = 6;
     static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
         int ax, ay, bx, by, gx, steps;
     };
@@ -422,6 +425,7 @@ struct PushTask {
 struct BallTask {
     static constexpr int ID = TMA_TASK_BALL3D, OBS = 6, NACT = 5, ADIM = 1, MAXSTEPS = 200, SW = 9, RW = 6, SDIM = 8;
     static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     static constexpr double MAX_TILT = 0.4363323129985824;     // np.deg2rad(25.0)
     static constexpr double TILT_DELTA = 0.05235987755982989;  // np.deg2rad(3.0)
     struct S {
@@ -569,6 +573,7 @@ struct BallTask {
 struct WallJumpTask {
     static constexpr int ID = TMA_TASK_WALLJUMP, OBS = 4, NACT = 4, ADIM = 1, MAXSTEPS = 150, SW = 1, RW = 1, SDIM = 4;
     static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
         int x, in_air, wall, steps;
     };
@@ -634,6 +639,478 @@ struct WallJumpTask {
     __device__ static void from_flat(const double *f, S &s) { s = S{(int)f[0], (int)f[1], (int)f[2], (int)f[3]}; }
 };
 
+// ---- double <-> state / record words (SoA planes of 32-bit words) ----
+__device__ __forceinline__ double words_to_double(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+__device__ __forceinline__ void double_to_words(double d, uint32_t &lo, uint32_t &hi) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    lo = (uint32_t)b;
+    hi = (uint32_t)(b >> 32);
+}
+// legacy rk_double from its two tempered outputs, and np.random.uniform(lo, hi) on top of it (two roundings, as numpy's legacy path)
+__device__ __forceinline__ double mt_double_from(uint32_t a_hi27, uint32_t v2) { return ((double)a_hi27 * 67108864.0 + (double)(v2 >> 6)) / 9007199254740992.0; }
+__device__ __forceinline__ double uniform_from(double lo, double hi, double d) {
+    const double scale = hi - lo;
+    const double pr = scale * d;
+    return lo + pr;
+}
+// numpy / OpenBLAS summation orders of the float tasks below (probed, pinned by the fixtures; see oracle/tma_oracle.c): np.dot,
+// np.linalg.norm and `@` on 2- and 3-element float64 operands are one FMA chain from the left; the 3x3 matrix-vector product
+// starts from the middle column.
+__device__ __forceinline__ double dot2_np(double a0, double b0, double a1, double b1) { return fma(a1, b1, a0 * b0); }
+__device__ __forceinline__ double dot3_np(const double *a, const double *b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ==========================================================================================
+// Bicycle -- backend/examples/bicycle.py:14-37 (constants), :40-58 (reset), :60-125 (step), :127-141 (obs); adapter
+// backend/mlagents/envs.py:228-239 (Discrete(3), unbounded Box(7), 2000-step limit).  SURVEY.md 8f rank N3.
+// float64 physics with sin / cos / tan / pow from the device math library: parity <= 1e-5 (observed: identical to ~1e-15), the
+// oracle (libm) is bit-exact against the reference fixtures.
+// ==========================================================================================
+struct BicycleTask {
+    static constexpr int ID = TMA_TASK_BICYCLE, OBS = 7, NACT = 3, ADIM = 1, MAXSTEPS = 2000, SW = 19, RW = 8, SDIM = 10;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = false;
+    static constexpr double MAX_PHI = 0.78539816339744828, MAX_DELTA = 0.52359877559829882;  // np.pi / 4, np.pi / 6
+    struct S {
+        double x, z, theta, phi, phi_dot, delta, gx, gz, dist;
+        int steps;
+    };
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+        double *d = &s.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = words_to_double(st[(2 * k) * N + i], st[(2 * k + 1) * N + i]);
+        s.steps = (int)st[18 * N + i];
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) {
+        const double *d = &s.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint32_t lo, hi;
+            double_to_words(d[k], lo, hi);
+            st[(2 * k) * N + i] = lo;
+            st[(2 * k + 1) * N + i] = hi;
+        }
+        st[18 * N + i] = (uint32_t)s.steps;
+    }
+    // record = {phi, phi_dot, goal_x, goal_z} as doubles
+    __device__ static void make_rec(double phi, double phi_dot, double radius, double angle, uint32_t *rec) {
+        double_to_words(phi, rec[0], rec[1]);
+        double_to_words(phi_dot, rec[2], rec[3]);
+        double_to_words(radius * cos(angle), rec[4], rec[5]);
+        double_to_words(radius * sin(angle), rec[6], rec[7]);
+    }
+    __device__ static void from_rec(const uint32_t *rec, S &s) {
+        s.x = s.z = s.theta = s.delta = 0.0;
+        s.phi = words_to_double(rec[0], rec[1]);
+        s.phi_dot = words_to_double(rec[2], rec[3]);
+        s.gx = words_to_double(rec[4], rec[5]);
+        s.gz = words_to_double(rec[6], rec[7]);
+        s.dist = sqrt(dot2_np(s.gx, s.gx, s.gz, s.gz));
+        s.steps = 0;
+    }
+    __device__ static void draw(MT &mt, uint8_t *, int, uint32_t *rec) {
+        const double phi = mt.uniform(-0.1, 0.1), phi_dot = mt.uniform(-0.1, 0.1);
+        const double radius = mt.uniform(15, 25), angle = mt.uniform(-MAX_PHI, MAX_PHI);
+        make_rec(phi, phi_dot, radius, angle, rec);
+    }
+    // two resets of four uniform doubles (8 outputs each); the second one counts
+    struct Fast {
+        static constexpr int W = 16, W_SMALL = 16;
+        int k = 0;
+        uint32_t ah = 0;
+        double u[4] = {0.0, 0.0, 0.0, 0.0};
+        __device__ __forceinline__ bool done() const { return k >= 16; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (k >= 8) {
+                if ((k & 1) == 0) {
+                    ah = v >> 5;
+                } else {
+                    const double d = mt_double_from(ah, v);
+                    const int idx = (k - 8) >> 1;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (j == idx) u[j] = d;
+                }
+            }
+            k++;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const {
+            make_rec(uniform_from(-0.1, 0.1, u[0]), uniform_from(-0.1, 0.1, u[1]), uniform_from(15, 25, u[2]), uniform_from(-MAX_PHI, MAX_PHI, u[3]), rec);
+        }
+    };
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        const double g = 9.8, h = 0.8, L = 1.0, v = 5.0, dt = 0.02;
+        s.steps += 1;
+        double delta = s.delta + (a == 0 ? -0.05 : (a == 2 ? 0.05 : 0.0));
+        delta = clampd(delta, -MAX_DELTA, MAX_DELTA);
+        const double grav = (g / h) * sin(s.phi);
+        double cen = (v * v / (L * h)) * tan(delta);
+        cen = cen * cos(s.phi);
+        const double phi_ddot = grav - cen;
+        s.phi_dot = s.phi_dot + phi_ddot * dt;
+        s.phi = s.phi + s.phi_dot * dt;
+        delta = delta * 0.95;
+        s.delta = delta;
+        const double th = (v / L) * tan(delta);
+        s.theta = s.theta + th * dt;
+        const double ct = cos(s.theta), sn = sin(s.theta);
+        const double cx = v * ct;
+        s.x = s.x + cx * dt;
+        const double cz = v * sn;
+        s.z = s.z + cz * dt;
+        const double dx = s.gx - s.x, dz = s.gz - s.z;
+        const double nd = sqrt(dot2_np(dx, dx, dz, dz));
+        const double progress = (s.dist - nd) * 10.0;
+        s.dist = nd;
+        const double upright = (1.0 - sqrt(fabs(s.phi) / MAX_PHI)) * 0.2;  // reference: (...) ** 0.5 through libm pow, <= 1 ulp from sqrt
+        const double den = nd > 0 ? nd : 1.0;
+        const double heading = dot2_np(ct, dx / den, sn, dz / den) * 0.3;
+        const double steer = -(fabs(delta) / MAX_DELTA) * 0.1;
+        double rew = progress + upright;
+        rew = rew + heading;
+        rew = rew + steer;
+        bool d = false;
+        if (fabs(s.phi) > MAX_PHI) rew = -10.0, d = true;
+        if (s.steps > 2000) d = true;
+        if (nd < 2.0) rew = 50.0, d = true;
+        r = rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        const double dx = s.gx - s.x, dz = s.gz - s.z;
+        const double dist = sqrt(dot2_np(dx, dx, dz, dz));
+        double nx = 0.0, nz = 0.0;
+        if (dist > 0) nx = dx / dist, nz = dz / dist;
+        o[0] = (float)s.phi;
+        o[1] = (float)s.phi_dot;
+        o[2] = (float)s.delta;
+        o[3] = (float)cos(s.theta);
+        o[4] = (float)sin(s.theta);
+        o[5] = (float)nx;
+        o[6] = (float)nz;
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        const double *d = &s.x;
+        for (int k = 0; k < 9; k++) f[k] = d[k];
+        f[9] = s.steps;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        double *d = &s.x;
+        for (int k = 0; k < 9; k++) d[k] = f[k];
+        s.steps = (int)f[9];
+    }
+};
+
+// ==========================================================================================
+// BrickBreak -- backend/examples/brick_break.py:14-37 (constants), :39-47 (reset), :49-121 (step), :123-131 (obs); adapter
+// backend/mlagents/envs.py:214-225 (Discrete(3), unbounded Box(45), 2000-step limit).  The step is plain float64 add / multiply / compare
+// (bit-exact); the reset takes cos / sin of one uniform angle from the device math library.
+// ==========================================================================================
+struct BrickBreakTask {
+    static constexpr int ID = TMA_TASK_BRICKBREAK, OBS = 45, NACT = 3, ADIM = 1, MAXSTEPS = 2000, SW = 13, RW = 4, SDIM = 46;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = false;
+    struct S {
+        double paddle, bx, by, vx, vy;
+        uint32_t bricks_lo, bricks_hi;  // bit 8 r + c of the 40-bit brick mask (1 = present)
+        int steps;
+    };
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+        double *d = &s.paddle;
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = words_to_double(st[(2 * k) * N + i], st[(2 * k + 1) * N + i]);
+        s.bricks_lo = st[10 * N + i];
+        s.bricks_hi = st[11 * N + i];
+        s.steps = (int)st[12 * N + i];
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) {
+        const double *d = &s.paddle;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint32_t lo, hi;
+            double_to_words(d[k], lo, hi);
+            st[(2 * k) * N + i] = lo;
+            st[(2 * k + 1) * N + i] = hi;
+        }
+        st[10 * N + i] = s.bricks_lo;
+        st[11 * N + i] = s.bricks_hi;
+        st[12 * N + i] = (uint32_t)s.steps;
+    }
+    __device__ static void make_rec(double angle, uint32_t *rec) {  // record = ball velocity
+        double_to_words(cos(angle) * 1.5, rec[0], rec[1]);
+        double_to_words(sin(angle) * 1.5, rec[2], rec[3]);
+    }
+    __device__ static void from_rec(const uint32_t *rec, S &s) {
+        s.paddle = 20.0;
+        s.bx = 20.0;
+        s.by = 10.0;
+        s.vx = words_to_double(rec[0], rec[1]);
+        s.vy = words_to_double(rec[2], rec[3]);
+        s.bricks_lo = 0xFFFFFFFFu;
+        s.bricks_hi = 0xFFu;
+        s.steps = 0;
+    }
+    __device__ static void draw(MT &mt, uint8_t *, int, uint32_t *rec) { make_rec(mt.uniform(0.78539816339744828, 2.3561944901923448), rec); }
+    struct Fast {  // two resets of one uniform double; the second one counts
+        static constexpr int W = 4, W_SMALL = 4;
+        int k = 0;
+        uint32_t ah = 0;
+        double u = 0.0;
+        __device__ __forceinline__ bool done() const { return k >= 4; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (k == 2) ah = v >> 5;
+            if (k == 3) u = mt_double_from(ah, v);
+            k++;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const { make_rec(uniform_from(0.78539816339744828, 2.3561944901923448, u), rec); }
+    };
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static bool brick(const S &s, int k) { return ((k < 32 ? s.bricks_lo >> k : s.bricks_hi >> (k - 32)) & 1u) != 0; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        s.steps += 1;
+        if (a == 0) s.paddle -= 3;
+        else if (a == 2) s.paddle += 3;
+        s.paddle = clampd(s.paddle, 4.0, 36.0);
+        s.bx += s.vx;
+        s.by += s.vy;
+        double rew = 0.0;
+        if (s.bx <= 1 || s.bx >= 39) s.vx *= -1;
+        if (s.by >= 39) s.vy *= -1;
+        if (s.vy < 0 && s.by - 1 <= 2 && s.bx >= s.paddle - 4.0 && s.bx <= s.paddle + 4.0) {
+            s.vy *= -1;
+            const double offset = (s.bx - s.paddle) / 4.0;
+            s.vx += offset * 0.5;
+            rew = 0.1;
+        }
+        // first present brick in row-major order that contains the ball (the reference's nested loop with its two breaks)
+        bool hit = false;
+        for (int row = 0; row < 5 && !hit; row++) {
+            const double by0 = 20.0 + row * 2;
+            if (!(s.by >= by0 && s.by <= by0 + 2)) continue;
+            for (int c = 0; c < 8; c++) {
+                const int k = row * 8 + c;
+                const double bx0 = c * 5.0;
+                if (brick(s, k) && s.bx >= bx0 && s.bx <= bx0 + 5.0) {
+                    if (k < 32) s.bricks_lo &= ~(1u << k);
+                    else s.bricks_hi &= ~(1u << (k - 32));
+                    s.vy *= -1;
+                    rew = 1.0;
+                    hit = true;
+                    break;
+                }
+            }
+        }
+        bool d = false;
+        if (s.by < 1) rew = -1.0, d = true;
+        if (s.bricks_lo == 0u && s.bricks_hi == 0u) rew = 10.0, d = true;
+        if (s.steps > 2000) d = true;
+        r = rew;
+        done = d;
+    }
+    template <class O>
+    __device__ static void obs(const S &s, O o) {
+        o[0] = (float)(s.bx / 40.0);
+        o[1] = (float)(s.by / 40.0);
+        o[2] = (float)s.vx;
+        o[3] = (float)s.vy;
+        o[4] = (float)(s.paddle / 40.0);
+        for (int k = 0; k < 40; k++) o[5 + k] = brick(s, k) ? 1.0f : 0.0f;
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        f[0] = s.paddle, f[1] = s.bx, f[2] = s.by, f[3] = s.vx, f[4] = s.vy, f[5] = s.steps;
+        for (int k = 0; k < 40; k++) f[6 + k] = brick(s, k) ? 1.0 : 0.0;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        s.paddle = f[0], s.bx = f[1], s.by = f[2], s.vx = f[3], s.vy = f[4], s.steps = (int)f[5];
+        s.bricks_lo = s.bricks_hi = 0u;
+        for (int k = 0; k < 40; k++)
+            if (f[6 + k] != 0.0) {
+                if (k < 32) s.bricks_lo |= 1u << k;
+                else s.bricks_hi |= 1u << (k - 32);
+            }
+    }
+};
+
+// ==========================================================================================
+// Glider -- backend/examples/glider.py:14-53 (constants), :55-79 (wind), :81-88 (reset), :90-237 (step), :239-265 (obs); adapter
+// backend/mlagents/envs.py:242-253 (Discrete(5), unbounded Box(16), 4000-step limit).  float64 rigid-body step with sin / cos / atan2;
+// the reference's `x ** 2` (libm pow, within 1 ulp of x * x) is x * x here: parity <= 1e-5.
+// ==========================================================================================
+struct GliderTask {
+    static constexpr int ID = TMA_TASK_GLIDER, OBS = 16, NACT = 5, ADIM = 1, MAXSTEPS = 4000, SW = 26, RW = 7, SDIM = 14;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = false;
+    struct S {
+        double pos[3], vel[3], rot[3], av[3];
+        int wp, steps;
+    };
+    __device__ static double waypoint(int w, int k) { return k == 0 ? (w == 0 ? -160.0 : 160.0) : (k == 1 ? 0.0 : 70.0); }
+    __device__ static void unpack(const uint32_t *st, int64_t N, int64_t i, S &s) {
+        double *d = s.pos;
+#pragma unroll
+        for (int k = 0; k < 12; k++) d[k] = words_to_double(st[(2 * k) * N + i], st[(2 * k + 1) * N + i]);
+        s.wp = (int)st[24 * N + i];
+        s.steps = (int)st[25 * N + i];
+    }
+    __device__ static void pack(uint32_t *st, int64_t N, int64_t i, const S &s) {
+        const double *d = s.pos;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            uint32_t lo, hi;
+            double_to_words(d[k], lo, hi);
+            st[(2 * k) * N + i] = lo;
+            st[(2 * k + 1) * N + i] = hi;
+        }
+        st[24 * N + i] = (uint32_t)s.wp;
+        st[25 * N + i] = (uint32_t)s.steps;
+    }
+    // record = {ang_vel(3) as doubles, waypoint index}
+    __device__ static void from_rec(const uint32_t *rec, S &s) {
+        s.pos[0] = 0.0, s.pos[1] = 0.0, s.pos[2] = 60.0;
+        s.vel[0] = 15.0, s.vel[1] = 0.0, s.vel[2] = -1.0;
+        s.rot[0] = s.rot[1] = s.rot[2] = 0.0;
+        for (int k = 0; k < 3; k++) s.av[k] = words_to_double(rec[2 * k], rec[2 * k + 1]);
+        s.wp = (int)rec[6];
+        s.steps = 0;
+    }
+    __device__ static void draw(MT &mt, uint8_t *, int, uint32_t *rec) {
+        for (int k = 0; k < 3; k++) double_to_words(mt.uniform(-0.1, 0.1), rec[2 * k], rec[2 * k + 1]);
+        rec[6] = mt.interval(1u);  // np.random.randint(0, 2): one masked 32-bit draw
+    }
+    struct Fast {  // two resets of three uniform doubles + one masked draw (7 outputs each); the second one counts
+        static constexpr int W = 14, W_SMALL = 14;
+        int k = 0;
+        uint32_t ah = 0, wp = 0;
+        double u[3] = {0.0, 0.0, 0.0};
+        __device__ __forceinline__ bool done() const { return k >= 14; }
+        __device__ __forceinline__ void feed(uint32_t v) {
+            if (k >= 7) {
+                const int j = k - 7;
+                if (j == 6) {
+                    wp = v & 1u;
+                } else if ((j & 1) == 0) {
+                    ah = v >> 5;
+                } else {
+                    const double d = mt_double_from(ah, v);
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        if (q == (j >> 1)) u[q] = d;
+                }
+            }
+            k++;
+        }
+        __device__ __forceinline__ void finish(uint32_t *rec) const {
+            for (int q = 0; q < 3; q++) double_to_words(uniform_from(-0.1, 0.1, u[q]), rec[2 * q], rec[2 * q + 1]);
+            rec[6] = wp;
+        }
+    };
+    __device__ static int steps(const S &s) { return s.steps; }
+    __device__ static void step(S &s, int a, const float *, double &r, bool &done) {
+        const double dt = 0.02, two_pi = 6.283185307179586, pi = 3.141592653589793;
+        s.steps += 1;
+        double tq[3] = {0.0, 0.0, 0.0};  // roll, pitch, yaw torque
+        if (a == 1) tq[0] = -15.0, tq[2] = 4.0;
+        else if (a == 2) tq[0] = 15.0, tq[2] = -4.0;
+        else if (a == 3) tq[1] = 10.0;
+        else if (a == 4) tq[1] = -10.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double w = s.av[k] + tq[k] * dt;
+            w = w * 0.95;
+            s.av[k] = w;
+            s.rot[k] = s.rot[k] + w * dt;
+        }
+        s.rot[0] = clampd(s.rot[0], -pi / 2, pi / 2);
+        s.rot[1] = clampd(s.rot[1], -pi / 4, pi / 4);
+        const double f1 = 1.0 / 250.0, f2 = 1.0 / 400.0;
+        const double u1 = sin(s.pos[0] * f1 * 2 * pi) * cos(s.pos[1] * f1 * 2 * pi) * 8.0 * 1.0;
+        const double u2 = sin(s.pos[0] * f2 * 2 * pi / 1.5) * cos(s.pos[1] * f1 * 2 * pi / 1.5) * 8.0 * 0.7;
+        const double va[3] = {s.vel[0] - 1.0, s.vel[1] - 0.5, s.vel[2] - (u1 + u2)};
+        const double vam = sqrt(dot3_np(va, va));
+        double aoa = va[0] != 0 ? atan2(-va[2], va[0]) : 0.0;
+        double aero[3] = {0.0, 0.0, 0.0};
+        if (vam > 0.1) {
+            const double CL = two_pi * aoa;
+            const double CD = 0.02 + 0.05 * (CL * CL);
+            const double q = 0.5 * 1.225 * (vam * vam) * 0.5;
+            const double F[3] = {0 + -(q * CD), 0.0, q * CL + 0};
+            const double cr = cos(s.rot[0]), sr = sin(s.rot[0]), cp = cos(s.rot[1]), sp = sin(s.rot[1]), cy = cos(s.rot[2]), sy = sin(s.rot[2]);
+            const double Rr[3][3] = {{1, 0, 0}, {0, cr, -sr}, {0, sr, cr}};
+            const double Rp[3][3] = {{cp, 0, sp}, {0, 1, 0}, {-sp, 0, cp}};
+            const double Ry[3][3] = {{cy, -sy, 0}, {sy, cy, 0}, {0, 0, 1}};
+            double T[3][3], R[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) T[i][j] = fma(Ry[i][2], Rp[2][j], fma(Ry[i][1], Rp[1][j], Ry[i][0] * Rp[0][j]));
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) R[i][j] = fma(T[i][2], Rr[2][j], fma(T[i][1], Rr[1][j], T[i][0] * Rr[0][j]));
+#pragma unroll
+            for (int i = 0; i < 3; i++) aero[i] = fma(R[i][2], F[2], fma(R[i][0], F[0], R[i][1] * F[1]));
+        } else {
+            aoa = 0;
+        }
+        const double total[3] = {aero[0] + 0, aero[1] + 0, aero[2] + -(1.5 * 9.81)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s.vel[k] = s.vel[k] + (total[k] / 1.5) * dt;
+            s.pos[k] = s.pos[k] + s.vel[k] * dt;
+        }
+        bool d = false;
+        const double vec[3] = {waypoint(s.wp, 0) - s.pos[0], waypoint(s.wp, 1) - s.pos[1], waypoint(s.wp, 2) - s.pos[2]};
+        const double dist = sqrt(dot3_np(vec, vec));
+        if (dist < 15.0) s.wp = (s.wp + 1) % 2;
+        const double vn = sqrt(dot3_np(s.vel, s.vel));
+        double vd[3], td[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) vd[k] = s.vel[k] / (vn + 1e-8), td[k] = vec[k] / (dist + 1e-8);
+        const double H = (dot3_np(vd, td) + 1) / 2;
+        const double E = clampd(vn / 30.0, 0, 2.0);
+        double rew = E * (H - E + 1);
+        const double lateral = fabs(s.pos[1]);
+        if (lateral > 250.0) {
+            const double pr = (lateral - 250.0) / 100.0;
+            rew -= 2.0 * (pr * pr);
+        }
+        if (s.pos[2] > 250.0) {
+            const double pr = (s.pos[2] - 250.0) / 50.0;
+            rew -= 2.0 * (pr * pr);
+        } else if (s.pos[2] < 25.0) {
+            rew -= 0.5;
+        }
+        if (s.pos[2] < 5.0) rew = -50.0, d = true;
+        if (fabs(aoa) > 0.26179938779914941) rew = -50.0, d = true;  // np.deg2rad(15)
+        if (dist > 500) rew = -50.0, d = true;
+        if (s.steps > 4000) d = true;
+        r = rew;
+        done = d;
+    }
+    __device__ static void obs(const S &s, float *o) {
+        const double vec[3] = {waypoint(s.wp, 0) - s.pos[0], waypoint(s.wp, 1) - s.pos[1], waypoint(s.wp, 2) - s.pos[2]};
+        const double dist = sqrt(dot3_np(vec, vec));
+        o[0] = (float)(s.vel[2] / 10.0);
+        o[1] = (float)((s.pos[2] - 50.0) / 50.0);
+        o[2] = (float)s.rot[0];
+        o[3] = (float)s.rot[1];
+        o[4] = (float)sin(s.rot[2]);
+        o[5] = (float)cos(s.rot[2]);
+        for (int k = 0; k < 3; k++) o[6 + k] = (float)s.av[k];
+        for (int k = 0; k < 3; k++) o[9 + k] = (float)(s.vel[k] / 20.0);
+        for (int k = 0; k < 3; k++) o[12 + k] = (float)(vec[k] / (dist + 1e-8));
+        o[15] = (float)(dist / 100.0);
+    }
+    __device__ static void to_flat(const S &s, double *f) {
+        const double *d = s.pos;
+        for (int k = 0; k < 12; k++) f[k] = d[k];
+        f[12] = s.wp, f[13] = s.steps;
+    }
+    __device__ static void from_flat(const double *f, S &s) {
+        double *d = s.pos;
+        for (int k = 0; k < 12; k++) d[k] = f[k];
+        s.wp = (int)f[12], s.steps = (int)f[13];
+    }
+};
+
 // ==========================================================================================
 // Crawler-shape (BUILD-DEFINED, parity unpinned against the reference: the reference's "ant" task is
 // gym.make("Ant-v5") over MuJoCo, backend/mlagents/envs.py:274-277, backend/examples/crawler.py:31-85).
@@ -643,6 +1120,7 @@ struct CrawlerTask {
     static constexpr int NJ = 20;
     static constexpr int ID = TMA_TASK_CRAWLER, OBS = 172, NACT = 0, ADIM = NJ, MAXSTEPS = 1000, SW = 3 * NJ + 9, RW = 0, SDIM = 3 * NJ + 9;
     static constexpr bool USES_MT = false, NATIVE_TRUNC_RULE = false;
+    static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
         float q[NJ], qd[NJ], pa[NJ], root[8];
         int steps;

@@ -118,5 +118,17 @@ def make_walljump_env() -> HipSingleEnv:
     return HipSingleEnv("walljump")
 
 
+def make_brick_break_env() -> HipSingleEnv:
+    return HipSingleEnv("brickbreak")
+
+
+def make_bicycle_env() -> HipSingleEnv:
+    return HipSingleEnv("bicycle")
+
+
+def make_glider_env() -> HipSingleEnv:
+    return HipSingleEnv("glider")
+
+
 def make_ant_env() -> HipSingleEnv:
     return HipSingleEnv("crawler")

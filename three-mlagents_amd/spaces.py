@@ -93,6 +93,12 @@ def task_spaces(task_name: str):
         return Box(-1.0, 1.0, shape=(4,), dtype=np.float32), Discrete(5)
     if task_name == "walljump":  # envs.py:202-211
         return Box(-1.0, 1.0, shape=(4,), dtype=np.float32), Discrete(4)
+    if task_name == "bicycle":  # envs.py:228-239
+        return Box(-np.inf, np.inf, shape=(7,), dtype=np.float32), Discrete(3)
+    if task_name == "brickbreak":  # envs.py:214-225
+        return Box(-np.inf, np.inf, shape=(45,), dtype=np.float32), Discrete(3)
+    if task_name == "glider":  # envs.py:242-253
+        return Box(-np.inf, np.inf, shape=(16,), dtype=np.float32), Discrete(5)
     if task_name == "crawler":
         return Box(-np.inf, np.inf, shape=(172,), dtype=np.float32), Box(-1.0, 1.0, shape=(20,), dtype=np.float32)
     raise KeyError(task_name)

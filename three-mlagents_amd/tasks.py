@@ -54,6 +54,9 @@ gridworld  gridworld  foundation   100000  100  1  0.75  yes
 ball3d     ball3d     foundation   150000   30  8  150   yes
 push       push       benchmark    200000  100  1  0.65  yes
 walljump   walljump   benchmark    150000  100  1  0.7   yes
+brickbreak brickbreak benchmark    500000   50  8  -     yes
+bicycle    bicycle    benchmark    500000   50  8  -     yes
+glider     glider     frontier    1000000   50  8  -     yes
 ant        crawler    benchmark   3000000   20  8  -     no
 """
 
@@ -72,7 +75,7 @@ ENGINE_TASKS = _parse(_ROWS)
 
 _SPELLINGS = {"crawler": "ant"}
 # ids the reference's catalogue also lists; no kernels here (out of the hot-path scope)
-_REFERENCE_ONLY = frozenset("brickbreak bicycle glider labyrinth astrodynamics kraken worm foodcollector intersection minecraft simcity fish "
+_REFERENCE_ONLY = frozenset("labyrinth astrodynamics kraken worm foodcollector intersection minecraft simcity fish "
                             "self-driving-car".split())
 
 
