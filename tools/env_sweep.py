@@ -10,7 +10,9 @@ import torch
 
 from three_mlagents_amd.vec_env import HipEnvEngine
 
-B_STEP = {"basic": 110, "gridworld": 90, "ball3d": 114, "push": 74, "crawler": 80 + 2 * 69 * 4 + 688 + 6}
+B_STEP = {"basic": 110, "gridworld": 90, "ball3d": 114, "push": 74, "crawler": 80 + 2 * 69 * 4 + 688 + 6,
+          # same formula (act + 2 * state + 4 * D + 6) for the 8f tasks: state words SW of csrc/tma_tasks.h
+          "walljump": 4 + 2 * 4 + 16 + 6, "bicycle": 4 + 2 * 76 + 28 + 6, "brickbreak": 4 + 2 * 52 + 180 + 6, "glider": 4 + 2 * 104 + 64 + 6}
 
 
 def run(task, n, depth, iters, per_launch):
@@ -40,7 +42,8 @@ def run(task, n, depth, iters, per_launch):
     if per_launch == 1:  # state in and out of HBM every step: the SURVEY 8d bytes are what the launch moves
         rec.update(alg_GBps=sps * B_STEP[task] / 1e9, frac_of_8TBps=sps * B_STEP[task] / 8e12)
     else:  # the state stays in registers between the steps of a launch: only outputs (obs + reward + 2 flags) leave per step; NOT a roofline figure
-        out_bytes = {"basic": 84 + 6, "gridworld": 16 + 6, "ball3d": 24 + 6, "push": 16 + 6, "crawler": 688 + 6}[task]
+        out_bytes = {"basic": 84 + 6, "gridworld": 16 + 6, "ball3d": 24 + 6, "push": 16 + 6, "crawler": 688 + 6, "walljump": 16 + 6, "bicycle": 28 + 6,
+                     "brickbreak": 180 + 6, "glider": 64 + 6}[task]
         rec.update(output_bytes_per_env_step=out_bytes, output_GBps=sps * out_bytes / 1e9,
                    note="multi-step launch: state is register-resident, SURVEY-formula bytes do not apply; throughput figure only")
     return rec
