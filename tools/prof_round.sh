@@ -14,6 +14,9 @@ cp $(ls -t gpurun_out/${R}_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_ball3d_bf16 -- python bench.py --gpus 1 --steps 3 --warmup 1 --task ball3d --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_ball3d_bf16.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench_ball3d_bf16.log > gpurun_out/${R}_bench_ball3d_bf16_n1.json
 cp $(ls -t gpurun_out/${R}_bench_ball3d_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_ball3d_bf16_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_crawler_bf16 -- python bench.py --gpus 1 --steps 2 --warmup 1 --task crawler --n-envs 2048 --n-steps 2048 --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_crawler_bf16.log 2>&1
+grep -E "^\{" gpurun_out/${R}_bench_crawler_bf16.log > gpurun_out/${R}_bench_crawler_bf16_n1.json
+cp $(ls -t gpurun_out/${R}_bench_crawler_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_crawler_bf16_kernel_stats.csv
 # the reference's literal batch_size = 256: one persistent launch per epoch (ppo_epoch_h64p_kernel), 4096 envs x 256 steps = 4096 optimizer steps per launch
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_literal256 -- python tools/time_epoch256.py 4096 256 > gpurun_out/${R}_literal256.log 2>&1
 cp $(ls -t gpurun_out/${R}_literal256/*/*kernel_stats.csv | head -1) gpurun_out/${R}_literal256_kernel_stats.csv
@@ -94,7 +97,8 @@ PY
 python - "$R" <<'PY'
 import csv, sys
 R = sys.argv[1]
-for name in (f"gpurun_out/{R}_bench_n1_kernel_stats.csv", f"gpurun_out/{R}_bench_ball3d_bf16_kernel_stats.csv", f"gpurun_out/{R}_literal256_kernel_stats.csv"):
+for name in (f"gpurun_out/{R}_bench_n1_kernel_stats.csv", f"gpurun_out/{R}_bench_ball3d_bf16_kernel_stats.csv", f"gpurun_out/{R}_bench_crawler_bf16_kernel_stats.csv",
+             f"gpurun_out/{R}_literal256_kernel_stats.csv"):
     print(name)
     for r in list(csv.DictReader(open(name)))[:8]:
         print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
