@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 201
+#define TMA_VERSION 202
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -152,6 +152,11 @@ typedef struct {
     const float *returns;
     int T;
     int64_t N;
+    const float *packed;    /* optional, NULL = absent: [T][N][tma_ppo_packed_floats / (T*N)] sample records {obs (padded to a multiple of 4), log_prob,
+                               advantage, action bits, return} written by tma_ppo_pack_samples from the five planes above.  With it,
+                               tma_ppo_epoch_prepare reads ONE record per sample instead of the advantage plane and leaves the epoch's records
+                               in minibatch order in the workspace; the H = 64 gradient kernel then streams them (one 64-byte line per sample
+                               and net instead of five scattered ones).  Results are bit-identical with and without it. */
 } tma_rollout;
 
 typedef struct {
@@ -173,6 +178,10 @@ typedef struct {
     int normalize_advantage;
 } tma_ppo_hparams;
 
+/* Sample records for tma_rollout.packed: floats the plane needs for this policy shape and T x N samples (0: the shape has no use for it --
+ * today: hidden 64, Discrete head, <= 8 observations), and the pass that fills it (once per rollout, after the advantages and returns exist). */
+int64_t tma_ppo_packed_floats(const tma_policy_dims *d, int T, int64_t N);
+int tma_ppo_pack_samples(const tma_rollout *rb, const tma_policy_dims *d, float *packed_out, void *stream);
 /* bytes of the update workspace for a policy shape (loss-stat slots, norm partials, partial-gradient slabs, sample-offset cache;
  * bf16 layouts with 33..64 or 161..192 observations: + a dz1 cache of 2 * 262144 * hidden bf16 for the dW1 launch; f32 layouts with
  * hidden 128/192/256 and 161..176 observations: the same in f32) */

@@ -549,13 +549,16 @@ def test_global_advantage_statistics_of_a_two_rank_minibatch(D, H, A, cont):
 
 
 @pytest.mark.parametrize("task,hidden,mfma,batch", [("gridworld", 64, "f32", 256), ("gridworld", 64, "f32", 4096), ("ball3d", 256, "bf16", 2048), ("push", 64, "f32", 1024)])
-def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch):
+def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch, monkeypatch):
     """tma_ppo_train_epoch_local (one call per epoch) against the same epoch issued minibatch by minibatch through tma_ppo_epoch_prepare +
     tma_ppo_minibatch_grad + tma_ppo_adam_step_local: bit-identical parameters, derived images and optimizer state; deterministic.
     (batch 256 / 1024 / 2048 on 64-wide nets also exercise the small-minibatch gradient kernel: 4-wave blocks, one tile per wave.)"""
     from three_mlagents_amd import _lib
     from three_mlagents_amd.harness import make_vector_env
     from three_mlagents_amd.ppo import PPO
+
+    if task == "push":
+        monkeypatch.setenv("TMA_PACKED", "1")  # one case runs with the opt-in sample records (tma_rollout.packed)
 
     def build():
         env = make_vector_env(task, n_envs=64, seed=4)
@@ -570,6 +573,8 @@ def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch
     L, total = _lib.lib(), 64 * 64
     perm_seed = (b.seed * 2654435761 + 12345) & 0xFFFFFFFF
     step = 0
+    if b._packed is not None:  # the view carries sample records: fill them, as train() does once per rollout
+        _lib.check(L.tma_ppo_pack_samples(C.byref(b._rollout_view), C.byref(b.policy.dims), _lib.ptr(b._packed), b._stream()))
     for epoch in range(2):
         prepared = batch >= 256
         if prepared:
@@ -689,3 +694,59 @@ def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypat
     assert torch.allclose(m0, m1, rtol=1e-4, atol=1e-8) and torch.allclose(v0, v1, rtol=1e-4, atol=1e-10)
     for k in ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/approx_kl", "train/clip_fraction", "train/n_samples"):
         assert abs(s0[k] - s1[k]) <= 1e-6 * max(1.0, abs(s1[k])), (k, s0[k], s1[k])
+
+
+@pytest.mark.parametrize("D,A,B", [(4, 5, 512), (6, 5, 1024), (7, 3, 512), (8, 9, 768), (3, 2, 256)])
+def test_packed_sample_records_change_nothing_but_the_traffic(D, A, B, monkeypatch):
+    """tma_rollout.packed (tma_ppo_pack_samples): the epoch-prepare pass and the H = 64 gradient kernel read one record per sample instead
+    of five planes.  Same values, same summation orders: parameters, moments and statistics after three epochs must be IDENTICAL with and
+    without the records (per-minibatch launches: the persistent batch-256 kernel does not read them), ragged last minibatch included."""
+    from three_mlagents_amd import _lib
+
+    monkeypatch.setenv("TMA_NO_PERSIST", "1")
+    T, N, H = 25, 72, 64  # 1800 samples: not a multiple of any of the batch sizes
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    res = []
+    for use_packed in (False, True):
+        pol, sd = _policy(D, H, A, False)
+        obs, actions, old_lp, adv, ret = _rollout(pol, sd, D, A, False, T, N)
+        d = {k: v.to(dev).contiguous() for k, v in dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret).items()}
+        n_packed = int(L.tma_ppo_packed_floats(C.byref(pol.dims), T, N))
+        assert n_packed == T * N * (((D + 3) // 4) * 4 + 4)
+        packed = torch.full((n_packed,), float("nan"), device=dev) if use_packed else None
+        rv = _lib.Rollout(_lib.ptr(d["obs"]), _lib.ptr(d["actions"]), _lib.ptr(d["old_lp"]), _lib.ptr(d["adv"]), _lib.ptr(d["ret"]), T, N, _lib.ptr(packed))
+        if use_packed:
+            _lib.check(L.tma_ppo_pack_samples(C.byref(rv), C.byref(pol.dims), _lib.ptr(packed), _lib.stream_ptr()))
+            rec = packed.view(T * N, -1).cpu()
+            xs = rec.shape[1] - 4
+            assert torch.equal(rec[:, :D], obs.reshape(T * N, D)) and float(rec[:, D:xs].abs().sum()) == 0.0
+            assert torch.equal(rec[:, xs], old_lp.reshape(-1)) and torch.equal(rec[:, xs + 1], adv.reshape(-1)) and torch.equal(rec[:, xs + 3], ret.reshape(-1))
+            assert torch.equal(rec[:, xs + 2].view(torch.int32), actions.reshape(-1).to(torch.int32))
+        hpar = _lib.PPOHParams(HP["clip_range"], HP["ent_coef"], HP["vf_coef"], 1)
+        grad = torch.zeros(pol.n_trainable, device=dev)
+        m, v = torch.zeros(pol.n_trainable, device=dev), torch.zeros(pol.n_trainable, device=dev)
+        ws = torch.zeros(int(L.tma_ppo_workspace_bytes(C.byref(pol.dims))), dtype=torch.uint8, device=dev)
+        n_mb, step = (T * N + B - 1) // B, 1
+        for epoch in range(3):
+            _lib.check(L.tma_ppo_train_epoch_local(_lib.ptr(pol.params), C.byref(pol.dims), C.byref(rv), 91, epoch, B, C.byref(hpar), _lib.ptr(grad),
+                                                   _lib.ptr(m), _lib.ptr(v), step, 3e-4, 0.9, 0.999, 1e-5, 0.5, _lib.ptr(ws), _lib.stream_ptr()))
+            step += n_mb
+        out = (C.c_double * 8)()
+        _lib.check(L.tma_ppo_pop_stats(_lib.ptr(ws), out, _lib.stream_ptr()))
+        res.append((pol.params.clone().cpu(), m.cpu(), v.cpu(), list(out)))
+    (p0, m0, v0, s0), (p1, m1, v1, s1) = res
+    assert torch.isfinite(p0).all() and s0[5] == 3 * T * N
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1) and s0 == s1
+
+
+def test_packed_records_are_refused_for_shapes_without_them():
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    for D, H, A in ((16, 64, 5), (4, 256, 5)):  # wide observations / the column-parallel kernels gather from the planes
+        pol, _ = _policy(D, H, A, False)
+        assert L.tma_ppo_packed_floats(C.byref(pol.dims), 8, 64) == 0
+        rv = _lib.Rollout(None, None, None, None, None, 8, 64, None)
+        buf = torch.zeros(16, device="cuda")
+        assert L.tma_ppo_pack_samples(C.byref(rv), C.byref(pol.dims), _lib.ptr(buf), _lib.stream_ptr()) == _lib.TMA_ERR_INVALID

@@ -24,7 +24,8 @@ class PolicyDims(C.Structure):
 
 
 class Rollout(C.Structure):
-    _fields_ = [("obs", _vp), ("actions", _vp), ("log_probs", _vp), ("advantages", _vp), ("returns", _vp), ("T", _i32), ("N", _i64)]
+    _fields_ = [("obs", _vp), ("actions", _vp), ("log_probs", _vp), ("advantages", _vp), ("returns", _vp), ("T", _i32), ("N", _i64),
+                ("packed", _vp)]  # (optional sample records, tma_ppo_pack_samples; None = absent)
 
 
 class Minibatch(C.Structure):
@@ -77,6 +78,8 @@ SIGNATURES = {
     "tma_policy_values": (_i32, [_vp, _pd, _vp, _i64, _vp, _vp]),
     "tma_policy_bootstrap": (_i32, [_vp, _pd, _vp, _vp, _i64, _f64, _vp, _vp]),
     "tma_ppo_workspace_bytes": (_i64, [_pd]),
+    "tma_ppo_packed_floats": (_i64, [_pd, _i32, _i64]),
+    "tma_ppo_pack_samples": (_i32, [C.POINTER(Rollout), _pd, _vp, _vp]),
     "tma_ppo_minibatch_grad": (_i32, [_vp, _pd, C.POINTER(Rollout), C.POINTER(Minibatch), C.POINTER(PPOHParams), _vp, _vp, _vp]),
     "tma_debug_time_grad_kernel": (_i32, [_i32]),
     "tma_debug_poison_lds": (_i32, [_u32, _vp]),

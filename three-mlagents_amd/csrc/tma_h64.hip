@@ -352,11 +352,33 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
         const int64_t jc = j < mb.count ? j : 0;
         return mb.offs ? mb.offs[jc] : (int32_t)sample_offset(mb, mb.start + jc, rb.T, rb.N);
     };
-    int32_t nx_off = offset_of((int64_t)block_net * wpb + wave);
+    int32_t nx_off = mb.recs ? 0 : offset_of((int64_t)block_net * wpb + wave);
     int32_t pf_off = 0;
     float pf_x[KS1C], pf_m0 = 0.0f, pf_m1 = 0.0f;
     int32_t pf_act = 0;
+    // mb.recs (prepared epochs over a rollout view with packed sample records): the tile's 16 samples are 16 consecutive records of
+    // RS floats -- one contiguous block, no offsets, everything a sample needs in one 64-byte line
+    const int XS = (D + 3) & ~3, RS = XS + 4;
+    const float *const recs = mb.recs;
     auto fetch = [&](int64_t tl) {
+        if (recs) {
+            const int64_t j = (tl << 4) + r16;
+            const float *rec = recs + (j < mb.count ? j : 0) * RS;
+#pragma unroll
+            for (int ks = 0; ks < KS1C; ks++) {
+                const int c = 4 * ks + g;
+                pf_x[ks] = rec[c < XS ? c : 0];
+            }
+            if constexpr (IS_PI) {
+                const float4 q = *reinterpret_cast<const float4 *>(rec + XS);
+                pf_m0 = q.x;
+                pf_m1 = q.y;
+                pf_act = __float_as_int(q.z);
+            } else {
+                pf_m0 = rec[XS + 3];
+            }
+            return;
+        }
         pf_off = nx_off;
         nx_off = offset_of(tl + tile_stride);
         const int64_t row = pf_off;

@@ -25,6 +25,8 @@ static inline bool f32_two_pass(const PLayout &L) { return !L.bf16 && L.fr_pi >=
 static inline int64_t dz1_cache_bytes(const PLayout &L) {  // both nets; bf16 images or f32 MFMA operands
     return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : (f32_two_pass(L) ? 2 * DZ1_CAP * L.H * 4 : 0);
 }
+// floats per packed sample record {obs padded to a multiple of 4 | log_prob, advantage, action bits, return}; 0: shape without them
+static inline int rec_floats(const PLayout &L) { return (L.img_pi >= 0 && L.D <= 8) ? ((L.D + 3) & ~3) + 4 : 0; }
 static inline int slab_cap(const PLayout &L) { return (L.bf16 || L.fr_pi >= 0) ? BF_SLABS : H64_BLOCKS; }  // partial-gradient slabs in the workspace
 
 struct Minibatch {
@@ -36,6 +38,8 @@ struct Minibatch {
     int64_t stats_n;              // rows the advantage partials were summed over: count, or the global minibatch under data parallelism
     const double *adv_part;       // (sum, sum of squares) partials of this minibatch's advantages, adv_n_part pairs: kernels that fold the
     int adv_n_part;               // statistics themselves (H = 64, bf16 wide) read them; the others get (mean, std) from adv_final_kernel
+    const float *recs;            // optional: this minibatch's sample records in minibatch order (row j at recs + j * rec_floats), left by the
+                                  // epoch-prepare pass when the rollout view carries packed records
 };
 
 __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {
@@ -50,6 +54,7 @@ struct Rollout {
     const float *log_probs, *advantages, *returns;
     int T;
     int64_t N;
+    const float *packed;  // optional sample records (tma_ppo_pack_samples), rec_floats(L) floats per sample
 };
 struct HParams {
     float clip_range, ent_coef, vf_coef;
