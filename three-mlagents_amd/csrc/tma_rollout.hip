@@ -1003,7 +1003,8 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     if (N != env->v.N) return fail(TMA_ERR_INVALID, "rollout buffers are for %lld envs, the env handle has %lld", (long long)N, (long long)env->v.N);
     const PLayout L = make_layout(d->obs_dim, d->hidden, d->act_dim, d->continuous, d->mfma_dtype);
     const bool fused = L.img_pi >= 0 && env->is_reset &&
-                       (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D || env->task == TMA_TASK_WALLJUMP) &&
+                       (env->task == TMA_TASK_GRIDWORLD || env->task == TMA_TASK_PUSH || env->task == TMA_TASK_BALL3D || env->task == TMA_TASK_WALLJUMP ||
+                        env->task == TMA_TASK_BICYCLE || env->task == TMA_TASK_GLIDER) &&
                        d->obs_dim == tma_task_obs_dim(env->task) && d->act_dim == tma_task_num_actions(env->task);
     // 256-wide bf16 policies on the Discrete tasks with observations of up to 32 floats: fused chunk with register-resident weights
     static const bool no_wide_fused = getenv("TMA_NO_WIDE_FUSED") != nullptr;  // test hook: the per-step composition
@@ -1048,6 +1049,8 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
             if (env->task == TMA_TASK_GRIDWORLD) rc = launch_chunk<GridTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             else if (env->task == TMA_TASK_PUSH) rc = launch_chunk<PushTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             else if (env->task == TMA_TASK_WALLJUMP) rc = launch_chunk<WallJumpTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_BICYCLE) rc = launch_chunk<BicycleTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_GLIDER) rc = launch_chunk<GliderTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             else rc = launch_chunk<BallTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
             if (rc) return rc;
             rc = tma_env_internal_after_steps(env, n, stream);

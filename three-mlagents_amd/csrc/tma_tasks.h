@@ -667,8 +667,8 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) { retur
 // oracle (libm) is bit-exact against the reference fixtures.
 // ==========================================================================================
 struct BicycleTask {
-    static constexpr int ID = TMA_TASK_BICYCLE, OBS = 7, NACT = 3, ADIM = 1, MAXSTEPS = 2000, SW = 19, RW = 8, SDIM = 10;
-    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = false;
+    static constexpr int ID = TMA_TASK_BICYCLE, OBS = 7, NACT = 3, ADIM = 1, MAXSTEPS = 2000, SW = 20, RW = 8, SDIM = 10;  // (SW: 19 words used, sizeof(S) / 4 = 20)
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = true;
     static constexpr double MAX_PHI = 0.78539816339744828, MAX_DELTA = 0.52359877559829882;  // np.pi / 4, np.pi / 6
     struct S {
         double x, z, theta, phi, phi_dot, delta, gx, gz, dist;
@@ -937,7 +937,7 @@ struct BrickBreakTask {
 // ==========================================================================================
 struct GliderTask {
     static constexpr int ID = TMA_TASK_GLIDER, OBS = 16, NACT = 5, ADIM = 1, MAXSTEPS = 4000, SW = 26, RW = 7, SDIM = 14;
-    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = false;
+    static constexpr bool USES_MT = true, NATIVE_TRUNC_RULE = false, FUSED_ROLLOUT = true;
     struct S {
         double pos[3], vel[3], rot[3], av[3];
         int wp, steps;
