@@ -4,9 +4,10 @@
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load it.  The product path (three-mlagents_amd/) never does.
  *
- * Parity status: the env layer (Basic, GridWorld, Ball3D, Push, the Gymnasium adapter rule, the
- * DummyVecEnv/Monitor bookkeeping) is PINNED against golden vectors produced by importing the
- * reference's own files (tools/gen_golden.py -> tests/golden/*.npz).  GAE follows the published
+ * Parity status: the env layer (Basic, GridWorld, Ball3D, Push, WallJump, Bicycle, BrickBreak, Glider, the
+ * Gymnasium adapter rule, the DummyVecEnv/Monitor bookkeeping) is PINNED, bit for bit, against golden vectors
+ * produced by importing the reference's own files (tools/gen_golden.py -> tests/golden/*.npz; the three
+ * float64 tasks with numpy's libm code paths, see that script's docstring).  GAE follows the published
  * stable-baselines3 2.9.0 algorithm (third-party, not vendored in the reference; pin
  * backend/uv.lock:1686-1687): "parity unpinned" for that function.  The Crawler-shape env is
  * build-defined (the reference delegates to MuJoCo Ant-v5, backend/mlagents/envs.py:274-277):
