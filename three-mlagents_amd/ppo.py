@@ -306,7 +306,7 @@ class PPO:
             raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
         if global_stats and getattr(self, "_adv_sums", None) is None:
             self._adv_sums = torch.zeros(2 * ((total + self.batch_size - 1) // self.batch_size), dtype=torch.float64, device=self.device)
-        if self.world_size == 1:
+        if self.world_size == 1 and not os.environ.get("TMA_DP_PATH"):  # (TMA_DP_PATH=1: time the data-parallel host loop on one GPU)
             # one GPU: a whole epoch (prepare + every minibatch's gradient and optimizer step) is issued natively by ONE call -- at the
             # reference's literal batch_size = 256 that is 16 384 optimizer steps without a host-language round trip in between
             n_mb = (total + self.batch_size - 1) // self.batch_size
@@ -338,9 +338,10 @@ class PPO:
                                     count * self.world_size if global_stats else 0)
                 _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
                                                     C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
-                import torch.distributed as tdist
+                if self.world_size > 1:
+                    import torch.distributed as tdist
 
-                tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
+                    tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
                 self._adam_step += 1
                 _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                                C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
