@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
     const int my_row = g * 4 + r16;  // meaningful for owner lanes (r16 < 4)
     const int64_t i = row0 + my_row;
     const bool active = (r16 < 4) && (i < N);
-    const uint32_t gi = v.env_offset + (uint32_t)i;
     typename T::S s;
     double er = 0.0;
     uint32_t ce = 0;
@@ -367,7 +366,7 @@ template <class T>
 __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
                                                                        uint32_t rng_seed, uint32_t rng_step0, float gamma) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    constexpr int M = WideLds::M, H = WideLds::H, NTW = WideLds::NTW, KS2 = WideLds::KS2, lda = WideLds::LDA, ldx = WideLds::LDX, D = T::OBS;
+    constexpr int M = WideLds::M, NTW = WideLds::NTW, KS2 = WideLds::KS2, lda = WideLds::LDA, ldx = WideLds::LDX, D = T::OBS;
     static_assert(D <= 32 && T::NACT > 0, "fused wide rollout: observations of up to 32 floats, Discrete actions");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -659,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
                                                                          int n_steps, uint32_t rng_seed, uint32_t rng_step0, float gamma) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     using W = WideContLds<T>;
-    constexpr int M = W::M, H = W::H, NTW = W::NTW, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
+    constexpr int M = W::M, NTW = W::NTW, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
     static_assert(T::NACT == 0 && AD <= 32 && KS1 % 2 == 0 && !T::USES_MT, "fused wide rollout, Box actions: <= 32 action dims, inline resets");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
