@@ -27,9 +27,8 @@ from .evaluation import evaluate_policy
 from .ppo import PPO
 from .vec_env import HipVecEnv
 
-POLICIES_DIR = Path("policies")
-RUNS_DIR = Path("runs")
-ALGORITHMS: dict[str, type] = {"ppo": PPO}  # the one algorithm north_star puts on the GPU
+POLICIES_DIR, RUNS_DIR = (Path(name) for name in ("policies", "runs"))
+ALGORITHMS = dict(ppo=PPO)  # the one algorithm north_star puts on the GPU
 _SB3_NAMES = {"a2c", "dqn", "ppo", "sac", "td3"}  # what the reference's table accepts (training.py:31-37)
 
 # (name, type, default) -- the reference's request / result records (training.py:40-68); `device` is an engine-only extra
@@ -43,7 +42,7 @@ TrainConfig = dataclasses.make_dataclass("TrainConfig", [f if len(f) == 2 else (
 TrainResult = dataclasses.make_dataclass("TrainResult", _RESULT, frozen=True)
 
 
-def make_vector_env(task_id: str, *, n_envs: int, seed: int, monitor_dir=None, device=None, env_offset: int = 0) -> HipVecEnv:
+def make_vector_env(task_id, *, n_envs, seed, monitor_dir=None, device=None, env_offset=0):
     """Seam S2.  Env `rank` of the vector starts from seed + env_offset + rank; Monitor sums are kept by the step kernel."""
     venv = HipVecEnv(tasks.resolve(task_id).kernel, int(n_envs), seed=seed, device=device, env_offset=env_offset)
     venv.monitor_dir = monitor_dir
@@ -77,7 +76,7 @@ class _Run:
         self.id, self.root = run_id, RUNS_DIR / task.id / run_id
         self.monitor, self.eval, self.tb, self.best = (self.root / d for d in ("monitor", "eval", "tb", "best_model"))
         for d in (POLICIES_DIR, self.monitor, self.eval, self.tb):
-            d.mkdir(parents=True, exist_ok=True)
+            os.makedirs(d, exist_ok=True)
         self.zip_name = f"{task.policy_prefix}_{run_id}.zip"
         self.zip_path = POLICIES_DIR / self.zip_name
         self.metadata = self.root / "metadata.json"
@@ -110,12 +109,12 @@ def train_task(config, *, callback=None, model_kwargs=None):
         mean, std = statistics.fmean(returns), statistics.pstdev(returns)
         from . import __version__
 
-        run.metadata.write_text(json.dumps({
-            "task": task.card(), "config": dataclasses.asdict(config), "algorithm": algo, "run_id": run.id, "model_filename": run.zip_name,
-            "model_path": str(run.zip_path), "mean_reward": mean, "std_reward": std, "episode_rewards": list(map(float, returns)),
-            "episode_lengths": list(map(int, lengths)), "train_log": model.logger_values,
-            "software": {"three_mlagents_amd": __version__, "engine": "libtma_hip.so (gfx950)"}, "created_at": time.strftime("%Y-%m-%dT%H:%M:%S%z"),
-        }, indent=2, default=str), encoding="utf-8")
+        record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, run_id=run.id, model_filename=run.zip_name,
+                      model_path=str(run.zip_path), mean_reward=mean, std_reward=std, episode_rewards=[float(r) for r in returns],
+                      episode_lengths=[int(n) for n in lengths], train_log=model.logger_values,
+                      software=dict(three_mlagents_amd=__version__, engine="libtma_hip.so (gfx950)"), created_at=time.strftime("%Y-%m-%dT%H:%M:%S%z"))
+        with open(run.metadata, "w", encoding="utf-8") as fh:
+            json.dump(record, fh, indent=2, default=str)
     return TrainResult(task.id, algo, run.id, run.zip_name, str(run.zip_path), str(run.root), mean, std, episodes, budget, str(run.metadata))
 
 
@@ -145,8 +144,8 @@ def evaluate_model(task_id, name_or_path, *, episodes=None, deterministic=True, 
     n = int(episodes or task.eval_episodes)
     with contextlib.closing(make_vector_env(task.id, n_envs=1, seed=seed)) as env:
         returns, lengths = evaluate_policy(model, env, n_eval_episodes=n, deterministic=deterministic, return_episode_rewards=True)
-    return {"task_id": task.id, "model": str(path), "episodes": n, "mean_reward": statistics.fmean(returns), "std_reward": statistics.pstdev(returns),
-            "episode_rewards": list(map(float, returns)), "episode_lengths": list(map(int, lengths))}
+    return dict(task_id=task.id, model=str(path), episodes=n, mean_reward=statistics.fmean(returns), std_reward=statistics.pstdev(returns),
+                episode_rewards=[float(r) for r in returns], episode_lengths=[int(k) for k in lengths])
 
 
 def predict_action(task_id, obs, model_filename=None):
