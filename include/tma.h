@@ -153,10 +153,9 @@ typedef struct {
     int T;
     int64_t N;
     const float *packed;    /* optional, NULL = absent: [T][N][tma_ppo_packed_floats / (T*N)] sample records {obs (padded to a multiple of 4), log_prob,
-                               advantage, action bits, return} written by tma_ppo_pack_samples from the five planes above.  With it,
-                               tma_ppo_epoch_prepare reads ONE record per sample instead of the advantage plane and leaves the epoch's records
-                               in minibatch order in the workspace; the H = 64 gradient kernel then streams them (one 64-byte line per sample
-                               and net instead of five scattered ones).  Results are bit-identical with and without it. */
+                               advantage, action bits, return} written by tma_ppo_pack_samples from the five planes above.  With it the H = 64
+                               gradient kernel reads ONE record (one 64-byte line) per sample and net instead of gathering from five planes.
+                               Results are bit-identical with and without it. */
 } tma_rollout;
 
 typedef struct {

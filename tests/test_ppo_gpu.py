@@ -561,7 +561,7 @@ def test_native_epoch_loop_matches_per_minibatch_calls(task, hidden, mfma, batch
     from three_mlagents_amd.ppo import PPO
 
     if task == "push":
-        monkeypatch.setenv("TMA_PACKED", "1")  # one case runs with the opt-in sample records (tma_rollout.packed)
+        monkeypatch.setenv("TMA_NO_PACKED", "1")  # one case gathers from the planes (no sample records, tma_rollout.packed = NULL)
 
     def build():
         env = make_vector_env(task, n_envs=64, seed=4)
@@ -701,9 +701,9 @@ def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypat
 
 @pytest.mark.parametrize("D,A,B", [(4, 5, 512), (6, 5, 1024), (7, 3, 512), (8, 9, 768), (3, 2, 256)])
 def test_packed_sample_records_change_nothing_but_the_traffic(D, A, B, monkeypatch):
-    """tma_rollout.packed (tma_ppo_pack_samples): the epoch-prepare pass and the H = 64 gradient kernel read one record per sample instead
-    of five planes.  Same values, same summation orders: parameters, moments and statistics after three epochs must be IDENTICAL with and
-    without the records (per-minibatch launches: the persistent batch-256 kernel does not read them), ragged last minibatch included."""
+    """tma_rollout.packed (tma_ppo_pack_samples): the H = 64 gradient kernel reads one record per sample instead of gathering from five
+    planes.  Same values, same summation orders: parameters, moments and statistics after three epochs must be IDENTICAL with and without the
+    records (per-minibatch launches: the persistent batch-256 kernel does not read them), ragged last minibatch included."""
     from three_mlagents_amd import _lib
 
     monkeypatch.setenv("TMA_NO_PERSIST", "1")

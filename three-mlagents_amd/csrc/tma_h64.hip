@@ -352,18 +352,20 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
         const int64_t jc = j < mb.count ? j : 0;
         return mb.offs ? mb.offs[jc] : (int32_t)sample_offset(mb, mb.start + jc, rb.T, rb.N);
     };
-    int32_t nx_off = mb.recs ? 0 : offset_of((int64_t)block_net * wpb + wave);
+    int32_t nx_off = offset_of((int64_t)block_net * wpb + wave);
     int32_t pf_off = 0;
     float pf_x[KS1C], pf_m0 = 0.0f, pf_m1 = 0.0f;
     int32_t pf_act = 0;
-    // mb.recs (prepared epochs over a rollout view with packed sample records): the tile's 16 samples are 16 consecutive records of
-    // RS floats -- one contiguous block, no offsets, everything a sample needs in one 64-byte line
+    // rb.packed (tma_ppo_pack_samples): everything a sample needs sits in ONE record of RS floats {obs | log_prob, advantage, action, return} --
+    // one 64-byte line per sample and net instead of the planes' five
     const int XS = (D + 3) & ~3, RS = XS + 4;
-    const float *const recs = mb.recs;
+    const float *const packed = rb.packed;
     auto fetch = [&](int64_t tl) {
-        if (recs) {
-            const int64_t j = (tl << 4) + r16;
-            const float *rec = recs + (j < mb.count ? j : 0) * RS;
+        pf_off = nx_off;
+        nx_off = offset_of(tl + tile_stride);
+        const int64_t row = pf_off;
+        if (packed) {
+            const float *rec = packed + row * RS;
 #pragma unroll
             for (int ks = 0; ks < KS1C; ks++) {
                 const int c = 4 * ks + g;
@@ -379,9 +381,6 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
             }
             return;
         }
-        pf_off = nx_off;
-        nx_off = offset_of(tl + tile_stride);
-        const int64_t row = pf_off;
 #pragma unroll
         for (int ks = 0; ks < KS1C; ks++) {
             const int c = 4 * ks + g;

@@ -246,11 +246,8 @@ __global__ __launch_bounds__(256) void policy_fwd_kernel(const float *__restrict
 constexpr int ADV_BLOCKS = 128;
 // gridDim.y > 1 (tma_ppo_epoch_prepare): blockIdx.y = minibatch k of an epoch split into chunks of `batch` rows; partials and
 // offsets of minibatch k land at partials + 2 * k * gridDim.x and offs_out + k * batch.
-// packed != nullptr (rollout view with sample records, rs floats each): the advantage comes out of the sample's record -- the same value, one
-// 64-byte line that also holds everything else the gradient kernels need -- and the record is copied to recs_out in minibatch order.
 __global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restrict__ adv, Minibatch mb, int T, int64_t N, double *partials,
-                                                          int32_t *__restrict__ offs_out, int64_t batch = 0, const float *__restrict__ packed = nullptr,
-                                                          int rs = 0, float *__restrict__ recs_out = nullptr) {
+                                                          int32_t *__restrict__ offs_out, int64_t batch = 0) {
     __shared__ double s1[4], s2[4];
     if (gridDim.y > 1 || batch > 0) {
         const int64_t k = blockIdx.y, s0 = k * batch;
@@ -258,7 +255,6 @@ __global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restric
         mb.start += s0, mb.count = cnt;
         partials += 2 * k * gridDim.x;
         if (offs_out) offs_out += s0;
-        if (recs_out) recs_out += s0 * rs;
     }
     int nb = (int)((mb.count + 1023) / 1024);  // partial blocks this minibatch uses: the same split as a stand-alone launch
     if (nb > (int)gridDim.x) nb = gridDim.x;
@@ -269,18 +265,7 @@ __global__ __launch_bounds__(256) void adv_partial_kernel(const float *__restric
     for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
         const int64_t off = sample_offset(mb, mb.start + j, T, N);
         if (offs_out) offs_out[j] = (int32_t)off;
-        double x;
-        if (packed) {
-            const float4 *src = reinterpret_cast<const float4 *>(packed + off * rs);
-            float4 *dst = reinterpret_cast<float4 *>(recs_out + j * rs);
-            float4 q[3];
-            const int nq = rs >> 2;  // 2 or 3 chunks of 16 bytes
-            for (int c = 0; c < nq; c++) q[c] = src[c];
-            for (int c = 0; c < nq; c++) dst[c] = q[c];
-            x = (double)q[nq - 1].y;
-        } else {
-            x = (double)adv[off];
-        }
+        const double x = (double)adv[off];
         a += x;
         b += x * x;
     }
@@ -2026,15 +2011,10 @@ int tma_launch_slab_zero_w1(float *slabs, int n_slabs, const PLayout &L, hipStre
 
 extern "C" {
 
-// byte offset of the epoch's permuted sample records (behind everything else; present when rec_floats(L) > 0)
-static inline int64_t recs_base(const PLayout &L) {
-    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L);
-}
-
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return recs_base(L) + OFFS_CAP * (int64_t)rec_floats(L) * 4;
+    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L);
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -2124,8 +2104,8 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         return fail(TMA_ERR_INVALID, "minibatch [%lld, +%lld) outside the %lld-sample rollout", (long long)mbi->start, (long long)mbi->count, (long long)total);
     hipStream_t s = (hipStream_t)stream;
     const PLayout L = layout_of(d);
-    Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N, rb->packed};
-    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr, mbi->count, nullptr, 0, nullptr};
+    Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N, rec_floats(L) > 0 ? rb->packed : nullptr};
+    Minibatch M{mbi->indices, mbi->perm_seed, mbi->perm_epoch, mbi->start, mbi->count, total, nullptr, mbi->count, nullptr, 0};
     const bool prepared = mbi->prepared_batch > 0;
     if (mbi->stats_count != 0) {
         if (!prepared || mbi->stats_count < mbi->count)
@@ -2152,7 +2132,6 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
         adv_part = reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4) + 2 * (mbi->start / mbi->prepared_batch) * stride;
         M.offs = reinterpret_cast<int32_t *>(ws + offs_base) + mbi->start;
-        if (rb->packed && rec_floats(L) > 0) M.recs = reinterpret_cast<const float *>(ws + recs_base(L)) + mbi->start * rec_floats(L);
     }
     // offsets cache: written by the advantage pass, read by every gradient kernel (saves the permutation arithmetic per sample)
     int32_t *offs = (!prepared && mbi->count <= OFFS_CAP && (hpar.normalize_advantage || L.bf16)) ? reinterpret_cast<int32_t *>(ws + offs_base) : nullptr;
@@ -2355,11 +2334,9 @@ int tma_ppo_epoch_prepare(const tma_rollout *rb, const tma_minibatch *epoch, int
     if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
     const int64_t n_mb = ceil_div(total, batch_size);
     if (n_mb > 65535) return fail(TMA_ERR_INVALID, "too many minibatches per epoch (%lld)", (long long)n_mb);
-    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr, total, nullptr, 0, nullptr};
-    const int rs = rb->packed ? rec_floats(L) : 0;
+    Minibatch M{epoch->indices, epoch->perm_seed, epoch->perm_epoch, 0, total, total, nullptr, total, nullptr, 0};
     adv_partial_kernel<<<dim3(stride, (unsigned)n_mb), dim3(256), 0, (hipStream_t)stream>>>(
-        rb->advantages, M, rb->T, rb->N, reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4), reinterpret_cast<int32_t *>(ws + offs_base), batch_size,
-        rs ? rb->packed : nullptr, rs, rs ? reinterpret_cast<float *>(ws + recs_base(L)) : nullptr);
+        rb->advantages, M, rb->T, rb->N, reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4), reinterpret_cast<int32_t *>(ws + offs_base), batch_size);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }

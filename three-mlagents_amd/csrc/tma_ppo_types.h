@@ -38,8 +38,6 @@ struct Minibatch {
     int64_t stats_n;              // rows the advantage partials were summed over: count, or the global minibatch under data parallelism
     const double *adv_part;       // (sum, sum of squares) partials of this minibatch's advantages, adv_n_part pairs: kernels that fold the
     int adv_n_part;               // statistics themselves (H = 64, bf16 wide) read them; the others get (mean, std) from adv_final_kernel
-    const float *recs;            // optional: this minibatch's sample records in minibatch order (row j at recs + j * rec_floats), left by the
-                                  // epoch-prepare pass when the rollout view carries packed records
 };
 
 __device__ __forceinline__ int64_t sample_offset(const Minibatch &mb, int64_t j, int T, int64_t N) {

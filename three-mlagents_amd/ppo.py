@@ -238,9 +238,8 @@ class PPO:
                                        _lib.ptr(b["log_probs"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]), _lib.ptr(b["terminal_obs"]),
                                        _lib.ptr(b["last_values"]), N, self._tobs_slots)
         # sample records for the update (include/tma.h tma_rollout.packed): filled once per rollout at the top of train()
-        # opt-in (TMA_PACKED=1): measured on MI355X the records cut the gradient kernel's gather traffic but the extra passes cost more than
-        # they save -- the kernel never waits for its gathers
-        use_records = T * N <= (1 << 22) and self.batch_size >= 256 and bool(os.environ.get("TMA_PACKED"))
+        # on by default where the shape has them (TMA_NO_PACKED=1: gather from the planes, the A/B switch of DESIGN.md section 10-3)
+        use_records = not os.environ.get("TMA_NO_PACKED")
         n_packed = _lib.lib().tma_ppo_packed_floats(C.byref(self.policy.dims), T, N) if use_records else 0
         self._packed = torch.empty(n_packed, dtype=torch.float32, device=dev) if n_packed > 0 else None
         self._rollout_view = _lib.Rollout(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["log_probs"]), _lib.ptr(b["advantages"]),
@@ -297,7 +296,7 @@ class PPO:
         scale = 1.0 / self.world_size
         perm_seed = (self.seed * 2654435761 + 12345) & 0xFFFFFFFF
         can_prepare = total <= (1 << 22) and self.batch_size >= 256  # limits of tma_ppo_epoch_prepare (include/tma.h)
-        if getattr(self, "_packed", None) is not None:  # one streaming pass: the epochs' prepare passes and gradient kernels read records
+        if getattr(self, "_packed", None) is not None:  # one streaming pass per rollout: the gradient kernels then read one record per sample
             _lib.check(L.tma_ppo_pack_samples(C.byref(self._rollout_view), C.byref(self.policy.dims), _lib.ptr(self._packed), self._stream()))
         # data parallel: every rank normalises a minibatch's advantages with the mean / std of the GLOBAL minibatch (the rows of all
         # ranks), as one SB3 run over the concatenated batch would -- one all-reduce of 16 B per minibatch, once per epoch
