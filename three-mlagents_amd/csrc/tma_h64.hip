@@ -485,14 +485,17 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
                                                               const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
                                                               double *__restrict__ stat_slots) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    // policy blocks first, value blocks behind them: with 128 pairs the two blocks of pair p (same tiles, same sample records) are workgroups p and
+    // 128 + p -- dispatched round-robin over the 8 XCDs they land on the SAME XCD, so the second reader of a record finds its line in that L2
+    const int n_pairs = gridDim.x >> 1, pair = (int)blockIdx.x % n_pairs;
+    const bool pi_block = (int)blockIdx.x < n_pairs;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
     if constexpr (VER == 1) {
-        if ((blockIdx.x & 1) == 0) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+        if (pi_block) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
         else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
     } else {
-        if ((blockIdx.x & 1) == 0) grad_h64t_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+        if (pi_block) grad_h64t_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
         else grad_h64t_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
     }
 }
