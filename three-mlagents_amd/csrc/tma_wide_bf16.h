@@ -26,6 +26,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// Two elements per VALU instruction where the operation allows it (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 run at twice the scalar rate):
+// the epilogues of this kernel are instruction-issue-bound.  Component for component the same IEEE operations as
+// tma_tanh and as dz = dh * (1 - h * h), hence the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 tma_tanh2(f32x2 x) {
+    const f32x2 t = x * 2.8853900817779268f;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(t[0]);
+    e[1] = __builtin_amdgcn_exp2f(t[1]);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
+}
+__device__ __forceinline__ f32x2 delta2(f32x2 dh, f32x2 h) {
+    const f32x2 hh = h * h;
+    const f32x2 om = 1.0f - hh;
+    return dh * om;
+}
 
 // B fragment `idx` of a fragment-major image.  The load is made through an explicit global (address space 1) pointer: a
 // pointer that went through the LICM-defeating asm in the gradient kernel is "generic" to the compiler, and a flat_load
@@ -175,9 +195,13 @@ __device__ __forceinline__ void bf_hidden_layer(const bf16_t *Ain, int ldin, int
         for (int mt = 0; mt < MT; mt++) {
             bf16x4 q;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
-                Aout[(16 * mt + 4 * g + r) * ldo + n] = q[r];
+            for (int r0 = 0; r0 < 4; r0 += 2) {
+                const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
+                q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
+#pragma unroll
+                for (int r = r0; r < r0 + 2; r++) {
+                    Aout[(16 * mt + 4 * g + r) * ldo + n] = q[r];
+                }
             }
             if constexpr (STORE_T) *t_quad<MT>(Tout, n, mt, g) = q;
         }
@@ -605,9 +629,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int mt = 0; mt < MT; mt++) {
                     bf16x4 q;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
-                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    for (int r0 = 0; r0 < 4; r0 += 2) {
+                        const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
+                        q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
+#pragma unroll
+                        for (int r = r0; r < r0 + 2; r++) {
+                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        }
                     }
                     *t_quad<MT>(T1, n, mt, g) = q;
                 }
@@ -696,9 +724,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         for (int mt = 0; mt < MT; mt++) {
                             bf16x4 q;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                q[r] = (bf16_t)tma_tanh(acc[jj][mt][r]);
-                                if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                            for (int r0 = 0; r0 < 4; r0 += 2) {
+                                const f32x2 th = tma_tanh2(f32x2{acc[jj][mt][r0], acc[jj][mt][r0 + 1]});
+                                q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
+#pragma unroll
+                                for (int r = r0; r < r0 + 2; r++) {
+                                    if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                                }
                             }
                             *t_quad<MT>(T2, n, mt, g) = q;
                         }
@@ -748,9 +780,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int mt = 0; mt < MT; mt++) {
                     bf16x4 q;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        q[r] = (bf16_t)tma_tanh(acc[j][mt][r]);
-                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    for (int r0 = 0; r0 < 4; r0 += 2) {
+                        const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
+                        q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
+#pragma unroll
+                        for (int r = r0; r < r0 + 2; r++) {
+                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        }
                     }
                     *t_quad<MT>(T2, n, mt, g) = q;
                 }
@@ -943,11 +979,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const bf16x4 h4 = *tq;
                     bf16x4 q;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float h = (float)h4[r];
-                        const float dz = dh[r] * (1.0f - h * h);
-                        q[r] = (bf16_t)dz;
-                        if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                    for (int r0 = 0; r0 < 4; r0 += 2) {
+                        const f32x2 dz = delta2(f32x2{dh[r0], dh[r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                        q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
+#pragma unroll
+                        for (int r = r0; r < r0 + 2; r++) {
+                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                        }
                     }
                     *tq = q;
                 }
@@ -1047,10 +1085,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             const bf16x4 h4 = *tq;
                             bf16x4 q;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const float h = (float)h4[r];
-                                const float dz = dh[jj][mt][r] * (1.0f - h * h);
-                                q[r] = (bf16_t)dz;
+                            for (int r0 = 0; r0 < 4; r0 += 2) {
+                                const f32x2 dz = delta2(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                                q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                             }
                             *tq = q;
                         }
@@ -1102,10 +1139,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const bf16x4 h4 = *tq;
                 bf16x4 q;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float h = (float)h4[r];
-                    const float dz = dh1[j][mt][r] * (1.0f - h * h);
-                    q[r] = (bf16_t)dz;
+                for (int r0 = 0; r0 < 4; r0 += 2) {
+                    const f32x2 dz = delta2(f32x2{dh1[j][mt][r0], dh1[j][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                    q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                 }
                 *tq = q;
             }
