@@ -22,7 +22,8 @@ def golden():
 
     def load(name):
         if name not in cache:
-            cache[name] = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+            with np.load(os.path.join(GOLDEN, f"{name}.npz")) as z:  # a dict of arrays: an NpzFile decompresses a member on EVERY access
+                cache[name] = {k: z[k] for k in z.files}
         return cache[name]
 
     return load

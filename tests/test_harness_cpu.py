@@ -75,6 +75,12 @@ def test_records_and_train_errors():  # training.py:40-68,105-114
         harness.train_task(harness.TrainConfig("basic", algorithm="dqn"))  # known to SB3, not on the engine
     with pytest.raises(KeyError):
         harness.train_task(harness.TrainConfig("nope"))
+    # the reference's catalogue default for basic / gridworld / push / walljump is DQN (registry.py:59,91,107,123): the engine's PPO stands in,
+    # and the harness reports which algorithm it replaced (written to metadata.json as `substituted_for`)
+    assert harness._algorithm_for(None, tasks.resolve("gridworld")) == ("ppo", "dqn")
+    assert harness._algorithm_for(None, tasks.resolve("ball3d")) == ("ppo", None)
+    assert harness._algorithm_for("PPO", tasks.resolve("push")) == ("ppo", None)
+    assert {t.id for t in tasks.ENGINE_TASKS.values() if t.default_algorithm == "dqn"} == {"basic", "gridworld", "push", "walljump"}
 
 
 def test_runner_grammar():  # cli.py:14-41
@@ -174,6 +180,50 @@ def test_bridge_message_shapes_without_a_gpu():
     t = sent[-1]
     assert t["file_url"] == "/policies/gridworld_policy_x.zip" and t["session_uuid"] == "ab12cd34" and t["eval_episodes"] == 7 and out["mean_reward"] == 0.5
     assert set(bridge.STATE_FIELDS) == {"basic", "gridworld", "push", "ball3d", "walljump", "bicycle", "brickbreak", "glider"}
+
+
+def test_bridge_connected_predicate_is_exact():
+    """run_for_websocket stops on `application_state != CONNECTED` as the reference does (websocket_training.py:159): the state named
+    DISCONNECTED -- which also ENDS in "CONNECTED" -- is a closed socket."""
+    import enum
+
+    from three_mlagents_amd import bridge
+
+    class WebSocketState(enum.Enum):  # starlette's shape
+        CONNECTING = 0
+        CONNECTED = 1
+        DISCONNECTED = 2
+        RESPONSE = 3
+
+    class Sock:
+        application_state = WebSocketState.CONNECTED
+
+    s = Sock()
+    assert bridge._connected(s)
+    for st in (WebSocketState.DISCONNECTED, WebSocketState.CONNECTING, WebSocketState.RESPONSE):
+        s.application_state = st
+        assert not bridge._connected(s), st
+    s.application_state = "WebSocketState.CONNECTED"
+    assert bridge._connected(s)
+    s.application_state = "WebSocketState.DISCONNECTED"
+    assert not bridge._connected(s)
+
+    class Plain:  # no state attribute at all: only max_steps bounds the loop
+        pass
+
+    assert bridge._connected(Plain())
+
+    class Closable:
+        def __init__(self):
+            self.flag = False
+
+        def closed(self):
+            return self.flag
+
+    c = Closable()
+    assert bridge._connected(c)
+    c.flag = True
+    assert not bridge._connected(c)
 
 
 def _sb3_like_policy(D, H, A, continuous):

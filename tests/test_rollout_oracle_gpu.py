@@ -1,0 +1,127 @@
+"""The kernels bench.py times, checked directly against the CPU oracle at BASELINE.json's config sizes.
+
+`tma_rollout_collect` runs the fused rollout chunks (`rollout_chunk2_h64_kernel`, `rollout_chunk_wide_bf_kernel`,
+`rollout_chunk_wide_cont_kernel`, the per-step composition for the f32 256-wide nets); their env step is inlined in those kernels.
+Here the actions a fused rollout RECORDED are replayed through `orc.OracleVecEnv` (the C restatement of
+backend/examples/{gridworld.py:67-95, ball3d.py:74-113, push.py:62-125}, backend/mlagents/envs.py:60-84,125-152 with DummyVecEnv /
+Monitor semantics, pinned bit-exact to the reference fixtures by tests/test_oracle_golden.py) with the same seed and env offset, and
+every buffer the rollout wrote is compared with what the oracle produces: observations of every slot, rewards before the timeout
+bootstrap (and the bootstrap re-applied from the oracle's terminal observations), terminated / truncated flags, the Monitor
+(return, length) of every finished episode in per-env order, and the final episode index of every env.
+
+Integer tasks (GridWorld, Push, Basic): bit-exact.  Ball3D: <= 1e-5 (north_star) with a bounded count of elements that are not
+bit-identical (device sin(double) vs glibc).  Crawler: against the build's own C port -- parity UNPINNED (MuJoCo Ant-v5 is not
+importable) -- same tolerance.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: float tasks within 1e-5
+
+# (task, n_envs, n_steps, hidden, mfma_dtype, env_offset): BASELINE.json configs[1], [2], [3] (one GPU's shard), [0], [4] (shard, shortened)
+CASES = [
+    pytest.param("gridworld", 4096, 1024, 64, "f32", 0, id="gridworld-4096x1024-h64-f32"),
+    pytest.param("ball3d", 4096, 1024, 256, "bf16", 0, id="ball3d-4096x1024-h256-bf16"),
+    pytest.param("push", 2048, 2048, 256, "bf16", 2048, id="push-2048x2048-h256-bf16-shard1"),
+    pytest.param("basic", 8, 1024, 256, "f32", 0, id="basic-8x1024-h256-f32"),
+    pytest.param("crawler", 2048, 256, 256, "bf16", 4096, id="crawler-2048x256-h256-bf16-shard2-unpinned"),
+    # the other fused H = 64 instantiations at the headline size
+    pytest.param("push", 4096, 512, 64, "f32", 0, id="push-4096x512-h64-f32"),
+    pytest.param("ball3d", 4096, 512, 64, "f32", 0, id="ball3d-4096x512-h64-f32"),
+]
+
+
+def _replay(task, N, T, hidden, mfma, env_offset, seed=1):
+    from three_mlagents_amd import _lib
+    from three_mlagents_amd.ppo import PPO
+    from three_mlagents_amd.vec_env import HipVecEnv
+
+    exact = task in ("gridworld", "push", "basic")
+    env = HipVecEnv(task, N, seed=seed, env_offset=env_offset)  # default ring depth: the configuration bench.py runs
+    eng = env.engine
+    eng.episode_log(1 << 21)
+    model = PPO("MlpPolicy", env, n_steps=T, batch_size=max(256, N * T // 32), n_epochs=1, seed=seed,
+                policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
+    assert model.collect_rollouts()
+    b = {k: v.cpu().numpy() for k, v in model.buf.items() if k in ("obs", "actions", "rewards", "values", "terminated", "truncated")}
+    log_r, log_l, log_e, seen = eng.pop_episode_log()
+    assert seen == len(log_r)  # the log did not overflow
+    ep_index = eng.episode_index().cpu().numpy().astype(np.uint32)
+
+    ref = orc.OracleVecEnv(task, N, seed=seed, env_offset=env_offset, threads=8)
+    inexact, compared = 0, 0
+
+    def cmp(name, got, want, t):
+        nonlocal inexact, compared
+        if exact:
+            assert np.array_equal(got, want), (task, name, t)
+        else:
+            assert np.allclose(got, want, rtol=0, atol=TOL), (task, name, t, float(np.abs(got - want).max()))
+            inexact += int((got != want).sum())
+        compared += got.size
+
+    cmp("reset_obs", b["obs"][0], ref.reset(), 0)
+    trunc_rows = []  # (t, env) of every timeout, with the oracle's terminal observation and pre-bootstrap reward
+    ep_events = []   # (env, return, length) of every finished episode, in (t, env) order
+    for t in range(T):
+        r = ref.step(b["actions"][t])
+        assert np.array_equal(b["terminated"][t], r["term"]) and np.array_equal(b["truncated"][t], r["trunc"]), (task, t)
+        cmp("obs", b["obs"][t + 1], r["obs"], t)
+        keep = r["trunc"] == 0
+        cmp("rewards (no timeout)", b["rewards"][t][keep], r["rew32"][keep], t)
+        idx = np.nonzero(r["trunc"])[0]
+        if idx.size:
+            trunc_rows.append((np.full(idx.size, t), idx, r["term_obs"][idx].copy(), r["rew32"][idx].copy()))
+        done = np.nonzero(r["term"] | r["trunc"])[0]
+        if done.size:
+            ep_events.append((done, r["ep_ret"][done].copy(), r["ep_len"][done].copy()))
+    assert np.array_equal(ep_index, ref.episode_index()), task
+
+    # timeout bootstrap (SB3 collect_rollouts: rewards[i] += gamma * V(terminal_obs_i)): the library's bootstrap entry point applied to the
+    # ORACLE's rewards and terminal observations of every timed-out (t, env) must give the rewards the fused rollout stored
+    n_trunc = sum(len(x[0]) for x in trunc_rows)
+    if n_trunc:
+        tt = np.concatenate([x[0] for x in trunc_rows])
+        ii = np.concatenate([x[1] for x in trunc_rows])
+        tobs = torch.from_numpy(np.concatenate([x[2] for x in trunc_rows])).cuda().contiguous()
+        rew = torch.from_numpy(np.concatenate([x[3] for x in trunc_rows])).cuda().contiguous()
+        flags = torch.ones(n_trunc, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().tma_policy_bootstrap(_lib.ptr(model.policy.params), C.byref(model.policy.dims), _lib.ptr(tobs), _lib.ptr(flags), n_trunc,
+                                                   model.gamma, _lib.ptr(rew), _lib.stream_ptr()))
+        cmp("rewards (timeout bootstrap)", b["rewards"][tt, ii], rew.cpu().numpy(), "all")
+
+    # Monitor rows: the device episode log holds (return, length, env) of every finished episode; per env they must be the oracle's, in order
+    n_events = sum(len(x[0]) for x in ep_events)
+    assert len(log_r) == n_events, (len(log_r), n_events)
+    if n_events:
+        oe = np.concatenate([x[0] for x in ep_events])
+        orr = np.concatenate([x[1] for x in ep_events]).astype(np.float32)
+        ol = np.concatenate([x[2] for x in ep_events])
+        o_order = np.argsort(oe, kind="stable")
+        g_order = np.argsort(log_e, kind="stable")
+        assert np.array_equal(log_e[g_order], oe[o_order]) and np.array_equal(log_l[g_order], ol[o_order]), task
+        cmp("episode returns", log_r[g_order], orr[o_order], "all")
+    env.close()
+    return dict(inexact=inexact, compared=compared, timeouts=n_trunc, episodes=n_events)
+
+
+@pytest.mark.parametrize("task,N,T,hidden,mfma,env_offset", CASES)
+def test_fused_rollout_replayed_through_the_oracle(task, N, T, hidden, mfma, env_offset):
+    st = _replay(task, N, T, hidden, mfma, env_offset)
+    print(f"[{task} {N}x{T} H={hidden} {mfma}] compared {st['compared']} elements, not bit-identical {st['inexact']}, "
+          f"timeouts {st['timeouts']}, episodes {st['episodes']}")
+    assert st["episodes"] > 0
+    if task in ("gridworld", "ball3d", "basic", "push"):
+        assert st["timeouts"] > 0  # the bootstrap branch was exercised
+    if task in ("gridworld", "push", "basic"):
+        assert st["inexact"] == 0
+    else:
+        # bounded so that "a visible fraction of the elements differs in the last bit" cannot pass: 0.1 % of the compared elements
+        assert st["inexact"] <= 64 + st["compared"] // 1000, st

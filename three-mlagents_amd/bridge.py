@@ -5,7 +5,7 @@ The reference streams three kinds of JSON messages over an accepted FastAPI WebS
 with the artefact names when it returns (lines 98-112), and `run_step` frames (an optional `state` from `env.get_state_for_viz()`)
 while a saved policy drives one visualisation env (lines 141-185).  This module emits the same message shapes from the engine's
 callback protocol and device envs.  It never imports a web framework: `websocket` is any object with an awaitable `send_json(dict)`;
-a `closed()` predicate (or an `application_state` whose name ends in CONNECTED, as starlette's has) stops the run loop.
+a `closed()` predicate (or an `application_state` whose name is not exactly CONNECTED, as starlette's has) stops the run loop.
 """
 from __future__ import annotations
 
@@ -101,7 +101,11 @@ def _connected(websocket) -> bool:
     if callable(closed):
         return not closed()
     state = getattr(websocket, "application_state", None)
-    return state is None or str(getattr(state, "name", state)).endswith("CONNECTED")
+    if state is None:
+        return True
+    # the reference loops on `application_state == WebSocketState.CONNECTED` (websocket_training.py:159): an exact comparison --
+    # "DISCONNECTED" also ENDS in "CONNECTED"
+    return str(getattr(state, "name", state)).rsplit(".", 1)[-1] == "CONNECTED"
 
 
 async def run_for_websocket(websocket, task_id: str, *, model_filename=None, seed: int = 10_001, sleep_seconds: float = 0.03, max_steps=None,

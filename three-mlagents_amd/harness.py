@@ -57,11 +57,13 @@ def ppo_defaults(task: tasks.EngineTask) -> dict[str, Any]:
                 ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs={"net_arch": {"pi": width, "vf": list(width)}, **extra})
 
 
-def _algorithm_for(requested: str | None) -> tuple[str, str | None]:
+def _algorithm_for(requested: str | None, task: tasks.EngineTask | None = None) -> tuple[str, str | None]:
     """-> (engine algorithm, name it stands in for).  An explicit non-PPO request is an error; a task whose catalogue default is
-    another SB3 algorithm (the reference defaults most tasks to DQN) runs the engine's PPO and the substitution is recorded."""
+    another SB3 algorithm (the reference defaults basic / gridworld / push / walljump to DQN with one env) runs the engine's PPO and
+    the substitution is returned -- train_task writes it into metadata.json (`substituted_for`) and warns when verbose."""
     if requested is None:
-        return "ppo", None
+        default = getattr(task, "default_algorithm", "ppo")
+        return "ppo", (default if default != "ppo" else None)
     want = requested.lower()
     if want in ALGORITHMS:
         return want, None
@@ -84,7 +86,12 @@ class _Run:
 
 def train_task(config, *, callback=None, model_kwargs=None):
     task = tasks.resolve(config.task_id)
-    algo, _ = _algorithm_for(config.algorithm)
+    algo, stands_in_for = _algorithm_for(config.algorithm, task)
+    if stands_in_for and config.verbose:
+        import warnings
+
+        warnings.warn(f"task '{task.id}': the reference's default algorithm is {stands_in_for.upper()}; this engine trains PPO instead "
+                      f"(recorded as substituted_for in metadata.json)", stacklevel=2)
     budget = int(config.total_timesteps or task.total_timesteps)
     n_envs = int(config.n_envs or task.n_envs)
     episodes = int(config.eval_episodes or task.eval_episodes)
@@ -109,7 +116,7 @@ def train_task(config, *, callback=None, model_kwargs=None):
         mean, std = statistics.fmean(returns), statistics.pstdev(returns)
         from . import __version__
 
-        record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, run_id=run.id, model_filename=run.zip_name,
+        record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, substituted_for=stands_in_for, run_id=run.id, model_filename=run.zip_name,
                       model_path=str(run.zip_path), mean_reward=mean, std_reward=std, episode_rewards=[float(r) for r in returns],
                       episode_lengths=[int(n) for n in lengths], train_log=model.logger_values,
                       software=dict(three_mlagents_amd=__version__, engine="libtma_hip.so (gfx950)"), created_at=time.strftime("%Y-%m-%dT%H:%M:%S%z"))

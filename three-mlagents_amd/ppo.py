@@ -237,7 +237,7 @@ class PPO:
         self._rb = _lib.RolloutBuffers(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["rewards"]), _lib.ptr(b["values"]),
                                        _lib.ptr(b["log_probs"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]), _lib.ptr(b["terminal_obs"]),
                                        _lib.ptr(b["last_values"]), N, self._tobs_slots)
-        # sample records for the update (include/tma.h tma_rollout.packed): filled once per rollout at the top of train()
+        # sample records for the update (include/tma.h tma_rollout.packed): filled once per rollout at the end of collect_rollouts()
         # on by default where the shape has them (TMA_NO_PACKED=1: gather from the planes, the A/B switch of DESIGN.md section 10-3)
         use_records = not os.environ.get("TMA_NO_PACKED")
         n_packed = _lib.lib().tma_ppo_packed_floats(C.byref(self.policy.dims), T, N) if use_records else 0
@@ -245,6 +245,10 @@ class PPO:
         self._rollout_view = _lib.Rollout(_lib.ptr(b["obs"]), _lib.ptr(b["actions"]), _lib.ptr(b["log_probs"]), _lib.ptr(b["advantages"]),
                                           _lib.ptr(b["returns"]), T, N, _lib.ptr(self._packed) if self._packed is not None else None)
         self._hp = _lib.PPOHParams(self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0)
+        # data parallel: global advantage statistics come from tma_ppo_epoch_prepare's partials -- its limits are checked HERE, before any
+        # rank has collected a rollout, not inside train()
+        if self.world_size > 1 and self.normalize_advantage and not (T * N <= (1 << 22) and self.batch_size >= 256):
+            raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
@@ -286,6 +290,10 @@ class PPO:
         _lib.check(L.tma_gae_flags(_lib.ptr(b["rewards"]), _lib.ptr(b["values"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]),
                                    _lib.ptr(b["last_values"]), self.gamma, self.gae_lambda, T, self.n_envs, _lib.ptr(b["advantages"]),
                                    _lib.ptr(b["returns"]), self._stream()))
+        if self._packed is not None:  # one streaming pass per rollout: the gradient kernels then read one record per sample.  Done HERE, right
+            # behind the advantages / returns it copies, so that the `packed` pointer of the rollout view is never stale for a direct
+            # tma_ppo_minibatch_grad caller between collect_rollouts() and train()
+            _lib.check(L.tma_ppo_pack_samples(C.byref(self._rollout_view), C.byref(self.policy.dims), _lib.ptr(self._packed), self._stream()))
         return True
 
     # -- update ---------------------------------------------------------------------------
@@ -296,13 +304,10 @@ class PPO:
         scale = 1.0 / self.world_size
         perm_seed = (self.seed * 2654435761 + 12345) & 0xFFFFFFFF
         can_prepare = total <= (1 << 22) and self.batch_size >= 256  # limits of tma_ppo_epoch_prepare (include/tma.h)
-        if getattr(self, "_packed", None) is not None:  # one streaming pass per rollout: the gradient kernels then read one record per sample
-            _lib.check(L.tma_ppo_pack_samples(C.byref(self._rollout_view), C.byref(self.policy.dims), _lib.ptr(self._packed), self._stream()))
         # data parallel: every rank normalises a minibatch's advantages with the mean / std of the GLOBAL minibatch (the rows of all
         # ranks), as one SB3 run over the concatenated batch would -- one all-reduce of 16 B per minibatch, once per epoch
         global_stats = self.world_size > 1 and self.normalize_advantage
-        if global_stats and not can_prepare:
-            raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
+        assert can_prepare or not global_stats  # (checked in _setup_model)
         if global_stats and getattr(self, "_adv_sums", None) is None:
             self._adv_sums = torch.zeros(2 * ((total + self.batch_size - 1) // self.batch_size), dtype=torch.float64, device=self.device)
         if self.world_size == 1 and not os.environ.get("TMA_DP_PATH"):  # (TMA_DP_PATH=1: time the data-parallel host loop on one GPU)

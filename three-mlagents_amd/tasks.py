@@ -25,6 +25,7 @@ class EngineTask(NamedTuple):
     n_envs: int
     reward_threshold: float | None = None
     pinned: bool = True   # False: dynamics are build-defined, no reference vectors exist
+    default_algorithm: str = "ppo"  # the reference's catalogue default (registry.py `default_algorithm`); the engine runs PPO either way
 
     @property
     def ppo_n_steps(self) -> int:
@@ -45,19 +46,19 @@ class EngineTask(NamedTuple):
         return {**self._asdict(), "ppo_n_steps": self.ppo_n_steps, "trainable": True, **lib_facts}
 
 
-# id  kernel  tier  timesteps  eval_episodes  n_envs  reward_threshold  pinned
+# id  kernel  tier  timesteps  eval_episodes  n_envs  reward_threshold  pinned  default_algorithm (registry.py:59,75,91,107,123,139,154,169,231)
 # ("ant": the reference delegates to gymnasium Ant-v5 / MuJoCo, envs.py:274-277; the engine's kernel is the BASELINE 172-observation /
 #  20-action articulated chain: same shapes, build-defined dynamics, parity unpinned)
 _ROWS = """
-basic      basic      foundation    25000   50  1  0.85  yes
-gridworld  gridworld  foundation   100000  100  1  0.75  yes
-ball3d     ball3d     foundation   150000   30  8  150   yes
-push       push       benchmark    200000  100  1  0.65  yes
-walljump   walljump   benchmark    150000  100  1  0.7   yes
-brickbreak brickbreak benchmark    500000   50  8  -     yes
-bicycle    bicycle    benchmark    500000   50  8  -     yes
-glider     glider     frontier    1000000   50  8  -     yes
-ant        crawler    benchmark   3000000   20  8  -     no
+basic      basic      foundation    25000   50  1  0.85  yes  dqn
+gridworld  gridworld  foundation   100000  100  1  0.75  yes  dqn
+ball3d     ball3d     foundation   150000   30  8  150   yes  ppo
+push       push       benchmark    200000  100  1  0.65  yes  dqn
+walljump   walljump   benchmark    150000  100  1  0.7   yes  dqn
+brickbreak brickbreak benchmark    500000   50  8  -     yes  ppo
+bicycle    bicycle    benchmark    500000   50  8  -     yes  ppo
+glider     glider     frontier    1000000   50  8  -     yes  ppo
+ant        crawler    benchmark   3000000   20  8  -     no  ppo
 """
 
 
@@ -65,9 +66,9 @@ def _parse(rows: str) -> dict[str, EngineTask]:
     table = {}
     for line in rows.split("\n"):
         if line.strip():
-            tid, kern, tier, steps, episodes, envs, thr, pinned = line.split()
+            tid, kern, tier, steps, episodes, envs, thr, pinned, algo = line.split()
             table[tid] = EngineTask(tid, kern, tid + "_policy", tier, int(steps), int(episodes), int(envs), None if thr == "-" else float(thr),
-                                    pinned == "yes")
+                                    pinned == "yes", algo)
     return table
 
 

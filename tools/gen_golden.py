@@ -381,7 +381,7 @@ def main():
         "walljump": (16, 700, 1, 15),
         "bicycle": (16, 500, 1, 16),
         "brickbreak": (16, 900, 1, 17),
-        "glider": (8, 700, 1, 18),
+        "glider": (16, 2600, 1, 18),
     }
     floats = [t for t in FLOAT_TASKS if not want or t in want]
     if floats and os.environ.get("NPY_DISABLE_CPU_FEATURES") != NO_AVX512:
