@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 202
+#define TMA_VERSION 203
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -96,8 +96,12 @@ int tma_env_episode_index(tma_env *h, uint32_t *out, void *stream);
  * to HOST memory, reports how many were stored (*n_stored) and how many episodes ended since the last pop (*n_seen >= *n_stored when the
  * log overflowed), and empties the log.  Synchronises `stream`. */
 int tma_env_episode_log(tma_env *env, int64_t capacity);
-int tma_env_pop_episode_log(tma_env *env, float *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored,
+int tma_env_pop_episode_log(tma_env *env, double *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored,
                             int64_t *n_seen, void *stream);
+/* SB3 Monitor file rows (backend/mlagents/training.py:85-86: every env is wrapped in Monitor(env, filename), which appends one `r,l,t` line
+ * per finished episode): appends n lines "round(ret, 6),len,round(t, 6)" to `path`, printed like Python prints those values.  HOST arrays,
+ * no GPU work, thread-safe for distinct paths: the Python layer calls it from a writer thread. */
+int tma_monitor_append_rows(const char *path, const double *ret, const int32_t *len, const double *t, int64_t n);
 /* Monitor aggregate since the last call: out[0]=sum of episode returns, out[1]=sum of lengths, out[2]=count.
  * Synchronises `stream`. */
 int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream);
@@ -256,9 +260,12 @@ typedef struct {
                                rewards[t] += gamma * V(terminal_obs[t]) of K consecutive steps in ONE launch over K*N rows
                                instead of one small launch per vector step */
 } tma_rollout_buffers;
+/* deterministic != 0: actions are the distribution's mode (first maximal logit / Gaussian mean) instead of samples -- what SB3's
+ * evaluate_policy(deterministic=True) asks of the policy (backend/mlagents/training.py:177-184,240-247); evaluation.py runs whole evaluation
+ * chunks through this entry point and reads the finished episodes from the env's episode log. */
 int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin, int t_end,
                         int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma, int compute_last_values,
-                        void *stream);
+                        int deterministic, void *stream);
 /* GAE from done flags (episode_starts[t+1] == terminated[t] | truncated[t]): same arithmetic as tma_gae */
 int tma_gae_flags(const float *rewards, const float *values, const uint8_t *terminated, const uint8_t *truncated,
                   const float *last_values, double gamma, double gae_lambda, int T, int64_t N, float *adv_out, float *ret_out,

@@ -57,3 +57,32 @@ def test_no_cpu_fallback_without_gpu():
 
     with pytest.raises(RuntimeError):
         HipEnvEngine("gridworld", 8)
+
+
+def test_monitor_rows_are_printed_like_python_prints_them(tmp_path):
+    """tma_monitor_append_rows (host code, no GPU): SB3's Monitor writes `round(r, 6),l,round(t, 6)` through csv.DictWriter
+    (reference training.py:85-86) -- the native writer must produce the same numbers, and the same text in positional notation."""
+    import ctypes as C
+
+    import numpy as np
+
+    from three_mlagents_amd import _lib
+
+    rng = np.random.default_rng(0)
+    r = np.concatenate([rng.normal(size=500) * 10.0 ** rng.integers(-4, 4, 500), [0.0, 1.0, -1.0, 0.95, -0.03, 150.0, 1e-7, 0.1 + 0.2, 123456.789]])
+    length = rng.integers(1, 4000, len(r)).astype(np.int32)
+    t = np.cumsum(rng.random(len(r)))
+    path = tmp_path / "0.monitor.csv"
+    path.write_text("#{}\nr,l,t\n")
+    _lib.check(_lib.lib().tma_monitor_append_rows(str(path).encode(), r.ctypes.data_as(C.c_void_p), length.ctypes.data_as(C.c_void_p),
+                                                  t.ctypes.data_as(C.c_void_p), len(r)))
+    lines = path.read_text().splitlines()
+    assert lines[:2] == ["#{}", "r,l,t"] and len(lines) == 2 + len(r)
+    for line, rv, lv, tv in zip(lines[2:], r, length, t):
+        a, b, c = line.split(",")
+        assert float(a) == round(float(rv), 6) and int(b) == int(lv) and float(c) == round(float(tv), 6), line
+        if 1e-4 <= abs(round(float(rv), 6)) < 1e15:  # (Python switches to exponent form below 1e-4: "3.5e-05" vs "0.000035", the same number)
+            assert a == repr(round(float(rv), 6)), (a, rv)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().tma_monitor_append_rows(str(tmp_path / "no" / "such" / "dir.csv").encode(), r.ctypes.data_as(C.c_void_p),
+                                                      length.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), 1))

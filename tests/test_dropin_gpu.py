@@ -261,3 +261,61 @@ def test_saved_zip_follows_the_sb3_layout(tmp_path):
         assert torch.equal(again.policy.params, model.policy.params) and torch.equal(again.exp_avg, model.exp_avg) and torch.equal(again.exp_avg_sq, model.exp_avg_sq)
         assert again._adam_step == model._adam_step and again.num_timesteps == model.num_timesteps and again.n_steps == 32
         env.close(), env2.close()
+
+
+@pytest.mark.parametrize("task,hidden,mfma,n_envs,episodes", [("gridworld", 64, "f32", 64, 100), ("ball3d", 256, "bf16", 48, 30), ("basic", 256, "f32", 8, 50),
+                                                             ("ant", 256, "bf16", 40, 40), ("push", 64, "f32", 7, 20)])
+def test_device_side_evaluation_equals_the_per_step_loop(task, hidden, mfma, n_envs, episodes):
+    """evaluate_policy (native deterministic rollout chunks over all envs of the evaluation vector, episodes read from the device episode
+    log: reference training.py:177-184,240-247) reports exactly the episodes the per-step host loop reports -- returns (f64 Monitor sums),
+    lengths and order -- for the fused H = 64 / bf16-wide / Box-action kernels and the per-step path, and for sampled actions too."""
+    from three_mlagents_amd.evaluation import evaluate_policy, evaluate_policy_stepwise
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    train_env = make_vector_env(task, n_envs=64, seed=1)
+    model = PPO("MlpPolicy", train_env, n_steps=32, batch_size=512, n_epochs=2, seed=1, ent_coef=0.01, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
+    model.learn(2 * 64 * 32)  # (a policy that is not the orthogonal init: the argmax is not degenerate)
+    env_a, env_b = make_vector_env(task, n_envs=n_envs, seed=10_001), make_vector_env(task, n_envs=n_envs, seed=10_001)
+    for det in (True, False):
+        ra, la = evaluate_policy(model, env_a, n_eval_episodes=episodes, deterministic=det, return_episode_rewards=True)
+        rb, lb = evaluate_policy_stepwise(model, env_b, n_eval_episodes=episodes, deterministic=det, return_episode_rewards=True)
+        assert len(ra) == len(rb) == episodes and la == lb, (task, det)
+        assert ra == rb, (task, det, max(abs(x - y) for x, y in zip(ra, rb)))
+    ra2, la2 = evaluate_policy(model, env_a, n_eval_episodes=episodes, deterministic=True, return_episode_rewards=True, chunk_steps=7)
+    rb2, lb2 = evaluate_policy_stepwise(model, env_b, n_eval_episodes=episodes, deterministic=True, return_episode_rewards=True)
+    assert ra2 == rb2 and la2 == lb2  # a chunk length that divides nothing
+    m, s = evaluate_policy(model, env_a, n_eval_episodes=episodes)
+    assert abs(m - float(np.mean(rb2))) < 1e-12 and abs(s - float(np.std(rb2))) < 1e-12
+    for e in (train_env, env_a, env_b):
+        e.close()
+
+
+def test_eval_callback_repeats_rows_while_the_policy_has_not_moved(tmp_path, monkeypatch):
+    """train_task at 4096 envs: `eval_freq // n_envs` is 2 vector steps (reference training.py:156), i.e. 512 evaluation rows per
+    1024-step rollout on a policy that cannot change inside a rollout.  Every row is kept (the reference's cadence); the episodes are
+    run once per optimizer state."""
+    monkeypatch.chdir(tmp_path)
+    from three_mlagents_amd import harness
+    from three_mlagents_amd.callbacks import EvalCallback
+
+    seen = {}
+    orig = EvalCallback._on_training_end
+
+    def spy(self):
+        seen["cb"] = self
+        orig(self)
+
+    monkeypatch.setattr(EvalCallback, "_on_training_end", spy)
+    cfg = harness.TrainConfig("gridworld", total_timesteps=2 * 4096 * 1024, n_envs=4096, eval_episodes=100, run_name="big", verbose=0)
+    res = harness.train_task(cfg, model_kwargs={"batch_size": 131072, "policy_kwargs": {"net_arch": [64, 64]}})
+    cb = seen["cb"]
+    assert cb.eval_freq == 2 and len(cb.evaluations_timesteps) == 2 * 1024 // 2
+    assert cb.n_fresh_evaluations == 2  # once per rollout (the optimizer stepped in between), not 1024 times
+    ev = np.load(tmp_path / "runs" / "gridworld" / "big" / "eval" / "evaluations.npz")
+    assert ev["timesteps"].shape == (1024,) and ev["results"].shape == (1024, 100) and ev["ep_lengths"].shape == (1024, 100)
+    assert np.array_equal(ev["results"][0], ev["results"][511]) and not np.array_equal(ev["results"][0], ev["results"][512])
+    assert ev["timesteps"][0] == 2 * 4096 and ev["timesteps"][-1] == 2 * 4096 * 1024
+    assert res.eval_episodes == 100 and res.total_timesteps == 2 * 4096 * 1024
+    meta = json.loads((tmp_path / "runs" / "gridworld" / "big" / "metadata.json").read_text())
+    assert meta["substituted_for"] == "dqn" and len(meta["episode_rewards"]) == 100

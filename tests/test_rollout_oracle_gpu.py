@@ -32,6 +32,8 @@ CASES = [
     pytest.param("push", 2048, 2048, 256, "bf16", 2048, id="push-2048x2048-h256-bf16-shard1"),
     pytest.param("basic", 8, 1024, 256, "f32", 0, id="basic-8x1024-h256-f32"),
     pytest.param("crawler", 2048, 256, 256, "bf16", 4096, id="crawler-2048x256-h256-bf16-shard2-unpinned"),
+    # (Crawler episodes run to the 1000-step limit: a narrower vector long enough for every env to finish one, timeout bootstrap included)
+    pytest.param("crawler", 512, 1040, 256, "bf16", 4096, id="crawler-512x1040-h256-bf16-shard2-unpinned"),
     # the other fused H = 64 instantiations at the headline size
     pytest.param("push", 4096, 512, 64, "f32", 0, id="push-4096x512-h64-f32"),
     pytest.param("ball3d", 4096, 512, 64, "f32", 0, id="ball3d-4096x512-h64-f32"),
@@ -102,7 +104,7 @@ def _replay(task, N, T, hidden, mfma, env_offset, seed=1):
     assert len(log_r) == n_events, (len(log_r), n_events)
     if n_events:
         oe = np.concatenate([x[0] for x in ep_events])
-        orr = np.concatenate([x[1] for x in ep_events]).astype(np.float32)
+        orr = np.concatenate([x[1] for x in ep_events])  # f64: Monitor's Python-float sum of the episode's rewards
         ol = np.concatenate([x[2] for x in ep_events])
         o_order = np.argsort(oe, kind="stable")
         g_order = np.argsort(log_e, kind="stable")
@@ -117,9 +119,8 @@ def test_fused_rollout_replayed_through_the_oracle(task, N, T, hidden, mfma, env
     st = _replay(task, N, T, hidden, mfma, env_offset)
     print(f"[{task} {N}x{T} H={hidden} {mfma}] compared {st['compared']} elements, not bit-identical {st['inexact']}, "
           f"timeouts {st['timeouts']}, episodes {st['episodes']}")
-    assert st["episodes"] > 0
-    if task in ("gridworld", "ball3d", "basic", "push"):
-        assert st["timeouts"] > 0  # the bootstrap branch was exercised
+    if T >= orc.max_episode_steps(task):
+        assert st["episodes"] > 0 and st["timeouts"] > 0  # Monitor rows and the bootstrap branch were exercised
     if task in ("gridworld", "push", "basic"):
         assert st["inexact"] == 0
     else:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tma_env_set_state": (_i32, [_vp, _vp, _vp]),
     "tma_env_episode_index": (_i32, [_vp, _vp, _vp]),
     "tma_env_episode_log": (_i32, [_vp, _i64]),
+    "tma_monitor_append_rows": (_i32, [C.c_char_p, _vp, _vp, _vp, _i64]),
     "tma_env_pop_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
     "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
@@ -92,7 +93,7 @@ SIGNATURES = {
     "tma_ppo_train_epoch_local": (_i32, [_vp, _pd, C.POINTER(Rollout), _u32, _u32, _i64, C.POINTER(PPOHParams), _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                          _f64, _vp, _vp]),
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
-    "tma_rollout_collect": (_i32, [_vp, _vp, _pd, C.POINTER(RolloutBuffers), _i32, _i32, _i32, _u32, _u32, _u32, _f64, _i32, _vp]),
+    "tma_rollout_collect": (_i32, [_vp, _vp, _pd, C.POINTER(RolloutBuffers), _i32, _i32, _i32, _u32, _u32, _u32, _f64, _i32, _i32, _vp]),
 }
 
 _lib = None

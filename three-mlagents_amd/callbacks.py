@@ -148,8 +148,16 @@ def as_callback(cb) -> BaseCallback:
 
 
 class EvalCallback(BaseCallback):
-    """Periodic deterministic evaluation (SB3 EvalCallback as configured at training.py:152-161): every `eval_freq`
-    calls, run `n_eval_episodes`, append to `<log_path>/evaluations.npz`, keep the best model."""
+    """Periodic deterministic evaluation (SB3 EvalCallback as configured at training.py:152-161): every `eval_freq` calls, run
+    `n_eval_episodes`, append a row to `<log_path>/evaluations.npz`, keep the best model.
+
+    The row cadence is SB3's (one row per `eval_freq` calls).  Two things differ in how a row is produced: (1) the evaluation itself is
+    device-side (evaluation.py: native rollout chunks over every env of `eval_env`); (2) every evaluation starts from `reset()`, whose
+    episode seeds are fixed (seed + env + k * 2^20), so with `deterministic=True` its result is a function of the parameters alone --
+    while the optimizer has not stepped since the last evaluation (`model._n_updates` / Adam step unchanged: `on_step` calls inside
+    one rollout; with thousands of envs `eval_freq // n_envs` is a handful of vector steps) the previous result is repeated instead
+    of re-running identical episodes.  `evaluations.npz` is rewritten when a fresh evaluation ran and at training end, not once per
+    repeated row."""
 
     def __init__(self, eval_env, best_model_save_path=None, log_path=None, eval_freq=10000, n_eval_episodes=5, deterministic=True, verbose=0, warn=True):
         super().__init__(verbose)
@@ -158,25 +166,48 @@ class EvalCallback(BaseCallback):
         self.best_mean_reward = -np.inf
         self.last_mean_reward = -np.inf
         self.evaluations_timesteps, self.evaluations_results, self.evaluations_length = [], [], []
+        self.n_fresh_evaluations = 0
+        self._cached_key, self._cached = None, None
+        self._dirty = False
+
+    def _policy_key(self):
+        m = self.model
+        return (getattr(m, "_n_updates", None), getattr(m, "_adam_step", None), id(getattr(m, "policy", None)))
+
+    def _flush(self) -> None:
+        if self._dirty and self.log_path is not None:
+            os.makedirs(self.log_path, exist_ok=True)
+            np.savez(os.path.join(self.log_path, "evaluations"), timesteps=self.evaluations_timesteps, results=self.evaluations_results,
+                     ep_lengths=self.evaluations_length)
+        self._dirty = False
 
     def _on_step(self) -> bool:
         if self.eval_freq > 0 and self.n_calls % self.eval_freq == 0:
-            from .evaluation import evaluate_policy
+            key = self._policy_key()
+            fresh = not (self.deterministic and key == self._cached_key and None not in key[:2])
+            if fresh:
+                from .evaluation import evaluate_policy
 
-            rewards, lengths = evaluate_policy(self.model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
-                                               return_episode_rewards=True)
+                rew, length = evaluate_policy(self.model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
+                                              return_episode_rewards=True)
+                self._cached = (np.asarray(rew, np.float64), np.asarray(length, np.int64))
+                self._cached_key = key
+                self.n_fresh_evaluations += 1
+            rewards, lengths = self._cached
             self.evaluations_timesteps.append(self.num_timesteps)
             self.evaluations_results.append(rewards)
             self.evaluations_length.append(lengths)
-            if self.log_path is not None:
-                os.makedirs(self.log_path, exist_ok=True)
-                np.savez(os.path.join(self.log_path, "evaluations"), timesteps=self.evaluations_timesteps, results=self.evaluations_results,
-                         ep_lengths=self.evaluations_length)
+            self._dirty = True
             self.last_mean_reward = float(np.mean(rewards))
-            if self.verbose >= 1:
-                print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
-            if self.last_mean_reward > self.best_mean_reward:
-                self.best_mean_reward = self.last_mean_reward
-                if self.best_model_save_path is not None:
-                    self.model.save(os.path.join(self.best_model_save_path, "best_model"))
+            if fresh:
+                self._flush()
+                if self.verbose >= 1:
+                    print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
+                if self.last_mean_reward > self.best_mean_reward:
+                    self.best_mean_reward = self.last_mean_reward
+                    if self.best_model_save_path is not None:
+                        self.model.save(os.path.join(self.best_model_save_path, "best_model"))
         return True
+
+    def _on_training_end(self) -> None:
+        self._flush()

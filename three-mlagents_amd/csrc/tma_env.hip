@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -698,7 +699,7 @@ int tma_env_episode_log(tma_env *h, int64_t capacity) {
     (void)hipFree(v.log_ret), (void)hipFree(v.log_len), (void)hipFree(v.log_env), (void)hipFree(v.log_n);
     v.log_ret = nullptr, v.log_len = nullptr, v.log_env = nullptr, v.log_n = nullptr, v.log_cap = 0;
     if (capacity == 0) return TMA_OK;
-    TMA_HIP(hipMalloc(&v.log_ret, sizeof(float) * (size_t)capacity));
+    TMA_HIP(hipMalloc(&v.log_ret, sizeof(double) * (size_t)capacity));
     TMA_HIP(hipMalloc(&v.log_len, sizeof(int32_t) * (size_t)capacity));
     TMA_HIP(hipMalloc(&v.log_env, sizeof(int32_t) * (size_t)capacity));
     TMA_HIP(hipMalloc(&v.log_n, sizeof(unsigned long long)));
@@ -707,7 +708,7 @@ int tma_env_episode_log(tma_env *h, int64_t capacity) {
     return TMA_OK;
 }
 
-int tma_env_pop_episode_log(tma_env *h, float *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored, int64_t *n_seen,
+int tma_env_pop_episode_log(tma_env *h, double *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored, int64_t *n_seen,
                             void *stream) {
     if (!h || !n_stored || !n_seen || max_records < 0 || (max_records > 0 && (!ret_host || !len_host || !env_host)))
         return fail(TMA_ERR_INVALID, "tma_env_pop_episode_log: null argument");
@@ -721,13 +722,43 @@ int tma_env_pop_episode_log(tma_env *h, float *ret_host, int32_t *len_host, int3
     int64_t n = (int64_t)std::min<unsigned long long>(seen, (unsigned long long)v.log_cap);
     if (n > max_records) n = max_records;
     if (n > 0) {
-        TMA_HIP(hipMemcpyAsync(ret_host, v.log_ret, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+        TMA_HIP(hipMemcpyAsync(ret_host, v.log_ret, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
         TMA_HIP(hipMemcpyAsync(len_host, v.log_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
         TMA_HIP(hipMemcpyAsync(env_host, v.log_env, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
     }
     TMA_HIP(hipMemsetAsync(v.log_n, 0, sizeof(unsigned long long), s));
     TMA_HIP(hipStreamSynchronize(s));
     *n_stored = n, *n_seen = (int64_t)seen;
+    return TMA_OK;
+}
+
+// SB3 Monitor rows (reference training.py:85-86 wraps every env in a Monitor that writes `r,l,t` per finished episode): appends n rows
+// "round(r, 6),l,round(t, 6)" to `path` the way Python prints them (shortest form of the 6-decimal value: trailing zeros dropped, at least
+// one digit behind the point).  Plain host code, no GPU call: ppo.py runs it on a writer thread so that formatting 10^5 rows per
+// iteration (4096 envs, ~30-step episodes) never sits between two GPU iterations.
+static int fmt6(char *dst, double v) {
+    int n = snprintf(dst, 40, "%.6f", v);
+    while (n > 2 && dst[n - 1] == '0' && dst[n - 2] != '.') n--;
+    return n;
+}
+int tma_monitor_append_rows(const char *path, const double *ret, const int32_t *len, const double *t, int64_t n) {
+    if (!path || n < 0 || (n > 0 && (!ret || !len || !t))) return fail(TMA_ERR_INVALID, "tma_monitor_append_rows: null argument");
+    FILE *f = fopen(path, "a");
+    if (!f) return fail(TMA_ERR_INVALID, "tma_monitor_append_rows: cannot open %s", path);
+    std::vector<char> buf(1 << 16);
+    size_t used = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (used + 128 > buf.size()) {
+            fwrite(buf.data(), 1, used, f);
+            used = 0;
+        }
+        used += (size_t)fmt6(buf.data() + used, ret[i]);
+        used += (size_t)snprintf(buf.data() + used, 16, ",%d,", (int)len[i]);
+        used += (size_t)fmt6(buf.data() + used, t[i]);
+        buf[used++] = '\n';
+    }
+    fwrite(buf.data(), 1, used, f);
+    fclose(f);
     return TMA_OK;
 }
 

@@ -11,7 +11,7 @@ struct EnvView {
     uint32_t *st, *ring, *cur_ep, *filled_hi;
     double *ep_ret, *stats;
     // optional episode log (tma_env_episode_log): one record per finished episode, appended in execution order
-    float *log_ret;             // [log_cap] Monitor return (sum of float(reward) in step order)
+    double *log_ret;            // [log_cap] Monitor return: the f64 sum of the episode's rewards in step order (SB3 Monitor sums Python floats)
     int32_t *log_len, *log_env; // [log_cap] episode length, env index within the vector
     unsigned long long *log_n;  // episodes seen since the last pop (records beyond log_cap are counted, not stored)
     long long log_cap;
@@ -22,7 +22,7 @@ __device__ __forceinline__ void log_episode(const EnvView &v, int64_t env, doubl
     if (v.log_n == nullptr) return;
     const unsigned long long k = atomicAdd(v.log_n, 1ull);
     if (k < (unsigned long long)v.log_cap) {
-        v.log_ret[k] = (float)ep_return;
+        v.log_ret[k] = ep_return;
         v.log_len[k] = (int32_t)steps;
         v.log_env[k] = (int32_t)env;
     }

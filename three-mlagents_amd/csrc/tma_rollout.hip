@@ -34,7 +34,7 @@ struct ChunkPtrs {
 
 template <class T>
 __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
-                                                                uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+                                                                uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -86,10 +86,15 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
             const float sum = gsum16(e);
             const float lse = m + logf(sum);
             const float lp = x - lse;
-            const float c = gscan16(e / sum);
-            const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
-            const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-            const int act = min((int)cnt, A - 1);
+            int act;
+            if (det) {  // deterministic evaluation (SB3 predict(deterministic=True)): first maximal logit, as policy_fwd_h64_kernel
+                act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
+            } else {
+                const float c = gscan16(e / sum);
+                const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                act = min((int)cnt, A - 1);
+            }
             const float lpa = gsum16((r16 == act) ? lp : 0.0f);
             const float vrow = gfirst_quad(vacc[r]);
             if (r16 == r) my_act = act, my_lp = lpa, my_v = vrow;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
 // wave 0 -- the two waves never store to the same address.  Same arithmetic per element as rollout_chunk_h64_kernel.
 template <class T>
 __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
-                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -254,10 +259,15 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
                 const float sum = gsum16(e);
                 const float lse = m + logf(sum);
                 const float lp = x - lse;
-                const float c = gscan16(e / sum);
-                const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
-                const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-                const int act = min((int)cnt, A - 1);
+                int act;
+                if (det) {  // deterministic evaluation: first maximal logit
+                    act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
+                } else {
+                    const float c = gscan16(e / sum);
+                    const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                    const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                    act = min((int)cnt, A - 1);
+                }
                 const float lpa = gsum16((r16 == act) ? lp : 0.0f);
                 if (r16 == r) my_act = act, my_lp = lpa;
             }
@@ -364,7 +374,7 @@ struct WideLds {
 
 template <class T>
 __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
-                                                                       uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+                                                                       uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     constexpr int M = WideLds::M, NTW = WideLds::NTW, KS2 = WideLds::KS2, lda = WideLds::LDA, ldx = WideLds::LDX, D = T::OBS;
     static_assert(D <= 32 && T::NACT > 0, "fused wide rollout: observations of up to 32 floats, Discrete actions");
@@ -499,10 +509,15 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
                     const float sm = gsum16(e);
                     const float lse = m + logf(sm);
                     const float lp = x - lse;
-                    const float c = gscan16(e / sm);
-                    const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
-                    const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-                    const int act = min((int)cnt, A - 1);
+                    int act;
+                    if (det) {  // deterministic evaluation: first maximal logit, as policy_fwd_wide_kernel
+                        act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
+                    } else {
+                        const float c = gscan16(e / sm);
+                        const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                        const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                        act = min((int)cnt, A - 1);
+                    }
                     const float lpa = gsum16((r16 == act) ? lp : 0.0f);
                     if (r16 == r) my_act = act, my_lp = lpa;
                 }
@@ -655,7 +670,7 @@ struct ObsImage {  // bf16 image row only (terminal observations: only the boots
 
 template <class T>
 __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0,
-                                                                         int n_steps, uint32_t rng_seed, uint32_t rng_step0, float gamma) {
+                                                                         int n_steps, uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     using W = WideContLds<T>;
     constexpr int M = W::M, NTW = W::NTW, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
@@ -832,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
                             const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
                             const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
                             const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
-                            const float a = mu + sd * z;
+                            const float a = det ? mu : mu + sd * z;  // deterministic evaluation: the mean (policy_fwd_wide_kernel)
                             const float d = a - mu;
                             lpsum += -(d * d) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
                             actl[lrow * 32 + col] = a;
@@ -927,19 +942,19 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
 
 template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
-                             uint32_t rng_step0, float gamma, hipStream_t s) {
+                             uint32_t rng_step0, float gamma, int det, hipStream_t s) {
     if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
         auto k = rollout_chunk_wide_bf_kernel<T>;
         const int smem = WideLds::bytes();
         TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     } else if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && ((T::OBS + 31) / 32) % 2 == 0) {
         auto k = rollout_chunk_wide_cont_kernel<T>;
         const int smem = WideContLds<T>::bytes();
         TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     } else {
@@ -949,7 +964,7 @@ static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L
 
 template <class T>
 static int launch_chunk(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed, uint32_t rng_step0,
-                        float gamma, hipStream_t s) {
+                        float gamma, int det, hipStream_t s) {
     const int64_t tiles = ceil_div(env->v.N, 16);
     const int wpb = tiles >= 1024 ? 4 : 1;  // BASELINE shape (256 tiles): one wave per block so all 256 CUs take part
     constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
@@ -958,13 +973,13 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
         const int smem2 = (2 * FWD_IMG + 4 * 16 * ldx + 4 * 16 * 66 + 32 + 32 + 4 + 32) * 4;
         auto k2 = rollout_chunk2_h64_kernel<T>;
         if (smem2 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
-        k2<<<dim3((unsigned)tiles), dim3(128), smem2, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+        k2<<<dim3((unsigned)tiles), dim3(128), smem2, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
     auto k = rollout_chunk_h64_kernel<T>;
     if (smem > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    k<<<dim3((unsigned)ceil_div(tiles, wpb)), dim3(64 * wpb), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma);
+    k<<<dim3((unsigned)ceil_div(tiles, wpb)), dim3(64 * wpb), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }
@@ -992,8 +1007,9 @@ extern "C" int tma_debug_poison_lds(unsigned pattern, void *stream) {
 
 extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin,
                                    int t_end, int T, uint32_t rng_seed, uint32_t rng_step0, uint32_t env_offset, double gamma,
-                                   int compute_last_values, void *stream) {
+                                   int compute_last_values, int deterministic, void *stream) {
     using namespace tma;
+    const int det = deterministic ? 1 : 0;
     if (!env || !params || !d || !b) return fail(TMA_ERR_INVALID, "tma_rollout_collect: null argument");
     if (!b->obs || !b->actions || !b->rewards || !b->values || !b->log_probs || !b->terminated || !b->truncated || !b->terminal_obs)
         return fail(TMA_ERR_INVALID, "tma_rollout_collect: rollout buffers has a null plane");
@@ -1023,7 +1039,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
             const int n = left < (t_end - t) ? left : (t_end - t);
             rc = dispatch_task(env->task, [&](auto task) {
                 using TT = decltype(task);
-                return launch_chunk_wide<TT>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+                return launch_chunk_wide<TT>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
             });
             if (rc) return rc;
             rc = tma_env_internal_after_steps(env, n, stream);
@@ -1045,12 +1061,12 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
             int rc = tma_env_steps_until_refill(env, &left);
             if (rc) return rc;
             const int n = left < (t_end - t) ? left : (t_end - t);
-            if (env->task == TMA_TASK_GRIDWORLD) rc = launch_chunk<GridTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
-            else if (env->task == TMA_TASK_PUSH) rc = launch_chunk<PushTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
-            else if (env->task == TMA_TASK_WALLJUMP) rc = launch_chunk<WallJumpTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
-            else if (env->task == TMA_TASK_BICYCLE) rc = launch_chunk<BicycleTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
-            else if (env->task == TMA_TASK_GLIDER) rc = launch_chunk<GliderTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
-            else rc = launch_chunk<BallTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, (hipStream_t)stream);
+            if (env->task == TMA_TASK_GRIDWORLD) rc = launch_chunk<GridTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_PUSH) rc = launch_chunk<PushTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_WALLJUMP) rc = launch_chunk<WallJumpTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_BICYCLE) rc = launch_chunk<BicycleTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
+            else if (env->task == TMA_TASK_GLIDER) rc = launch_chunk<GliderTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
+            else rc = launch_chunk<BallTask>(env, params, L, cp, t, n, rng_seed, rng_step0, (float)gamma, det, (hipStream_t)stream);
             if (rc) return rc;
             rc = tma_env_internal_after_steps(env, n, stream);
             if (rc) return rc;
@@ -1065,7 +1081,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     const int D = d->obs_dim, A = d->continuous ? d->act_dim : 1;
     const size_t act_elem = d->continuous ? sizeof(float) : sizeof(int32_t);
     const int K = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
-    if (K == 1) {
+    if (K == 1 && !det) {
         for (int t = t_begin; t < t_end; t++) {
             const float *obs_t = b->obs + (int64_t)t * N * D;
             float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
@@ -1092,7 +1108,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
             const float *obs_t = b->obs + (int64_t)t * N * D;
             float *obs_next = b->obs + (int64_t)(t + 1) * N * D;
             void *act_t = static_cast<char *>(b->actions) + (int64_t)t * N * A * act_elem;
-            int rc = tma_policy_act(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, 0, act_t, b->values + (int64_t)t * N,
+            int rc = tma_policy_act(params, d, obs_t, N, rng_seed, rng_step0 + (uint32_t)t, env_offset, det, act_t, b->values + (int64_t)t * N,
                                     b->log_probs + (int64_t)t * N, stream);
             if (rc) return rc;
             rc = tma_env_step(env, act_t, d->continuous ? TMA_ACT_F32 : TMA_ACT_I32, 0, 0, 1, obs_next, b->rewards + (int64_t)t * N,

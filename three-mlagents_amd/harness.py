@@ -29,6 +29,7 @@ from .vec_env import HipVecEnv
 
 POLICIES_DIR, RUNS_DIR = (Path(name) for name in ("policies", "runs"))
 ALGORITHMS = dict(ppo=PPO)  # the one algorithm north_star puts on the GPU
+EVAL_ENVS = int(os.environ.get("TMA_EVAL_ENVS", "64"))  # width of the evaluation vector (train_task / evaluate_model)
 _SB3_NAMES = {"a2c", "dqn", "ppo", "sac", "td3"}  # what the reference's table accepts (training.py:31-37)
 
 # (name, type, default) -- the reference's request / result records (training.py:40-68); `device` is an engine-only extra
@@ -102,7 +103,9 @@ def train_task(config, *, callback=None, model_kwargs=None):
             stack.callback(e.close)
             return e
 
-        venv, eval_env = opened(n_envs, 0, run.monitor), opened(1, 10_000)  # the eval env is seeded 10 000 past the training seed
+        # the eval vector is seeded 10 000 past the training seed (the reference: ONE env, episodes one after the other on the host; here the
+        # episodes are spread over up to EVAL_ENVS device envs stepped together -- evaluation.py, SB3's even split of episodes over envs)
+        venv, eval_env = opened(n_envs, 0, run.monitor), opened(max(1, min(EVAL_ENVS, episodes)), 10_000)
         hp = {**ppo_defaults(task), "tensorboard_log": str(run.tb), "verbose": config.verbose, **(model_kwargs or {})}
         model = ALGORITHMS[algo](config.policy or "MlpPolicy", venv, seed=config.seed, **hp)
         ev = dict(n_eval_episodes=episodes, deterministic=config.deterministic_eval)
@@ -149,7 +152,7 @@ def evaluate_model(task_id, name_or_path, *, episodes=None, deterministic=True, 
     path = find_policy(task, name_or_path)
     model = PPO.load(path)
     n = int(episodes or task.eval_episodes)
-    with contextlib.closing(make_vector_env(task.id, n_envs=1, seed=seed)) as env:
+    with contextlib.closing(make_vector_env(task.id, n_envs=max(1, min(EVAL_ENVS, n)), seed=seed)) as env:
         returns, lengths = evaluate_policy(model, env, n_eval_episodes=n, deterministic=deterministic, return_episode_rewards=True)
     return dict(task_id=task.id, model=str(path), episodes=n, mean_reward=statistics.fmean(returns), std_reward=statistics.pstdev(returns),
                 episode_rewards=[float(r) for r in returns], episode_lengths=[int(k) for k in lengths])

@@ -272,7 +272,7 @@ class PPO:
             te = min(T, t + chunk)
             _lib.check(L.tma_rollout_collect(eng._h, _lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rb), t, te, T,
                                              self.seed & 0xFFFFFFFF, (self._rollout_counter * T) & 0xFFFFFFFF, eng.env_offset & 0xFFFFFFFF,
-                                             self.gamma, 1, self._stream()))
+                                             self.gamma, 1, 0, self._stream()))
             for _ in range(te - t):
                 self.num_timesteps += self.n_envs * self.world_size
                 if callback is not None and not callback.on_step():
@@ -398,6 +398,7 @@ class PPO:
                 t_prev = time.time() - t0
                 if self.verbose >= 1 and self.rank == 0:
                     print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+        self._join_monitor_writer()
         cb.on_training_end()
         return self
 
@@ -438,15 +439,33 @@ class PPO:
         r, l, _, seen = self.env.engine.pop_episode_log()
         n = len(r)
         keep = np.arange(n) if n <= self.monitor_max_rows else np.linspace(0, n - 1, self.monitor_max_rows).astype(np.int64)
+        self._join_monitor_writer()  # (rows of the previous interval are on disk before this interval's header / comment lines)
         with open(path, "a", encoding="utf-8") as f:
             if new:
                 f.write("#" + json.dumps({"t_start": t_start, "env_id": getattr(self.env, "task_id", None)}) + "\n")
                 f.write("r,l,t\n")
             if len(keep) < seen:
                 f.write(f"# {seen} episodes finished in this interval, {len(keep)} rows kept; interval mean r={sum_ret / count:.6f} l={sum_len / count:.3f}\n")
-            for q, k in enumerate(keep):
-                t = t_begin + (t_end - t_begin) * (q + 1) / len(keep)
-                f.write(f"{round(float(r[k]), 6)},{int(l[k])},{round(t, 6)}\n")
+        if not len(keep):
+            return
+        # the rows themselves: formatted and appended natively (tma_monitor_append_rows) on a writer thread -- the ctypes call releases the
+        # GIL, so 10^5 rows per iteration (4096 envs, ~30-step episodes) cost the training loop nothing
+        rr, ll = np.ascontiguousarray(r[keep], np.float64), np.ascontiguousarray(l[keep], np.int32)
+        ts = np.ascontiguousarray(t_begin + (t_end - t_begin) * (np.arange(len(keep)) + 1.0) / len(keep), np.float64)
+        import threading
+
+        def work():
+            _lib.check(_lib.lib().tma_monitor_append_rows(path.encode(), rr.ctypes.data_as(C.c_void_p), ll.ctypes.data_as(C.c_void_p),
+                                                          ts.ctypes.data_as(C.c_void_p), len(rr)))
+
+        self._monitor_thread = threading.Thread(target=work, name="tma-monitor-writer", daemon=False)
+        self._monitor_thread.start()
+
+    def _join_monitor_writer(self) -> None:
+        th = getattr(self, "_monitor_thread", None)
+        if th is not None:
+            th.join()
+            self._monitor_thread = None
 
     # -- inference ------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):

@@ -175,11 +175,12 @@ class HipEnvEngine:
         self._log_cap = int(capacity)
 
     def pop_episode_log(self) -> tuple[np.ndarray, np.ndarray, np.ndarray, int]:
-        """(returns f32[n], lengths i32[n], env index i32[n], episodes seen) since the last pop, in the order the kernels logged them."""
+        """(returns f64[n], lengths i32[n], env index i32[n], episodes seen) since the last pop, in the order the kernels logged them
+        (per env: the order the episodes finished)."""
         cap = getattr(self, "_log_cap", 0)
         if cap <= 0:
             raise RuntimeError("episode log is off: call episode_log(capacity) first")
-        r, l, e = np.empty(cap, np.float32), np.empty(cap, np.int32), np.empty(cap, np.int32)
+        r, l, e = np.empty(cap, np.float64), np.empty(cap, np.int32), np.empty(cap, np.int32)
         n, seen = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().tma_env_pop_episode_log(self._h, r.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
                                                       cap, C.byref(n), C.byref(seen), self._stream()))
