@@ -142,6 +142,7 @@ def time_iterations(model, steps, warmup):
     torch.cuda.synchronize()
     dist.barrier()
     el = time.perf_counter() - t0
+    model._bench_local = (el, t_roll)  # this rank's own clock (dp_timing: per-rank rollout / update split)
     return dist.allreduce_max_float(el, device=model.device), dist.allreduce_max_float(t_roll, device=model.device)
 
 
@@ -197,7 +198,7 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
 def attach_pmc_traffic(roof, name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summaries (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2
     corrected as MI355X_MICROARCH.md prescribes); newest round first."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
         if os.path.exists(path):
             with open(path) as f:
@@ -302,14 +303,16 @@ def run_extra(cfg, args, dev):
     batch = cfg.get("batch") or max(256, total // 32)
     env, model = build_model(cfg["task"], cfg["n_envs"], cfg["n_steps"], cfg["hidden"], cfg["mfma"], batch, args.n_epochs, args.seed, dev)
     try:
-        steps = 2
-        el, t_roll = time_iterations(model, steps, 1)
+        steps, warm = cfg.get("steps", 10), cfg.get("warmup", 3)  # (SURVEY.md 8d asks for warm-up + >= 10 timed iterations; each is 50-200 ms)
+        el, t_roll = time_iterations(model, steps, warm)
         updates = steps * args.n_epochs * ((total + batch - 1) // batch)
         roof = grad_kernel_roofline(model, cfg["task"], cfg["hidden"], cfg["mfma"], batch, reps=12)
-        if cfg["task"] == "ball3d" and cfg["mfma"] == "bf16":
-            attach_pmc_traffic(roof, "gradbf_kernel")
+        if cfg["mfma"] == "bf16":
+            attach_pmc_traffic(roof, {"ball3d": "gradbf_kernel", "push": "gradbf_push_kernel", "crawler": "gradbf_crawler_kernel"}.get(cfg["task"], "none"))
+        elif cfg["task"] == "basic":
+            attach_pmc_traffic(roof, "gradwide_basic_kernel")
         res = {"config": cfg["name"], "task": cfg["task"], "envs_per_gpu": cfg["n_envs"], "n_steps": cfg["n_steps"], "hidden": cfg["hidden"],
-               "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": 1,
+               "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": warm,
                "env_steps_per_sec": steps * total / el, "ms_per_step": el / steps * 1e3, "rollout_ms": t_roll / steps * 1e3,
                "update_ms": (el - t_roll) / steps * 1e3, "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9),
                "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic")}}
@@ -353,6 +356,57 @@ def literal_batch_256(args, dev):
         env.close()
         del model, env
         torch.cuda.empty_cache()
+
+
+def harness_train_task(args, dev):
+    """The drop-in path end to end: wall time of harness.train_task (vector env + eval env construction, EvalCallback at the reference's
+    `eval_freq // n_envs` cadence, Monitor rows, TensorBoard / progress files, policy zip, final evaluation, metadata.json) for two PPO
+    iterations of the headline shape, next to the same two iterations through PPO directly (construction included on both sides)."""
+    import shutil
+    import tempfile
+
+    import torch
+
+    from three_mlagents_amd import harness
+
+    total = 2 * args.n_envs * args.n_steps
+    batch = max(256, args.n_envs * args.n_steps // 32)
+    pk = {"net_arch": {"pi": [args.hidden] * 2, "vf": [args.hidden] * 2}, "mfma_dtype": args.mfma_dtype}
+    res = {}
+    for rep in range(2):  # second pass: every kernel module is loaded, both legs see the same warm process
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        env, model = build_model(args.task, args.n_envs, args.n_steps, args.hidden, args.mfma_dtype, batch, args.n_epochs, args.seed, dev)
+        model.learn(total)
+        torch.cuda.synchronize()
+        t_direct = time.perf_counter() - t0
+        env.close()
+        del model, env
+        tmp = tempfile.mkdtemp(prefix="tma_bench_harness_")
+        cwd = os.getcwd()
+        try:
+            os.chdir(tmp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cfg = harness.TrainConfig(args.task, total_timesteps=total, n_envs=args.n_envs, seed=args.seed, run_name="bench", verbose=0)
+            out = harness.train_task(cfg, model_kwargs={"batch_size": batch, "n_epochs": args.n_epochs, "n_steps": args.n_steps, "policy_kwargs": pk})
+            torch.cuda.synchronize()
+            t_harness = time.perf_counter() - t0
+            rows = 0
+            mon = os.path.join(tmp, "runs", harness.tasks.resolve(args.task).id, "bench", "monitor", "0.monitor.csv")
+            if os.path.exists(mon):
+                with open(mon) as f:
+                    rows = sum(1 for ln in f if ln[:1] not in "#r")
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+        res = {"workload": f"train_task({args.task}, n_envs={args.n_envs}, total_timesteps={total}, batch_size={batch}, MLP {args.hidden}x{args.hidden}): two PPO "
+                           "iterations + EvalCallback (eval_freq 10000 // n_envs vector steps, 100 episodes on a 64-env device eval vector) + Monitor rows + tb / "
+                           "progress files + policy zip + final evaluation + metadata.json",
+               "train_task_seconds": t_harness, "direct_ppo_seconds": t_direct, "overhead_frac": t_harness / t_direct - 1.0,
+               "env_steps_per_sec_train_task": total / t_harness, "env_steps_per_sec_direct": total / t_direct, "monitor_rows_written": rows,
+               "mean_reward": out.mean_reward, "eval_episodes": out.eval_episodes, "pass": rep + 1}
+    return res
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -417,8 +471,18 @@ def cpu_baseline(args, seconds, batch):
             break
     t_upd = (time.perf_counter() - t1) / n_upd * (batch / bs)
     iter_s = total * roll_per_env_step + args.n_epochs * n_mb * t_upd
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
-        "value": total / iter_s, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "value": total / iter_s, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+        "reference_python_calibration": "BASELINE.md section 3 (measured in the survey container, 2.6 GHz Xeon, one core): the reference's own Python envs run "
+                                        "62-64 k raw env.step()/s/core for GridWorld (no policy, no VecEnv); through SB3's DummyVecEnv + PPO the reference "
+                                        "trains at about 1-2 k env-steps/s.  The C port timed here is the build's restatement, not the reference's Python: "
+                                        "its env-only rate (env_only_steps_per_s) is what relates to the 62-64 k figure",
         "sample": f"same schedule as the GPU leg ({args.task}, {N} envs x {T} steps, MLP {H}x{H}, {args.n_epochs} epochs x {n_mb} minibatches of {batch}), "
                   f"composed from two timed legs: rollout {Tc} vector steps x {N} envs + GAE ({t_roll:.2f} s; C oracle env with OpenMP + torch-CPU "
                   f"policy, {cores} threads) and {n_upd} optimizer steps on minibatches of {bs} samples ({t_upd * 1e3:.1f} ms each; torch-CPU autograd "
@@ -453,6 +517,8 @@ def main():
     batch = args.batch_size if args.batch_size > 0 else max(256, total // 32)
     env, model = build_model(args.task, N, T, args.hidden, args.mfma_dtype, batch, args.n_epochs, args.seed, dev, rank)
     log(f"rank {rank}/{world}: engine ready, N={N} T={T} batch={batch}")
+    if world > 1:
+        model.dp_timing = {}  # HIP events around the collectives of the first minibatches / epochs of every train() call
     el, t_roll = time_iterations(model, args.steps, args.warmup)
     log(f"timed region done: {el:.3f} s for {args.steps} iterations")
     env_steps = world * total * args.steps
@@ -475,6 +541,23 @@ def main():
         "update_ms": (el - t_roll) / args.steps * 1e3, "train_stats": {k: round(v, 6) for k, v in train_stats.items()},
     }
 
+    if world > 1:
+        # what a multi-GPU number is made of: per-collective HIP-event durations on rank 0 and every rank's own rollout / update split
+        import torch.distributed as td
+
+        mine = torch.tensor([model._bench_local[1] / args.steps * 1e3, (model._bench_local[0] - model._bench_local[1]) / args.steps * 1e3],
+                            dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(per_rank, mine)
+        timing = model.dp_timing_collect()
+        model.dp_timing = None
+        out["dp_timing"] = {
+            "backend": td.get_backend(), "grad_allreduce": timing["grad_allreduce_us"], "adv_sums_allreduce": timing["adv_allreduce_us"],
+            "grad_allreduces_per_iteration": updates // args.steps, "adv_sums_allreduces_per_iteration": args.n_epochs,
+            "per_rank_rollout_ms": [float(t[0]) for t in per_rank], "per_rank_update_ms": [float(t[1]) for t in per_rank],
+            "note": "durations are HIP events on rank 0's compute stream: from the end of the kernel that produced the tensor to the point where the "
+                    "reduced tensor is usable (collective + both stream hand-offs); update_ms - n * median is what the GPU spent in kernels",
+        }
     if rank == 0:
         roof = grad_kernel_roofline(model, args.task, args.hidden, args.mfma_dtype, batch)
         log(f"minibatch gradient kernel: median {roof['launch_us']:.1f} us (launch group of the call: {roof['launch_group_us']:.1f} us)")
@@ -501,6 +584,11 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     extras.append({"config": cfg["name"], "error": str(exc)})
             out["extra_configs"] = extras
+            try:
+                out["harness_train_task"] = harness_train_task(args, dev)
+                log(f"harness train_task: {out['harness_train_task']['train_task_seconds']:.3f} s vs direct {out['harness_train_task']['direct_ppo_seconds']:.3f} s")
+            except Exception as exc:  # noqa: BLE001
+                out["harness_train_task"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, batch)

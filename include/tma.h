@@ -223,11 +223,14 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
  * per-minibatch calls -- except on H = 64 policies at batch_size = 256 with T*N a multiple of it, where the epoch runs as ONE persistent
  * launch (csrc/tma_h64p.hip: weights in LDS, Adam moments in registers, eight workgroups of one XCD exchanging partial gradients through
  * the L2): same gradient sums and Adam arithmetic, the clip norm's f64 sum in another fixed order (parameters agree to the last bit or
- * two).  TMA_NO_PERSIST=1 in the environment selects the per-minibatch launches.  Should the kernel fail to place its workgroups it leaves
- * the parameters untouched and the next tma_ppo_pop_stats returns TMA_ERR_HIP. */
+ * two).  TMA_NO_PERSIST=1 in the environment selects the per-minibatch launches.  Should the kernel fail to place or synchronise its
+ * workgroups (it needs eight of them resident on one XCD) it commits nothing; this call notices (it waits for the persistent launch and
+ * reads one status word back), re-runs the epoch through the per-minibatch launches and counts the event (tma_ppo_persist_fallbacks). */
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
+/* How many epochs of tma_ppo_train_epoch_local on this workspace fell back from the persistent launch to per-minibatch launches.  Synchronises `stream`. */
+int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream);
 /* The minibatch order of the on-device permutation (the engine's stand-in for np.random.permutation in SB3's RolloutBuffer.get): writes, to
  * HOST memory, the env-major flat indices f = i*T + t of permuted rows [0, total) for (perm_seed, perm_epoch).  Minibatch m of size B is
  * rows [m*B, (m+1)*B).  Lets a caller reproduce or log the schedule; no GPU work. */

@@ -151,3 +151,10 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512 and d["value"] > 0
     assert d["value"] == pytest.approx(2 * 512 * 64 / (d["ms_per_step"] * 1e-3), rel=1e-6)  # whole-job env-steps of both ranks / max-over-ranks time
     assert "roofline" in d and "cpu_baseline" not in d and "extra_configs" not in d  # CPU baseline and extras are N = 1 legs
+    # what the first real multi-GPU run will be read by: per-collective timings and every rank's own rollout / update split
+    t = d["dp_timing"]
+    assert t["backend"] == "gloo" and len(t["per_rank_rollout_ms"]) == len(t["per_rank_update_ms"]) == 2
+    assert t["grad_allreduces_per_iteration"] == 10 * 32 and t["adv_sums_allreduces_per_iteration"] == 10
+    assert t["grad_allreduce"]["calls_timed"] == 64 and t["grad_allreduce"]["median_us"] > 0 and t["grad_allreduce"]["bytes"] == 9350 * 4
+    assert t["adv_sums_allreduce"]["calls_timed"] == 20 and t["adv_sums_allreduce"]["median_us"] > 0 and t["adv_sums_allreduce"]["bytes"] == 32 * 16
+    assert all(x > 0 for x in t["per_rank_rollout_ms"] + t["per_rank_update_ms"])

@@ -666,6 +666,42 @@ def test_persistent_epoch_kernel_equals_per_minibatch_launches(D, A, monkeypatch
         assert torch.allclose(snap0[k].cpu(), ref, rtol=0, atol=2e-5), (k, float((snap0[k].cpu() - ref).abs().max()))
 
 
+def test_persistent_epoch_kernel_falls_back_to_launches_when_it_cannot_run(monkeypatch, capfd):
+    """The persistent epoch kernel needs eight workgroups co-resident on one XCD.  When a launch cannot place / synchronise them it commits
+    nothing; tma_ppo_train_epoch_local then runs THAT epoch through the per-minibatch launches and counts the event -- training goes on with
+    the results of the launch path, bit for bit.  Failure is forced through the test hook TMA_PERSIST_FORCE_FAIL (the launch finds its abort
+    word set)."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(mode):
+        monkeypatch.delenv("TMA_NO_PERSIST", raising=False)
+        monkeypatch.delenv("TMA_PERSIST_FORCE_FAIL", raising=False)
+        if mode == "launches":
+            monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        elif mode == "forced_failure":
+            monkeypatch.setenv("TMA_PERSIST_FORCE_FAIL", "1")
+        env = make_vector_env("gridworld", n_envs=256, seed=4)
+        m = PPO("MlpPolicy", env, n_steps=64, batch_size=256, n_epochs=3, seed=4, policy_kwargs={"net_arch": [64, 64]})
+        m.collect_rollouts()
+        m.train()
+        st = m.pop_train_stats()  # (does not raise: the failure was handled where it happened)
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, m._adam_step, getattr(m, "persist_fallbacks", 0))
+        env.close()
+        return out
+
+    p_l, m_l, v_l, s_l, n_l, f_l = run("launches")
+    p_f, m_f, v_f, s_f, n_f, f_f = run("forced_failure")
+    p_p, m_p, v_p, s_p, n_p, f_p = run("persistent")
+    assert n_l == n_f == n_p == 3 * 64 and (f_l, f_f, f_p) == (0, 3, 0)  # every one of the three epochs fell back, and was counted
+    assert s_f["train/persist_fallbacks"] == 3.0 and "train/persist_fallbacks" not in s_p
+    assert torch.equal(p_f, p_l) and torch.equal(m_f, m_l) and torch.equal(v_f, v_l)  # the fallback IS the launch path
+    for k in ("train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/n_samples"):
+        assert s_f[k] == s_l[k], k
+    assert torch.allclose(p_p, p_l, rtol=0, atol=1e-6)  # and the persistent kernel itself still runs when it can
+    assert "per-minibatch launches instead" in capfd.readouterr().err  # said once on stderr
+
+
 def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
     """1024 optimizer steps in one persistent launch (GridWorld rollout of 1024 envs x 256 steps, the reference's batch_size = 256) against
     the same epoch as per-minibatch launches: the two paths differ only in the f64 summation order of the clip norm, so after a thousand

@@ -20,8 +20,9 @@
 // between CUs that share one L2, i.e. one XCD (MI355X_MICROARCH.md, inter-workgroup visibility).  The launch therefore carries more
 // workgroups than roles: each reads HW_REG_XCC_ID, the first claimer fixes the XCD and the first HP_NB workgroups ON THAT XCD take the
 // roles; the others exit.  Same-XCD placement is thus a checked property of the hardware ids, not an assumption about dispatch order.
-// Every spin is bounded: a role that cannot be filled (or a peer that never arrives) sets the abort word, the kernel leaves parameters
-// untouched and tma_ppo_pop_stats reports the failure.
+// Every spin is bounded: a role that cannot be filled (or a peer that never arrives) sets the abort word, the kernel commits nothing
+// (parameters, moments and statistics are only written behind the last step, and only while the abort word is clear) and
+// tma_ppo_train_epoch_local re-runs that epoch through the per-minibatch launches.
 #include "tma_h64_tile.h"
 
 #include <cstdlib>
@@ -33,7 +34,7 @@ constexpr int HP_GRID = 128;      // workgroups launched (16 per XCD under round
 constexpr int HP_SLAB_F = 6400;   // floats per slab / reduced-gradient array: >= one net's parameters for D <= 16, A <= 16 (6288)
 // byte offsets inside the persistent region (the workspace's partial-gradient slab area, which this path does not use otherwise)
 constexpr int HP_SYNC = 0;        // u32 words on lines of their own: [0] arrivals A policy net, [32] A value net, [96] claimed XCD + 1, [128] roles taken, [160] abort
-constexpr int HP_SQ = 1024;       // HP_NB granules of 16 bytes {step tag, -, f64 sum of squares of the block's reduced quarter}
+constexpr int HP_SQ = 1024;       // 2 x HP_NB granules of 16 bytes {step tag, -, f64 sum of squares of the block's reduced quarter}, by step parity
 constexpr int HP_TICKS = 2048;    // u64[16] phase ticks of role 0 (diagnostic, args.ticks)
 constexpr int HP_SLABS = 4096;
 constexpr int HP_G = HP_SLABS + HP_NB * HP_SLAB_F * 4;
@@ -382,14 +383,17 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
             if (lane == 0) {
                 const double sqb = ((red_sq[0] + red_sq[1]) + red_sq[2]) + red_sq[3];
                 const u32x2 h = __builtin_bit_cast(u32x2, sqb);
-                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(sqp) + 16 * role) = u32x4{tag, 0u, h[0], h[1]};
+                // granules are double-buffered by step parity: a block of the OTHER net may run one step ahead of a slow poller (sync A only
+                // couples the four blocks of one net) -- it then writes the other parity's granule and this step's stays intact until every
+                // block has passed sync B of the next step
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(sqp) + 16 * (role + HP_NB * (s & 1))) = u32x4{tag, 0u, h[0], h[1]};
             }
             HP_TICK(4);
             u32x4 gr;
             int spins = 0;
             bool fine = true;
             for (;;) {
-                gr = __builtin_amdgcn_raw_buffer_load_b128(r_sq, 16 * (lane & (HP_NB - 1)), 0, SC1);
+                gr = __builtin_amdgcn_raw_buffer_load_b128(r_sq, 16 * ((lane & (HP_NB - 1)) + HP_NB * (s & 1)), 0, SC1);
                 if (__builtin_amdgcn_ballot_w64(gr[0] != tag) == 0) break;
                 __builtin_amdgcn_s_sleep(1);
                 spins++;
@@ -481,6 +485,9 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
     }
 
     // ---- epilogue: statistics of this block's tiles; block 0 of each net writes the parameters, their derived copies and the moments ----
+    // (nothing is committed once any block gave up on a wait: the host re-runs the epoch through the per-minibatch launches from the
+    // untouched parameters -- tma_ppo_train_epoch_local)
+    if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     double stv[5] = {st.a, st.ent, st.kl, (double)st.clip, (double)st.n};
 #pragma unroll
     for (int qi = 0; qi < 5; qi++)
@@ -533,6 +540,10 @@ __global__ __launch_bounds__(256, 1) void ppo_epoch_h64p_kernel(EpochArgs a) {
     __syncthreads();
     const int role = role_s;
     if (role < 0 || role >= HP_NB) return;
+    if (__hip_atomic_load(sync + 160, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {  // abort word set before the launch (TMA_PERSIST_FORCE_FAIL)
+        if (threadIdx.x == 0) *a.err_out = 1;
+        return;
+    }
     if (role < 4) epoch_body<true, DT, NM>(a, role, smem);
     else epoch_body<false, DT, NM>(a, role - 4, smem);
     // a failed wait anywhere: record it for tma_ppo_pop_stats (parameters were left untouched by every block that saw the abort)
@@ -582,6 +593,8 @@ int tma_launch_epoch_h64p(float *params, const PLayout &L, const Rollout &R, con
     if (qp.P > HP_SLAB_F || nm > 3) return TMA_ERR_INVALID;
     const int smem = (IMG_FLOATS + 4 * a.rw) * 4;
     TMA_HIP(hipMemsetAsync(a.region, 0, HP_SLABS, s));
+    if (getenv("TMA_PERSIST_FORCE_FAIL") != nullptr)  // test hook: the launch finds its abort word set, commits nothing and reports the failure
+        TMA_HIP(hipMemsetAsync(a.region + HP_SYNC + 160 * 4, 1, 1, s));
     adam_table_kernel<<<dim3((unsigned)((a.n_mb + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<float2 *>(a.region + HP_TABLE), a.n_mb, first_step,
                                                                                    lr, beta1, beta2);
     TMA_LAUNCH_CHECK();

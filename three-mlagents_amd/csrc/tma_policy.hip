@@ -14,6 +14,7 @@
 #include "tma_ppo_types.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -2242,6 +2243,31 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     return TMA_OK;
 }
 
+// count a persistent-epoch fallback in the workspace (WS_PERSIST_ERR + 8: int64) and say so once per process
+__global__ void persist_count_kernel(long long *ctr) { *ctr += 1; }
+static int persist_fallback_note(char *ws, hipStream_t s) {
+    persist_count_kernel<<<dim3(1), dim3(1), 0, s>>>(reinterpret_cast<long long *>(ws + WS_PERSIST_ERR + 8));
+    static bool said = false;
+    if (!said) {
+        said = true;
+        fprintf(stderr, "libtma_hip: the persistent epoch kernel (csrc/tma_h64p.hip) could not place / synchronise its workgroups on one XCD; "
+                        "this epoch (and any later one that fails the same way) runs through the per-minibatch launches instead -- same results, "
+                        "lower optimizer-step rate.  TMA_NO_PERSIST=1 selects that path outright.\n");
+    }
+    return TMA_OK;
+}
+
+int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream) {
+    if (!workspace || !count_out) return fail(TMA_ERR_INVALID, "tma_ppo_persist_fallbacks: null argument");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, workspace) == hipSuccess) (void)hipSetDevice(attr.device);
+    long long v = 0;
+    TMA_HIP(hipMemcpyAsync(&v, static_cast<char *>(workspace) + WS_PERSIST_ERR + 8, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TMA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *count_out = (int64_t)v;
+    return TMA_OK;
+}
+
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch, int64_t batch_size,
                               const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr, double beta1,
                               double beta2, double eps, double max_grad_norm, void *workspace, void *stream) {
@@ -2266,9 +2292,20 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         const HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, hp->normalize_advantage ? 1 : 0, 0};
         int stride = (int)ceil_div(batch_size, 1024);
         if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
-        return tma_launch_epoch_h64p(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
-                                     reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size, exp_avg, exp_avg_sq,
-                                     first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
+        rc = tma_launch_epoch_h64p(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
+                                   reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size, exp_avg, exp_avg_sq,
+                                   first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
+        if (rc) return rc;
+        // The persistent kernel needs eight workgroups resident on one XCD at the same time; a concurrent kernel, a CU mask or a
+        // preempted wave can deny that, in which case it gives up on a bounded wait and commits NOTHING.  Check per epoch (one 4-byte
+        // read-back: the epoch is ~10^5 times longer) and, on failure, run this epoch through the per-minibatch launches below --
+        // training goes on, the event is counted (tma_ppo_persist_fallbacks) and reported once on stderr.
+        int persist_err = 0;
+        TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        TMA_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (!persist_err) return TMA_OK;
+        TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), (hipStream_t)stream));
+        persist_fallback_note(ws, (hipStream_t)stream);
     }
     int64_t step = first_step;
     for (int64_t start = 0; start < total; start += batch_size, step++) {

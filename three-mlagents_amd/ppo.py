@@ -196,6 +196,11 @@ class PPO:
         from . import dist as _dist
 
         self.world_size, self.rank = _dist.world_size(), _dist.rank()
+        # data-parallel diagnostics (bench.py `dp_timing`): set to a dict and train() records HIP events around every collective of its
+        # first `dp_timing_samples` minibatches / epochs -- {"grad_allreduce_us": [...], "adv_allreduce_us": [...]} after dp_timing_collect()
+        self.dp_timing: dict | None = None
+        self.dp_timing_samples = 64
+        self._dp_events: dict[str, list] = {"grad_allreduce_us": [], "adv_allreduce_us": []}
         if env is not None and _init_setup_model:
             self._setup_model()
 
@@ -335,7 +340,7 @@ class PPO:
                         _lib.check(L.tma_ppo_epoch_adv_sums(_lib.ptr(self.workspace), C.byref(self.policy.dims), self.batch_size, total,
                                                             _lib.ptr(self._adv_sums), direction, self._stream()))
                         if direction == 0:
-                            tdist.all_reduce(self._adv_sums)
+                            self._timed_all_reduce(self._adv_sums, "adv_allreduce_us")
             for start in range(0, total, self.batch_size):
                 count = min(self.batch_size, total - start)
                 mb = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, start, count, self.batch_size if can_prepare else 0,
@@ -343,9 +348,10 @@ class PPO:
                 _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
                                                     C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
                 if self.world_size > 1:
-                    import torch.distributed as tdist
-
-                    tdist.all_reduce(self.grad)  # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel
+                    # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel.  With the nccl backend the collective runs on the process
+                    # group's own stream: it waits for the gradient kernels through an event, the host returns as soon as it is queued (and
+                    # goes on to queue the optimizer launch, which waits for the collective through a second event) -- nothing blocks the host
+                    self._timed_all_reduce(self.grad, "grad_allreduce_us")
                 self._adam_step += 1
                 _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                                C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
@@ -353,12 +359,42 @@ class PPO:
             self._epoch_counter += 1
         self._n_updates += self.n_epochs
 
+    def _timed_all_reduce(self, tensor: torch.Tensor, key: str) -> None:
+        import torch.distributed as tdist
+
+        ev = self._dp_events[key] if self.dp_timing is not None and len(self._dp_events[key]) < self.dp_timing_samples else None
+        if ev is None:
+            tdist.all_reduce(tensor)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # on the compute stream, behind the kernel that produced `tensor`
+        tdist.all_reduce(tensor)
+        e1.record()  # behind the compute stream's wait for the collective
+        ev.append((e0, e1))
+
+    def dp_timing_collect(self) -> dict:
+        """Median / max duration (us, HIP events on the compute stream: producer kernel done -> reduced tensor usable) of the collectives
+        recorded since the last call.  Synchronises the device."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for key, evs in self._dp_events.items():
+            us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+            out[key] = {"calls_timed": len(us), "median_us": us[len(us) // 2] if us else None, "max_us": us[-1] if us else None,
+                        "bytes": int(self.grad.numel() * 4) if key.startswith("grad") else int(getattr(self, "_adv_sums", torch.empty(0)).numel() * 8)}
+            evs.clear()
+        return out
+
     def pop_train_stats(self) -> dict[str, float]:
         out = (C.c_double * 8)()
         _lib.check(_lib.lib().tma_ppo_pop_stats(_lib.ptr(self.workspace), out, self._stream()))
         n = max(out[5], 1.0)
+        fb = C.c_int64(0)
+        _lib.check(_lib.lib().tma_ppo_persist_fallbacks(_lib.ptr(self.workspace), C.byref(fb), self._stream()))
+        if fb.value:  # epochs the persistent batch-256 kernel handed back to the per-minibatch launches (include/tma.h)
+            self.persist_fallbacks = int(fb.value)
         return {"train/policy_gradient_loss": out[0] / n, "train/value_loss": out[1] / n, "train/entropy_loss": -out[2] / n,
-                "train/approx_kl": out[3] / n, "train/clip_fraction": out[4] / n, "train/grad_norm": out[6], "train/n_samples": out[5]}
+                "train/approx_kl": out[3] / n, "train/clip_fraction": out[4] / n, "train/grad_norm": out[6], "train/n_samples": out[5],
+                **({"train/persist_fallbacks": float(fb.value)} if fb.value else {})}
 
     # -- learn ----------------------------------------------------------------------------
     def learn(self, total_timesteps: int, callback=None, log_interval: int = 1, tb_log_name: str = "PPO", reset_num_timesteps: bool = True,
