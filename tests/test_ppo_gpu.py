@@ -330,6 +330,10 @@ def test_gae_flags_equals_sb3_layout():
                                                 # the 256-wide bf16 fused chunk (register-resident layer-2 weights, 32-env row groups; 200 = a ragged last group)
                                                 ("ball3d", 256, 200, "bf16"), ("gridworld", 256, 200, "bf16"), ("push", 256, 96, "bf16"), ("basic", 256, 40, "bf16"),
                                                 ("walljump", 256, 64, "bf16"), ("ball3d", 256, 200, "f32"),
+                                                # the f32 256-wide fused chunk (the reference's default net and dtype: policy net only, values / bootstrap in batches;
+                                                # 16-env tiles: 8 = the reference's own env count, 200 = a ragged last tile, 40 with Basic's inline resets)
+                                                ("basic", 256, 8, "f32"), ("basic", 256, 40, "f32"), ("gridworld", 256, 200, "f32"), ("push", 256, 72, "f32"),
+                                                ("walljump", 256, 64, "f32"), ("bicycle", 256, 40, "f32"), ("glider", 256, 40, "f32"),
                                                 # the Box-action fused chunk (Crawler shape: layer-1 fragments streamed, env state in LDS); 72 = a ragged group
                                                 ("crawler", 256, 72, "bf16"), ("crawler", 256, 40, "f32"),
                                                 # the float64-physics tasks of SURVEY 8f: fused on 64-wide and 256-wide bf16 nets (Bicycle, Glider), per-step otherwise

@@ -198,8 +198,8 @@ class EvalCallback(BaseCallback):
             self.evaluations_results.append(rewards)
             self.evaluations_length.append(lengths)
             self._dirty = True
-            self.last_mean_reward = float(np.mean(rewards))
             if fresh:
+                self.last_mean_reward = float(np.mean(rewards))
                 self._flush()
                 if self.verbose >= 1:
                     print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")

@@ -940,6 +940,228 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused rollout chunk for the reference's OWN default policy and dtype -- MLP(256, 256), f32 (backend/mlagents/training.py:363-365) -- on
+// the Discrete tasks with observations of up to 32 floats: ONE launch advances every env by n_steps vector steps.
+//
+// With f32 MFMA operands the layer-2 matrix of ONE net is 256 KB: it fits the registers of a 4-wave block (each wave keeps the 256 x 64
+// slice of its columns, 256 registers, for the whole launch) but two nets do not fit one CU.  So this kernel runs the POLICY net only
+// -- layer 1 -> barrier -> layer 2 -> barrier -> {head, softmax, sample, env step of the tile's 16 owner lanes, next observation into
+// LDS and into buffer slot t + 1} -> barrier -- and writes raw rewards plus the terminal observations of the chunk's steps; nothing in
+// a vector step needs the value net.  The caller then computes values[t0 .. t0 + n) with ONE batched tma_policy_values launch over the
+// chunk's n x N observation rows and the timeout bootstrap with ONE tma_policy_bootstrap launch over the chunk's terminal-observation slots
+// (rows are independent in both kernels: the same bits as one launch per step).  A block owns a tile of 16 envs: 4096 envs = 256 blocks,
+// one per CU; the reference's own 8-env runs are a single block.
+// Forward arithmetic = policy_fwd_wide_kernel<false, 0, 4, false> (same k order per accumulator, one sequential head chain), so actions
+// and log-probabilities are bit-identical to the per-step composition, which pays two launches, the observation's HBM round trip and
+// the whole weight matrix from L2 per vector step (28 us per step at 8 envs, 13 us at 4096).
+// ------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
+                                                                        float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,
+                                                                        uint32_t rng_step0, int det) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int M = 16, H = 256, NTW = 4, D = T::OBS, ldx = ((D + 3) & ~3) + 2, ld = H + 2, KS1 = (D + 3) >> 2, KS2 = H / 4;
+    static_assert(D <= 32 && T::NACT > 0, "fused f32 wide rollout: observations of up to 32 floats, Discrete actions");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int A = L.A, n_base = wave * 16 * NTW;
+    float *X = smem_f, *h1 = X + M * ldx, *h2 = h1 + M * ld;
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x * M;
+    // ---- this wave's weights: registers for the whole launch (the operands policy_fwd_wide_kernel fetches per step) ----
+    const Net P = pi_net(params, L);
+    float w1v[NTW][KS1], w2v[NTW][KS2], b1v[NTW], b2v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const int col = n_base + 16 * j + r16;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) {
+            const int k = 4 * ks + g;
+            const float w = P.W1t[(int64_t)(k < D ? k : 0) * H + col];
+            w1v[j][ks] = k < D ? w : 0.0f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) w2v[j][ks] = P.W2t[(int64_t)(4 * ks + g) * H + col];
+        b1v[j] = P.b1[col];
+        b2v[j] = P.b2[col];
+    }
+    float w3v[KS2];  // head operands of wave 0 (dense_head<1>: column r16 of W3t, zero beyond the A outputs)
+#pragma unroll
+    for (int ks = 0; ks < KS2; ks++) {
+        const float w = P.W3t[(int64_t)(4 * ks + g) * A + (r16 < A ? r16 : 0)];
+        w3v[ks] = r16 < A ? w : 0.0f;
+    }
+    const float b3v = r16 < A ? P.b3[r16] : 0.0f;
+    // ---- env state of the 16 owner lanes (wave 0, lanes r16 < 4: row = 4 g + r16, where the head's C layout leaves that row's action) ----
+    const int my_row = g * 4 + r16;
+    const int64_t i = row0 + my_row;
+    const bool owner = wave == 0 && r16 < 4 && i < N;
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    if (owner) {
+        T::unpack(v.st, N, i, s);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int e = threadIdx.x; e < M * ldx; e += blockDim.x) {  // observation tile of step t0 (columns >= D stay zero for the whole launch)
+        const int row = e / ldx, c = e - row * ldx;
+        X[e] = (row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f;
+    }
+    __syncthreads();
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        {  // layer 1: c = b1; c = mfma(X[:, 4 ks + g], W1t[4 ks + g][col], c) for ks = 0 .. KS1 - 1 -- one chain per column tile
+            f32x4 c[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) c[j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const float a = X[r16 * ldx + 4 * ks + g];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) c[j] = mfma16(a, w1v[j][ks], c[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h1[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c[j][r]);
+        }
+        __syncthreads();
+        {  // layer 2 (the A operand of a k-step serves the four column tiles: a quarter of the LDS reads of a tile-by-tile walk)
+            f32x4 c[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) c[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                const float a = h1[r16 * ld + 4 * ks + g];
+#pragma unroll
+                for (int j = 0; j < NTW; j++) c[j] = mfma16(a, w2v[j][ks], c[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c[j][r]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 acc = f32x4{b3v, b3v, b3v, b3v};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) acc = mfma16(h2[r16 * ld + 4 * ks + g], w3v[ks], acc);
+            int my_act = 0;
+            float my_lp = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t row = row0 + g * 4 + r;
+                const bool colok = r16 < A;
+                const float x = colok ? acc[r] : -INFINITY;
+                const float m = gmax16(x);
+                const float e = colok ? expf(x - m) : 0.0f;
+                const float sm = gsum16(e);
+                const float lse = m + logf(sm);
+                const float lp = x - lse;
+                int act;
+                if (det) {  // deterministic evaluation: first maximal logit, as policy_fwd_wide_kernel
+                    act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
+                } else {
+                    const float c = gscan16(e / sm);
+                    const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
+                    const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
+                    act = min((int)cnt, A - 1);
+                }
+                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
+                if (r16 == r) my_act = act, my_lp = lpa;
+            }
+            if (owner) {
+                const int64_t off = (int64_t)t * N + i;
+                b.actions[off] = my_act;
+                b.log_probs[off] = my_lp;
+                double r;
+                bool done;
+                T::step(s, my_act, nullptr, r, done);
+                const int steps = T::steps(s);
+                bool te, tr;
+                if constexpr (T::NATIVE_TRUNC_RULE) {  // backend/mlagents/envs.py:76
+                    te = done;
+                    tr = (steps >= T::MAXSTEPS) && !te;
+                } else {  // adapter rule, backend/mlagents/envs.py:139-145
+                    const bool hit = steps >= T::MAXSTEPS;
+                    te = done && !hit;
+                    tr = hit;
+                }
+                er += r;
+                b.rewards[off] = (float)r;  // (the timeout bootstrap is added by the caller's batched tma_policy_bootstrap)
+                b.terminated[off] = (uint8_t)te;
+                b.truncated[off] = (uint8_t)tr;
+                float o[D];
+                if (te || tr) {
+                    if (tr) {  // terminal observation of a timed-out row: slot (t - t0) of the chunk
+                        T::obs(s, o);
+                        float *dst = term_obs + ((int64_t)k * N + i) * D;
+#pragma unroll
+                        for (int c = 0; c < D; c++) dst[c] = o[c];
+                    }
+                    sret += er, slen += (double)steps, scnt += 1.0;
+                    log_episode(v, i, er, steps);
+                    er = 0.0;
+                    ce += 1;
+                    if constexpr (T::USES_MT) {
+                        uint32_t rec[T::RW > 0 ? T::RW : 1];
+                        const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
+#pragma unroll
+                        for (int q = 0; q < T::RW; q++) rec[q] = slot[(int64_t)q * N];
+                        T::from_rec(rec, s);
+                    } else {
+                        T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+                    }
+                }
+                T::obs(s, o);
+                float *dst = b.obs + ((int64_t)(t + 1) * N + i) * D;
+#pragma unroll
+                for (int c = 0; c < D; c++) dst[c] = o[c];
+#pragma unroll
+                for (int c = 0; c < D; c++) X[my_row * ldx + c] = o[c];  // (every read of this step's tile is behind the two barriers above)
+            }
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        T::pack(v.st, N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sret += __shfl_down(sret, o, 64);
+            slen += __shfl_down(slen, o, 64);
+            scnt += __shfl_down(scnt, o, 64);
+        }
+        if (lane == 0 && scnt > 0.0) {
+            double *slot = v.stats + (row0 >> 8) * 3;
+            atomicAdd(slot + 0, sret);
+            atomicAdd(slot + 1, slen);
+            atomicAdd(slot + 2, scnt);
+        }
+    }
+}
+
+template <class T>
+static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n, uint32_t rng_seed,
+                                 uint32_t rng_step0, int det, hipStream_t s) {
+    if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
+        auto k = rollout_chunk_wide_f32_kernel<T>;
+        constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
+        const int smem = 16 * (ldx + 2 * 258) * 4;
+        k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    } else {
+        return fail(TMA_ERR_INVALID, "no fused f32 wide rollout for this task");
+    }
+}
+
 template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
                              uint32_t rng_step0, float gamma, int det, hipStream_t s) {
@@ -1049,6 +1271,41 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
         if (compute_last_values && t_end == T) {
             if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
             return tma_policy_values(params, d, b->obs + (int64_t)T * N * d->obs_dim, N, b->last_values, stream);
+        }
+        return TMA_OK;
+    }
+    // the reference's default MLP(256, 256) in f32 on the Discrete tasks (observations of up to 32 floats): policy-only fused chunk + ONE
+    // batched value launch + ONE batched bootstrap launch per chunk of up to terminal_obs_slots steps
+    const bool fused_wide_f32 = !no_wide_fused && !L.bf16 && L.img_pi < 0 && L.H == 256 && env->is_reset && fused_disc &&
+                                d->obs_dim == tma_task_obs_dim(env->task);
+    if (fused_wide_f32) {
+        TMA_HIP(hipSetDevice(env->device));
+        ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
+        const int K = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
+        const int D = d->obs_dim;
+        int t = t_begin;
+        while (t < t_end) {
+            int left = 0;
+            int rc = tma_env_steps_until_refill(env, &left);
+            if (rc) return rc;
+            int n = left < (t_end - t) ? left : (t_end - t);
+            if (n > K) n = K;  // one terminal-observation slot per step of the chunk
+            rc = dispatch_task(env->task, [&](auto task) {
+                using TT = decltype(task);
+                return launch_chunk_wide_f32<TT>(env, params, L, cp, b->terminal_obs, t, n, rng_seed, rng_step0, det, (hipStream_t)stream);
+            });
+            if (rc) return rc;
+            rc = tma_policy_values(params, d, b->obs + (int64_t)t * N * D, (int64_t)n * N, b->values + (int64_t)t * N, stream);
+            if (rc) return rc;
+            rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, (int64_t)n * N, gamma, b->rewards + (int64_t)t * N, stream);
+            if (rc) return rc;
+            rc = tma_env_internal_after_steps(env, n, stream);
+            if (rc) return rc;
+            t += n;
+        }
+        if (compute_last_values && t_end == T) {
+            if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
+            return tma_policy_values(params, d, b->obs + (int64_t)T * N * D, N, b->last_values, stream);
         }
         return TMA_OK;
     }

@@ -222,8 +222,9 @@ class PPO:
         env.seed(self.seed)  # BaseAlgorithm.set_random_seed -> env.seed(seed): env i gets seed + i
         T, N, D, dev = self.n_steps, self.n_envs, eng.obs_dim, self.device
         f32 = torch.float32
-        # terminal-observation slots: the non-fused rollout path bootstraps this many steps per launch (include/tma.h)
-        self._tobs_slots = max(1, min(16, T, (256 << 20) // max(1, N * D * 4)))
+        # terminal-observation slots: the rollout paths that run the value net in batches (per-step launches; the fused f32 256-wide chunk,
+        # which carries the policy net only) bootstrap this many steps per launch (include/tma.h) -- up to one reset-ring window
+        self._tobs_slots = max(1, min(128, T, (256 << 20) // max(1, N * D * 4)))
         self.buf = dict(
             obs=torch.zeros((T + 1, N, D), dtype=f32, device=dev),
             actions=torch.zeros((T, N, A), dtype=f32, device=dev) if cont else torch.zeros((T, N), dtype=torch.int32, device=dev),
@@ -567,7 +568,7 @@ class PPO:
         opt = sb3_format.adam_state_dict(order, self.policy.named_from_flat(self.exp_avg) if has_moments else {},
                                          self.policy.named_from_flat(self.exp_avg_sq) if has_moments else {}, self._adam_step if has_moments else 0,
                                          self.learning_rate)
-        with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+        with zipfile.ZipFile(path, "w") as z:  # stored, not deflated: what SB3's save_to_zip_file writes (and EvalCallback saves a zip per new best)
             z.writestr("data", json.dumps(self._data(), indent=2, default=str))
             z.writestr("policy.pth", _pth(sd))
             z.writestr("policy.optimizer.pth", _pth(opt))
