@@ -370,7 +370,7 @@ def test_native_rollout_equals_stepwise_composition(task, hidden, N, mfma):
         obs = out["obs"][0].clone()
         assert torch.equal(obs, b["obs"][t + 1])
     assert torch.equal(model.policy.predict_values(obs), b["last_values"])
-    if task in ("gridworld", "ball3d", "walljump", "basic"):
+    if task in ("gridworld", "ball3d", "walljump", "basic") and N >= 40:
         assert int(b["truncated"].sum()) > 0  # the timeout-bootstrap branch was exercised
     # GAE of the rollout vs the oracle on the same planes
     done = (b["terminated"] | b["truncated"]).float().cpu().numpy()

@@ -37,7 +37,7 @@ class _EvalBuffers:
         self.actions = torch.zeros((K, N, policy.act_dim), dtype=f32, device=dev) if cont else torch.zeros((K, N), dtype=torch.int32, device=dev)
         self.rewards, self.values, self.log_probs = (torch.zeros((K, N), dtype=f32, device=dev) for _ in range(3))
         self.terminated, self.truncated = (torch.zeros((K, N), dtype=torch.uint8, device=dev) for _ in range(2))
-        self.tobs_slots = max(1, min(128, K, (64 << 20) // max(1, N * D * 4)))  # (chunk kernels without a value net need a slot per step)
+        self.tobs_slots = max(1, min(max(128, eng.ring_depth), K, (64 << 20) // max(1, N * D * 4)))  # (chunk kernels without a value net need a slot per step)
         self.terminal_obs = torch.zeros((self.tobs_slots, N, D), dtype=f32, device=dev)
         self.last_values = torch.zeros((N,), dtype=f32, device=dev)
         self.rb = _lib.RolloutBuffers(_lib.ptr(self.obs), _lib.ptr(self.actions), _lib.ptr(self.rewards), _lib.ptr(self.values), _lib.ptr(self.log_probs),

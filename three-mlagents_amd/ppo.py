@@ -224,7 +224,7 @@ class PPO:
         f32 = torch.float32
         # terminal-observation slots: the rollout paths that run the value net in batches (per-step launches; the fused f32 256-wide chunk,
         # which carries the policy net only) bootstrap this many steps per launch (include/tma.h) -- up to one reset-ring window
-        self._tobs_slots = max(1, min(128, T, (256 << 20) // max(1, N * D * 4)))
+        self._tobs_slots = max(1, min(max(128, eng.ring_depth), T, (256 << 20) // max(1, N * D * 4)))
         self.buf = dict(
             obs=torch.zeros((T + 1, N, D), dtype=f32, device=dev),
             actions=torch.zeros((T, N, A), dtype=f32, device=dev) if cont else torch.zeros((T, N), dtype=torch.int32, device=dev),

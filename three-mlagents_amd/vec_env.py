@@ -47,7 +47,8 @@ class HipEnvEngine:
         if ring_depth is None:
             # A refill launch is bound by the serial MT19937 seeding chain of its few thousand lanes, not by their number: a deeper
             # ring means proportionally fewer refill (and rollout-chunk) launches at the same cost each.  Memory = N * depth records.
-            ring_depth = 128 if num_envs <= 16384 else (64 if num_envs <= 131072 else 32)
+            # (a handful of envs -- the reference's own 1 .. 8: every chunk boundary is a few launches for almost no work, so the window is wider)
+            ring_depth = 512 if num_envs <= 64 else (128 if num_envs <= 16384 else (64 if num_envs <= 131072 else 32))
         self.task = _lib.task_id(task)  # KeyError for unknown tasks
         L = _lib.lib()
         self.num_envs = int(num_envs)
