@@ -358,6 +358,96 @@ __device__ __forceinline__ void h64t_tile(const float *wimg, float *slotA, float
     H64_TICK(9);
 }
 
+// ------------------------------------------------------------------------------------------
+// The FORWARD half of h64t_tile on its own (round 3): policy_fwd_h64_kernel and the fused H = 64 rollout chunks run the same transposed
+// register chain as the update kernels -- observation features straight from registers as the B operand, weights from the LDS image as
+// the A operand, tanh under the next k-step's MFMAs, no activation ever written to LDS -- instead of the LDS round-trip chain
+// (dense64_tanh_lds: every layer's output stored and read back as the next A operand, 3.6 us per vector step at 4096 envs).
+// Same instructions in the same order as the forward part of h64t_tile, so the log-probabilities / values a rollout stores are bit for
+// bit what the first epoch of the update recomputes from the same parameters.
+// wimg: forward part of the net's image ([0, IMG_FWD_FLOATS)); b1 / b2 / b3: its biases.  xb[ks] = observation feature 4 ks + g of sample
+// lane & 15 (0 beyond D).  Result: register r of lane group g holds head output g + 4 r of sample lane & 15 as o0[r] + o1[r].
+template <int KS1C>
+__device__ __forceinline__ void h64t_forward(const float *wimg, const float *b1, const float *b2, const float *b3, const float (&xb)[KS1C], int KS1,
+                                             f32x4 &o0, f32x4 &o1, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) h1[mt] = *reinterpret_cast<const f32x4 *>(b1 + 16 * mt + 4 * g);
+#pragma unroll
+    for (int ks = 0; ks < KS1C; ks++) {
+        if (ks < KS1) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + IMG_W1 + (4 * ks + g) * 64 + r16 * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(w[mt], xb[ks], h1[mt]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) h2[mt] = *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g);
+    chain64_act(wimg + IMG_W2F + 4 * g * 64 + r16 * 4, h1, h2, [&](int j, int r) { return tma_tanh(h1[j][r]); }, [](int) {});
+    const int acol = (r16 >> 2) + 4 * (r16 & 3);
+    o0 = f32x4{b3[g], b3[g + 4], b3[g + 8], b3[g + 12]}, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float w = wimg[IMG_W3F + (16 * j + 4 * g + r) * 16 + acol];
+            h2[j][r] = tma_tanh(h2[j][r]);
+            if ((4 * j + r) & 1) o1 = mfma16(w, h2[j][r], o1);
+            else o0 = mfma16(w, h2[j][r], o0);
+        }
+}
+
+__device__ __forceinline__ float xg_min(float v) { return xg_reduce(v, [](float a, float b) { return fminf(a, b); }); }
+
+// Categorical action and its log-probability from the head outputs of h64t_forward (output a = g + 4 r in register r of lane group g).
+// Sampling is the Gumbel-max form of the categorical draw: action = argmax_a (logit_a + G_a), G_a = -log(-log u_a), u_a from the counter
+// stream (seed, global env, step, a) -- exactly Categorical(softmax(logits)), and the noise does not depend on the logits, so it is formed
+// under the head's MFMAs and the action needs two cross-lane-group reductions instead of a prefix scan over the probabilities.
+// deterministic: the first maximal logit (SB3 predict(deterministic=True)).  Softmax / log-prob arithmetic = h64t_loss's.
+// Every lane of the sample's four lane groups returns the same (action, log-prob).
+__device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A, uint32_t rng_seed, uint32_t global_env, uint32_t rng_step, int det,
+                                         int &act_out, float &lp_out, int lane) {
+    const int g = lane >> 4;
+    float x[4], key[4];
+    bool ok[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        ok[r] = g + 4 * r < A;
+        x[r] = ok[r] ? o0[r] + o1[r] : -INFINITY;
+        m = fmaxf(m, x[r]);
+    }
+    m = xg_max(m);
+    float km = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float noise = 0.0f;
+        if (!det) {
+            const uint32_t h = mix32(rng_seed ^ (0x9E3779B9u * (uint32_t)(g + 4 * r + 1)), global_env, rng_step);
+            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+            noise = -__logf(-__logf(u));
+        }
+        key[r] = ok[r] ? x[r] + noise : -INFINITY;
+        km = fmaxf(km, key[r]);
+    }
+    km = xg_max(km);
+    float first = 99.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) first = fminf(first, (ok[r] && key[r] == km) ? (float)(g + 4 * r) : 99.0f);
+    const int act = (int)xg_min(first);
+    float ssum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) ssum += ok[r] ? __expf(x[r] - m) : 0.0f;
+    ssum = xg_sum(ssum);
+    const float lse = m + __logf(ssum);
+    float lpa = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) lpa += (g + 4 * r == act) ? (ok[r] ? x[r] - lse : 0.0f) : 0.0f;
+    act_out = act;
+    lp_out = xg_sum(lpa);
+}
+
 // accumulator register idx (0..104) of a NetAcc, and the flat parameter index it holds in lane `lane`
 constexpr int FL_HALF = 56, FL_REGS = 105;
 __device__ __forceinline__ float acc_reg(const NetAcc &a, int idx) {  // idx is a compile-time constant after unrolling

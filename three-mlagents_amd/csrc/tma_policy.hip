@@ -11,7 +11,7 @@
 //   clip_grad_norm_(max_grad_norm) + torch.optim.Adam(eps=1e-5).step()            -> grad_sumsq_kernel + adam_kernel
 // Formulas: SURVEY.md Appendix C.3 / C.5.  "Parity unpinned" at this boundary (SB3 is not importable here); checked
 // against a torch-CPU autograd restatement in tests/.
-#include "tma_ppo_types.h"
+#include "tma_h64_tile.h"
 
 #include <cmath>
 #include <cstdio>
@@ -1527,66 +1527,44 @@ __global__ __launch_bounds__(256) void policy_fwd_h64_kernel(const float *__rest
                                                              int32_t *__restrict__ actions_out, float *__restrict__ values_out,
                                                              float *__restrict__ logp_out, const float *__restrict__ boot_obs,
                                                              const uint8_t *__restrict__ boot_trunc, float gamma, float *__restrict__ boot_rewards) {
+    // (round 3) the transposed register chain of the update kernels (h64t_forward, tma_h64_tile.h): lane (g, s) works for row s of its tile,
+    // reads that row's observation features 4 ks + g straight from global memory into MFMA B operands, and nothing but the weight images
+    // lives in LDS.  Same instructions as the forward half of the update's tile: a rollout's log-probabilities and values are bit for bit
+    // what the first update epoch recomputes.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int D = L.D, A = L.A;
-    const int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
+    const int D = L.D, A = L.A, KS1 = (D + 3) >> 2;
     float *vimg = smem, *pimg = smem + FWD_IMG;
-    const int img_floats = (MODE == 0) ? 2 * FWD_IMG : FWD_IMG;
-    const int per_wave = 16 * (ldx + 2 * ld) + 32;
-    float *X = smem + img_floats + (int64_t)wave * per_wave;
-    float *h1 = X + 16 * ldx, *h2 = h1 + 16 * ld;
-    int64_t *row_off = reinterpret_cast<int64_t *>(h2 + 16 * ld);
     stage_fwd_image(params + L.img_vf, vimg);
     if constexpr (MODE == 0) stage_fwd_image(params + L.img_pi, pimg);
     __syncthreads();
     const int64_t n_tiles = (n + 15) >> 4;
+    auto features = [&](const float *src, int64_t row, bool ok, float (&xb)[4]) {  // (clamped addresses, masked values: no load sits behind a branch)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int c = 4 * ks + g;
+            const float x = src[(ok ? row : 0) * D + (c < D ? c : 0)];
+            xb[ks] = (ok && c < D) ? x : 0.0f;
+        }
+    };
     if constexpr (MODE != 2) {
         for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
-            const int64_t row0 = tile << 4;
-            if (lane < 16) row_off[lane] = (row0 + lane < n) ? row0 + lane : -1;
-            load_obs_tile(obs, row_off, D, X, ldx, lane);
-            const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
-            if constexpr (MODE == 1) {
-                if (r16 == 0)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int64_t row = row0 + g * 4 + r;
-                        if (row < n) values_out[row] = vacc[r];
-                    }
-            } else {
-                dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, h1, ld, lane);
-                dense64_tanh_lds<16>(h1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
-                const f32x4 acc = dense64_head_lds(h2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int64_t row = row0 + g * 4 + r;
-                    const bool colok = r16 < A;
-                    const float x = colok ? acc[r] : -INFINITY;
-                    const float m = gmax16(x);
-                    const float e = colok ? expf(x - m) : 0.0f;
-                    const float s = gsum16(e);
-                    const float lse = m + logf(s);
-                    const float lp = x - lse;
-                    int act;
-                    if (deterministic) {
-                        float mn = (colok && x == m) ? (float)r16 : 99.0f;
-                        mn = gmin16(mn);
-                        act = (int)mn;
-                    } else {
-                        const float c = gscan16(e / s);
-                        const float u = uniform01(mix32(rng_seed, env_offset + (uint32_t)row, rng_step));
-                        const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-                        act = min((int)cnt, A - 1);
-                    }
-                    const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                    const float vrow = gfirst_quad(vacc[r]);
-                    if (r16 == r && row < n) {
-                        actions_out[row] = act;
-                        logp_out[row] = lpa;
-                        values_out[row] = vrow;
-                    }
+            const int64_t row = (tile << 4) + r16;
+            const bool ok = row < n;
+            float xb[4];
+            features(obs, row, ok, xb);
+            f32x4 o0, o1;
+            h64t_forward<4>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+            if (ok && g == 0) values_out[row] = o0[0] + o1[0];
+            if constexpr (MODE == 0) {
+                h64t_forward<4>(pimg, pimg + IMG_FWD_FLOATS, pimg + IMG_FWD_FLOATS + 64, pimg + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+                int act;
+                float lp;
+                h64t_act(o0, o1, A, rng_seed, env_offset + (uint32_t)row, rng_step, deterministic, act, lp, lane);
+                if (ok && g == 0) {
+                    actions_out[row] = act;
+                    logp_out[row] = lp;
                 }
             }
         }
@@ -1594,22 +1572,17 @@ __global__ __launch_bounds__(256) void policy_fwd_h64_kernel(const float *__rest
     if constexpr (MODE != 1) {
         if (boot_trunc != nullptr) {
             for (int64_t tile = (int64_t)blockIdx.x * wpb + wave; tile < n_tiles; tile += (int64_t)gridDim.x * wpb) {
-                const int64_t row0 = tile << 4;
-                const int64_t rr = row0 + r16;
-                const bool tflag = (rr < n) && boot_trunc[rr] != 0;
+                const int64_t row = (tile << 4) + r16;
+                const bool tflag = (row < n) && boot_trunc[row < n ? row : 0] != 0;
                 if (__ballot(tflag) == 0ull) continue;
-                if (lane < 16) row_off[lane] = (row0 + lane < n) ? row0 + lane : -1;
-                load_obs_tile(boot_obs, row_off, D, X, ldx, lane);
-                const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
-                if (r16 == 0)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int64_t row = row0 + g * 4 + r;
-                        if (row < n && boot_trunc[row]) {
-                            const float gv = gamma * vacc[r];
-                            boot_rewards[row] = boot_rewards[row] + gv;
-                        }
-                    }
+                float xb[4];
+                features(boot_obs, row, row < n, xb);
+                f32x4 o0, o1;
+                h64t_forward<4>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+                if (tflag && g == 0) {
+                    const float gv = gamma * (o0[0] + o1[0]);
+                    boot_rewards[row] = boot_rewards[row] + gv;
+                }
             }
         }
     }
@@ -1621,8 +1594,7 @@ static int launch_fwd_h64(const float *params, const PLayout &L, const float *ob
                           float *boot_rewards, hipStream_t s) {
     const int64_t tiles = ceil_div(n, 16);
     const int wpb = tiles >= 512 ? 4 : (tiles >= 64 ? 2 : 1);
-    const int ldx = ((L.D + 3) & ~3) + 2;
-    const int smem = (((MODE == 0) ? 2 : 1) * FWD_IMG + wpb * (16 * (ldx + 2 * 66) + 32)) * 4;
+    const int smem = ((MODE == 0) ? 2 : 1) * FWD_IMG * 4;
     int64_t blocks = ceil_div(tiles, wpb);
     if (blocks > 2048) blocks = 2048;
     auto k = policy_fwd_h64_kernel<MODE>;

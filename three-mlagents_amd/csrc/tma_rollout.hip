@@ -6,7 +6,7 @@
 // and, after the last step, last_values = V(obs[T]).  Reference call path: model.learn() at
 // /root/reference/backend/mlagents/training.py:166-170 -> SB3 collect_rollouts (SURVEY.md §3.1 hot loop A, App. C.6).
 #include "tma_internal.h"
-#include "tma_ppo_types.h"
+#include "tma_h64_tile.h"
 
 #include <cstdlib>
 
@@ -32,20 +32,65 @@ struct ChunkPtrs {
     uint8_t *terminated, *truncated;
 };
 
+// (round 3) Both variants run the forward passes as the TRANSPOSED REGISTER CHAIN of the update kernels (h64t_forward, tma_h64_tile.h):
+// lane (g, s) works for env s of the tile, the observation features go straight from LDS words into MFMA B operands, no activation is
+// written to LDS, the action comes out of two cross-lane-group reductions (h64t_act) in every lane of the env's column, and the 16 lanes
+// of lane group 0 own the env states.  The LDS round-trip chain this replaces cost 3.6 us per vector step at 4096 envs.
+template <class T>
+__device__ __forceinline__ void chunk_env_step(const EnvView &v, const ChunkPtrs &b, typename T::S &s, double &er, uint32_t &ce, int64_t N, int64_t i,
+                                               int t, int act, float lp, float *Xn, float *XT, float &rew32, bool &tr_out, bool write_reward_if_trunc,
+                                               double &sret, double &slen, double &scnt) {
+    constexpr int D = T::OBS;
+    const int64_t off = (int64_t)t * N + i;
+    b.actions[off] = act;
+    b.log_probs[off] = lp;
+    double r;
+    bool done;
+    T::step(s, act, nullptr, r, done);
+    const int steps = T::steps(s);
+    const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+    const bool te = done && !hit, tr = hit;
+    er += r;
+    rew32 = (float)r;
+    b.terminated[off] = (uint8_t)te;
+    b.truncated[off] = (uint8_t)tr;
+    float o[D];
+    if (te || tr) {
+        if (tr) {
+            T::obs(s, o);
+#pragma unroll
+            for (int c = 0; c < D; c++) XT[c] = o[c];
+        }
+        sret += er, slen += (double)steps, scnt += 1.0;
+        log_episode(v, i, er, steps);
+        er = 0.0;
+        ce += 1;
+        uint32_t rec[T::RW];
+        const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
+#pragma unroll
+        for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * N];
+        T::from_rec(rec, s);
+    }
+    T::obs(s, o);
+    store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
+#pragma unroll
+    for (int c = 0; c < D; c++) Xn[c] = o[c];
+    if (!tr || write_reward_if_trunc) b.rewards[off] = rew32;
+    tr_out = tr;
+}
+
+constexpr int CH_LDX = 17;  // observation tiles [16 envs][17]: the odd row stride spreads the 16 rows of a feature column over the banks
+
 template <class T>
 __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    constexpr int D = T::OBS;
+    constexpr int D = T::OBS, KS1 = (D + 3) >> 2;
     const int A = L.A;
-    constexpr int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
     float *vimg = smem, *pimg = smem + FWD_IMG;
-    constexpr int per_wave = 16 * (2 * ldx + 2 * ld) + 32;
-    float *X = smem + 2 * FWD_IMG + (int64_t)wave * per_wave;
-    float *XT = X + 16 * ldx, *h1 = XT + 16 * ldx, *h2 = h1 + 16 * ld;
-    int64_t *row_off = reinterpret_cast<int64_t *>(h2 + 16 * ld);
+    float *X = smem + 2 * FWD_IMG + (int64_t)wave * (2 * 16 * CH_LDX), *XT = X + 16 * CH_LDX;  // this wave's observation / terminal-observation tiles
     stage_fwd_image(params + L.img_vf, vimg);
     stage_fwd_image(params + L.img_pi, pimg);
     __syncthreads();
@@ -53,9 +98,8 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
     const int64_t tile = (int64_t)blockIdx.x * wpb + wave;
     if (tile * 16 >= N) return;
     const int64_t row0 = tile << 4;
-    const int my_row = g * 4 + r16;  // meaningful for owner lanes (r16 < 4)
-    const int64_t i = row0 + my_row;
-    const bool active = (r16 < 4) && (i < N);
+    const int64_t i = row0 + r16;           // the env this lane's column stands for
+    const bool active = g == 0 && i < N;    // ... and the lane that owns its state and writes its outputs
     typename T::S s;
     double er = 0.0;
     uint32_t ce = 0;
@@ -64,92 +108,38 @@ __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const
         er = v.ep_ret[i];
         ce = v.cur_ep[i];
     }
-    if (lane < 16) row_off[lane] = (row0 + lane < N) ? (int64_t)t0 * N + row0 + lane : -1;
-    load_obs_tile(b.obs, row_off, D, X, ldx, lane);
-    for (int e = lane; e < 16 * ldx; e += 64) XT[e] = 0.0f;
+    for (int e = lane; e < 16 * CH_LDX; e += 64) {
+        const int row = e / CH_LDX, c = e - row * CH_LDX;
+        X[e] = (row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f;
+        XT[e] = 0.0f;
+    }
     double sret = 0.0, slen = 0.0, scnt = 0.0;
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k;
-        const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, h1, h2, ld, lane);
-        dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, h1, ld, lane);
-        dense64_tanh_lds<16>(h1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, h2, ld, lane);
-        const f32x4 acc = dense64_head_lds(h2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
-        int my_act = 0;
-        float my_lp = 0.0f, my_v = 0.0f;
+        float xb[KS1];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int64_t row = row0 + g * 4 + r;
-            const bool colok = r16 < A;
-            const float x = colok ? acc[r] : -INFINITY;
-            const float m = gmax16(x);
-            const float e = colok ? expf(x - m) : 0.0f;
-            const float sum = gsum16(e);
-            const float lse = m + logf(sum);
-            const float lp = x - lse;
-            int act;
-            if (det) {  // deterministic evaluation (SB3 predict(deterministic=True)): first maximal logit, as policy_fwd_h64_kernel
-                act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
-            } else {
-                const float c = gscan16(e / sum);
-                const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
-                const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-                act = min((int)cnt, A - 1);
-            }
-            const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-            const float vrow = gfirst_quad(vacc[r]);
-            if (r16 == r) my_act = act, my_lp = lpa, my_v = vrow;
-        }
+        for (int ks = 0; ks < KS1; ks++) xb[ks] = X[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
+        f32x4 o0, o1;
+        h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+        const float value = o0[0] + o1[0];
+        h64t_forward<KS1>(pimg, pimg + IMG_FWD_FLOATS, pimg + IMG_FWD_FLOATS + 64, pimg + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+        int act;
+        float lp;
+        h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
         bool tr_flag = false;
         float rew32 = 0.0f;
-        int64_t off = 0;
         if (active) {
-            off = (int64_t)t * N + i;
-            b.actions[off] = my_act;
-            b.values[off] = my_v;
-            b.log_probs[off] = my_lp;
-            double r;
-            bool done;
-            T::step(s, my_act, nullptr, r, done);
-            const int steps = T::steps(s);
-            const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
-            const bool te = done && !hit, tr = hit;
-            er += r;
-            rew32 = (float)r;
-            b.terminated[off] = (uint8_t)te;
-            b.truncated[off] = (uint8_t)tr;
-            float o[D];
-            if (te || tr) {
-                if (tr) {
-                    T::obs(s, o);
-#pragma unroll
-                    for (int c = 0; c < D; c++) XT[my_row * ldx + c] = o[c];
-                }
-                sret += er, slen += (double)steps, scnt += 1.0;
-                log_episode(v, i, er, steps);
-                er = 0.0;
-                ce += 1;
-                uint32_t rec[T::RW];
-                const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
-#pragma unroll
-                for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * N];
-                T::from_rec(rec, s);
-            }
-            T::obs(s, o);
-            store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
-#pragma unroll
-            for (int c = 0; c < D; c++) X[my_row * ldx + c] = o[c];
-            b.rewards[off] = rew32;
-            tr_flag = tr;
+            b.values[(int64_t)t * N + i] = value;
+            chunk_env_step<T>(v, b, s, er, ce, N, i, t, act, lp, X + r16 * CH_LDX, XT + r16 * CH_LDX, rew32, tr_flag, true, sret, slen, scnt);
         }
         if (__ballot(tr_flag) != 0ull) {  // timeout bootstrap: rewards += gamma * V(terminal_obs) where truncated
-            const f32x4 vt = value_tile_lds(vimg, XT, ldx, KS1, h1, h2, ld, lane);
+            float xt[KS1];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float vr = gfirst_quad(vt[r]);
-                if (r16 == r && tr_flag) {
-                    const float gv = gamma * vr;
-                    b.rewards[off] = rew32 + gv;
-                }
+            for (int ks = 0; ks < KS1; ks++) xt[ks] = XT[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];
+            h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xt, KS1, o0, o1, lane);
+            if (tr_flag) {
+                const float gv = gamma * (o0[0] + o1[0]);
+                b.rewards[(int64_t)t * N + i] = rew32 + gv;
             }
         }
     }
@@ -184,24 +174,20 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    constexpr int D = T::OBS;
+    constexpr int D = T::OBS, KS1 = (D + 3) >> 2;
     const int A = L.A;
-    constexpr int ldx = ((D + 3) & ~3) + 2, ld = 66, KS1 = (D + 3) >> 2;
     float *vimg = smem, *pimg = smem + FWD_IMG;
-    float *X0 = smem + 2 * FWD_IMG;                    // [2][16][ldx] observation tile, by step parity
-    float *XT0 = X0 + 2 * 16 * ldx;                    // [2][16][ldx] terminal observations of truncated rows
-    float *hp1 = XT0 + 2 * 16 * ldx, *hp2 = hp1 + 16 * ld, *hv1 = hp2 + 16 * ld, *hv2 = hv1 + 16 * ld;
-    float *rw = hv2 + 16 * ld;                         // [2][16] reward of a truncated row (before the bootstrap)
+    float *X0 = smem + 2 * FWD_IMG;                    // [2][16][CH_LDX] observation tile, by step parity
+    float *XT0 = X0 + 2 * 16 * CH_LDX;                 // [2][16][CH_LDX] terminal observations of truncated rows
+    float *rw = XT0 + 2 * 16 * CH_LDX;                 // [2][16] reward of a truncated row (before the bootstrap)
     int *trf = reinterpret_cast<int *>(rw + 32);       // [2][16] row truncated at this parity's step
     int *flag = trf + 32;                              // [2] any row truncated
-    int64_t *row_off = reinterpret_cast<int64_t *>(flag + 2 + 2);
     stage_fwd_image(params + L.img_vf, vimg);
     stage_fwd_image(params + L.img_pi, pimg);
     const int64_t N = v.N;
     const int64_t row0 = (int64_t)blockIdx.x << 4;
-    const int my_row = g * 4 + r16;  // meaningful for owner lanes (r16 < 4)
-    const int64_t i = row0 + my_row;
-    const bool active = (r16 < 4) && (i < N);
+    const int64_t i = row0 + r16;           // the env this lane's column stands for
+    const bool active = g == 0 && i < N;    // ... and the lane that owns its state (wave 0) / writes its value (wave 1)
     typename T::S s;
     double er = 0.0;
     uint32_t ce = 0;
@@ -211,106 +197,48 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
         ce = v.cur_ep[i];
     }
     if (wave == 0) {
-        if (lane < 16) row_off[lane] = (row0 + lane < N) ? (int64_t)t0 * N + row0 + lane : -1;
-        load_obs_tile(b.obs, row_off, D, X0, ldx, lane);
-        // the other parity's tile too: the owner lanes only ever write columns < D of it, and the last layer-1 k-step reads its padding
-        // columns (D = 6: columns 6, 7) -- uninitialised LDS there is harmless only while it is finite (0 x NaN = NaN)
-        for (int e = lane; e < 16 * ldx; e += 64) X0[16 * ldx + e] = 0.0f;
-        for (int e = lane; e < 2 * 16 * ldx; e += 64) XT0[e] = 0.0f;
+        for (int e = lane; e < 2 * 16 * CH_LDX; e += 64) {  // parity 0: the observations of step t0; every other word of the four tiles: zero
+            const int row = e / CH_LDX, c = e - row * CH_LDX;
+            X0[e] = (row < 16 && row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f;
+            XT0[e] = 0.0f;
+        }
         if (lane < 2) flag[lane] = 0;
+        if (lane < 32) trf[lane] = 0;
     }
     __syncthreads();
     double sret = 0.0, slen = 0.0, scnt = 0.0;
+    const float *img = wave == 1 ? vimg : pimg;
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k, p = k & 1, q = p ^ 1;
-        const float *X = X0 + p * 16 * ldx;
-        float *Xn = X0 + q * 16 * ldx, *XT = XT0 + p * 16 * ldx;
+        const float *X = X0 + p * 16 * CH_LDX;
+        float xb[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) xb[ks] = X[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
+        f32x4 o0, o1;
+        h64t_forward<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
         if (wave == 1) {
-            const f32x4 vacc = value_tile_lds(vimg, X, ldx, KS1, hv1, hv2, ld, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float vrow = gfirst_quad(vacc[r]);
-                if (r16 == r && active) b.values[(int64_t)t * N + i] = vrow;
-            }
+            if (active) b.values[(int64_t)t * N + i] = o0[0] + o1[0];
             if (k > 0 && flag[q]) {  // timeout bootstrap of step t-1: rewards = reward + gamma * V(terminal_obs) where truncated
-                const f32x4 vt = value_tile_lds(vimg, XT0 + q * 16 * ldx, ldx, KS1, hv1, hv2, ld, lane);
+                float xt[KS1];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float vr = gfirst_quad(vt[r]);
-                    if (r16 == r && active && trf[q * 16 + my_row]) {
-                        const float gv = gamma * vr;
-                        b.rewards[(int64_t)(t - 1) * N + i] = rw[q * 16 + my_row] + gv;
-                    }
+                for (int ks = 0; ks < KS1; ks++) xt[ks] = XT0[q * 16 * CH_LDX + r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];
+                h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xt, KS1, o0, o1, lane);
+                if (active && trf[q * 16 + r16]) {
+                    const float gv = gamma * (o0[0] + o1[0]);
+                    b.rewards[(int64_t)(t - 1) * N + i] = rw[q * 16 + r16] + gv;
                 }
             }
         } else {
-            dense64_tanh_lds<0>(X, ldx, KS1, pimg + IMG_W1, pimg + IMG_FWD_FLOATS, hp1, ld, lane);
-            dense64_tanh_lds<16>(hp1, ld, 16, pimg + IMG_W2F, pimg + IMG_FWD_FLOATS + 64, hp2, ld, lane);
-            const f32x4 acc = dense64_head_lds(hp2, ld, pimg + IMG_W3F, pimg + IMG_FWD_FLOATS + 128, lane);
-            int my_act = 0;
-            float my_lp = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int64_t row = row0 + g * 4 + r;
-                const bool colok = r16 < A;
-                const float x = colok ? acc[r] : -INFINITY;
-                const float m = gmax16(x);
-                const float e = colok ? expf(x - m) : 0.0f;
-                const float sum = gsum16(e);
-                const float lse = m + logf(sum);
-                const float lp = x - lse;
-                int act;
-                if (det) {  // deterministic evaluation: first maximal logit
-                    act = (int)gmin16((colok && x == m) ? (float)r16 : 99.0f);
-                } else {
-                    const float c = gscan16(e / sum);
-                    const float u = uniform01(mix32(rng_seed, v.env_offset + (uint32_t)row, rng_step0 + (uint32_t)t));
-                    const float cnt = gsum16((colok && c <= u) ? 1.0f : 0.0f);
-                    act = min((int)cnt, A - 1);
-                }
-                const float lpa = gsum16((r16 == act) ? lp : 0.0f);
-                if (r16 == r) my_act = act, my_lp = lpa;
-            }
+            int act;
+            float lp;
+            h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
             bool tr_flag = false;
             if (active) {
-                const int64_t off = (int64_t)t * N + i;
-                b.actions[off] = my_act;
-                b.log_probs[off] = my_lp;
-                double r;
-                bool done;
-                T::step(s, my_act, nullptr, r, done);
-                const int steps = T::steps(s);
-                const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
-                const bool te = done && !hit, tr = hit;
-                er += r;
-                const float rew32 = (float)r;
-                b.terminated[off] = (uint8_t)te;
-                b.truncated[off] = (uint8_t)tr;
-                float o[D];
-                if (te || tr) {
-                    if (tr) {
-                        T::obs(s, o);
-#pragma unroll
-                        for (int c = 0; c < D; c++) XT[my_row * ldx + c] = o[c];
-                        rw[p * 16 + my_row] = rew32;
-                    }
-                    sret += er, slen += (double)steps, scnt += 1.0;
-                    log_episode(v, i, er, steps);
-                    er = 0.0;
-                    ce += 1;
-                    uint32_t rec[T::RW];
-                    const uint32_t *slot = v.ring + ((int64_t)(ce % (uint32_t)v.D) * T::RW) * N + i;
-#pragma unroll
-                    for (int w = 0; w < T::RW; w++) rec[w] = slot[(int64_t)w * N];
-                    T::from_rec(rec, s);
-                }
-                T::obs(s, o);
-                store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
-#pragma unroll
-                for (int c = 0; c < D; c++) Xn[my_row * ldx + c] = o[c];
-                if (!tr) b.rewards[off] = rew32;  // truncated rows: wave 1 writes reward + bootstrap after the barrier
-                trf[p * 16 + my_row] = tr ? 1 : 0;
-                tr_flag = tr;
+                float rew32;
+                chunk_env_step<T>(v, b, s, er, ce, N, i, t, act, lp, X0 + q * 16 * CH_LDX + r16 * CH_LDX, XT0 + p * 16 * CH_LDX + r16 * CH_LDX, rew32, tr_flag,
+                                  false, sret, slen, scnt);  // truncated rows: wave 1 writes reward + bootstrap after the barrier
+                if (tr_flag) rw[p * 16 + r16] = rew32;
+                trf[p * 16 + r16] = tr_flag ? 1 : 0;
             }
             const bool any = __ballot(tr_flag) != 0ull;
             if (lane == 0) flag[p] = any ? 1 : 0;
@@ -320,14 +248,14 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     if (wave == 1) {  // bootstrap of the chunk's last step
         const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
         if (n_steps > 0 && flag[q]) {
-            const f32x4 vt = value_tile_lds(vimg, XT0 + q * 16 * ldx, ldx, KS1, hv1, hv2, ld, lane);
+            float xt[KS1];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float vr = gfirst_quad(vt[r]);
-                if (r16 == r && active && trf[q * 16 + my_row]) {
-                    const float gv = gamma * vr;
-                    b.rewards[(int64_t)t * N + i] = rw[q * 16 + my_row] + gv;
-                }
+            for (int ks = 0; ks < KS1; ks++) xt[ks] = XT0[q * 16 * CH_LDX + r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];
+            f32x4 o0, o1;
+            h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xt, KS1, o0, o1, lane);
+            if (active && trf[q * 16 + r16]) {
+                const float gv = gamma * (o0[0] + o1[0]);
+                b.rewards[(int64_t)t * N + i] = rw[q * 16 + r16] + gv;
             }
         }
         return;
@@ -1189,10 +1117,9 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
                         float gamma, int det, hipStream_t s) {
     const int64_t tiles = ceil_div(env->v.N, 16);
     const int wpb = tiles >= 1024 ? 4 : 1;  // BASELINE shape (256 tiles): one wave per block so all 256 CUs take part
-    constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
-    const int smem = (2 * FWD_IMG + wpb * (16 * (2 * ldx + 2 * 66) + 32)) * 4;
+    const int smem = (2 * FWD_IMG + wpb * 2 * 16 * CH_LDX) * 4;
     if (wpb == 1) {  // one tile per CU: split the policy and the value net of a tile over two waves
-        const int smem2 = (2 * FWD_IMG + 4 * 16 * ldx + 4 * 16 * 66 + 32 + 32 + 4 + 32) * 4;
+        const int smem2 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4) * 4;
         auto k2 = rollout_chunk2_h64_kernel<T>;
         if (smem2 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
         k2<<<dim3((unsigned)tiles), dim3(128), smem2, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
