@@ -59,6 +59,10 @@ def test_ppo_default_table():  # value table training.py:361-391
     assert (kw["gamma"], kw["gae_lambda"], kw["clip_range"], kw["ent_coef"], kw["vf_coef"], kw["max_grad_norm"]) == (0.99, 0.95, 0.2, 0.01, 0.5, 0.5)
     assert kw["policy_kwargs"] == {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}
     assert harness.ppo_defaults(tasks.resolve("push"))["n_steps"] == 2048 and "ppo" in harness.ALGORITHMS
+    # with the env count known the table keeps the reference's SCHEDULE (32 minibatches per epoch: 8 envs x 1024 / 256), never below its literal 256
+    g = tasks.resolve("gridworld")
+    assert [harness.ppo_defaults(g, n)["batch_size"] for n in (1, 8, 16, 4096)] == [256, 256, 512, 131072]
+    assert harness.ppo_defaults(tasks.resolve("push"), 2048)["batch_size"] == 2048 * 2048 // 32
 
 
 def test_records_and_train_errors():  # training.py:40-68,105-114
