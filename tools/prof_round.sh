@@ -1,29 +1,32 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): outputs under gpurun_out/, the summaries to commit are copied to profiles/ by hand.
-#  (1) rocprofv3 --kernel-trace --stats of the headline bench command (the timed region only: --no-extras --no-cpu-baseline, so that
+#  (1) timeout 300 rocprofv3 --kernel-trace --stats of the headline bench command (the timed region only: --no-extras --no-cpu-baseline, so that
 #      the per-kernel averages are those of the headline workload and not mixed with the batch-256 / other-config legs, which launch the same kernels
 #      at other sizes) and of the Ball3D 256x256 bf16 command;
 #  (2) HBM traffic (FETCH_SIZE, WRITE_SIZE in separate passes; MI355X_MICROARCH.md §HBM) of the step kernel and the gradient kernels;
 #  (3) SQ counters (MFMA busy cycles / instruction counts / wait cycles / LDS conflicts) of the three gradient kernels.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-R=${1:-r02}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench.log 2>&1
+R=${1:-r03}
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench.log > gpurun_out/${R}_bench_n1.json
 cp $(ls -t gpurun_out/${R}_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_n1_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_ball3d_bf16 -- python bench.py --gpus 1 --steps 3 --warmup 1 --task ball3d --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_ball3d_bf16.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_ball3d_bf16 -- python bench.py --gpus 1 --steps 3 --warmup 1 --task ball3d --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_ball3d_bf16.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench_ball3d_bf16.log > gpurun_out/${R}_bench_ball3d_bf16_n1.json
 cp $(ls -t gpurun_out/${R}_bench_ball3d_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_ball3d_bf16_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_crawler_bf16 -- python bench.py --gpus 1 --steps 2 --warmup 1 --task crawler --n-envs 2048 --n-steps 2048 --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_crawler_bf16.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_crawler_bf16 -- python bench.py --gpus 1 --steps 2 --warmup 1 --task crawler --n-envs 2048 --n-steps 2048 --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_crawler_bf16.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench_crawler_bf16.log > gpurun_out/${R}_bench_crawler_bf16_n1.json
 cp $(ls -t gpurun_out/${R}_bench_crawler_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_crawler_bf16_kernel_stats.csv
 # the reference's literal batch_size = 256: one persistent launch per epoch (ppo_epoch_h64p_kernel), 4096 envs x 256 steps = 4096 optimizer steps per launch
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_literal256 -- python tools/time_epoch256.py 4096 256 > gpurun_out/${R}_literal256.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_literal256 -- python tools/time_epoch256.py 4096 256 > gpurun_out/${R}_literal256.log 2>&1
 cp $(ls -t gpurun_out/${R}_literal256/*/*kernel_stats.csv | head -1) gpurun_out/${R}_literal256_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_step_$c -- python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2 > gpurun_out/${R}_pmc_step_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_grad_$c -- python tools/prof_grad.py > gpurun_out/${R}_pmc_grad_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_$c -- python tools/prof_grad_bf16.py ball3d 256 bf16 > gpurun_out/${R}_pmc_gradbf_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_step_$c -- python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2 > gpurun_out/${R}_pmc_step_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_grad_$c -- python tools/prof_grad.py > gpurun_out/${R}_pmc_grad_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_$c -- python tools/prof_grad_bf16.py ball3d 256 bf16 > gpurun_out/${R}_pmc_gradbf_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_push_$c -- python tools/prof_grad_bf16.py push 256 bf16 > gpurun_out/${R}_pmc_gradbf_push_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_crawler_$c -- python tools/prof_grad_bf16.py crawler 256 bf16 > gpurun_out/${R}_pmc_gradbf_crawler_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradwide_basic_$c -- python tools/prof_grad_bf16.py basic 256 f32 8 256 > gpurun_out/${R}_pmc_gradwide_basic_$c.log 2>&1
 done
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES"
@@ -31,9 +34,9 @@ SQ3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_
 i=0
 for set in "$SQ1" "$SQ2" "$SQ3"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_h64 -- python tools/prof_grad.py > gpurun_out/${R}_sq${i}_h64.log 2>&1
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_bf16 -- python tools/prof_grad_bf16.py ball3d 256 bf16 > gpurun_out/${R}_sq${i}_bf16.log 2>&1
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_f32w -- python tools/prof_grad_bf16.py ball3d 256 f32 > gpurun_out/${R}_sq${i}_f32w.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_h64 -- python tools/prof_grad.py > gpurun_out/${R}_sq${i}_h64.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_bf16 -- python tools/prof_grad_bf16.py ball3d 256 bf16 > gpurun_out/${R}_sq${i}_bf16.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${R}_sq${i}_f32w -- python tools/prof_grad_bf16.py ball3d 256 f32 > gpurun_out/${R}_sq${i}_f32w.log 2>&1
 done
 python - "$R" <<'PY'
 import collections, csv, glob, json, sys
@@ -49,7 +52,10 @@ def counters(dirname, kernel_substr):
 out = {}
 for tag, sub, alg, cmd in (("step", "step_kernel<tma::GridTask, 3>", 54 * 4194304, "python tools/env_sweep.py --tasks gridworld --sizes 4194304 --per-launch 1 --iters 2"),
                            ("grad", "ppo_grad_h64_kernel", None, "python tools/prof_grad.py"),
-                           ("gradbf", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py ball3d 256 bf16")):
+                           ("gradbf", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py ball3d 256 bf16"),
+                           ("gradbf_push", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py push 256 bf16"),
+                           ("gradbf_crawler", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py crawler 256 bf16  (both launches of the two-pass layout: per-launch mean)"),
+                           ("gradwide_basic", "ppo_grad_wide_kernel", None, "python tools/prof_grad_bf16.py basic 256 f32 8 256  (256 samples per launch)")):
     fs, n1 = counters(f"{R}_pmc_{tag}_FETCH_SIZE", sub)
     ws, n2 = counters(f"{R}_pmc_{tag}_WRITE_SIZE", sub)
     if not fs or not ws:
