@@ -27,7 +27,8 @@ enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 
 
 /* task ids (backend/mlagents/registry.py:52-116,225-240) */
 enum { TMA_TASK_BASIC = 0, TMA_TASK_GRIDWORLD = 1, TMA_TASK_BALL3D = 2, TMA_TASK_PUSH = 3, TMA_TASK_CRAWLER = 4, TMA_TASK_WALLJUMP = 5, TMA_TASK_BICYCLE = 6, TMA_TASK_BRICKBREAK = 7, TMA_TASK_GLIDER = 8,
-       TMA_NUM_TASKS = 9 };
+       TMA_TASK_ANT = 9, /* the reference's `ant` shapes (Ant-v5: 105 observations, 8 torques; envs.py:274-277) on the build's chain dynamics; CRAWLER = BASELINE.json's 172 / 20 shape */
+       TMA_NUM_TASKS = 10 };
 
 /* dtype of the `actions` buffer handed to tma_env_step */
 enum { TMA_ACT_I32 = 0, TMA_ACT_I64 = 1, TMA_ACT_F32 = 2 };
@@ -41,11 +42,11 @@ const char *tma_last_error(void);
 
 /* ---- task metadata: spaces declared by make_*_env (backend/mlagents/envs.py:35-44,162-199,274-277) ---- */
 int tma_task_id(const char *name, int *task_out);
-int tma_task_obs_dim(int task);           /* 21 / 4 / 6 / 4 / 172 / 4 */
+int tma_task_obs_dim(int task);           /* 21 / 4 / 6 / 4 / 172 / 4 / 7 / 45 / 16 / 105 */
 int tma_task_num_actions(int task);       /* Discrete(n); 0 for a Box action space */
-int tma_task_act_dim(int task);           /* Box action dim (crawler: 20), else 1 */
+int tma_task_act_dim(int task);           /* Box action dim (crawler: 20, ant: 8), else 1 */
 int tma_task_state_dim(int task);         /* doubles per env in the flat get/set_state layout */
-int tma_task_max_episode_steps(int task); /* 50 / 100 / 200 / 120 / 1000 / 150 / 2000 / 2000 / 4000 */
+int tma_task_max_episode_steps(int task); /* 50 / 100 / 200 / 120 / 1000 / 150 / 2000 / 2000 / 4000 / 1000 */
 
 /* ---- vector env: replaces make_vector_env + DummyVecEnv + Monitor + LegacySingleAgentGymAdapter +
  *      the task step()/reset() (backend/mlagents/training.py:71-89; backend/mlagents/envs.py:30-159;

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtma_oracle.so")
 
-TASK_IDS = {"basic": 0, "gridworld": 1, "ball3d": 2, "push": 3, "crawler": 4, "walljump": 5, "bicycle": 6, "brickbreak": 7, "glider": 8}
+TASK_IDS = {"basic": 0, "gridworld": 1, "ball3d": 2, "push": 3, "crawler": 4, "walljump": 5, "bicycle": 6, "brickbreak": 7, "glider": 8, "ant": 9}
 EP_STRIDE = 1 << 20
 
 
@@ -130,7 +130,7 @@ def legacy_step(task, state, action):
     obs = np.zeros(obs_dim(t), np.float32)
     r = np.zeros(1, np.float64)
     d = np.zeros(1, np.int32)
-    act = np.asarray(action, np.float32 if t == 4 else np.int32).reshape(-1).copy()
+    act = np.asarray(action, np.float32 if t in (4, 9) else np.int32).reshape(-1).copy()
     lib().orc_legacy_step(t, _p(st), _p(act), _p(obs), _p(r), _p(d))
     return st, obs, float(r[0]), bool(d[0])
 
@@ -158,7 +158,7 @@ class OracleVecEnv:
         return obs
 
     def step(self, actions):
-        if self.task == 4:
+        if self.task in (4, 9):
             act = np.ascontiguousarray(actions, np.float32).reshape(self.n, self.A)
         else:
             act = np.ascontiguousarray(actions, np.int32).reshape(self.n)

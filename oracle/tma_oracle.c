@@ -107,28 +107,33 @@ void orc_mt_uniform(uint32_t seed, double lo, double hi, double *out, int n) {
 #define CRAWLER_NJ 20
 #define CRAWLER_OBS 172
 #define CRAWLER_STATE (2 * CRAWLER_NJ + CRAWLER_NJ + 8 + 1) /* q, qd, prev action, root(8), steps */
+/* ORC_ANT: the same articulated chain with 8 joints and observations in gymnasium Ant-v5's order (the SHAPES the reference's `ant` task
+ * builds, backend/mlagents/envs.py:274-277: Box(105,) observations, Box(-1,1,(8,)) torques); dynamics build-defined, parity unpinned */
+#define ANT_NJ 8
+#define ANT_OBS 105
+#define ANT_STATE (3 * ANT_NJ + 8 + 1)
 
 int orc_obs_dim(int task) {
-    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS, 4, 7, 45, 16};
+    static const int d[] = {21, 4, 6, 4, CRAWLER_OBS, 4, 7, 45, 16, ANT_OBS};
     return d[task];
 }
 int orc_num_actions(int task) {
-    static const int d[] = {3, 5, 5, 5, 0, 4, 3, 3, 5};
+    static const int d[] = {3, 5, 5, 5, 0, 4, 3, 3, 5, 0};
     return d[task];
 }
-int orc_act_dim(int task) { return task == ORC_CRAWLER ? CRAWLER_NJ : 1; }
+int orc_act_dim(int task) { return task == ORC_CRAWLER ? CRAWLER_NJ : (task == ORC_ANT ? ANT_NJ : 1); }
 int orc_state_dim(int task) {
-    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE, 4, 10, 46, 14};
+    static const int d[] = {2, 8, 8, 6, CRAWLER_STATE, 4, 10, 46, 14, ANT_STATE};
     return d[task];
 }
 int orc_max_episode_steps(int task) {
-    static const int d[] = {50, 100, 200, 120, 1000, 150, 2000, 2000, 4000};
+    static const int d[] = {50, 100, 200, 120, 1000, 150, 2000, 2000, 4000, 1000};
     return d[task];
 }
 
 /* position of the step counter in the flat state vector */
 static int orc_steps_index(int task) {
-    static const int d[] = {1, 7, 6, 5, 3 * CRAWLER_NJ + 8, 3, 9, 5, 13};
+    static const int d[] = {1, 7, 6, 5, 3 * CRAWLER_NJ + 8, 3, 9, 5, 13, 3 * ANT_NJ + 8};
     return d[task];
 }
 
@@ -433,8 +438,8 @@ static float cr_cos(float x) { /* degree-10 Taylor */
 }
 static float cr_clip(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-static void crawler_obs(const double *st, float *obs) {
-    const double *q = st, *qd = st + CRAWLER_NJ, *pa = st + 2 * CRAWLER_NJ, *root = st + 3 * CRAWLER_NJ;
+static void chain_obs(const double *st, float *obs, const int nj) {
+    const double *q = st, *qd = st + nj, *pa = st + 2 * nj, *root = st + 3 * nj;
     /* 12 root features */
     float pitch = (float)root[3], roll = (float)root[4];
     obs[0] = (float)root[0];
@@ -450,9 +455,9 @@ static void crawler_obs(const double *st, float *obs) {
     obs[10] = cr_cos(roll);
     obs[11] = (float)root[0] - 0.55f;
     /* 8 features per joint */
-    for (int j = 0; j < CRAWLER_NJ; j++) {
+    for (int j = 0; j < nj; j++) {
         float qj = (float)q[j], qdj = (float)qd[j];
-        float qn = (float)q[(j + 1) % CRAWLER_NJ];
+        float qn = (float)q[(j + 1) % nj];
         float s = cr_sin(qj), c = cr_cos(qj);
         float side = (j & 1) ? -1.0f : 1.0f;
         float contact = -(s + side * pitch * 0.5f);
@@ -467,33 +472,34 @@ static void crawler_obs(const double *st, float *obs) {
         o[7] = qj * qj;
     }
 }
-static void crawler_reset_hash(uint32_t seed, double *st) {
+static void chain_reset_hash(uint32_t seed, double *st, const int nj) {
     /* counter-based init (no MT19937): small random joint angles / velocities, upright root */
-    for (int j = 0; j < CRAWLER_NJ; j++) {
+    for (int j = 0; j < nj; j++) {
         uint32_t h0 = orc_mix32(seed, (uint32_t)j, 0x51u), h1 = orc_mix32(seed, (uint32_t)j, 0x52u);
         float u0 = (float)(h0 >> 8) * (1.0f / 16777216.0f), u1 = (float)(h1 >> 8) * (1.0f / 16777216.0f);
         st[j] = (double)((u0 - 0.5f) * 0.2f);
-        st[CRAWLER_NJ + j] = (double)((u1 - 0.5f) * 0.2f);
-        st[2 * CRAWLER_NJ + j] = 0.0;
+        st[nj + j] = (double)((u1 - 0.5f) * 0.2f);
+        st[2 * nj + j] = 0.0;
     }
-    double *root = st + 3 * CRAWLER_NJ;
+    double *root = st + 3 * nj;
     root[0] = (double)0.55f;
     for (int k = 1; k < 8; k++) root[k] = 0.0;
-    st[3 * CRAWLER_NJ + 8] = 0;
+    st[3 * nj + 8] = 0;
 }
-static void crawler_step(double *st, const float *act, float *obs, double *reward, int *done) {
+static void ant_obs(const double *st, float *obs);
+static void chain_step(double *st, const float *act, float *obs, double *reward, int *done, const int nj) {
     const float dt = 0.05f, gear = 8.0f, kq = 4.0f, cq = 1.5f, kc = 1.0f;
-    float q[CRAWLER_NJ], qd[CRAWLER_NJ], a[CRAWLER_NJ];
-    double *root = st + 3 * CRAWLER_NJ;
-    for (int j = 0; j < CRAWLER_NJ; j++) {
+    float q[20], qd[20], a[20];
+    double *root = st + 3 * nj;
+    for (int j = 0; j < nj; j++) {
         q[j] = (float)st[j];
-        qd[j] = (float)st[CRAWLER_NJ + j];
+        qd[j] = (float)st[nj + j];
         a[j] = cr_clip(act[j], -1.0f, 1.0f);
     }
     float thrust_x = 0.0f, thrust_y = 0.0f, asym = 0.0f, ctrl = 0.0f, lift = 0.0f;
-    float nq[CRAWLER_NJ], nqd[CRAWLER_NJ];
-    for (int j = 0; j < CRAWLER_NJ; j++) {
-        float ql = q[(j + CRAWLER_NJ - 1) % CRAWLER_NJ], qr = q[(j + 1) % CRAWLER_NJ];
+    float nq[20], nqd[20];
+    for (int j = 0; j < nj; j++) {
+        float ql = q[(j + nj - 1) % nj], qr = q[(j + 1) % nj];
         float lap = (ql + qr) - 2.0f * q[j];
         float acc = gear * a[j];
         acc = acc - kq * q[j];
@@ -513,7 +519,7 @@ static void crawler_step(double *st, const float *act, float *obs, double *rewar
         nqd[j] = v;
         float c = cr_cos(p), s = cr_sin(p);
         float side = (j & 1) ? -1.0f : 1.0f;
-        float w = (j < CRAWLER_NJ / 2) ? 1.0f : -1.0f;
+        float w = (j < nj / 2) ? 1.0f : -1.0f;
         thrust_x = thrust_x + (side * v) * c;
         thrust_y = thrust_y + (w * v) * c;
         asym = asym + side * s;
@@ -528,12 +534,12 @@ static void crawler_step(double *st, const float *act, float *obs, double *rewar
     rr = rr + dt * (0.05f * thrust_y - 6.0f * roll - 1.2f * rr);
     pitch = pitch + dt * pr;
     roll = roll + dt * rr;
-    z = 0.25f + 0.015f * lift; /* mean cos(q) in [0.36,1] -> z in about [0.36,0.55] */
+    z = 0.25f + (nj == 20 ? 0.015f : 0.3f / (float)nj) * lift; /* mean cos(q) in [0.36,1] -> z in about [0.36,0.55] */
     x = x + dt * vx;
-    for (int j = 0; j < CRAWLER_NJ; j++) {
+    for (int j = 0; j < nj; j++) {
         st[j] = (double)nq[j];
-        st[CRAWLER_NJ + j] = (double)nqd[j];
-        st[2 * CRAWLER_NJ + j] = (double)a[j];
+        st[nj + j] = (double)nqd[j];
+        st[2 * nj + j] = (double)a[j];
     }
     root[0] = z;
     root[1] = vx;
@@ -543,14 +549,52 @@ static void crawler_step(double *st, const float *act, float *obs, double *rewar
     root[5] = pr;
     root[6] = rr;
     root[7] = x;
-    st[3 * CRAWLER_NJ + 8] += 1;
+    st[3 * nj + 8] += 1;
     int unhealthy = (z < 0.38f) || (fabsf(pitch) > 1.0f) || (fabsf(roll) > 1.0f);
     float rew = 1.0f + vx;
     rew = rew - 0.5f * ctrl * 0.05f;
     *reward = (double)rew;
-    *done = unhealthy || st[3 * CRAWLER_NJ + 8] >= 1000;
-    crawler_obs(st, obs);
+    *done = unhealthy || st[3 * nj + 8] >= 1000;
+    if (nj == ANT_NJ) ant_obs(st, obs);
+    else chain_obs(st, obs, nj);
 }
+
+/* Ant-v5 observation order over the 8-joint chain state (csrc/tma_tasks.h ChainTask<8, 1>::obs) */
+static void ant_obs(const double *st, float *obs) {
+    const double *q = st, *qd = st + ANT_NJ, *root = st + 3 * ANT_NJ;
+    float pitch = (float)root[3], roll = (float)root[4];
+    float hp = 0.5f * pitch, hr = 0.5f * roll;
+    float sp = cr_sin(hp), cp = cr_cos(hp), sr = cr_sin(hr), cr = cr_cos(hr);
+    obs[0] = (float)root[0];
+    obs[1] = cp * cr;
+    obs[2] = sr * cp;
+    obs[3] = sp * cr;
+    obs[4] = -(sp * sr);
+    for (int j = 0; j < ANT_NJ; j++) obs[5 + j] = (float)q[j];
+    obs[13] = (float)root[1];
+    obs[14] = (float)root[2];
+    obs[15] = 0.0f;
+    obs[16] = (float)root[6];
+    obs[17] = (float)root[5];
+    obs[18] = 0.0f;
+    for (int j = 0; j < ANT_NJ; j++) obs[19 + j] = (float)qd[j];
+    for (int b = 0; b < 13; b++) {
+        float cz = 0.0f;
+        if (b >= 1 && b <= ANT_NJ) {
+            int j = b - 1;
+            float side = (j & 1) ? -1.0f : 1.0f;
+            float contact = -(cr_sin((float)q[j]) + side * pitch * 0.5f);
+            cz = contact > 0.0f ? (contact < 1.0f ? contact : 1.0f) : 0.0f;
+        }
+        float *p = obs + 27 + 6 * b;
+        p[0] = 0.0f, p[1] = 0.0f, p[2] = cz, p[3] = 0.0f, p[4] = 0.0f, p[5] = 0.0f;
+    }
+}
+static void crawler_obs(const double *st, float *obs) { chain_obs(st, obs, 20); }
+static void crawler_reset_hash(uint32_t seed, double *st) { chain_reset_hash(seed, st, 20); }
+static void crawler_step(double *st, const float *act, float *obs, double *reward, int *done) { chain_step(st, act, obs, reward, done, 20); }
+static void ant_reset_hash(uint32_t seed, double *st) { chain_reset_hash(seed, st, ANT_NJ); }
+static void ant_step(double *st, const float *act, float *obs, double *reward, int *done) { chain_step(st, act, obs, reward, done, ANT_NJ); }
 
 /* =========================================================================================
  * numpy / OpenBLAS summation orders the three float tasks below depend on (probed against numpy 2.2.6 + its bundled
@@ -819,6 +863,7 @@ static void task_obs(int task, const double *st, float *obs) {
     case ORC_BALL3D: ball_obs(st, obs); break;
     case ORC_PUSH: push_obs(st, obs); break;
     case ORC_CRAWLER: crawler_obs(st, obs); break;
+    case ORC_ANT: ant_obs(st, obs); break;
     case ORC_WALLJUMP: wj_obs(st, obs); break;
     case ORC_BICYCLE: bike_obs(st, obs); break;
     case ORC_BRICKBREAK: brick_obs(st, obs); break;
@@ -848,6 +893,7 @@ void orc_reset_from_seed(int task, uint32_t seed, double *st, float *obs) {
         push_reset(&rng, st);
         break;
     case ORC_CRAWLER: crawler_reset_hash(seed, st); break;
+    case ORC_ANT: ant_reset_hash(seed, st); break;
     case ORC_WALLJUMP:
         orc_mt_seed(&rng, seed);
         wj_reset(&rng, st);
@@ -881,6 +927,7 @@ void orc_legacy_step(int task, double *st, const void *action, float *obs, doubl
     case ORC_BALL3D: ball_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_PUSH: push_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_CRAWLER: crawler_step(st, (const float *)action, obs, reward, done); break;
+    case ORC_ANT: ant_step(st, (const float *)action, obs, reward, done); break;
     case ORC_WALLJUMP: wj_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_BICYCLE: bike_step(st, *(const int32_t *)action, obs, reward, done); break;
     case ORC_BRICKBREAK: brick_step(st, *(const int32_t *)action, obs, reward, done); break;
@@ -946,7 +993,7 @@ void orc_vec_step(orc_vec *v, const void *actions, float *obs_out, float *rew32_
         float obs[CRAWLER_OBS];
         double r;
         int done, terminated, truncated;
-        const void *act = task == ORC_CRAWLER ? (const void *)((const float *)actions + (size_t)i * v->A)
+        const void *act = (task == ORC_CRAWLER || task == ORC_ANT) ? (const void *)((const float *)actions + (size_t)i * v->A)
                                               : (const void *)((const int32_t *)actions + i);
         orc_legacy_step(task, st, act, obs, &r, &done);
         int steps = (int)st[orc_steps_index(task)];

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-enum { ORC_BASIC = 0, ORC_GRIDWORLD = 1, ORC_BALL3D = 2, ORC_PUSH = 3, ORC_CRAWLER = 4, ORC_WALLJUMP = 5, ORC_BICYCLE = 6, ORC_BRICKBREAK = 7, ORC_GLIDER = 8 };
+enum { ORC_BASIC = 0, ORC_GRIDWORLD = 1, ORC_BALL3D = 2, ORC_PUSH = 3, ORC_CRAWLER = 4, ORC_WALLJUMP = 5, ORC_BICYCLE = 6, ORC_BRICKBREAK = 7, ORC_GLIDER = 8, ORC_ANT = 9 };
 
 #define ORC_MAX_STATE 80   /* upper bound on doubles per env in the flat state vector */
 #define ORC_EP_STRIDE (1u << 20)

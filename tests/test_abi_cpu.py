@@ -27,11 +27,12 @@ def test_task_metadata_matches_reference_spaces():
     L = _lib.lib()
     # backend/mlagents/envs.py:38-44,166-199 ; max_episode_steps envs.py:35 + examples MAX_STEPS_PER_EP
     expect = {"basic": (21, 3, 50), "gridworld": (4, 5, 100), "ball3d": (6, 5, 200), "push": (4, 5, 120), "crawler": (172, 0, 1000), "walljump": (4, 4, 150),
-              "bicycle": (7, 3, 2000), "brickbreak": (45, 3, 2000), "glider": (16, 5, 4000)}
+              "bicycle": (7, 3, 2000), "brickbreak": (45, 3, 2000), "glider": (16, 5, 4000), "ant": (105, 0, 1000)}
     for name, (d, a, m) in expect.items():
         t = _lib.task_id(name)
         assert (L.tma_task_obs_dim(t), L.tma_task_num_actions(t), L.tma_task_max_episode_steps(t)) == (d, a, m)
-    assert _lib.task_id("ant") == _lib.task_id("crawler")
+    # `ant`: the shapes of the reference's Ant-v5 task (envs.py:274-277); `crawler`: BASELINE.json's 172 / 20 shape -- two tasks, one chain
+    assert _lib.task_id("ant") != _lib.task_id("crawler") and (L.tma_task_act_dim(_lib.task_id("ant")), L.tma_task_act_dim(_lib.task_id("crawler"))) == (8, 20)
 
 
 def test_status_codes_map_to_reference_exception_types():

@@ -21,7 +21,7 @@ def _engine(task, n, **kw):
 
 def _cmp(task, name, got, ref, ctx):
     got, ref = np.asarray(got), np.asarray(ref)
-    if task in ("ball3d", "crawler") and got.dtype.kind == "f":
+    if task in ("ball3d", "crawler", "ant") and got.dtype.kind == "f":
         assert np.allclose(got, ref, rtol=0, atol=FLOAT_TOL), (task, name, ctx, np.abs(got - ref).max())
         return int((got != ref).sum())
     assert np.array_equal(got, ref), (task, name, ctx)
@@ -100,7 +100,7 @@ def test_golden_transitions_state_injection(golden, task):
     eng.close()
 
 
-@pytest.mark.parametrize("task", TASKS + ["crawler"])
+@pytest.mark.parametrize("task", TASKS + ["crawler", "ant"])
 @pytest.mark.parametrize("mode", ["actions", "tape_multi"])
 def test_against_oracle_many_envs(task, mode):
     n, T, base, tape_seed, offset, depth = 1000, 192, 7, 99, 5000, 16
@@ -108,13 +108,13 @@ def test_against_oracle_many_envs(task, mode):
     ref = orc.OracleVecEnv(task, n, seed=base, env_offset=offset)
     inexact = _cmp(task, "reset", eng.reset().cpu().numpy(), ref.reset(), 0)
     n_act = orc.num_actions(task)
-    if task == "crawler":
+    if task in ("crawler", "ant"):
         rng = np.random.default_rng(3)
-        actions = rng.uniform(-1.3, 1.3, size=(T, n, 20)).astype(np.float32)
+        actions = rng.uniform(-1.3, 1.3, size=(T, n, orc.act_dim(task))).astype(np.float32)
     else:
         actions = orc.action_tape(tape_seed, n, T, n_act, env_offset=offset)
     outs = []
-    if mode == "actions" or task == "crawler":
+    if mode == "actions" or task in ("crawler", "ant"):
         dev_actions = torch.from_numpy(actions).cuda()
         for t in range(T):
             o = eng.step(dev_actions[t])

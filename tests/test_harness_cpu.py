@@ -10,18 +10,19 @@ from three_mlagents_amd import harness, tasks
 
 
 def test_engine_task_table():
-    assert set(tasks.ENGINE_TASKS) == {"basic", "gridworld", "ball3d", "push", "ant", "walljump", "brickbreak", "bicycle", "glider"}
+    assert set(tasks.ENGINE_TASKS) == {"basic", "gridworld", "ball3d", "push", "ant", "crawler", "walljump", "brickbreak", "bicycle", "glider"}
     for t in tasks.ENGINE_TASKS.values():
         card = t.card()
         assert card["trainable"] is True and card["id"] == t.id and card["policy_prefix"].endswith("_policy")
     assert tasks.resolve("gridworld").ppo_n_steps == 1024 and tasks.resolve("push").ppo_n_steps == 2048  # foundation vs benchmark tier
-    assert tasks.resolve("ant").pinned is False and tasks.resolve("gridworld").pinned  # crawler dynamics are build-defined
+    assert tasks.resolve("ant").pinned is False and tasks.resolve("crawler").pinned is False and tasks.resolve("gridworld").pinned  # chain dynamics are build-defined
     # library facts ride on the card when the .so is built (it is, in this repo)
-    assert tasks.resolve("basic").card()["obs_dim"] == 21 and tasks.resolve("ant").card()["act_dim"] == 20
+    assert tasks.resolve("basic").card()["obs_dim"] == 21 and tasks.resolve("ant").card()["act_dim"] == 8 and tasks.resolve("ant").card()["obs_dim"] == 105
+    assert tasks.resolve("crawler").card()["act_dim"] == 20 and tasks.resolve("crawler").card()["obs_dim"] == 172
 
 
 def test_name_resolution_and_error_types():  # test_mlagents.py:47-49 + registry.py:359-369
-    assert tasks.resolve("Crawler").id == "ant" and tasks.resolve("GRIDWORLD").kernel == "gridworld"
+    assert tasks.resolve("Crawler").id == "crawler" and tasks.resolve("ANT").kernel == "ant" and tasks.resolve("GRIDWORLD").kernel == "gridworld"
     with pytest.raises(KeyError):
         tasks.resolve("not-a-task")
     assert tasks.resolve("brick-break").kernel == "brickbreak" and tasks.resolve("Bicycle").id == "bicycle"  # registry.py:354 spelling

@@ -335,7 +335,7 @@ def test_gae_flags_equals_sb3_layout():
                                                 ("basic", 256, 8, "f32"), ("basic", 256, 40, "f32"), ("gridworld", 256, 200, "f32"), ("push", 256, 72, "f32"),
                                                 ("walljump", 256, 64, "f32"), ("bicycle", 256, 40, "f32"), ("glider", 256, 40, "f32"),
                                                 # the Box-action fused chunk (Crawler shape: layer-1 fragments streamed, env state in LDS); 72 = a ragged group
-                                                ("crawler", 256, 72, "bf16"), ("crawler", 256, 40, "f32"),
+                                                ("crawler", 256, 72, "bf16"), ("crawler", 256, 40, "f32"), ("ant", 256, 72, "bf16"), ("ant", 256, 40, "f32"),
                                                 # the float64-physics tasks of SURVEY 8f: fused on 64-wide and 256-wide bf16 nets (Bicycle, Glider), per-step otherwise
                                                 ("bicycle", 64, 200, "f32"), ("glider", 64, 200, "f32"), ("bicycle", 256, 72, "bf16"), ("glider", 256, 72, "bf16"),
                                                 ("brickbreak", 64, 100, "f32")])
@@ -348,7 +348,7 @@ def test_native_rollout_equals_stepwise_composition(task, hidden, N, mfma):
     from three_mlagents_amd.vec_env import HipVecEnv
 
     # N = 200: two-wave fused kernel (one tile per block); N = 16400: >= 1024 tiles, the four-tiles-per-block single-wave kernel
-    T = {"ball3d": 230, "gridworld": 130, "walljump": 170, "basic": 60, "crawler": 40, "bicycle": 110, "glider": 110, "brickbreak": 70}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
+    T = {"ball3d": 230, "gridworld": 130, "walljump": 170, "basic": 60, "crawler": 40, "ant": 40, "bicycle": 110, "glider": 110, "brickbreak": 70}.get(task, 48)  # long enough to reach the time limit (timeout-bootstrap path)
     env = HipVecEnv(task, N, seed=3, ring_depth=16)
     model = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [hidden, hidden], "mfma_dtype": mfma})
     _lib.check(_lib.lib().tma_debug_poison_lds(0, _lib.stream_ptr()))  # NaNs in every LDS word the rollout kernels do not write themselves

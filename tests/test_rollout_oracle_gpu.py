@@ -34,6 +34,7 @@ CASES = [
     pytest.param("crawler", 2048, 256, 256, "bf16", 4096, id="crawler-2048x256-h256-bf16-shard2-unpinned"),
     # (Crawler episodes run to the 1000-step limit: a narrower vector long enough for every env to finish one, timeout bootstrap included)
     pytest.param("crawler", 512, 1040, 256, "bf16", 4096, id="crawler-512x1040-h256-bf16-shard2-unpinned"),
+    pytest.param("ant", 512, 1040, 256, "bf16", 0, id="ant-105x8-512x1040-h256-bf16-unpinned"),
     # the reference's default net and dtype (f32 256 x 256) at the headline size: the policy-only fused chunk + batched values / bootstrap
     pytest.param("gridworld", 4096, 256, 256, "f32", 0, id="gridworld-4096x256-h256-f32"),
     # the other fused H = 64 instantiations at the headline size

@@ -367,7 +367,8 @@ constexpr TaskMeta meta_of(const char *n) {
 }
 static const TaskMeta kMeta[TMA_NUM_TASKS] = {meta_of<BasicTask>("basic"), meta_of<GridTask>("gridworld"), meta_of<BallTask>("ball3d"),
                                               meta_of<PushTask>("push"), meta_of<CrawlerTask>("crawler"), meta_of<WallJumpTask>("walljump"),
-                                              meta_of<BicycleTask>("bicycle"), meta_of<BrickBreakTask>("brickbreak"), meta_of<GliderTask>("glider")};
+                                              meta_of<BicycleTask>("bicycle"), meta_of<BrickBreakTask>("brickbreak"), meta_of<GliderTask>("glider"),
+                                              meta_of<AntTask>("ant")};
 
 }  // namespace tma
 
@@ -457,11 +458,7 @@ int tma_task_id(const char *name, int *task_out) {
             *task_out = t;
             return TMA_OK;
         }
-    if (strcmp(name, "ant") == 0) {  // registry id of the Crawler demo (backend/mlagents/registry.py:225)
-        *task_out = TMA_TASK_CRAWLER;
-        return TMA_OK;
-    }
-    return fail(TMA_ERR_UNKNOWN_TASK, "Unknown task '%s'. Available: ball3d, basic, bicycle, brickbreak, crawler, glider, gridworld, push, walljump", name);
+    return fail(TMA_ERR_UNKNOWN_TASK, "Unknown task '%s'. Available: ant, ball3d, basic, bicycle, brickbreak, crawler, glider, gridworld, push, walljump", name);
 }
 #define META_GETTER(fn, field)                                 \
     int fn(int task) {                                         \

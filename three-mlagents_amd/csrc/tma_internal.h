@@ -90,6 +90,7 @@ static int dispatch_task(int task, F &&f) {
     case TMA_TASK_BICYCLE: return f(tma::BicycleTask{});
     case TMA_TASK_BRICKBREAK: return f(tma::BrickBreakTask{});
     case TMA_TASK_GLIDER: return f(tma::GliderTask{});
+    case TMA_TASK_ANT: return f(tma::AntTask{});
     }
     return tma::fail(TMA_ERR_UNKNOWN_TASK, "unknown task id %d", task);
 }

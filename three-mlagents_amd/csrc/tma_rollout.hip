@@ -1173,9 +1173,9 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     // 256-wide bf16 policies on the Discrete tasks with observations of up to 32 floats: fused chunk with register-resident weights
     static const bool no_wide_fused = getenv("TMA_NO_WIDE_FUSED") != nullptr;  // test hook: the per-step composition
     const bool task_fused = dispatch_task(env->task, [](auto t) { return decltype(t)::FUSED_ROLLOUT ? 1 : 0; }) == 1;
-    const bool fused_disc = task_fused && !d->continuous && env->task != TMA_TASK_CRAWLER && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
+    const bool fused_disc = task_fused && !d->continuous && env->task != TMA_TASK_CRAWLER && env->task != TMA_TASK_ANT && d->act_dim == tma_task_num_actions(env->task) && d->obs_dim <= 32;
     // ... and on the Crawler shape (Box actions, 172 observations): layer-1 fragments streamed per step, env state in LDS
-    const bool fused_cont = d->continuous && env->task == TMA_TASK_CRAWLER && d->act_dim == tma_task_act_dim(env->task);
+    const bool fused_cont = d->continuous && (env->task == TMA_TASK_CRAWLER || env->task == TMA_TASK_ANT) && d->act_dim == tma_task_act_dim(env->task);
     const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && env->is_reset && d->obs_dim == tma_task_obs_dim(env->task) && (fused_disc || fused_cont);
     if (fused_wide) {
         TMA_HIP(hipSetDevice(env->device));

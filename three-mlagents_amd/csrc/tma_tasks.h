@@ -1115,10 +1115,22 @@ struct GliderTask {
 // Crawler-shape (BUILD-DEFINED, parity unpinned against the reference: the reference's "ant" task is
 // gym.make("Ant-v5") over MuJoCo, backend/mlagents/envs.py:274-277, backend/examples/crawler.py:31-85).
 // 172-dim obs, Box(-1,1,(20,)) actions, 1000-step limit.  Restated 1:1 from oracle/tma_oracle.c.
+//
+// Two instantiations of one articulated chain of NJ torque-driven joints on a root body:
+//   CrawlerTask = ChainTask<20, 0>: BASELINE.json configs[4] "Crawler (Ant) 172-dim obs / 20-dim action" (12 root + 8 per joint features);
+//   AntTask     = ChainTask<8, 1>:  the SHAPES of what the reference's `ant` task actually builds, gymnasium Ant-v5 with
+//                 exclude_current_positions_from_observation (envs.py:274-277): Box(105,) observations in Ant-v5's order -- 13 qpos
+//                 (z, orientation quaternion, 8 joint angles), 14 qvel (3 linear, 3 angular, 8 joint), 78 contact-force entries
+//                 (13 bodies x 6, clipped to [-1, 1]) -- and Box(-1, 1, (8,)) torques.  A policy zip the reference trained on Ant-v5
+//                 loads and runs against it; the DYNAMICS are the build's chain, not MuJoCo's (parity unpinned either way).
 // ==========================================================================================
-struct CrawlerTask {
-    static constexpr int NJ = 20;
-    static constexpr int ID = TMA_TASK_CRAWLER, OBS = 172, NACT = 0, ADIM = NJ, MAXSTEPS = 1000, SW = 3 * NJ + 9, RW = 0, SDIM = 3 * NJ + 9;
+template <int NJ_, int LAYOUT>
+struct ChainTask {
+    static constexpr int NJ = NJ_;
+    static constexpr int ID = LAYOUT == 0 ? TMA_TASK_CRAWLER : TMA_TASK_ANT, OBS = LAYOUT == 0 ? 12 + 8 * NJ : 105;
+    static constexpr int NACT = 0, ADIM = NJ, MAXSTEPS = 1000, SW = 3 * NJ + 9, RW = 0, SDIM = 3 * NJ + 9;
+    static_assert(LAYOUT == 0 || NJ == 8, "the Ant-v5 observation layout has 8 joints");
+    static constexpr float ZL = NJ == 20 ? 0.015f : 0.3f / NJ;  // root height = 0.25 + ZL * sum cos(q): 0.55 with every joint at rest
     static constexpr bool USES_MT = false, NATIVE_TRUNC_RULE = false;
     static constexpr bool FUSED_ROLLOUT = true;  // the fused rollout-chunk kernels are instantiated for this task (tma_rollout.hip)
     struct S {
@@ -1230,7 +1242,7 @@ struct CrawlerTask {
         rr = rr + dt * (0.05f * thrust_y - 6.0f * roll - 1.2f * rr);
         pitch = pitch + dt * pr;
         roll = roll + dt * rr;
-        z = 0.25f + 0.015f * lift;
+        z = 0.25f + ZL * lift;
         x = x + dt * vx;
         s.root[0] = z, s.root[1] = vx, s.root[2] = vy, s.root[3] = pitch, s.root[4] = roll, s.root[5] = pr, s.root[6] = rr, s.root[7] = x;
         s.steps += 1;
@@ -1240,11 +1252,37 @@ struct CrawlerTask {
         r = (double)rew;
         done = unhealthy || s.steps >= 1000;
     }
-    // writes straight to the destination row (172 floats) -- too wide to stage in registers.  `o` is a float pointer or anything with
+    // writes straight to the destination row (172 / 105 floats) -- too wide to stage in registers.  `o` is a float pointer or anything with
     // operator[] / operator+ (the fused rollout writes the global row and the bf16 LDS image in one pass)
     template <class O>
     __device__ static void obs(const S &s, O o) {
         float pitch = s.root[3], roll = s.root[4];
+        if constexpr (LAYOUT == 1) {
+            // Ant-v5 order.  qpos[2:]: z, quaternion (w, x, y, z) of the (pitch, roll) attitude, joint angles
+            const float hp = 0.5f * pitch, hr = 0.5f * roll;
+            const float sp = csin(hp), cp = ccos(hp), sr = csin(hr), cr = ccos(hr);
+            o[0] = s.root[0], o[1] = cp * cr, o[2] = sr * cp, o[3] = sp * cr, o[4] = -(sp * sr);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) o[5 + j] = s.q[j];
+            // qvel: root linear (x, y, z) and angular (roll, pitch, yaw) velocity, joint velocities
+            o[13] = s.root[1], o[14] = s.root[2], o[15] = 0.0f, o[16] = s.root[6], o[17] = s.root[5], o[18] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) o[19 + j] = s.qd[j];
+            // contact forces, 13 bodies x 6: the z-force slot of bodies 1 .. 8 carries joint j's ground contact, everything else is zero
+#pragma unroll
+            for (int bdy = 0; bdy < 13; bdy++) {
+                float cz = 0.0f;
+                if (bdy >= 1 && bdy <= NJ) {
+                    const int j = bdy - 1;
+                    const float side = (j & 1) ? -1.0f : 1.0f;
+                    const float contact = -(csin(s.q[j]) + side * pitch * 0.5f);
+                    cz = contact > 0.0f ? (contact < 1.0f ? contact : 1.0f) : 0.0f;
+                }
+                auto p = o + (27 + 6 * bdy);
+                p[0] = 0.0f, p[1] = 0.0f, p[2] = cz, p[3] = 0.0f, p[4] = 0.0f, p[5] = 0.0f;
+            }
+            return;
+        }
         o[0] = s.root[0], o[1] = s.root[1], o[2] = s.root[2], o[3] = pitch, o[4] = roll, o[5] = s.root[5], o[6] = s.root[6];
         o[7] = csin(pitch), o[8] = ccos(pitch), o[9] = csin(roll), o[10] = ccos(roll), o[11] = s.root[0] - 0.55f;
 #pragma unroll
@@ -1268,5 +1306,7 @@ struct CrawlerTask {
         s.steps = (int)f[3 * NJ + 8];
     }
 };
+using CrawlerTask = ChainTask<20, 0>;
+using AntTask = ChainTask<8, 1>;
 
 }  // namespace tma

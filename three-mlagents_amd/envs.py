@@ -131,4 +131,10 @@ def make_glider_env() -> HipSingleEnv:
 
 
 def make_ant_env() -> HipSingleEnv:
+    """The reference's `ant` factory (envs.py:274-277) by shape: 105 observations in Ant-v5's order, 8 torques; dynamics build-defined."""
+    return HipSingleEnv("ant")
+
+
+def make_crawler_env() -> HipSingleEnv:
+    """BASELINE.json configs[4]: the 172-observation / 20-action articulated chain (build-defined, no counterpart in the reference)."""
     return HipSingleEnv("crawler")

@@ -82,7 +82,7 @@ except Exception:  # noqa: BLE001
 def task_spaces(task_name: str):
     """(observation_space, action_space) exactly as the reference's factories declare them
     (backend/mlagents/envs.py:38-44 basic, :166-175 ball3d, :178-187 gridworld, :190-199 push; crawler is the
-    BASELINE 172/20 synthetic shape standing in for envs.py:274-277)."""
+    BASELINE 172/20 synthetic shape; ant carries the shapes of envs.py:274-277 on the same build-defined dynamics)."""
     if task_name == "basic":
         return Box(0.0, 1.0, shape=(21,), dtype=np.float32), Discrete(3)
     if task_name == "ball3d":
@@ -99,6 +99,8 @@ def task_spaces(task_name: str):
         return Box(-np.inf, np.inf, shape=(45,), dtype=np.float32), Discrete(3)
     if task_name == "glider":  # envs.py:242-253
         return Box(-np.inf, np.inf, shape=(16,), dtype=np.float32), Discrete(5)
-    if task_name == "crawler":
+    if task_name == "crawler":  # BASELINE.json configs[4]: 172 observations, 20 actions
         return Box(-np.inf, np.inf, shape=(172,), dtype=np.float32), Box(-1.0, 1.0, shape=(20,), dtype=np.float32)
+    if task_name == "ant":  # envs.py:274-277: the spaces gymnasium's Ant-v5 declares (exclude_current_positions_from_observation=True)
+        return Box(-np.inf, np.inf, shape=(105,), dtype=np.float32), Box(-1.0, 1.0, shape=(8,), dtype=np.float32)
     raise KeyError(task_name)

@@ -47,8 +47,9 @@ class EngineTask(NamedTuple):
 
 
 # id  kernel  tier  timesteps  eval_episodes  n_envs  reward_threshold  pinned  default_algorithm (registry.py:59,75,91,107,123,139,154,169,231)
-# ("ant": the reference delegates to gymnasium Ant-v5 / MuJoCo, envs.py:274-277; the engine's kernel is the BASELINE 172-observation /
-#  20-action articulated chain: same shapes, build-defined dynamics, parity unpinned)
+# ("ant": the reference delegates to gymnasium Ant-v5 / MuJoCo, envs.py:274-277.  The engine's `ant` kernel has Ant-v5's SHAPES -- 105 observations in
+#  its order, 8 torques -- so a policy zip the reference trained loads and runs; `crawler` is BASELINE.json's 172-observation / 20-action chain.
+#  Both run the build's articulated-chain dynamics: parity unpinned)
 _ROWS = """
 basic      basic      foundation    25000   50  1  0.85  yes  dqn
 gridworld  gridworld  foundation   100000  100  1  0.75  yes  dqn
@@ -58,7 +59,8 @@ walljump   walljump   benchmark    150000  100  1  0.7   yes  dqn
 brickbreak brickbreak benchmark    500000   50  8  -     yes  ppo
 bicycle    bicycle    benchmark    500000   50  8  -     yes  ppo
 glider     glider     frontier    1000000   50  8  -     yes  ppo
-ant        crawler    benchmark   3000000   20  8  -     no  ppo
+ant        ant        benchmark   3000000   20  8  -     no  ppo
+crawler    crawler    benchmark   3000000   20  8  -     no  ppo
 """
 
 
@@ -74,7 +76,7 @@ def _parse(rows: str) -> dict[str, EngineTask]:
 
 ENGINE_TASKS = _parse(_ROWS)
 
-_SPELLINGS = {"crawler": "ant"}
+_SPELLINGS: dict[str, str] = {}
 # ids the reference's catalogue also lists; no kernels here (out of the hot-path scope)
 _REFERENCE_ONLY = frozenset("labyrinth astrodynamics kraken worm foodcollector intersection minecraft simcity fish "
                             "self-driving-car".split())

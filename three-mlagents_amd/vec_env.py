@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from .spaces import task_spaces
 
-TASK_ALIASES = {"ant": "crawler"}
+TASK_ALIASES: dict[str, str] = {}  # (round 3: "ant" is a task of its own -- the reference's Ant-v5 shapes; "crawler" is BASELINE's 172 / 20 shape)
 
 
 def _require_gpu(device):
