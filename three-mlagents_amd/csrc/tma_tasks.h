@@ -1252,41 +1252,46 @@ struct ChainTask {
         r = (double)rew;
         done = unhealthy || s.steps >= 1000;
     }
-    // writes straight to the destination row (172 / 105 floats) -- too wide to stage in registers.  `o` is a float pointer or anything with
-    // operator[] / operator+ (the fused rollout writes the global row and the bf16 LDS image in one pass)
+    // The observation row in ITEMS independent pieces: item 0 = the root block, item 1 + j = the block of joint j (LAYOUT 1: of body j).
+    // obs() is the loop over the items; the fused rollout chunk gives every (row, item) pair to a thread of its own, so the 32 rows of a
+    // block go out as coalesced stores by all 512 threads instead of 172 scattered stores per row by one owner lane -- one source, same bits.
+    // `o` is a float pointer or anything with operator[] / operator+ (the fused rollout writes the global row and the bf16 LDS image in one pass).
+    static constexpr int OBS_ITEMS = LAYOUT == 0 ? NJ + 1 : 14;
     template <class O>
-    __device__ static void obs(const S &s, O o) {
-        float pitch = s.root[3], roll = s.root[4];
+    __device__ static void obs_item(const S &s, int item, O o) {
+        const float pitch = s.root[3], roll = s.root[4];
         if constexpr (LAYOUT == 1) {
-            // Ant-v5 order.  qpos[2:]: z, quaternion (w, x, y, z) of the (pitch, roll) attitude, joint angles
-            const float hp = 0.5f * pitch, hr = 0.5f * roll;
-            const float sp = csin(hp), cp = ccos(hp), sr = csin(hr), cr = ccos(hr);
-            o[0] = s.root[0], o[1] = cp * cr, o[2] = sr * cp, o[3] = sp * cr, o[4] = -(sp * sr);
+            if (item == 0) {
+                // Ant-v5 order.  qpos[2:]: z, quaternion (w, x, y, z) of the (pitch, roll) attitude, joint angles
+                const float hp = 0.5f * pitch, hr = 0.5f * roll;
+                const float sp = csin(hp), cp = ccos(hp), sr = csin(hr), cr = ccos(hr);
+                o[0] = s.root[0], o[1] = cp * cr, o[2] = sr * cp, o[3] = sp * cr, o[4] = -(sp * sr);
 #pragma unroll
-            for (int j = 0; j < NJ; j++) o[5 + j] = s.q[j];
-            // qvel: root linear (x, y, z) and angular (roll, pitch, yaw) velocity, joint velocities
-            o[13] = s.root[1], o[14] = s.root[2], o[15] = 0.0f, o[16] = s.root[6], o[17] = s.root[5], o[18] = 0.0f;
+                for (int j = 0; j < NJ; j++) o[5 + j] = s.q[j];
+                // qvel: root linear (x, y, z) and angular (roll, pitch, yaw) velocity, joint velocities
+                o[13] = s.root[1], o[14] = s.root[2], o[15] = 0.0f, o[16] = s.root[6], o[17] = s.root[5], o[18] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < NJ; j++) o[19 + j] = s.qd[j];
-            // contact forces, 13 bodies x 6: the z-force slot of bodies 1 .. 8 carries joint j's ground contact, everything else is zero
-#pragma unroll
-            for (int bdy = 0; bdy < 13; bdy++) {
-                float cz = 0.0f;
-                if (bdy >= 1 && bdy <= NJ) {
-                    const int j = bdy - 1;
-                    const float side = (j & 1) ? -1.0f : 1.0f;
-                    const float contact = -(csin(s.q[j]) + side * pitch * 0.5f);
-                    cz = contact > 0.0f ? (contact < 1.0f ? contact : 1.0f) : 0.0f;
-                }
-                auto p = o + (27 + 6 * bdy);
-                p[0] = 0.0f, p[1] = 0.0f, p[2] = cz, p[3] = 0.0f, p[4] = 0.0f, p[5] = 0.0f;
+                for (int j = 0; j < NJ; j++) o[19 + j] = s.qd[j];
+                return;
             }
-            return;
-        }
-        o[0] = s.root[0], o[1] = s.root[1], o[2] = s.root[2], o[3] = pitch, o[4] = roll, o[5] = s.root[5], o[6] = s.root[6];
-        o[7] = csin(pitch), o[8] = ccos(pitch), o[9] = csin(roll), o[10] = ccos(roll), o[11] = s.root[0] - 0.55f;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
+            // contact forces, 13 bodies x 6: the z-force slot of bodies 1 .. 8 carries joint j's ground contact, everything else is zero
+            const int bdy = item - 1;
+            float cz = 0.0f;
+            if (bdy >= 1 && bdy <= NJ) {
+                const int j = bdy - 1;
+                const float side = (j & 1) ? -1.0f : 1.0f;
+                const float contact = -(csin(s.q[j]) + side * pitch * 0.5f);
+                cz = contact > 0.0f ? (contact < 1.0f ? contact : 1.0f) : 0.0f;
+            }
+            auto p = o + (27 + 6 * bdy);
+            p[0] = 0.0f, p[1] = 0.0f, p[2] = cz, p[3] = 0.0f, p[4] = 0.0f, p[5] = 0.0f;
+        } else {
+            if (item == 0) {
+                o[0] = s.root[0], o[1] = s.root[1], o[2] = s.root[2], o[3] = pitch, o[4] = roll, o[5] = s.root[5], o[6] = s.root[6];
+                o[7] = csin(pitch), o[8] = ccos(pitch), o[9] = csin(roll), o[10] = ccos(roll), o[11] = s.root[0] - 0.55f;
+                return;
+            }
+            const int j = item - 1;
             float qj = s.q[j], qn = s.q[(j + 1) % NJ];
             float sn = csin(qj), c = ccos(qj);
             float side = (j & 1) ? -1.0f : 1.0f;
@@ -1294,6 +1299,11 @@ struct ChainTask {
             auto p = o + (12 + 8 * j);
             p[0] = qj, p[1] = s.qd[j] * 0.1f, p[2] = sn, p[3] = c, p[4] = s.pa[j], p[5] = qn - qj, p[6] = contact > 0.0f ? contact : 0.0f, p[7] = qj * qj;
         }
+    }
+    template <class O>
+    __device__ static void obs(const S &s, O o) {
+#pragma unroll
+        for (int item = 0; item < OBS_ITEMS; item++) obs_item(s, item, o);
     }
     __device__ static void to_flat(const S &s, double *f) {
         for (int j = 0; j < NJ; j++) f[j] = s.q[j], f[NJ + j] = s.qd[j], f[2 * NJ + j] = s.pa[j];
