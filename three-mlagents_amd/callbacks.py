@@ -156,8 +156,8 @@ class EvalCallback(BaseCallback):
     episode seeds are fixed (seed + env + k * 2^20), so with `deterministic=True` its result is a function of the parameters alone --
     while the optimizer has not stepped since the last evaluation (`model._n_updates` / Adam step unchanged: `on_step` calls inside
     one rollout; with thousands of envs `eval_freq // n_envs` is a handful of vector steps) the previous result is repeated instead
-    of re-running identical episodes.  `evaluations.npz` is rewritten when a fresh evaluation ran and at training end, not once per
-    repeated row."""
+    of re-running identical episodes.  `evaluations.npz` is rewritten after a fresh evaluation (at most every `flush_interval_s`
+    seconds: the file grows by hundreds of rows per rollout at thousands of envs) and at training end, not once per repeated row."""
 
     def __init__(self, eval_env, best_model_save_path=None, log_path=None, eval_freq=10000, n_eval_episodes=5, deterministic=True, verbose=0, warn=True):
         super().__init__(verbose)
@@ -174,7 +174,15 @@ class EvalCallback(BaseCallback):
         m = self.model
         return (getattr(m, "_n_updates", None), getattr(m, "_adam_step", None), id(getattr(m, "policy", None)))
 
-    def _flush(self) -> None:
+    flush_interval_s = 2.0  # evaluations.npz is rewritten whole (SB3 does the same): at most this often while training, and once at the end
+
+    def _flush(self, force: bool = True) -> None:
+        import time as _time
+
+        now = _time.monotonic()
+        if not force and now - getattr(self, "_last_flush", -1e9) < self.flush_interval_s:
+            return
+        self._last_flush = now
         if self._dirty and self.log_path is not None:
             os.makedirs(self.log_path, exist_ok=True)
             np.savez(os.path.join(self.log_path, "evaluations"), timesteps=self.evaluations_timesteps, results=self.evaluations_results,
@@ -200,7 +208,7 @@ class EvalCallback(BaseCallback):
             self._dirty = True
             if fresh:
                 self.last_mean_reward = float(np.mean(rewards))
-                self._flush()
+                self._flush(force=self.n_fresh_evaluations <= 1)
                 if self.verbose >= 1:
                     print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
                 if self.last_mean_reward > self.best_mean_reward:

@@ -181,7 +181,10 @@ class HipEnvEngine:
         cap = getattr(self, "_log_cap", 0)
         if cap <= 0:
             raise RuntimeError("episode log is off: call episode_log(capacity) first")
-        r, l, e = np.empty(cap, np.float64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+        host = getattr(self, "_log_host", None)
+        if host is None or len(host[0]) != cap:  # (staging buffers are kept: a fresh 16 MB of pages per pop costs a millisecond)
+            host = self._log_host = (np.empty(cap, np.float64), np.empty(cap, np.int32), np.empty(cap, np.int32))
+        r, l, e = host
         n, seen = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().tma_env_pop_episode_log(self._h, r.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
                                                       cap, C.byref(n), C.byref(seen), self._stream()))
