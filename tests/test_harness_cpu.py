@@ -315,3 +315,49 @@ def test_sb3_zip_members_without_sb3(monkeypatch):
         assert float(opt.state[next(iter(net.parameters()))]["step"]) == 8.0
         fresh = sf.adam_state_dict(order, {}, {}, step=0, lr=3e-4)  # an untrained model: empty state, still loadable
         torch.optim.Adam(net.parameters()).load_state_dict(fresh)
+
+
+def test_eval_callback_runs_episodes_once_per_optimizer_state(tmp_path, monkeypatch):
+    """EvalCallback (training.py:152-161 configures SB3's): the reference's row cadence -- one row of `evaluations.npz` per `eval_freq` calls --
+    with the episodes re-run only after the optimizer stepped (a deterministic evaluation from fixed reset seeds is a function of the
+    parameters alone); a stochastic evaluation is never repeated from the cache.  No GPU: the evaluation itself is a stand-in."""
+    from three_mlagents_amd import callbacks, evaluation
+
+    calls = []
+
+    def fake_evaluate(model, env, n_eval_episodes, deterministic, return_episode_rewards):
+        calls.append(model._n_updates)
+        return [float(model._n_updates)] * n_eval_episodes, [7] * n_eval_episodes
+
+    monkeypatch.setattr(evaluation, "evaluate_policy", fake_evaluate)
+
+    class Model:
+        num_timesteps, _n_updates, _adam_step, policy = 0, 0, 0, object()
+
+        def get_env(self):
+            return None
+
+        def save(self, path):
+            saved.append(path)
+
+    saved = []
+    for deterministic, want_fresh in ((True, 3), (False, 12)):
+        calls.clear()
+        m = Model()
+        cb = callbacks.EvalCallback(object(), log_path=str(tmp_path / f"e{int(deterministic)}"), best_model_save_path=str(tmp_path / "best"), eval_freq=2,
+                                    n_eval_episodes=4, deterministic=deterministic)
+        cb.flush_interval_s = 0.0
+        cb.init_callback(m)
+        cb.on_training_start()
+        for rollout in range(3):
+            for _ in range(8):  # eight vector steps of one rollout: the policy cannot move in between
+                m.num_timesteps += 4096
+                assert cb.on_step()
+            m._n_updates += 10  # train(): ten epochs
+            m._adam_step += 320
+        cb.on_training_end()
+        assert len(calls) == want_fresh == cb.n_fresh_evaluations
+        ev = np.load(tmp_path / f"e{int(deterministic)}" / "evaluations.npz")
+        assert ev["timesteps"].tolist() == [4096 * 2 * k for k in range(1, 13)] and ev["results"].shape == (12, 4) and ev["ep_lengths"].shape == (12, 4)
+        assert ev["results"][:, 0].tolist() == [0.0] * 4 + [10.0] * 4 + [20.0] * 4  # rows of a rollout repeat that rollout's evaluation
+    assert len(saved) == 6  # a new best after every optimizer state, in both runs
