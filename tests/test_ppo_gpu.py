@@ -706,6 +706,43 @@ def test_persistent_epoch_kernel_falls_back_to_launches_when_it_cannot_run(monke
     # (the library also says so on stderr, once per process: not asserted here -- an earlier fallback in the same process would have used it up)
 
 
+@pytest.mark.parametrize("task,n_envs,n_steps,batch", [("gridworld", 256, 64, 1024), ("gridworld", 256, 64, 768), ("gridworld", 512, 128, 8192),
+                                                     ("gridworld", 128, 64, 512), ("gridworld", 300, 10, 1000)])
+def test_optimizer_step_folded_into_the_next_gradient_launch_is_bit_identical(monkeypatch, task, n_envs, n_steps, batch):
+    """H = 64 fast path, minibatches of >= 256 samples: tma_ppo_train_epoch_local runs the clip + Adam step of minibatch k in the prologue of
+    gradient launch k + 1 (every workgroup redoes it for its net and builds its LDS weight image from the results) instead of a launch of its
+    own.  Same routine, same inputs: parameters (derived copies and images included), both Adam moments and the statistics equal the
+    one-optimizer-launch-per-minibatch sequence (TMA_NO_ADAM_FOLD) bit for bit -- ragged last minibatches (768: 256 left over; 1000: 3 full
+    + none left; both directions of the state ping-pong) included."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(fold):
+        monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        if fold:
+            monkeypatch.delenv("TMA_NO_ADAM_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("TMA_NO_ADAM_FOLD", "1")
+        env = make_vector_env(task, n_envs=n_envs, seed=11)
+        m = PPO("MlpPolicy", env, n_steps=n_steps, batch_size=batch, n_epochs=3, seed=11, policy_kwargs={"net_arch": [64, 64]})
+        for _ in range(2):
+            m.collect_rollouts()
+            m.train()
+        st = m.pop_train_stats()
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, m._adam_step, m.grad.cpu() if hasattr(m, "grad") else None)
+        env.close()
+        return out
+
+    p0, m0, v0, s0, n0, g0 = run(False)
+    p1, m1, v1, s1, n1, g1 = run(True)
+    assert n0 == n1 == 2 * 3 * -(-(n_envs * n_steps) // batch)
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    if g0 is not None:
+        assert torch.equal(g0, g1) and float(g1.abs().max()) == 0.0  # the gradient buffer is left zeroed either way
+    for k in s0:
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+
+
 def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
     """1024 optimizer steps in one persistent launch (GridWorld rollout of 1024 envs x 256 steps, the reference's batch_size = 256) against
     the same epoch as per-minibatch launches: the two paths differ only in the f64 summation order of the clip norm, so after a thousand

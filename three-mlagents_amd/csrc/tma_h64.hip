@@ -326,10 +326,136 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
 
 
 // DIRECT (small minibatches): 4-wave blocks, one wave per SIMD, one tile per wave; the block reduction runs over four copies.
+// LDS image slots of parameter x of one net (flat [W1t | b1 | W2t | b2 | W3t | b3] order): the image part of scatter_derived_h64
+__device__ __forceinline__ void image_store_h64(float *wimg, int D, int n_out, int x, float val) {
+    constexpr int H = 64;
+    if (x < D * H) {
+        const int k = x >> 6, n = x & 63;
+        wimg[IMG_W1 + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        return;
+    }
+    x -= D * H;
+    if (x < H) {
+        wimg[IMG_B1 + x] = val;
+        return;
+    }
+    x -= H;
+    if (x < H * H) {
+        const int k = x >> 6, n = x & 63;
+        wimg[IMG_W2F + k * 64 + (n & 15) * 4 + (n >> 4)] = val;
+        wimg[IMG_W2B + n * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * H;
+    if (x < H) {
+        wimg[IMG_B2 + x] = val;
+        return;
+    }
+    x -= H;
+    if (x < H * n_out) {
+        const int k = x / n_out, a = x - k * n_out;
+        wimg[IMG_W3F + k * 16 + a] = val;
+        wimg[IMG_W3B + a * 64 + (k & 15) * 4 + (k >> 4)] = val;
+        return;
+    }
+    x -= H * n_out;
+    if (x < n_out) wimg[IMG_B3 + x] = val;
+}
+
+// The pending optimizer step of AdamFold for this workgroup's net, results into the LDS image (and, from workgroup 0 of the net, into the
+// next half of the state double buffer).  clip_grad_norm_ + Adam exactly as adam_scatter_h64_kernel: same fold of the norm partials, same
+// adam_update_h64.  Ownership is chosen for the LDS stores: threads 0..255 own one 4 x 4 block of W2t each -- rows kr + 16 jj, columns
+// nr + 16 j -- which is one float4 per row of the forward image ([k][n & 15][n >> 4]) and one float4 per column of the input-gradient image
+// ([n][k & 15][k >> 4]): 8 ds_write_b128 per thread instead of 32 scalar stores, half of them 64-way bank conflicts (a wave covers 8 nr x 8
+// kr, so a b128 store meets 8 lanes per bank group: twice the ideal 4 passes).  The other <= 2 192 parameters (W1t, the biases, the head)
+// go round-robin over the remaining threads (all of them in a 256-thread workgroup).  Every load is issued before the clip coefficient is
+// folded, so the prologue is one memory round trip.
+template <bool IS_PI>
+__device__ __forceinline__ void fold_adam_into_image(const AdamFold &f, const PLayout &L, float *wimg, int block_net) {
+    __shared__ double fold_red[4];
+    __shared__ float fold_coef;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int base = IS_PI ? L.pW1t : L.vW1t, pn = (IS_PI ? L.vW1t : L.log_std) - base, n_out = IS_PI ? L.A : 1;
+    const int w2_off = L.D * 64 + 64, n_other = pn - 4096;
+    const bool own_w2 = tid < 256;
+    const int o_base = nthr > 256 ? 256 : 0, o_thr = nthr - o_base, o_tid = tid - o_base;
+    const int nr = ((tid >> 6) & 1) * 8 + (tid & 7), kr = ((tid >> 7) & 1) * 8 + ((tid >> 3) & 7);
+    constexpr int NO = 9;  // other parameters per thread (2 192 / 256 < 9)
+    float g2[4][4], m2[4][4], v2[4][4], p2[4][4], go[NO], mo[NO], vo[NO], po[NO];
+    if (own_w2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = base + w2_off + (kr + 16 * jj) * 64 + nr + 16 * j;
+                g2[jj][j] = f.grad[e], m2[jj][j] = f.m_cur[e], v2[jj][j] = f.v_cur[e], p2[jj][j] = f.p_cur[e];
+            }
+    }
+    if (o_tid >= 0) {
+#pragma unroll
+        for (int i = 0; i < NO; i++) {
+            const int y = o_tid + i * o_thr, x = y < w2_off ? y : y + 4096, e = base + (y < n_other ? x : 0);
+            go[i] = f.grad[e], mo[i] = f.m_cur[e], vo[i] = f.v_cur[e], po[i] = f.p_cur[e];
+        }
+    }
+    if (tid < 256) {
+        double a = tid < f.n_part ? f.sq_part[tid] : 0.0;
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((tid & 63) == 0) fold_red[tid >> 6] = a;
+    }
+    // image regions no parameter lands in (rows k >= D of W1, head columns >= n_out, padding) are zeros in the staged image; LDS is not
+    for (int e = tid; e < 1024; e += nthr) wimg[IMG_W1 + e] = 0.0f, wimg[IMG_W3F + e] = 0.0f, wimg[IMG_W3B + e] = 0.0f;
+    if (tid < 32) wimg[IMG_B3 + tid] = 0.0f;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = ((fold_red[0] + fold_red[1]) + fold_red[2]) + fold_red[3];
+        const float total_norm = (float)sqrt(tot);
+        float coef = f.max_norm / (total_norm + 1e-6f);
+        coef = coef > 1.0f ? 1.0f : coef;
+        if (f.max_norm <= 0.0f) coef = 1.0f;
+        fold_coef = coef;
+        if (IS_PI && block_net == 0) f.norm_out[0] = (double)total_norm, f.norm_out[1] = (double)coef;
+    }
+    __syncthreads();
+    const float coef = fold_coef, inv_bc2 = 1.0f / f.bc2_sqrt;
+    const bool keep = block_net == 0;
+    if (own_w2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float gv = (g2[jj][j] * 1.0f) * coef;
+                p2[jj][j] = adam_update_h64(p2[jj][j], gv, m2[jj][j], v2[jj][j], f.beta1, f.beta2, inv_bc2, f.eps, f.lr_step);
+                if (keep) {
+                    const int e = base + w2_off + (kr + 16 * jj) * 64 + nr + 16 * j;
+                    f.p_nxt[e] = p2[jj][j], f.m_nxt[e] = m2[jj][j], f.v_nxt[e] = v2[jj][j];
+                }
+            }
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)  // forward image: row k = kr + 16 jj, slot [nr][j = 0..3]
+            *reinterpret_cast<float4 *>(wimg + IMG_W2F + (kr + 16 * jj) * 64 + nr * 4) = float4{p2[jj][0], p2[jj][1], p2[jj][2], p2[jj][3]};
+#pragma unroll
+        for (int j = 0; j < 4; j++)  // input-gradient image: row n = nr + 16 j, slot [kr][jj = 0..3]
+            *reinterpret_cast<float4 *>(wimg + IMG_W2B + (nr + 16 * j) * 64 + kr * 4) = float4{p2[0][j], p2[1][j], p2[2][j], p2[3][j]};
+    }
+    if (o_tid >= 0) {
+#pragma unroll
+        for (int i = 0; i < NO; i++) {
+            const int y = o_tid + i * o_thr, x = y < w2_off ? y : y + 4096;
+            if (y < n_other) {
+                const float gv = (go[i] * 1.0f) * coef;
+                const float pnew = adam_update_h64(po[i], gv, mo[i], vo[i], f.beta1, f.beta2, inv_bc2, f.eps, f.lr_step);
+                image_store_h64(wimg, L.D, n_out, x, pnew);
+                if (keep) f.p_nxt[base + x] = pnew, f.m_nxt[base + x] = mo[i], f.v_nxt[base + x] = vo[i];
+            }
+        }
+    }
+}
+
 template <bool IS_PI, int DT, bool DIRECT = false>
 __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const double *__restrict__ adv_part, int n_part, float *__restrict__ slab,
-                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net) {
+                                               double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net, const AdamFold &fold) {
 #ifdef TMA_H64_TICKS
     const unsigned long long kern_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -395,7 +521,8 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
         }
     };
     fetch((int64_t)block_net * wpb + wave);
-    stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
+    if (fold.grad != nullptr) fold_adam_into_image<IS_PI>(fold, L, wimg, block_net);  // (uniform) the previous minibatch's optimizer step, then its weights
+    else stage_copy(params + (IS_PI ? L.img_pi : L.img_vf), wimg, IMG_FLOATS);
     if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {  // fold the minibatch advantage partials (same order as adv_final_kernel)
         double a = 0.0, bsum = 0.0;
         for (int k = threadIdx.x; k < n_part; k += 64) a += adv_part[2 * k], bsum += adv_part[2 * k + 1];
@@ -483,7 +610,7 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
 template <int DT, int VER>
 __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                               const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
-                                                              double *__restrict__ stat_slots) {
+                                                              double *__restrict__ stat_slots, AdamFold fold) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // policy blocks first, value blocks behind them: with 128 pairs the two blocks of pair p (same tiles, same sample records) are workgroups p and
     // 128 + p -- dispatched round-robin over the 8 XCDs they land on the SAME XCD, so the second reader of a record finds its line in that L2
@@ -495,8 +622,8 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
         if (pi_block) grad_h64_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
         else grad_h64_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
     } else {
-        if (pi_block) grad_h64t_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
-        else grad_h64t_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+        if (pi_block) grad_h64t_body<true, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair, fold);
+        else grad_h64t_body<false, DT>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair, fold);
     }
 }
 
@@ -504,13 +631,13 @@ __global__ __launch_bounds__(512, 2) void ppo_grad_h64_kernel(const float *__res
 template <int DT>
 __global__ __launch_bounds__(256, 1) void ppo_grad_h64_small_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                     const double *__restrict__ adv_part, int n_part, float *__restrict__ slabs,
-                                                                    double *__restrict__ stat_slots) {
+                                                                    double *__restrict__ stat_slots, AdamFold fold) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
     float *slab = slabs + (int64_t)pair * L.P;
     double *slot = stat_slots + (int64_t)pair * 8;
-    if ((blockIdx.x & 1) == 0) grad_h64t_body<true, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
-    else grad_h64t_body<false, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair);
+    if ((blockIdx.x & 1) == 0) grad_h64t_body<true, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair, fold);
+    else grad_h64t_body<false, DT, true>(params, L, rb, mb, hp, adv_part, n_part, slab, slot, smem, n_pairs, pair, fold);
 }
 
 }  // namespace tma
@@ -528,7 +655,9 @@ static int grad_h64_smem_bytes(const PLayout &L, int wpb, int ver) {
 // H = 64 persistent gradient kernel over one minibatch (>= 256 samples): 2 x n_pairs blocks of 8 waves, block pair p writes slab p.
 // Returns the number of slabs written through *n_slabs_out (the caller runs slab_reduce_kernel over them).
 int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R, const Minibatch &M, const HParams &hpar, const double *adv_part,
-                        int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s) {
+                        int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s, const AdamFold *foldp) {
+    AdamFold fold{};
+    if (foldp) fold = *foldp;
     static const int ver = getenv("TMA_H64_V1") ? 1 : 2;  // (development switch: the round-1 LDS-round-trip tile chain)
     static const int stagger = getenv("TMA_H64_STAGGER") ? atoi(getenv("TMA_H64_STAGGER")) : 0;
     HParams hps = hpar;
@@ -539,7 +668,7 @@ int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R,
         const int smem = (IMG_FLOATS + 4 * T_PER_WAVE) * 4;
         auto launch_small = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            k<<<dim3((unsigned)(2 * blocks)), dim3(256), smem, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots);
+            k<<<dim3((unsigned)(2 * blocks)), dim3(256), smem, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots, fold);
             return TMA_OK;
         };
         const int rc = L.D == 4 ? launch_small(ppo_grad_h64_small_kernel<4>) : (L.D == 6 ? launch_small(ppo_grad_h64_small_kernel<6>) : launch_small(ppo_grad_h64_small_kernel<0>));
@@ -553,7 +682,7 @@ int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R,
     if (blocks4 > H64_BLOCKS) blocks4 = H64_BLOCKS;
     auto launch = [&](auto k) -> int {
         if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
-        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots);
+        k<<<dim3((unsigned)(2 * blocks4)), dim3(64 * wpb4), smem4, s>>>(params, L, R, M, hps, adv_part, n_part, slabs, slots, fold);
         return TMA_OK;
     };
     int rc;

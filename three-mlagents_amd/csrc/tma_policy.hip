@@ -1135,7 +1135,8 @@ static int grad_wide_smem_bytes(const PLayout &L) {
 // sq_part (optional): sq_part[blockIdx.x] = sum of squares of this block's 64 finished gradient entries (f64, fixed order) -- lets
 // tma_ppo_adam_step_local skip its own pass over the gradient for the norm.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs_pi, int P, float *__restrict__ grad,
-                                                          int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0, double *__restrict__ sq_part = nullptr) {
+                                                          int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0, double *__restrict__ sq_part = nullptr,
+                                                          int overwrite = 0) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -1166,7 +1167,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     if (q == 0) {
         float gnew = 0.0f;
         if (e < P) {
-            gnew = grad[e] + (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+            // (overwrite: the previous minibatch's gradient is still there -- its optimizer step ran inside the gradient launch, AdamFold)
+            gnew = (overwrite ? 0.0f : grad[e]) + (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
             grad[e] = gnew;
         }
         if (sq_part) {
@@ -1234,10 +1236,11 @@ __global__ __launch_bounds__(64) void grad_sumsq64_kernel(const float *__restric
 // tma_ppo_adam_step_local, H == 64 fast path: one thread per parameter over ceil(P / 256) blocks.  The norm comes from the
 // sum-of-squares partials slab_reduce_kernel left (every block folds them in the same fixed order), and each thread writes its
 // updated parameter to the flat buffer AND to its derived copies / image slots -- no single-block optimizer, no refresh launch.
-__global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
-                                                               float *__restrict__ v, PLayout L, const double *__restrict__ sq_part, int n_part,
-                                                               float max_norm, float lr_step, float beta1, float beta2, float bc2_sqrt, float eps,
-                                                               double *norm_out, float scale) {
+// (p_src, m_src, v_src): the state before the step -- the same buffers, or the other half of the AdamFold double buffer.
+__global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *params, float *__restrict__ grad, float *m, float *v, PLayout L,
+                                                               const double *__restrict__ sq_part, int n_part, float max_norm, float lr_step,
+                                                               float beta1, float beta2, float bc2_sqrt, float eps, double *norm_out, float scale,
+                                                               const float *p_src, const float *m_src, const float *v_src) {
     __shared__ double red[4];
     __shared__ float coef_s;
     double a = (int)threadIdx.x < n_part ? sq_part[threadIdx.x] : 0.0;
@@ -1258,8 +1261,8 @@ __global__ __launch_bounds__(256) void adam_scatter_h64_kernel(float *__restrict
     if (e >= L.P) return;
     const float gv = (grad[e] * scale) * coef_s;
     grad[e] = 0.0f;
-    float mm = m[e], vv = v[e];
-    const float pn = adam_update_h64(params[e], gv, mm, vv, beta1, beta2, 1.0f / bc2_sqrt, eps, lr_step);
+    float mm = m_src[e], vv = v_src[e];
+    const float pn = adam_update_h64(p_src[e], gv, mm, vv, beta1, beta2, 1.0f / bc2_sqrt, eps, lr_step);
     m[e] = mm;
     v[e] = vv;
     params[e] = pn;
@@ -1467,6 +1470,13 @@ struct GradTimer {
 };
 
 // where slab_reduce_kernel leaves its sum-of-squares partials (one per 64 parameters) for tma_ppo_adam_step_local
+// second half of the (parameters, exp_avg, exp_avg_sq) double buffer of the optimizer step folded into the H = 64 gradient launches
+// (AdamFold, tma_ppo_train_epoch_local): 3 x P floats behind everything else in the workspace
+static inline int64_t fold_state_offset(const PLayout &L) {
+    return (WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L) + 15) & ~(int64_t)15;
+}
+static inline int64_t fold_state_bytes(const PLayout &L) { return L.img_pi >= 0 ? 3 * (((int64_t)L.P + 3) & ~(int64_t)3) * 4 : 0; }
+
 static double *sq_partials(char *ws, const PLayout &L) {
     const int n = (int)ceil_div(L.P, 64);
     if (n <= 256) return reinterpret_cast<double *>(ws + WS_NORM_PART);
@@ -1994,7 +2004,7 @@ extern "C" {
 int64_t tma_ppo_workspace_bytes(const tma_policy_dims *d) {
     if (!d || check_dims(d)) return WS_BYTES;
     const PLayout L = layout_of(d);
-    return WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L);
+    return fold_state_offset(L) + fold_state_bytes(L);
 }
 
 int tma_policy_param_count(const tma_policy_dims *d, int64_t *n_trainable, int64_t *n_total) {
@@ -2071,8 +2081,9 @@ int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const fl
     return launch_fwd<2>(params, d, terminal_obs, n, 0, 0, 0, 1, nullptr, nullptr, nullptr, truncated, (float)gamma, rewards_inout, (hipStream_t)stream);
 }
 
-int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
-                           float *grad, void *workspace, void *stream) {
+// fold (H = 64 fast path only): the previous minibatch's optimizer step, done in the prologue of this gradient launch (AdamFold)
+static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
+                               float *grad, void *workspace, void *stream, const AdamFold *fold, int overwrite) {
     int rc = enter(d);
     if (rc) return rc;
     if (!params || !rb || !mbi || !hp || !grad || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_minibatch_grad: null argument");
@@ -2134,13 +2145,14 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
         int lrc;
         {
             GradTimer timer(s);
-            lrc = tma_launch_grad_h64(params, L, R, M, hpar, adv_part, nbk, slabs, slots, &blocks4, s);
+            lrc = tma_launch_grad_h64(params, L, R, M, hpar, adv_part, nbk, slabs, slots, &blocks4, s, fold);
         }
         if (lrc) return lrc;
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L));
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L), overwrite);
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
+    if (fold || overwrite) return fail(TMA_ERR_INVALID, "internal: folded optimizer step outside the H = 64 fast path");
     if (L.bf16) {  // column-parallel bf16-MFMA kernel (tma_bf16.hip) + deterministic slab reduction
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         int n_pi = 0, n_vf = 0, lrc;
@@ -2247,6 +2259,11 @@ int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream)
     return TMA_OK;
 }
 
+int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
+                           float *grad, void *workspace, void *stream) {
+    return minibatch_grad_impl(params, d, rb, mbi, hp, grad, workspace, stream, nullptr, 0);
+}
+
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch, int64_t batch_size,
                               const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr, double beta1,
                               double beta2, double eps, double max_grad_norm, void *workspace, void *stream) {
@@ -2287,6 +2304,42 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         persist_fallback_note(ws, (hipStream_t)stream);
     }
     int64_t step = first_step;
+    const bool no_fold = getenv("TMA_NO_ADAM_FOLD") != nullptr;  // test / measurement switch: one optimizer launch per minibatch (read per epoch)
+    const int64_t tail = total % batch_size;
+    if (L.img_pi >= 0 && prepared && (tail == 0 || tail >= 256) && total > batch_size && !no_fold) {
+        // H = 64 fast path, every minibatch on the LDS-image kernel: the optimizer step of minibatch k runs in the prologue of gradient
+        // launch k + 1 (AdamFold: every workgroup redoes it for its net and builds its weight image from the results), so a minibatch
+        // costs two launches (gradient, slab reduction) instead of three; the state ping-pongs between (params, exp_avg, exp_avg_sq) and
+        // the workspace copy, and the epoch's last step is the ordinary optimizer launch, which leaves everything (derived copies and
+        // images included) in the caller's buffers.  Same arithmetic on the same inputs as the unfolded sequence: bit-identical.
+        char *ws = static_cast<char *>(workspace);
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t Pp = ((int64_t)L.P + 3) & ~(int64_t)3;
+        float *alt = reinterpret_cast<float *>(ws + fold_state_offset(L));
+        float *bufs[2][3] = {{params, exp_avg, exp_avg_sq}, {alt, alt + Pp, alt + 2 * Pp}};
+        int cur = 0;
+        const double *sqp = sq_partials(ws, L);
+        for (int64_t start = 0; start < total; start += batch_size, step++) {
+            const int64_t count = start + batch_size <= total ? batch_size : total - start;
+            const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, batch_size, 0};
+            AdamFold f{};
+            if (start > 0) {  // the step of the previous minibatch (index step - 1)
+                const double bc1 = 1.0 - pow(beta1, (double)(step - 1)), bc2 = 1.0 - pow(beta2, (double)(step - 1));
+                f = AdamFold{grad, sqp, (int)ceil_div(L.P, 64), bufs[cur][0], bufs[cur][1], bufs[cur][2], bufs[cur ^ 1][0], bufs[cur ^ 1][1],
+                             bufs[cur ^ 1][2], (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)sqrt(bc2), (float)eps,
+                             reinterpret_cast<double *>(ws + WS_NORM_OUT)};
+            }
+            rc = minibatch_grad_impl(params, d, rb, &mb, hp, grad, workspace, stream, start > 0 ? &f : nullptr, start > 0 ? 1 : 0);
+            if (rc) return rc;
+            if (start > 0) cur ^= 1;
+        }
+        const double bc1 = 1.0 - pow(beta1, (double)(step - 1)), bc2 = 1.0 - pow(beta2, (double)(step - 1));
+        adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
+            params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2,
+            (float)sqrt(bc2), (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f, bufs[cur][0], bufs[cur][1], bufs[cur][2]);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     for (int64_t start = 0; start < total; start += batch_size, step++) {
         const int64_t count = start + batch_size <= total ? batch_size : total - start;
         const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared ? batch_size : 0, 0};
@@ -2400,7 +2453,8 @@ int tma_ppo_adam_step(float *params, float *grad, float *exp_avg, float *exp_avg
         if (scat_h64)
             adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, sqp, n_part,
                                                                                              (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
-                                                                                             (float)bc2_sqrt, (float)eps, norm_out, (float)grad_scale);
+                                                                                             (float)bc2_sqrt, (float)eps, norm_out, (float)grad_scale, params,
+                                                                                             exp_avg, exp_avg_sq);
         else
             adam_scatter_wide_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(params, grad, exp_avg, exp_avg_sq, L, sqp, n_part,
                                                                                               (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
@@ -2446,7 +2500,7 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
     if (h64)
         adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
             params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,
-            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f);
+            (float)bc2_sqrt, (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f, params, exp_avg, exp_avg_sq);
     else
         adam_scatter_wide_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
             params, grad, exp_avg, exp_avg_sq, L, sqp, (int)ceil_div(L.P, 64), (float)max_grad_norm, (float)step_size, (float)beta1, (float)beta2,

@@ -60,6 +60,21 @@ struct HParams {
     int debug;  // TMA_BF_DEBUG (profiling aid, default 0): bit mask of phases the bf16 wide kernel skips -- timing attribution only
 };
 
+// A pending optimizer step applied in the PROLOGUE of the next H = 64 gradient launch (tma_ppo_train_epoch_local, round 3): instead of a
+// separate clip + Adam launch between two minibatches, every workgroup of the next gradient kernel redoes the step for ITS net's 4 675
+// parameters (adam_update_h64: the same routine, the same inputs, hence the same bits in every workgroup and as the optimizer launch) and
+// builds its LDS weight image from the results instead of staging it from memory; workgroup 0 of each net writes the new state to the
+// other half of a double buffer (the running launch still reads the old half).  grad == nullptr: no pending step, stage the image.
+struct AdamFold {
+    const float *grad;       // reduced gradient of the previous minibatch [P] (slab_reduce_kernel, overwrite mode)
+    const double *sq_part;   // its sum-of-squares partials, one per 64 parameters
+    int n_part;
+    const float *p_cur, *m_cur, *v_cur;  // trainable parameters / Adam moments before the step
+    float *p_nxt, *m_nxt, *v_nxt;        // ... and after it
+    float max_norm, lr_step, beta1, beta2, bc2_sqrt, eps;  // (bc2_sqrt = sqrt(1 - beta2^t), lr_step = lr / (1 - beta1^t))
+    double *norm_out;        // [2] total gradient norm, clip coefficient (statistics)
+};
+
 struct Net {
     const float *W1t, *b1, *W2t, *b2, *W3t, *b3, *W2, *W3;
 };
@@ -157,7 +172,8 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
 
 // tma_h64.hip: the H = 64 persistent gradient kernel (internal, not part of the C ABI)
 int tma_launch_grad_h64(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
-                        const double *adv_part, int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s);
+                        const double *adv_part, int n_part, float *slabs, double *slots, int *n_slabs_out, hipStream_t s,
+                        const tma::AdamFold *fold = nullptr);
 
 // tma_h64p.hip: one whole epoch at batch_size = 256 as a single persistent launch (H = 64 fast-path layouts)
 bool tma_epoch_h64p_eligible(const tma::PLayout &L, int64_t batch_size, int64_t total);
