@@ -547,8 +547,28 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     float *bias = hpart + 4 * 2 * 2 * 256;  // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
-    const float amean = hp.normalize_advantage ? ws_adv[0] : 0.0f;
-    const float astd = hp.normalize_advantage ? ws_adv[1] : 1.0f;
+    // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
+    // one-block launch in front of every minibatch (4.8 us of a 70 us step at 256 samples); the prologue's barrier below publishes them
+    (void)ws_adv;
+    __shared__ float adv_ms[2];
+    if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {
+        double a = 0.0, bsum = 0.0;
+        for (int k = threadIdx.x; k < mb.adv_n_part; k += 64) a += mb.adv_part[2 * k], bsum += mb.adv_part[2 * k + 1];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            bsum += __shfl_down(bsum, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            const double n = (double)mb.stats_n, mean = a / n;
+            double var = n > 1.0 ? (bsum - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0.0) var = 0.0;
+            adv_ms[0] = (float)mean;
+            adv_ms[1] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float amean = (IS_PI && hp.normalize_advantage) ? adv_ms[0] : 0.0f;
+    const float astd = (IS_PI && hp.normalize_advantage) ? adv_ms[1] : 1.0f;
     Net Q = IS_PI ? pi_net(params, L) : vf_net(params, L);
     const f32x4 z4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
@@ -1325,8 +1345,20 @@ __global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restric
                                                                 double *norm_out, float scale) {
     __shared__ double red[4];
     __shared__ float coef_s;
+    // this thread's element first (its four loads fly under the fold of the norm partials), then the partials sixteen loads at a time:
+    // one memory round trip per batch instead of one per partial (a thread of the 137 k-parameter net folds 9 of them); same order of additions
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < L.P;
+    const float g_e = live ? grad[e] : 0.0f, m_e = live ? m[e] : 0.0f, v_e = live ? v[e] : 0.0f, p_e = live ? params[e] : 0.0f;
     double a = 0.0;
-    for (int b = threadIdx.x; b < n_part; b += 256) a += sq_part[b];
+    for (int b0 = threadIdx.x; b0 < n_part; b0 += 256 * 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[u] = b0 + 256 * u < n_part ? sq_part[b0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (b0 + 256 * u < n_part) a += t[u];
+    }
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -1340,17 +1372,16 @@ __global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restric
         if (blockIdx.x == 0) norm_out[0] = (double)total_norm, norm_out[1] = (double)coef;
     }
     __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= L.P) return;
-    const float gv = (grad[e] * scale) * coef_s;
+    if (!live) return;
+    const float gv = (g_e * scale) * coef_s;
     grad[e] = 0.0f;
-    float mm = m[e], vv = v[e];
+    float mm = m_e, vv = v_e;
     mm = mm + (gv - mm) * (1.0f - beta1);
     vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
     m[e] = mm;
     v[e] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    const float pn = params[e] - lr_step * (mm / denom);
+    const float pn = p_e - lr_step * (mm / denom);
     params[e] = pn;
     if (e < L.log_std) scatter_derived_wide(params, L, e, pn);
 }
@@ -2132,8 +2163,10 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         M.offs = offs;
     }
     M.adv_part = adv_part, M.adv_n_part = nbk;
+    static const bool force_wide = getenv("TMA_FORCE_WIDE") != nullptr;  // test hook: take the column-parallel kernel at any batch size
+    const bool wide_f32 = !L.bf16 && (L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 8 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024;
     if (hpar.normalize_advantage) {
-        if (!h64 && !L.bf16) {  // the H = 64 and bf16 wide kernels fold the partials themselves
+        if (!h64 && !L.bf16 && !wide_f32) {  // the H = 64 and the column-parallel kernels fold the partials themselves
             adv_final_kernel<<<dim3(1), dim3(64), 0, s>>>(adv_part, nbk, M.stats_n, ws_adv);
             TMA_LAUNCH_CHECK();
         }
@@ -2165,8 +2198,7 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
-    static const bool force_wide = getenv("TMA_FORCE_WIDE") != nullptr;  // test hook: take the column-parallel kernel at any batch size
-    if ((L.H == 128 || L.H == 192 || L.H == 256) && (tiles >= 8 || force_wide) && grad_wide_smem_bytes(L) <= 160 * 1024) {
+    if (wide_f32) {
         // column-parallel register-accumulating kernel + deterministic slab reduction
         const int smemw = grad_wide_smem_bytes(L);
         const int64_t groups = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
