@@ -304,11 +304,19 @@ def test_timeout_bootstrap():
     assert torch.equal(r.cpu()[~trunc.bool()], rew[~trunc.bool()])
 
 
-def test_gae_flags_equals_sb3_layout():
+@pytest.mark.parametrize("T,N", [(129, 70), (1, 1), (7, 16), (128, 17), (300, 129), (1024, 4096), (33, 70000)])
+@pytest.mark.parametrize("scan", [False, True])
+def test_gae_flags_equals_sb3_layout(monkeypatch, T, N, scan):
+    """Both GAE kernels -- the producer / consumer kernel of small vectors (16 envs per workgroup, 128-step chunks through LDS: ragged env
+    groups, partial and single chunks, T = 1) and the one-thread-per-env scan (TMA_GAE_SCAN=1, and every vector beyond 65 536 envs) -- in
+    both buffer layouts (engine flags / SB3 episode_starts + dones) against the C oracle, which equals the literal NumPy loop: bit for bit."""
     from three_mlagents_amd import _lib
 
-    rng = np.random.default_rng(1)
-    T, N = 129, 70
+    if scan:
+        monkeypatch.setenv("TMA_GAE_SCAN", "1")
+    else:
+        monkeypatch.delenv("TMA_GAE_SCAN", raising=False)
+    rng = np.random.default_rng(1 + T + N)
     r, v = rng.normal(size=(T, N)).astype(np.float32), rng.normal(size=(T, N)).astype(np.float32)
     term = (rng.random((T, N)) < 0.05).astype(np.uint8)
     trunc = ((rng.random((T, N)) < 0.03) & (term == 0)).astype(np.uint8)
@@ -316,13 +324,20 @@ def test_gae_flags_equals_sb3_layout():
     done = (term | trunc).astype(np.float32)
     es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
     adv_ref, ret_ref = orc.gae(r, v, es, lv, done[-1].astype(np.uint8))
-    adv_np, ret_np = sb3_ref.gae_numpy(r, v, es, lv, done[-1].astype(bool))
-    assert np.array_equal(adv_ref, adv_np) and np.array_equal(ret_ref, ret_np)  # C oracle == literal numpy restatement
+    if T * N <= 100_000:
+        adv_np, ret_np = sb3_ref.gae_numpy(r, v, es, lv, done[-1].astype(bool))
+        assert np.array_equal(adv_ref, adv_np) and np.array_equal(ret_ref, ret_np)  # C oracle == literal numpy restatement
     t = [torch.from_numpy(x).cuda() for x in (r, v, term, trunc, lv)]
-    adv, ret = torch.empty_like(t[0]), torch.empty_like(t[0])
+    adv, ret = torch.full_like(t[0], float("nan")), torch.full_like(t[0], float("nan"))
     _lib.check(_lib.lib().tma_gae_flags(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(t[3]), _lib.ptr(t[4]), 0.99, 0.95, T, N, _lib.ptr(adv),
                                         _lib.ptr(ret), _lib.stream_ptr()))
     assert np.array_equal(adv.cpu().numpy(), adv_ref) and np.array_equal(ret.cpu().numpy(), ret_ref)
+    # SB3 layout: float episode_starts[T][N] + the final dones[N]
+    es_t, dn_t = torch.from_numpy(es).cuda(), torch.from_numpy(done[-1].astype(np.uint8)).cuda()
+    adv2, ret2 = torch.full_like(t[0], float("nan")), torch.full_like(t[0], float("nan"))
+    _lib.check(_lib.lib().tma_gae(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(es_t), _lib.ptr(t[4]), _lib.ptr(dn_t), 0.99, 0.95, T, N, _lib.ptr(adv2),
+                                  _lib.ptr(ret2), _lib.stream_ptr()))
+    assert np.array_equal(adv2.cpu().numpy(), adv_ref) and np.array_equal(ret2.cpu().numpy(), ret_ref)
 
 
 @pytest.mark.parametrize("task,hidden,N,mfma", [("gridworld", 64, 200, "f32"), ("push", 64, 200, "f32"), ("ball3d", 64, 200, "f32"), ("walljump", 64, 200, "f32"),
