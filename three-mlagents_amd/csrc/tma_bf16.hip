@@ -26,7 +26,8 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         // 256 blocks = one per CU.  A policy-net row group costs 1.15-1.3x a value-net one (the loss), so the policy net gets
         // 136 or 144 of the blocks; with fewer row groups than that, one block per group.
         const int64_t groups = ceil_div(M.count, 16 * MTc);
-        const int cap_pi = L.cont ? 144 : 136, cap_vf = 256 - cap_pi;  // (Categorical loss is cheaper than the DiagGaussian one)
+        static const int npi_env = getenv("TMA_BF_NPI") ? atoi(getenv("TMA_BF_NPI")) : 0;  // development switch: policy-net block count
+        const int cap_pi = npi_env > 0 ? npi_env : (L.cont ? 144 : 136), cap_vf = 256 - cap_pi;  // (Categorical loss is cheaper than the DiagGaussian one)
         const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
         if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab
             const int zrc = tma_launch_slab_zero_w1(slabs, n_pi, L, s);

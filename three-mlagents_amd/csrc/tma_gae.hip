@@ -1,4 +1,5 @@
-// tma_gae.hip -- GAE(lambda) advantages + returns over a (T, N) rollout, one thread per env, reverse scan over T.
+// tma_gae.hip -- GAE(lambda) advantages + returns over a (T, N) rollout: a producer / consumer kernel for vectors of up to 65 536 envs
+// (gae_pc_kernel below) and the one-thread-per-env reverse scan over T for larger ones (gae_kernel).
 //
 // Replaces stable-baselines3 2.9.0 RolloutBuffer.compute_returns_and_advantage (third-party; the buffer is built by
 // PPO(...) at /root/reference/backend/mlagents/training.py:150 with gamma/gae_lambda from training.py:383-384).
