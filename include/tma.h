@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 203
+#define TMA_VERSION 204
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -220,7 +220,10 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
 /* One whole epoch of PPO.train on ONE GPU in a single call: [tma_ppo_epoch_prepare] + for every minibatch of batch_size rows of the
  * (perm_seed, perm_epoch) permutation: tma_ppo_minibatch_grad + tma_ppo_adam_step_local, issued natively with no host-language round trip
  * in between (at the reference's literal batch_size = 256 and 4096 envs an epoch is 16 384 optimizer steps: backend/mlagents/training.py:379).
- * first_step = Adam step index of the epoch's first minibatch (>= 1); grad must be zero on entry and is zero on return.  Bit-identical to the
+ * first_step = Adam step index of the epoch's first minibatch (>= 1); grad must be zero on entry and is zero on return.  On H = 64 fast-path
+ * policies with every minibatch >= 256 rows the optimizer step of minibatch k runs in the prologue of gradient launch k + 1 (two launches per
+ * minibatch; the state ping-pongs between the caller's buffers and a copy in the workspace and ends in the caller's buffers; TMA_NO_ADAM_FOLD=1
+ * in the environment: one optimizer launch per minibatch).  Bit-identical to the
  * per-minibatch calls -- except on H = 64 policies at batch_size = 256 with T*N a multiple of it, where the epoch runs as ONE persistent
  * launch (csrc/tma_h64p.hip: weights in LDS, Adam moments in registers, eight workgroups of one XCD exchanging partial gradients through
  * the L2): same gradient sums and Adam arithmetic, the clip norm's f64 sum in another fixed order (parameters agree to the last bit or
@@ -230,6 +233,20 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
+/* One epoch of PPO.train on ONE RANK of a data-parallel job (env shards per GPU, one gradient all-reduce per
+ * minibatch; the reference itself is one process, backend/mlagents/training.py:71-89,150): for every minibatch of batch_size local rows --
+ * tma_ppo_minibatch_grad, then `allreduce(ctx, grad, n_trainable)` (the caller's collective: SUM over the ranks, in place, enqueued on
+ * `stream` or ordered against it -- torch.distributed.all_reduce on the current stream does that; must return 0), then
+ * clip_grad_norm_ + Adam on grad * grad_scale (1 / world size) -- issued natively, the collective being the only host-language call per
+ * minibatch.  Bit-identical to tma_ppo_minibatch_grad / all-reduce / tma_ppo_adam_step(grad_scale) called in a loop.
+ * prepared_batch: batch_size if the caller ran tma_ppo_epoch_prepare (+ tma_ppo_epoch_adv_sums) for this epoch, else 0;
+ * stats_world: multiplier of a minibatch's row count for its advantage statistics (world size with global statistics, else 0 = local).
+ * grad must be zero on entry and is zero on return. */
+typedef int (*tma_allreduce_fn)(void *ctx, float *buffer, int64_t count);
+int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
+                           int64_t batch_size, int64_t prepared_batch, int stats_world, const tma_ppo_hparams *hp, float *grad, float *exp_avg,
+                           float *exp_avg_sq, int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm,
+                           double grad_scale, tma_allreduce_fn allreduce, void *ctx, void *workspace, void *stream);
 /* How many epochs of tma_ppo_train_epoch_local on this workspace fell back from the persistent launch to per-minibatch launches.  Synchronises `stream`. */
 int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream);
 /* The minibatch order of the on-device permutation (the engine's stand-in for np.random.permutation in SB3's RolloutBuffer.get): writes, to

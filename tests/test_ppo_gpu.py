@@ -758,6 +758,43 @@ def test_optimizer_step_folded_into_the_next_gradient_launch_is_bit_identical(mo
         assert s0[k] == s1[k], (k, s0[k], s1[k])
 
 
+@pytest.mark.parametrize("task,hidden,n_envs,n_steps,batch", [("gridworld", 64, 256, 64, 1024), ("gridworld", 64, 256, 64, 768), ("gridworld", 64, 300, 10, 1000),
+                                                            ("gridworld", 64, 64, 16, 256), ("ball3d", 256, 64, 32, 512)])
+def test_native_data_parallel_epoch_equals_the_single_gpu_epoch(monkeypatch, task, hidden, n_envs, n_steps, batch):
+    """tma_ppo_train_epoch_dp (the minibatch loop of a data-parallel rank: gradient, all-reduce callback, sum of squares + optimizer step on
+    grad / world) at world size 1 (TMA_DP_PATH=1: the callback is a no-op) against the single-GPU epoch call, with and without the
+    optimizer step folded into the next gradient launch there: the same bits from all three."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(mode):
+        monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        for k in ("TMA_DP_PATH", "TMA_NO_ADAM_FOLD"):
+            monkeypatch.delenv(k, raising=False)
+        if mode in ("dp", "dp_unfolded"):
+            monkeypatch.setenv("TMA_DP_PATH", "1")
+        if mode == "dp_unfolded":
+            monkeypatch.setenv("TMA_NO_ADAM_FOLD", "1")
+        env = make_vector_env(task, n_envs=n_envs, seed=13)
+        m = PPO("MlpPolicy", env, n_steps=n_steps, batch_size=batch, n_epochs=3, seed=13, policy_kwargs={"net_arch": [hidden, hidden]})
+        for _ in range(2):
+            m.collect_rollouts()
+            m.train()
+        st = m.pop_train_stats()
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, m._adam_step, m.grad.cpu())
+        env.close()
+        return out
+
+    ref = run("local")
+    for mode in ("dp", "dp_unfolded"):
+        got = run(mode)
+        assert got[4] == ref[4] == 2 * 3 * -(-(n_envs * n_steps) // batch)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), mode
+        assert float(got[5].abs().max()) == 0.0
+        for k in ref[3]:
+            assert got[3][k] == ref[3][k], (mode, k)
+
+
 def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
     """1024 optimizer steps in one persistent launch (GridWorld rollout of 1024 envs x 256 steps, the reference's batch_size = 256) against
     the same epoch as per-minibatch launches: the two paths differ only in the f64 summation order of the clip norm, so after a thousand

@@ -2383,6 +2383,34 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
     return TMA_OK;
 }
 
+int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch, int64_t batch_size,
+                           int64_t prepared_batch, int stats_world, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq,
+                           int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm, double grad_scale,
+                           tma_allreduce_fn allreduce, void *ctx, void *workspace, void *stream) {
+    int rc = enter(d);
+    if (rc) return rc;
+    if (!params || !rb || !hp || !grad || !exp_avg || !exp_avg_sq || !workspace || !allreduce) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: null argument");
+    if (rb->T < 1 || rb->N < 1 || batch_size < 1 || first_step < 1) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: T, N, batch_size and first_step must be >= 1");
+    if (prepared_batch != 0 && prepared_batch != batch_size) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: prepared_batch must be 0 or batch_size");
+    if (stats_world < 0 || (stats_world > 0 && prepared_batch == 0)) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: global statistics need a prepared epoch");
+    const int64_t total = (int64_t)rb->T * rb->N;
+    const PLayout L = layout_of(d);
+    // (The optimizer step is NOT folded into the next gradient launch here, as tma_ppo_train_epoch_local does: the clip norm must come from the
+    // all-reduced gradient, and taking it in every workgroup's prologue -- 147 64-lane f64 shuffle trees through the LDS crossbar of each CU --
+    // measured 3.4 us per minibatch SLOWER than the sum-of-squares + optimizer launches it would replace: DESIGN.md section 10.)
+    int64_t step = first_step;
+    for (int64_t start = 0; start < total; start += batch_size, step++) {
+        const int64_t count = start + batch_size <= total ? batch_size : total - start;
+        const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared_batch, stats_world > 0 ? count * stats_world : 0};
+        rc = tma_ppo_minibatch_grad(params, d, rb, &mb, hp, grad, workspace, stream);
+        if (rc) return rc;
+        if (allreduce(ctx, grad, L.P) != 0) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: the all-reduce callback failed");
+        rc = tma_ppo_adam_step(params, grad, exp_avg, exp_avg_sq, d, step, lr, beta1, beta2, eps, max_grad_norm, grad_scale, workspace, stream);
+        if (rc) return rc;
+    }
+    return TMA_OK;
+}
+
 // sample records (tma_rollout.packed): thread = buffer row; {obs | zero padding | log_prob, advantage, action bits, return}
 __global__ __launch_bounds__(256) void pack_samples_kernel(Rollout rb, int D, int rs, int64_t total, float *__restrict__ out) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;

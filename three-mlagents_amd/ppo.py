@@ -342,21 +342,32 @@ class PPO:
                                                             _lib.ptr(self._adv_sums), direction, self._stream()))
                         if direction == 0:
                             self._timed_all_reduce(self._adv_sums, "adv_allreduce_us")
-            for start in range(0, total, self.batch_size):
-                count = min(self.batch_size, total - start)
-                mb = _lib.Minibatch(None, perm_seed, self._epoch_counter & 0xFFFFFFFF, start, count, self.batch_size if can_prepare else 0,
-                                    count * self.world_size if global_stats else 0)
-                _lib.check(L.tma_ppo_minibatch_grad(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view),
-                                                    C.byref(mb), C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.workspace), self._stream()))
-                if self.world_size > 1:
-                    # RCCL sum over xGMI; scaled by 1/world inside the Adam kernel.  With the nccl backend the collective runs on the process
-                    # group's own stream: it waits for the gradient kernels through an event, the host returns as soon as it is queued (and
-                    # goes on to queue the optimizer launch, which waits for the collective through a second event) -- nothing blocks the host
-                    self._timed_all_reduce(self.grad, "grad_allreduce_us")
-                self._adam_step += 1
-                _lib.check(L.tma_ppo_adam_step(_lib.ptr(self.policy.params), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                               C.byref(self.policy.dims), self._adam_step, self.learning_rate, 0.9, 0.999, 1e-5,
-                                               self.max_grad_norm, scale, _lib.ptr(self.workspace), self._stream()))
+            # the minibatch loop itself is native (tma_ppo_train_epoch_dp): gradient launches, this callback, optimizer launches.  The callback is
+            # the only host-language call per minibatch.  RCCL sum over xGMI, scaled by 1/world inside the optimizer arithmetic; with the nccl
+            # backend the collective runs on the process group's own stream and is ordered against the compute stream through events on both
+            # sides -- the host returns as soon as it is queued.
+            if getattr(self, "_allreduce_cb", None) is None:
+                def _cb(_ctx, _buf, _count, self=self):
+                    try:
+                        if self.world_size > 1:
+                            self._timed_all_reduce(self.grad, "grad_allreduce_us")
+                        return 0
+                    except Exception as exc:  # (an exception must not unwind through the C frames)
+                        self._allreduce_error = exc
+                        return 1
+
+                self._allreduce_cb = _lib.AllReduceFn(_cb)
+            n_mb = (total + self.batch_size - 1) // self.batch_size
+            self._allreduce_error = None
+            rc = L.tma_ppo_train_epoch_dp(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view), perm_seed,
+                                          self._epoch_counter & 0xFFFFFFFF, self.batch_size, self.batch_size if can_prepare else 0,
+                                          self.world_size if global_stats else 0, C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                          _lib.ptr(self.exp_avg_sq), self._adam_step + 1, self.learning_rate, 0.9, 0.999, 1e-5, self.max_grad_norm, scale,
+                                          self._allreduce_cb, None, _lib.ptr(self.workspace), self._stream())
+            if self._allreduce_error is not None:
+                raise self._allreduce_error
+            _lib.check(rc)
+            self._adam_step += n_mb
             self._epoch_counter += 1
         self._n_updates += self.n_epochs
 
