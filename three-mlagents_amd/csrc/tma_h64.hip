@@ -278,7 +278,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
 // conflict-free b32 stores at immediate offsets), then wave w sums registers w, w + 8, ... over the eight copies in wave order (the order
 // of flush_segment, so the bits match) and stores them to the slab.  Two halves of <= 56 registers keep the staging inside the tile
 // region's 112 KiB; all eight waves stay busy in both phases, against three store / barrier / strided-sum / barrier rounds before.
-template <bool IS_PI, int NWV = 8>  // NWV: waves per block (8; small-minibatch blocks: 4)
+template <bool IS_PI, int KS1C, int NWV = 8>  // NWV: waves per block (8; small-minibatch blocks: 4)
 __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, NetAcc &acc, const PLayout &L, int D, int NOUT, float *slab) {
     constexpr int QN = (FL_HALF + NWV - 1) / NWV;
 #pragma unroll
@@ -294,7 +294,7 @@ __device__ __forceinline__ void flush_all_t(float *stage, int wave, int lane, Ne
 #pragma unroll
         for (int q = 0; q < QN; q++) {
             const int i = wave + NWV * q, cnt = half ? FL_REGS - FL_HALF : FL_HALF;
-            offs[half][q] = i < cnt ? slab_offset_t<IS_PI>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
+            offs[half][q] = i < cnt ? slab_offset_t<IS_PI, KS1C>(half * FL_HALF + i, lane, L, D, NOUT) : -1;
         }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -591,9 +591,9 @@ __device__ __forceinline__ void grad_h64t_body(const float *__restrict__ params,
     if (lane == 0)
         for (int q = 0; q < 5; q++) red[wave * 5 + q] = stv[q];
     if constexpr (DIRECT) {
-        flush_all_t<IS_PI, 4>(smem, wave, lane, acc, L, D, NOUT, slab);  // 4-wave blocks of the small-minibatch kernel
+        flush_all_t<IS_PI, KS1C, 4>(smem, wave, lane, acc, L, D, NOUT, slab);  // 4-wave blocks of the small-minibatch kernel
     } else {
-        flush_all_t<IS_PI>(smem, wave, lane, acc, L, D, NOUT, slab);  // (8 waves per block: tma_launch_grad_h64)
+        flush_all_t<IS_PI, KS1C>(smem, wave, lane, acc, L, D, NOUT, slab);  // (8 waves per block: tma_launch_grad_h64)
     }
 #ifdef TMA_H64_TICKS
     if (tick_on && lane == 0) g_h64_ticks[IS_PI ? 0 : 1][13] += __builtin_amdgcn_s_memtime() - loop_t1;

@@ -49,6 +49,20 @@ constexpr int LDT = 68;
 constexpr int T_PER_WAVE = 2 * 16 * LDT + 256 + 256;  // slot A, slot B, dz3 [16][16], X [16][16]
 __device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ ((row & 1) << 4)); }
 
+// ---- The two SMALL weight gradients of a tile on v_mfma_f32_4x4x1_16b_f32 (round 3).  dW1 = X^T . dz1 has D <= 8 useful rows and dW3 = h2^T . dz3
+// has n_out <= 8 useful columns; as 16x16x4 MFMAs each is 16 instructions of 32 cycles with 3/4 (GridWorld: D = 4, 5 actions) of every tile
+// padding.  The 4x4x1 instruction is sixteen independent 4 x 4 outer products in 8 cycles (measured: tools/mfma4x4_probe.hip; D(lane 4b + j,
+// register i) = A(lane 4b + i) * B(lane 4b + j) + C): one instruction per SAMPLE, accumulating
+//   dW1[k = 4 blk + i][n = lane]            : A(lane) = X[s][4 blk + (lane & 3)],  B(lane) = dz1[s][lane]   (blk < KS1C <= 2 observation blocks)
+//   dW3[k = 4 (lane >> 2) + i][a = j + 4 h] : A(lane) = h2[s][lane],               B(lane) = dz3[s][a = (lane & 3) + 4 h]   (h < 2 halves of <= 8 outputs)
+// in registers i = 0..3 -- 128 / 256 cycles of matrix pipe instead of 512 each, 640 of a tile's 8 064 less.  The accumulators live in the
+// first KS1C entries of NetAcc::w1[0] and the first two of NetAcc::w3 (the other entries stay zero and are never stored); the bias sums are
+// formed exactly as bwd_weight_acc_t forms them.  Wider observations / heads keep the 16x16x4 form.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+template <int KS1C>
+constexpr bool w1_blocks() { return KS1C <= 2; }
+__device__ __forceinline__ bool w3_blocks(int NOUT) { return NOUT <= 8; }
+
 // all-reduce over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the lane groups holding one sample's 16 head outputs): VALU only
 template <class F>
 __device__ __forceinline__ float xg_reduce(float v, F op) {
@@ -301,7 +315,32 @@ __device__ __forceinline__ void h64t_tile(const float *wimg, float *slotA, float
         }
     }
     // dW3 (off the dependent path) right behind the chain's MFMAs: the pipe works on it while dh2 matures and dz2 is formed
-    bwd_weight_acc_t<4, 1, true, false>(slotB, dz3t, acc.w3, acc.b3, lane);
+    if (w3_blocks(NOUT)) {  // (uniform)
+        {
+            float bf[4];
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) bf[sk] = dz3t[(4 * sk + g) * 16 + r16];
+            acc.b3[0] += (bf[0] + bf[1]) + (bf[2] + bf[3]);
+        }
+        const bool two = NOUT > 4;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {  // (eight samples of operands at a time: 24 registers)
+            float av[8], b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                av[u] = slotB[tsw(s0 + u, lane)];                  // h2[s][k = lane]
+                b0[u] = dz3t[(s0 + u) * 16 + 4 * (lane & 3)];      // dz3[s][a = lane & 3]: tile column m = 4 a
+                b1[u] = dz3t[(s0 + u) * 16 + 4 * (lane & 3) + 1];  // dz3[s][a = 4 + (lane & 3)]: column m = 4 (a & 3) + 1
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc.w3[0][0] = mfma4(av[u], b0[u], acc.w3[0][0]);
+                if (two) acc.w3[1][0] = mfma4(av[u], b1[u], acc.w3[1][0]);
+            }
+        }
+    } else {
+        bwd_weight_acc_t<4, 1, true, false>(slotB, dz3t, acc.w3, acc.b3, lane);
+    }
     H64_TICK(5);
     // ---- dz2 = dh2 * (1 - h2^2) over h2 (dW3 has read h2: LDS operations of one wave execute in order), dh1^T = W2 . dz2^T (chain),
     // then dW2 (64 MFMAs, off the path) with dz1 = dh1 * (1 - h1^2) formed between its k-tiles ----
@@ -354,7 +393,31 @@ __device__ __forceinline__ void h64t_tile(const float *wimg, float *slotA, float
     }
     store_tile_t(slotA, h1, r16, g);  // dz1 over h1
     H64_TICK(8);
-    bwd_weight_acc_t<1, 4, false, true>(Xt, slotA, acc.w1, acc.b1, lane);
+    if constexpr (w1_blocks<KS1C>()) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            float bf[4];
+#pragma unroll
+            for (int sk = 0; sk < 4; sk++) bf[sk] = slotA[tsw(4 * sk + g, nt * 16 + r16)];
+            acc.b1[nt] += (bf[0] + bf[1]) + (bf[2] + bf[3]);
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            float bv[8], xa[KS1C][8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                bv[u] = slotA[tsw(s0 + u, lane)];  // dz1[s][n = lane]
+#pragma unroll
+                for (int blk = 0; blk < KS1C; blk++) xa[blk][u] = Xt[(s0 + u) * 16 + 4 * blk + (lane & 3)];  // X[s][k = 4 blk + (lane & 3)]
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int blk = 0; blk < KS1C; blk++) acc.w1[0][blk] = mfma4(xa[blk][u], bv[u], acc.w1[0][blk]);
+        }
+    } else {
+        bwd_weight_acc_t<1, 4, false, true>(Xt, slotA, acc.w1, acc.b1, lane);
+    }
     H64_TICK(9);
 }
 
@@ -459,11 +522,15 @@ __device__ __forceinline__ float acc_reg(const NetAcc &a, int idx) {  // idx is 
     return a.b3[0];
 }
 // slab element of accumulator register idx in lane `lane` (-1: padding, nothing to store)
-template <bool IS_PI>
+template <bool IS_PI, int KS1C>
 __device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L, int D, int NOUT) {
     const int r16 = lane & 15, g = lane >> 4;
     const int perm = (r16 >> 2) + 4 * (r16 & 3);  // head: tile column m <-> output a(m)
     if (idx < 16) {
+        if constexpr (w1_blocks<KS1C>()) {  // register i of observation block blk: dW1[k = 4 blk + i][n = lane]
+            const int blk = idx >> 2, k = 4 * blk + (idx & 3);
+            return (blk < KS1C && k < D) ? (IS_PI ? L.pW1t : L.vW1t) + k * 64 + lane : -1;
+        }
         const int k = 4 * g + (idx & 3), n = (idx >> 2) * 16 + r16;
         return k < D ? (IS_PI ? L.pW1t : L.vW1t) + k * 64 + n : -1;
     }
@@ -472,6 +539,10 @@ __device__ __forceinline__ int slab_offset_t(int idx, int lane, const PLayout &L
         return (IS_PI ? L.pW2t : L.vW2t) + k * 64 + n;
     }
     if (idx < 96) {
+        if (w3_blocks(NOUT)) {  // register i of output half h: dW3[k = 4 (lane >> 2) + i][a = (lane & 3) + 4 h]
+            const int t = idx - 80, h = t >> 2, k = 4 * (lane >> 2) + (t & 3), a = (lane & 3) + 4 * h;
+            return (h < 2 && a < NOUT) ? (IS_PI ? L.pW3t : L.vW3t) + k * NOUT + a : -1;
+        }
         const int t = idx - 80, k = (t >> 2) * 16 + 4 * g + (t & 3);
         return perm < NOUT ? (IS_PI ? L.pW3t : L.vW3t) + k * NOUT + perm : -1;
     }

@@ -112,15 +112,23 @@ __device__ __forceinline__ uint32_t img_slots(int x, int D, int NOUT, uint32_t n
 // A wave's accumulators into its flat copy (position space above).  Every store is unconditional at a lane base + compile-time offset:
 // lanes that hold padding / replicas write, with the same offsets, into the dump area behind the copy (64 + max(240, 51 * NOUT) + 16
 // floats at `dump`) -- a predicate per store costs an exec save / restore around each ds_write.
+template <int KS1C>
 __device__ __forceinline__ void scatter_acc_flat(float *region, const NetAcc &acc, int lane, int D, int NOUT, const NetPos &q) {
     const int r16 = lane & 15, g = lane >> 4;
     const int perm = (r16 >> 2) + 4 * (r16 & 3);  // head: tile column m <-> output a(m)
     const int dl = q.P + lane;
+    if constexpr (w1_blocks<KS1C>()) {  // 4x4x1 form (tma_h64_tile.h): register i of observation block blk holds W1t[k = 4 blk + i][n = lane]
 #pragma unroll
-    for (int r = 0; r < 4; r++) {  // W1t[k = 4g + r][n = 16 nt + r16]
-        float *p = region + ((4 * g + r < D) ? 4 * g * 64 + r16 : dl);
+        for (int blk = 0; blk < KS1C; blk++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) p[r * 64 + nt * 16] = acc.w1[0][nt][r];
+            for (int i = 0; i < 4; i++) region[(4 * blk + i < D) ? (4 * blk + i) * 64 + lane : dl] = acc.w1[0][blk][i];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {  // W1t[k = 4g + r][n = 16 nt + r16]
+            float *p = region + ((4 * g + r < D) ? 4 * g * 64 + r16 : dl);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) p[r * 64 + nt * 16] = acc.w1[0][nt][r];
+        }
     }
     {  // W2t[k = 16 kt + 4g + r][n = 16 nt + r16]
         float *p = region + q.oW2 + 4 * g * 64 + r16;
@@ -131,7 +139,15 @@ __device__ __forceinline__ void scatter_acc_flat(float *region, const NetAcc &ac
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[(kt * 16 + r) * 64 + nt * 16] = acc.w2[kt][nt][r];
     }
-    {  // W3t[k = 16 kt + 4g + r][a = perm]
+    if (w3_blocks(NOUT)) {  // (uniform) 4x4x1 form: register i of output half h holds W3t[k = 4 (lane >> 2) + i][a = (lane & 3) + 4 h]
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int a = (lane & 3) + 4 * h;
+            float *p = region + (a < NOUT ? q.oW3 + 4 * (lane >> 2) * NOUT + a : dl);
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[a < NOUT ? i * NOUT : 0] = acc.w3[h][0][i];
+        }
+    } else {  // W3t[k = 16 kt + 4g + r][a = perm]
         float *p = region + (perm < NOUT ? q.oW3 + 4 * g * NOUT + perm : dl);
 #pragma unroll
         for (int kt = 0; kt < 4; kt++)
@@ -314,7 +330,7 @@ __device__ __forceinline__ void epoch_body(const EpochArgs &a, int j, float *sme
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc.b1[nt] = xg_sum(acc.b1[nt]), acc.b2[nt] = xg_sum(acc.b2[nt]);
         acc.b3[0] = xg_sum(acc.b3[0]);
-        scatter_acc_flat(region, acc, lane, D, NOUT, q);
+        scatter_acc_flat<KS1C>(region, acc, lane, D, NOUT, q);
         __syncthreads();
 #pragma unroll
         for (int i0 = 0; i0 < NS; i0 += 2) {  // two slots at a time: their eight LDS reads in flight, no branch between issue and use
