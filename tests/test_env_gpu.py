@@ -143,6 +143,48 @@ def test_against_oracle_many_envs(task, mode):
     eng.close()
 
 
+def _random_shapes():
+    rng = np.random.default_rng(20260)
+    cases = []
+    for task in TASKS + ["bicycle", "brickbreak", "glider"]:
+        for _ in range(3):
+            depth = int(rng.choice([2, 3, 5, 16, 64, 512]))  # (the engine takes ring depths in [2, 4096])
+            cases.append((task, int(rng.choice([1, 2, 3, 63, 64, 65, 127, 257, 1000])), depth, int(rng.integers(1, 5)) * depth + int(rng.integers(0, depth)),
+                          int(rng.integers(0, 2**31 - 1)), int(rng.choice([0, 1, 4096, 2**20 - 3]))))
+    return cases
+
+
+@pytest.mark.parametrize("task,n,depth,T,seed,offset", _random_shapes())
+def test_against_oracle_random_shapes(task, n, depth, T, seed, offset):
+    """Seeded random draws of (env count, reset-ring depth, steps -- not a multiple of the ring depth, so launches of uneven length and a refill
+    in between --, base seed, env offset of the shard) per task, device-generated action tape: every plane against the C oracle.  Edge shapes
+    in the draw set: one env, two steps per launch, a 64-lane wave plus or minus one env, an offset that carries into the episode-seed bits."""
+    eng = _engine(task, n, seed=seed, env_offset=offset, ring_depth=depth)
+    ref = orc.OracleVecEnv(task, n, seed=seed, env_offset=offset)
+    inexact = _cmp(task, "reset", eng.reset().cpu().numpy(), ref.reset(), 0)
+    tape_seed = seed ^ 0x5A5A
+    actions = orc.action_tape(tape_seed, n, T, orc.num_actions(task), env_offset=offset)
+    float_task = task in ("ball3d", "bicycle", "brickbreak", "glider")
+    cmp_task = "ball3d" if float_task else task  # (_cmp's tolerance branch)
+    t = 0
+    while t < T:
+        k = min(depth, T - t, eng.steps_until_refill())
+        o = eng.step(None, n_steps=k, tape_seed=tape_seed, tape_t0=t)
+        for s in range(k):
+            r = ref.step(actions[t + s])
+            done = (r["term"] | r["trunc"]).astype(bool)
+            inexact += _cmp(cmp_task, "obs", o["obs"][s].cpu().numpy(), r["obs"], t + s)
+            inexact += _cmp(cmp_task, "rew", o["rew"][s].cpu().numpy(), r["rew32"], t + s)
+            assert np.array_equal(o["term"][s].cpu().numpy(), r["term"]) and np.array_equal(o["trunc"][s].cpu().numpy(), r["trunc"]), (task, t + s)
+            inexact += _cmp(cmp_task, "term_obs", o["term_obs"][s].cpu().numpy()[done], r["term_obs"][done], t + s)
+            assert np.array_equal(o["ep_len"][s].cpu().numpy(), r["ep_len"]), (task, t + s)
+        t += k
+    assert np.array_equal(eng.episode_index().cpu().numpy().astype(np.uint32), ref.episode_index())
+    if not float_task:
+        assert inexact == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("task", ["gridworld", "push"])
 def test_refill_fallback_generator_is_exact(task):
     """With the register-resident MT19937 window shortened, most seeds need the general in-memory generator: the
