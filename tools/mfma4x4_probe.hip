@@ -1,5 +1,5 @@
 // Operand layout of v_mfma_f32_4x4x1_16b_f32 on gfx950, found by experiment: A lane l = l + 1, B lane l = 1000 (l + 1): D register i of lane l
-// shows which A lane and which B lane met.  Build: hipcc --offload-arch=gfx950 -o /tmp/mfma4x4_probe tools/mfma4x4_probe.hip
+// shows which A lane and which B lane met.  Build: hipcc --offload-arch=gfx950 -O2 -o tools/bin/mfma4x4_probe tools/mfma4x4_probe.hip (tools/bin/ is git-ignored)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
