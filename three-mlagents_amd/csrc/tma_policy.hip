@@ -601,6 +601,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     auto sload = [&](int s) -> f32x4 {  // s in [0, SL): compile-time after unrolling.  Order: [layer 1: q outer, tile inner] [layer-2 forward] [input-gradient]
         if (s < S1) return frag_f32(fr1, (nt0 + s % NTW) * NQ1C + s / NTW, lane0);
         const int u = s - S1, half = u >= NTW * NQ, t = half ? u - NTW * NQ : u;
+#ifdef TMA_WIDE_RING_HOT  // timing-only build: every ring load hits one of two L1-resident fragments (wrong results; what does the stream cost?)
+        return frag_f32(fr + half * H * H, (nt0 + 0) * NQ + (t & 1), lane0);
+#endif
         return frag_f32(fr + half * H * H, (nt0 + t / NQ) * NQ + t % NQ, lane0);
     };
     f32x4 ring[R];
