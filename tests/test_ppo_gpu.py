@@ -795,6 +795,31 @@ def test_native_data_parallel_epoch_equals_the_single_gpu_epoch(monkeypatch, tas
             assert got[3][k] == ref[3][k], (mode, k)
 
 
+def test_data_parallel_epoch_reports_a_failing_collective(monkeypatch):
+    """An exception raised by the all-reduce inside PPO.train's callback does not unwind through the native loop: the callback returns
+    non-zero, tma_ppo_train_epoch_dp stops with an error, and train() re-raises the ORIGINAL exception."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    monkeypatch.setenv("TMA_DP_PATH", "1")
+    env = make_vector_env("gridworld", n_envs=64, seed=3)
+    m = PPO("MlpPolicy", env, n_steps=16, batch_size=256, n_epochs=1, seed=3, policy_kwargs={"net_arch": [64, 64]})
+    m.collect_rollouts()
+    m.world_size = 2  # (pretend: the callback then calls the collective)
+
+    class Boom(RuntimeError):
+        pass
+
+    def failing(tensor, key):
+        raise Boom("link down")
+
+    monkeypatch.setattr(m, "_timed_all_reduce", failing)
+    monkeypatch.setattr(m, "normalize_advantage", False)
+    with pytest.raises(Boom, match="link down"):
+        m.train()
+    env.close()
+
+
 def test_persistent_epoch_kernel_long_epoch_stays_with_the_launch_path(monkeypatch):
     """1024 optimizer steps in one persistent launch (GridWorld rollout of 1024 envs x 256 steps, the reference's batch_size = 256) against
     the same epoch as per-minibatch launches: the two paths differ only in the f64 summation order of the clip norm, so after a thousand
