@@ -249,6 +249,28 @@ def step_kernel_rooflines(out, args, env, model, world):
         "note": f"{N} envs move {N * lay / 1e6:.2f} MB per launch: launch-latency-bound, not HBM-bound (SURVEY.md 7.3-4); the training rollout uses the "
                 "fused multi-step kernel instead; see roofline_step_kernel_saturated for the HBM-bound regime",
     }
+    # GAE over the rollout that was just collected (20 B per (t, env) in SB3's layout; the engine's flag bytes make it 18)
+    try:
+        T = model.n_steps
+        adv_o, ret_o = torch.empty_like(b["rewards"]), torch.empty_like(b["rewards"])
+
+        def gae_once():
+            _lib.check(L.tma_gae_flags(_lib.ptr(b["rewards"]), _lib.ptr(b["values"]), _lib.ptr(b["terminated"]), _lib.ptr(b["truncated"]),
+                                       _lib.ptr(b["last_values"]), 0.99, 0.95, T, N, _lib.ptr(adv_o), _lib.ptr(ret_o), model._stream()))
+
+        for _ in range(3):
+            gae_once()
+        _, gae_us = timed_kernel_us(gae_once, 20, sync)
+        gae_bytes = T * N * 18
+        gae_gbps = gae_bytes / (gae_us * 1e-6) / 1e9
+        out["roofline_gae_kernel"] = {
+            "kernel": "tma::gae_pc_kernel (producer / consumer chunks through LDS)" if N <= 65536 else "tma::gae_kernel", "bound": "hbm", "achieved": gae_gbps,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gae_gbps / HBM_PEAK_GBPS, "traffic": None, "launch_us": gae_us, "bytes_per_t_env": 18,
+            "note": f"T = {T}, N = {N}: {gae_bytes / 1e6:.0f} MB per call; the recurrence is one rounded f32 chain per env (bit-identical to SB3's loop), so "
+                    "at rollout sizes the bound is that chain (about 25 cycles per step on the chain wave), not HBM"}
+        del adv_o, ret_o
+    except Exception as exc:  # noqa: BLE001
+        out["roofline_gae_kernel"] = {"error": str(exc)}
     # the same kernel where it is HBM-bound: 4M envs, 1 step per launch, device-generated action tape
     try:
         if world > 1:
