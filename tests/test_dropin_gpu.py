@@ -41,6 +41,36 @@ def test_trainable_env_contracts_match_declared_spaces():  # test_mlagents.py:51
             env.close()
 
 
+@pytest.mark.parametrize("task", ["basic", "gridworld", "push", "walljump"])
+def test_single_env_returns_the_reference_python_float_reward(golden, task):
+    """Seam S1: `env.step()` of the reference returns a Python float computed in float64 (Basic's goal step: -0.01 + 0.1 =
+    0.09000000000000001, backend/mlagents/envs.py:65-84).  HipSingleEnv hands back exactly that float -- from the per-task table of the
+    finite float64 reward set (envs.reward_table), not a decimal rounding of the kernel's float32 -- asserted `==` against `rewards_f64` of
+    the reference-generated fixture over whole multi-episode trajectories of two envs of the vector."""
+    from three_mlagents_amd.tasks import make_env
+
+    g = golden(task)
+    n_envs, T, base_seed = (int(x) for x in g["meta"][:3])
+    env = make_env(task)
+    try:
+        for i in (0, n_envs - 1):
+            obs, _ = env.reset(seed=base_seed + i)
+            assert np.array_equal(obs, g["reset_obs"][i])
+            seen = set()
+            for t in range(min(T, 400)):
+                obs, r, te, tr, _ = env.step(int(g["actions"][t, i]))
+                assert isinstance(r, float) and r == float(g["rewards_f64"][t, i]), (task, i, t, r, float(g["rewards_f64"][t, i]))
+                assert te == bool(g["terminated"][t, i]) and tr == bool(g["truncated"][t, i])
+                seen.add(r)
+                if te or tr:
+                    assert np.array_equal(obs, g["terminal_obs"][t, i])
+                    obs, _ = env.reset()
+                assert np.array_equal(obs, g["obs"][t, i])
+            assert len(seen) >= 2
+    finally:
+        env.close()
+
+
 def test_single_env_matches_reference_seeded_reset(golden):
     from three_mlagents_amd.tasks import make_env
 
@@ -108,14 +138,23 @@ def test_cli_train_and_evaluate(tmp_path, monkeypatch, capsys):  # cli.py:70-95 
     assert os.path.exists(tmp_path / "policies" / "basic_policy_t1.zip")
     meta = json.loads((tmp_path / "runs" / "basic" / "t1" / "metadata.json").read_text())
     assert meta["run_id"] == "t1" and len(meta["episode_rewards"]) == 4 and meta["task"]["id"] == "basic"
+    assert meta["schedule"]["batch_size"] == 256 and meta["schedule"]["batch_size_from"] == "256 * max(1, n_envs // 8)"  # the reference's literal value at its env count
     assert os.path.exists(tmp_path / "runs" / "basic" / "t1" / "eval" / "evaluations.npz")
     prog = (tmp_path / "runs" / "basic" / "t1" / "tb" / "progress.csv").read_text().splitlines()
     assert "rollout/ep_rew_mean" in prog[0] and "train/approx_kl" in prog[0] and len(prog) >= 2
-    mon = (tmp_path / "runs" / "basic" / "t1" / "monitor" / "0.monitor.csv").read_text().splitlines()  # SB3 Monitor layout: one row per episode
-    assert mon[0].startswith("#{") and "t_start" in json.loads(mon[0][1:]) and mon[1] == "r,l,t"
-    rows = [ln.split(",") for ln in mon[2:] if not ln.startswith("#")]
-    assert len(rows) >= 4096 // 50 and all(len(r) == 3 and 1 <= int(r[1]) <= 50 for r in rows)  # Basic: at most 50 steps per episode
-    assert [float(r[2]) for r in rows] == sorted(float(r[2]) for r in rows)
+    # SB3 Monitor layout, one file per env of the vector as the reference writes them (training.py:84-86: monitor_dir / f"{rank}"), one row per episode
+    mdir = tmp_path / "runs" / "basic" / "t1" / "monitor"
+    assert sorted(p.name for p in mdir.iterdir()) == [f"{k}.monitor.csv" for k in range(8)]
+    n_rows = 0
+    for k in range(8):
+        mon = (mdir / f"{k}.monitor.csv").read_text().splitlines()
+        assert mon[0].startswith("#{") and "t_start" in json.loads(mon[0][1:]) and mon[1] == "r,l,t"
+        rows = [ln.split(",") for ln in mon[2:] if not ln.startswith("#")]
+        assert all(len(r) == 3 and 1 <= int(r[1]) <= 50 for r in rows)  # Basic: at most 50 steps per episode
+        assert sum(int(r[1]) for r in rows) <= 1024 and len(rows) >= 1024 // 50 - 1  # the env's own steps (one 1024-step rollout), cut into its episodes
+        assert [float(r[2]) for r in rows] == sorted(float(r[2]) for r in rows)
+        n_rows += len(rows)
+    assert n_rows >= 8192 // 50 - 8
     from three_mlagents_amd.tb_events import read_scalars
 
     tb_dir = tmp_path / "runs" / "basic" / "t1" / "tb" / "PPO_1"
@@ -319,3 +358,6 @@ def test_eval_callback_repeats_rows_while_the_policy_has_not_moved(tmp_path, mon
     assert res.eval_episodes == 100 and res.total_timesteps == 2 * 4096 * 1024
     meta = json.loads((tmp_path / "runs" / "gridworld" / "big" / "metadata.json").read_text())
     assert meta["substituted_for"] == "dqn" and len(meta["episode_rewards"]) == 100
+    # the schedule that was trained with is on record (deviation 10: batch_size follows the env count unless given / TMA_LITERAL_BATCH)
+    assert meta["schedule"] == {"batch_size": 131072, "n_steps": 1024, "n_epochs": 10, "n_envs": 4096, "minibatches_per_epoch": 32,
+                                "reference_batch_size": 256, "literal_batch_env": False, "batch_size_from": "model_kwargs"}

@@ -60,10 +60,15 @@ def test_ppo_default_table():  # value table training.py:361-391
     assert (kw["gamma"], kw["gae_lambda"], kw["clip_range"], kw["ent_coef"], kw["vf_coef"], kw["max_grad_norm"]) == (0.99, 0.95, 0.2, 0.01, 0.5, 0.5)
     assert kw["policy_kwargs"] == {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}
     assert harness.ppo_defaults(tasks.resolve("push"))["n_steps"] == 2048 and "ppo" in harness.ALGORITHMS
-    # with the env count known the table keeps the reference's SCHEDULE (32 minibatches per epoch: 8 envs x 1024 / 256), never below its literal 256
+    # with the env count known the table scales the literal 256 by n_envs / 8 (the reference's env count): the reference's minibatches per
+    # epoch for every task, never below its literal 256
     g = tasks.resolve("gridworld")
-    assert [harness.ppo_defaults(g, n)["batch_size"] for n in (1, 8, 16, 4096)] == [256, 256, 512, 131072]
-    assert harness.ppo_defaults(tasks.resolve("push"), 2048)["batch_size"] == 2048 * 2048 // 32
+    assert [harness.ppo_defaults(g, n)["batch_size"] for n in (1, 8, 15, 16, 4096)] == [256, 256, 256, 512, 131072]
+    assert harness.ppo_defaults(tasks.resolve("push"), 2048)["batch_size"] == 2048 * 2048 // 64  # n_steps 2048: 64 minibatches, as 8 x 2048 / 256
+    for name in ("brickbreak", "bicycle", "glider", "ant", "crawler", "ball3d", "push"):  # benchmark-tier tasks at their default 8 envs
+        t = tasks.resolve(name)
+        assert harness.ppo_defaults(t, t.n_envs)["batch_size"] == 256 or t.n_envs >= 16, name
+        assert harness.ppo_defaults(t, 8)["batch_size"] == 256, name
 
 
 def test_records_and_train_errors():  # training.py:40-68,105-114
@@ -361,3 +366,20 @@ def test_eval_callback_runs_episodes_once_per_optimizer_state(tmp_path, monkeypa
         assert ev["timesteps"].tolist() == [4096 * 2 * k for k in range(1, 13)] and ev["results"].shape == (12, 4) and ev["ep_lengths"].shape == (12, 4)
         assert ev["results"][:, 0].tolist() == [0.0] * 4 + [10.0] * 4 + [20.0] * 4  # rows of a rollout repeat that rollout's evaluation
     assert len(saved) == 6  # a new best after every optimizer state, in both runs
+
+
+@pytest.mark.parametrize("task", ["basic", "gridworld", "push", "walljump"])
+def test_reward_table_is_the_reference_float64_reward_set(task):
+    """envs.reward_table maps every float32 reward of the reference-generated fixtures to exactly the float64 the reference returned
+    (`rewards_f64`: Basic 0.09000000000000001, Push -0.060000000000000005, ...), with no two float64 values behind one float32."""
+    import os
+
+    from three_mlagents_amd.envs import reward_table
+
+    tab = reward_table(task)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{task}.npz"))
+    for pre in ("", "b_"):
+        r32, r64 = g[pre + "rewards_f32"].reshape(-1), g[pre + "rewards_f64"].reshape(-1)
+        assert np.array_equal(np.array([tab[float(x)] for x in r32]), r64)
+    assert all(float(np.float32(v)) == k for k, v in tab.items())
+    assert reward_table("ball3d") == {}

@@ -700,6 +700,8 @@ def test_persistent_epoch_kernel_falls_back_to_launches_when_it_cannot_run(monke
             monkeypatch.setenv("TMA_NO_PERSIST", "1")
         elif mode == "forced_failure":
             monkeypatch.setenv("TMA_PERSIST_FORCE_FAIL", "1")
+        elif mode == "failure_after_commit":  # the launch runs and commits EVERYTHING, then is declared failed: the worst case of a late abort
+            monkeypatch.setenv("TMA_PERSIST_FORCE_FAIL", "late")
         env = make_vector_env("gridworld", n_envs=256, seed=4)
         m = PPO("MlpPolicy", env, n_steps=64, batch_size=256, n_epochs=3, seed=4, policy_kwargs={"net_arch": [64, 64]})
         m.collect_rollouts()
@@ -712,6 +714,12 @@ def test_persistent_epoch_kernel_falls_back_to_launches_when_it_cannot_run(monke
     p_l, m_l, v_l, s_l, n_l, f_l = run("launches")
     p_f, m_f, v_f, s_f, n_f, f_f = run("forced_failure")
     p_p, m_p, v_p, s_p, n_p, f_p = run("persistent")
+    p_c, m_c, v_c, s_c, n_c, f_c = run("failure_after_commit")
+    #  a block may raise the abort word after another has committed: the epoch call snapshots parameters / moments / statistic slots
+    # before the launch and restores them before the fallback, so even a fully committed launch that is declared failed changes nothing
+    assert n_c == 3 * 64 and f_c == 3 and torch.equal(p_c, p_l) and torch.equal(m_c, m_l) and torch.equal(v_c, v_l)
+    for k in ("train/policy_gradient_loss", "train/value_loss", "train/approx_kl", "train/n_samples"):
+        assert s_c[k] == s_l[k], k
     assert n_l == n_f == n_p == 3 * 64 and (f_l, f_f, f_p) == (0, 3, 0)  # every one of the three epochs fell back, and was counted
     assert s_f["train/persist_fallbacks"] == 3.0 and "train/persist_fallbacks" not in s_p
     assert torch.equal(p_f, p_l) and torch.equal(m_f, m_l) and torch.equal(v_f, v_l)  # the fallback IS the launch path

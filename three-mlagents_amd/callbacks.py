@@ -66,6 +66,10 @@ class BaseCallback:
     def _on_training_end(self) -> None:
         pass
 
+    def flush(self) -> None:
+        """Write out whatever the callback buffers in memory; PPO.learn calls it when training unwinds on an exception (on_training_end does
+        not run then).  Engine extension of the SB3 protocol: SB3's own callbacks write as they go."""
+
 
 class CallbackList(BaseCallback):
     def __init__(self, callbacks):
@@ -97,6 +101,10 @@ class CallbackList(BaseCallback):
     def _on_training_end(self) -> None:
         for c in self.callbacks:
             c.on_training_end()
+
+    def flush(self) -> None:
+        for c in self.callbacks:
+            c.flush()
 
 
 class _Duck(BaseCallback):
@@ -135,6 +143,9 @@ class _Duck(BaseCallback):
 
     def on_training_end(self) -> None:
         self._call("on_training_end")
+
+    def flush(self) -> None:
+        self._call("flush")
 
 
 def as_callback(cb) -> BaseCallback:
@@ -218,4 +229,7 @@ class EvalCallback(BaseCallback):
         return True
 
     def _on_training_end(self) -> None:
+        self._flush()
+
+    def flush(self) -> None:
         self._flush()

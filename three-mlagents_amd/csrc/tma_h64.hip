@@ -659,6 +659,7 @@ int tma_launch_grad_h64(const float *params, const PLayout &L, const Rollout &R,
     AdamFold fold{};
     if (foldp) fold = *foldp;
     static const int ver = getenv("TMA_H64_V1") ? 1 : 2;  // (development switch: the round-1 LDS-round-trip tile chain)
+    if (ver == 1 && foldp && foldp->grad) return TMA_ERR_INVALID;  // the round-1 chain has no optimizer prologue: refuse instead of dropping the step
     static const int stagger = getenv("TMA_H64_STAGGER") ? atoi(getenv("TMA_H64_STAGGER")) : 0;
     HParams hps = hpar;
     hps.debug = stagger;

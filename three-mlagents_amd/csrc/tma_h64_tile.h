@@ -488,7 +488,8 @@ __device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A
         float noise = 0.0f;
         if (!det) {
             const uint32_t h = mix32(rng_seed ^ (0x9E3779B9u * (uint32_t)(g + 4 * r + 1)), global_env, rng_step);
-            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+            // 23 bits: k + 0.5 is exact for k < 2^23, so u <= 1 - 2^-24 < 1 (with 24 bits k = 0xFFFFFF rounds to 2^24: u == 1, noise == +inf)
+            const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
             noise = -__logf(-__logf(u));
         }
         key[r] = ok[r] ? x[r] + noise : -INFINITY;

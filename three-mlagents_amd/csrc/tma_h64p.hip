@@ -25,6 +25,7 @@
 // tma_ppo_train_epoch_local re-runs that epoch through the per-minibatch launches.
 #include "tma_h64_tile.h"
 
+#include <cstring>
 #include <cstdlib>
 
 namespace tma {
@@ -612,7 +613,8 @@ int tma_launch_epoch_h64p(float *params, const PLayout &L, const Rollout &R, con
     if (qp.P > HP_SLAB_F || nm > 3) return TMA_ERR_INVALID;
     const int smem = (IMG_FLOATS + 4 * a.rw) * 4;
     TMA_HIP(hipMemsetAsync(a.region, 0, HP_SLABS, s));
-    if (getenv("TMA_PERSIST_FORCE_FAIL") != nullptr)  // test hook: the launch finds its abort word set, commits nothing and reports the failure
+    const char *force_fail = getenv("TMA_PERSIST_FORCE_FAIL");
+    if (force_fail != nullptr && strcmp(force_fail, "late") != 0)  // test hook: the launch finds its abort word set, commits nothing and reports the failure
         TMA_HIP(hipMemsetAsync(a.region + HP_SYNC + 160 * 4, 1, 1, s));
     adam_table_kernel<<<dim3((unsigned)((a.n_mb + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<float2 *>(a.region + HP_TABLE), a.n_mb, first_step,
                                                                                    lr, beta1, beta2);

@@ -13,6 +13,7 @@
 // against a torch-CPU autograd restatement in tests/.
 #include "tma_h64_tile.h"
 
+#include <cstring>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2323,6 +2324,17 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         const HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, hp->normalize_advantage ? 1 : 0, 0};
         int stride = (int)ceil_div(batch_size, 1024);
         if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+        // Snapshot of what the launch may commit (trainable parameters, both moments, its 64 statistic slots) in the idle half of the AdamFold
+        // double buffer: "commit nothing after an abort" is a per-block decision inside the kernel, so a block that gives up on its LAST wait
+        // can raise the abort word after another block has already written its net -- the fallback below restores the snapshot first and is
+        // therefore the same results whatever the kernel managed to write (4 small device copies per ~10^5 us epoch).
+        hipStream_t ps = (hipStream_t)stream;
+        const int64_t Pp = ((int64_t)L.P + 3) & ~(int64_t)3;
+        float *snap = reinterpret_cast<float *>(ws + fold_state_offset(L));
+        TMA_HIP(hipMemcpyAsync(snap, params, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(snap + Pp, exp_avg, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(snap + 2 * Pp, exp_avg_sq, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(ws + WS_PERSIST_SNAP, ws + WS_STATS, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
         rc = tma_launch_epoch_h64p(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
                                    reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size, exp_avg, exp_avg_sq,
                                    first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
@@ -2334,9 +2346,17 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         int persist_err = 0;
         TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
         TMA_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (const char *ff = getenv("TMA_PERSIST_FORCE_FAIL"))  // test hook "late": the launch ran and committed EVERYTHING, then is declared failed
+            if (!strcmp(ff, "late")) persist_err = 1;
         if (!persist_err) return TMA_OK;
-        TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), (hipStream_t)stream));
-        persist_fallback_note(ws, (hipStream_t)stream);
+        TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), ps));
+        TMA_HIP(hipMemcpyAsync(params, snap, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(exp_avg, snap + Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(exp_avg_sq, snap + 2 * Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+        TMA_HIP(hipMemcpyAsync(ws + WS_STATS, ws + WS_PERSIST_SNAP, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
+        rc = launch_sync(params, L, ps);  // derived copies and weight images of the restored parameters
+        if (rc) return rc;
+        persist_fallback_note(ws, ps);
     }
     int64_t step = first_step;
     const bool no_fold = getenv("TMA_NO_ADAM_FOLD") != nullptr;  // test / measurement switch: one optimizer launch per minibatch (read per epoch)

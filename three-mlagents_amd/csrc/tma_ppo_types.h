@@ -8,6 +8,7 @@ constexpr int WS_ADV = 0;             // float[2]: minibatch advantage mean, std
 constexpr int WS_NORM_PART = 64;      // byte offset of double[256] grad sum-of-squares partials
 constexpr int WS_NORM_OUT = 64 + 256 * 8;  // double[2]: total grad norm, clip coefficient
 constexpr int WS_PERSIST_ERR = 2176;  // int32: set when the persistent epoch kernel (tma_h64p.hip) gave up on a wait; read + cleared by tma_ppo_pop_stats
+constexpr int WS_PERSIST_SNAP = 2560;  // double[8][8]: the persistent epoch launch's statistic slots before the launch (restored on fallback)
 constexpr int WS_ADV_PART = 4096;     // byte offset of double[128][2] advantage (sum, sumsq) partials
 constexpr int WS_STATS = 8192;        // byte offset of double[MAX_GRAD_BLOCKS][8] loss statistic slots
 constexpr int MAX_GRAD_BLOCKS = 2048;

@@ -14,6 +14,45 @@ import numpy as np
 import torch
 
 
+_REWARD_TABLES: dict[str, dict[float, float]] = {}
+
+
+def reward_table(task_id: str) -> dict[float, float]:
+    """float32 reward (as a Python float) -> the float64 the reference's step() returns for it, for the tasks whose reward takes finitely
+    many values.  Each value is formed here by the same float64 operations in the same order as the reference forms it -- Basic
+    (backend/mlagents/envs.py:65-72): -0.01, then += 0.1 or += 1.0; GridWorld (examples/gridworld.py:75-90): -0.01 or +-1.0 assigned;
+    Push (examples/push.py:77,112-122): -0.01 += 0.05 * d(agent, box) += 0.3 * d(box, goal) with the distance changes in {-1, 0, 1} (a push
+    moves the box with the agent, so only one of the two is non-zero), -= 0.05 on a cancelled push (both changes 0), 1.0 assigned on the goal
+    row; WallJump (examples/walljump.py:59,77,81,91): -0.01, -= 0.02 (wall) or -= 0.03 (needless jump), 1.0 assigned."""
+    vals: list[float] = []
+    if task_id == "basic":
+        for bonus in (None, 0.1, 1.0):
+            r = -0.01
+            if bonus is not None:
+                r += bonus
+            vals.append(r)
+    elif task_id == "gridworld":
+        vals = [-0.01, 1.0, -1.0]
+    elif task_id == "push":
+        for d_ab, d_bg in ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1), (-1, 1), (1, -1), (1, 1)):
+            r = -0.01
+            r += 0.05 * d_ab
+            r += 0.3 * d_bg
+            vals.append(r)
+        r = -0.01
+        r += 0.05 * 0
+        r += 0.3 * 0
+        r -= 0.05
+        vals += [r, 1.0]
+    elif task_id == "walljump":
+        vals = [-0.01, -0.01 - 0.02, -0.01 - 0.03, 1.0]
+    table: dict[float, float] = {}
+    for v in vals:
+        key = float(np.float32(v))
+        assert table.setdefault(key, v) == v, (task_id, key)  # two different float64 values behind one float32 would make the table ambiguous
+    return table
+
+
 class HipSingleEnv:
     metadata = {"render_modes": []}
     render_mode = None
@@ -81,10 +120,16 @@ class HipSingleEnv:
         return obs.astype(np.float32), reward, term, trunc, info
 
     def _reward64(self, out) -> float:
-        """The reference returns python floats computed in float64 (e.g. -0.01, 0.09000000000000001); the kernel's float32
-        reward is the float32 rounding of one of a small set of float64 values per task, recovered here."""
+        """The reference returns Python floats computed in float64 (-0.01, 0.09000000000000001, ...); the kernel's float32 reward is the
+        float32 rounding of one of a small finite set of such values per task (`reward_table`): hand back exactly that float64."""
         r32 = float(out["rew"][0, 0].item())
-        r6 = round(r32, 6)
+        table = _REWARD_TABLES.get(self.task_id)
+        if table is None:
+            table = _REWARD_TABLES[self.task_id] = reward_table(self.task_id)
+        exact = table.get(r32)
+        if exact is not None:
+            return exact
+        r6 = round(r32, 6)  # tasks without a finite reward set (float64 physics): the shortest decimal that rounds to the same float32
         return r6 if np.float32(r6) == np.float32(r32) else r32
 
     def close(self) -> None:

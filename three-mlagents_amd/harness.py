@@ -53,15 +53,17 @@ def make_vector_env(task_id, *, n_envs, seed, monitor_dir=None, device=None, env
 def ppo_defaults(task: tasks.EngineTask, n_envs: int | None = None) -> dict[str, Any]:
     """Hyper-parameters the reference hands to SB3's PPO (value table: training.py:361-391).
 
-    `batch_size`: the reference's 256 is 1/32 of ITS rollout (n_steps 1024 x the 8 envs it trains with: 32 minibatches per epoch).  With
-    `n_envs` given, the table keeps that schedule -- 32 minibatches per epoch, never below the literal 256 -- instead of the literal number:
-    at 4096 envs a batch of 256 would be 163 840 optimizer steps per iteration on minibatches that fill 3 % of the GPU.  Identical to the
-    reference at up to 8 envs; TMA_LITERAL_BATCH=1 (or an explicit model_kwargs["batch_size"]) selects 256 at any size."""
+    `batch_size`: the reference's 256 (training.py:379) is 32 samples per env of the 8 envs it trains with.  With `n_envs` given, the table
+    scales the literal number by the env count over the reference's 8 -- `256 * max(1, n_envs // 8)`: the same minibatches-per-epoch as the
+    reference whatever the task's n_steps (32 at n_steps 1024, 64 at 2048), never below the literal 256 -- because at 4096 envs a batch of 256
+    would be 163 840 optimizer steps per iteration on minibatches that fill 3 % of the GPU.  Exactly the reference's 256 at up to 15 envs for
+    EVERY task; TMA_LITERAL_BATCH=1 (or an explicit model_kwargs["batch_size"]) selects 256 at any size.  `train_task` records the value that
+    was used and the switch in metadata.json (`schedule`)."""
     width = [256, 256]
     extra = {"mfma_dtype": "bf16"} if os.environ.get("TMA_MFMA_DTYPE", "").lower() == "bf16" else {}  # engine knob, BASELINE configs[2]
     batch = 256
     if n_envs is not None and not os.environ.get("TMA_LITERAL_BATCH"):
-        batch = max(256, int(n_envs) * task.ppo_n_steps // 32)
+        batch = 256 * max(1, int(n_envs) // 8)
     return dict(learning_rate=3e-4, n_steps=task.ppo_n_steps, batch_size=batch, n_epochs=10, gamma=0.99, gae_lambda=0.95, clip_range=0.2,
                 ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs={"net_arch": {"pi": width, "vf": list(width)}, **extra})
 
@@ -115,8 +117,6 @@ def train_task(config, *, callback=None, model_kwargs=None):
         # episodes are spread over up to EVAL_ENVS device envs stepped together -- evaluation.py, SB3's even split of episodes over envs)
         venv, eval_env = opened(n_envs, 0, run.monitor), opened(max(1, min(EVAL_ENVS, episodes)), 10_000)
         hp = {**ppo_defaults(task, n_envs), "tensorboard_log": str(run.tb), "verbose": config.verbose, **(model_kwargs or {})}
-        if "n_steps" in (model_kwargs or {}) and "batch_size" not in (model_kwargs or {}) and not os.environ.get("TMA_LITERAL_BATCH"):
-            hp["batch_size"] = max(256, n_envs * int(hp["n_steps"]) // 32)  # (the schedule follows an overridden rollout length too)
         model = ALGORITHMS[algo](config.policy or "MlpPolicy", venv, seed=config.seed, **hp)
         ev = dict(n_eval_episodes=episodes, deterministic=config.deterministic_eval)
         hooks = [EvalCallback(eval_env, log_path=str(run.eval), best_model_save_path=str(run.best), verbose=config.verbose,
@@ -129,7 +129,11 @@ def train_task(config, *, callback=None, model_kwargs=None):
         mean, std = statistics.fmean(returns), statistics.pstdev(returns)
         from . import __version__
 
-        record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, substituted_for=stands_in_for, run_id=run.id, model_filename=run.zip_name,
+        schedule = dict(batch_size=model.batch_size, n_steps=model.n_steps, n_epochs=model.n_epochs, n_envs=n_envs,
+                        minibatches_per_epoch=-(-n_envs * model.n_steps // model.batch_size), reference_batch_size=256,
+                        literal_batch_env=bool(os.environ.get("TMA_LITERAL_BATCH")), batch_size_from="model_kwargs" if "batch_size" in (model_kwargs or {})
+                        else ("TMA_LITERAL_BATCH" if os.environ.get("TMA_LITERAL_BATCH") else "256 * max(1, n_envs // 8)"))
+        record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, substituted_for=stands_in_for, schedule=schedule, run_id=run.id, model_filename=run.zip_name,
                       model_path=str(run.zip_path), mean_reward=mean, std_reward=std, episode_rewards=[float(r) for r in returns],
                       episode_lengths=[int(n) for n in lengths], train_log=model.logger_values,
                       software=dict(three_mlagents_amd=__version__, engine="libtma_hip.so (gfx950)"), created_at=time.strftime("%Y-%m-%dT%H:%M:%S%z"))

@@ -426,26 +426,38 @@ class PPO:
         if getattr(self.env, "monitor_dir", None) and self.rank == 0 and getattr(self.env.engine, "_log_cap", 0) == 0:
             self.env.engine.episode_log(self.monitor_log_capacity)  # per-episode Monitor rows (r, l, t)
         t_prev = 0.0
-        while self.num_timesteps < total_timesteps:
-            cb.on_rollout_start()
-            if not self.collect_rollouts(cb if callback is not None else None, chunk=getattr(cb, "chunk_steps", None)):
-                break
-            cb.on_rollout_end()
-            iteration += 1
-            self.train()
-            if log_interval is not None and iteration % log_interval == 0:
-                s_ret, s_len, cnt = self.env.engine.pop_episode_stats()
-                stats = self.pop_train_stats()
-                fps = self.num_timesteps / max(time.time() - t0, 1e-9)
-                stats.update({"time/fps": fps, "time/iterations": iteration, "time/total_timesteps": self.num_timesteps,
-                              "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
-                              "rollout/episodes": cnt, "train/n_updates": self._n_updates})
-                self.logger_values = stats
-                self._write_progress(stats)
-                self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0)
-                t_prev = time.time() - t0
-                if self.verbose >= 1 and self.rank == 0:
-                    print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+        try:
+            while self.num_timesteps < total_timesteps:
+                cb.on_rollout_start()
+                if not self.collect_rollouts(cb if callback is not None else None, chunk=getattr(cb, "chunk_steps", None)):
+                    break
+                cb.on_rollout_end()
+                iteration += 1
+                self.train()
+                if log_interval is not None and iteration % log_interval == 0:
+                    s_ret, s_len, cnt = self.env.engine.pop_episode_stats()
+                    stats = self.pop_train_stats()
+                    fps = self.num_timesteps / max(time.time() - t0, 1e-9)
+                    stats.update({"time/fps": fps, "time/iterations": iteration, "time/total_timesteps": self.num_timesteps,
+                                  "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
+                                  "rollout/episodes": cnt, "train/n_updates": self._n_updates})
+                    self.logger_values = stats
+                    self._write_progress(stats)
+                    self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0)
+                    t_prev = time.time() - t0
+                    if self.verbose >= 1 and self.rank == 0:
+                        print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+        except BaseException:
+            # learn() is unwinding (an all-reduce error, KeyboardInterrupt, a callback that raised): on_training_end will not run, so what the
+            # callbacks and the Monitor writer hold in memory goes to disk HERE -- SB3 writes evaluations.npz after every evaluation
+            self._join_monitor_writer(reraise=False)
+            flush = getattr(cb, "flush", None)
+            if callable(flush):
+                try:
+                    flush()
+                except Exception:  # noqa: BLE001 -- never mask the exception that is unwinding
+                    pass
+            raise
         self._join_monitor_writer()
         cb.on_training_end()
         return self
@@ -472,48 +484,81 @@ class PPO:
     monitor_log_capacity = 1 << 20  # episode records the device keeps between two log intervals
     monitor_max_rows = 100_000      # rows written per log interval (an evenly strided subsample beyond that)
 
+    monitor_per_env_limit = 64      # up to this many envs: one `<rank>.monitor.csv` per env, as the reference writes them (training.py:84-86)
+
     def _write_monitor(self, sum_ret: float, sum_len: float, count: float, t_begin: float, t_end: float, t_start: float) -> None:
-        """SB3 Monitor file (`<monitor_dir>/0.monitor.csv`, the directory make_vector_env passes; reference training.py:85-86): the JSON
-        header line, then one `r,l,t` row per finished episode of ANY env of the vector, in the order the kernels logged them (one file for
-        the whole vector: `load_results` concatenates per-env files anyway).  `t` is interpolated over the log interval -- the device does
-        not stamp wall-clock time.  More than monitor_max_rows episodes in one interval are subsampled with an even stride and a `#` comment
-        line records how many finished; if the device log overflowed, the interval's mean is added as a comment as well."""
+        """SB3 Monitor files under the directory make_vector_env passes (reference training.py:84-86: env `rank` of the vector is wrapped in
+        `Monitor(env, monitor_dir / f"{rank}")` -> `<rank>.monitor.csv`): the JSON header line, `r,l,t`, then one row per finished episode.
+        Up to `monitor_per_env_limit` envs every env gets its own file, as in the reference -- the device episode log carries the env index;
+        beyond that ONE `0.monitor.csv` holds the rows of every env in the order the kernels logged them (`load_results` concatenates per-env
+        files anyway; 4096 files per run would not be a service to anyone).  `t` is interpolated over the log interval -- the device does not
+        stamp wall-clock time.  More than monitor_max_rows episodes in one interval are subsampled with an even stride and a `#` comment line
+        records how many finished; if the device log overflowed, the interval's mean is added as a comment as well."""
         mdir = getattr(self.env, "monitor_dir", None)
         if not mdir or self.rank != 0 or not count:
             return
         os.makedirs(mdir, exist_ok=True)
-        path = os.path.join(str(mdir), "0.monitor.csv")
-        new = not os.path.exists(path)
-        r, l, _, seen = self.env.engine.pop_episode_log()
+        r, l, e, seen = self.env.engine.pop_episode_log()
         n = len(r)
         keep = np.arange(n) if n <= self.monitor_max_rows else np.linspace(0, n - 1, self.monitor_max_rows).astype(np.int64)
         self._join_monitor_writer()  # (rows of the previous interval are on disk before this interval's header / comment lines)
-        with open(path, "a", encoding="utf-8") as f:
-            if new:
-                f.write("#" + json.dumps({"t_start": t_start, "env_id": getattr(self.env, "task_id", None)}) + "\n")
-                f.write("r,l,t\n")
-            if len(keep) < seen:
-                f.write(f"# {seen} episodes finished in this interval, {len(keep)} rows kept; interval mean r={sum_ret / count:.6f} l={sum_len / count:.3f}\n")
-        if not len(keep):
+        per_env = self.n_envs <= self.monitor_per_env_limit
+        header = lambda rank: "#" + json.dumps({"t_start": t_start, "env_id": getattr(self.env, "task_id", None)}) + "\nr,l,t\n"  # noqa: E731
+        ts_all = t_begin + (t_end - t_begin) * (np.arange(len(keep)) + 1.0) / max(len(keep), 1)
+        jobs = []  # (path, returns f64, lengths i32, t f64)
+        if per_env:
+            written = getattr(self, "_monitor_files", None)
+            if written is None:
+                written = self._monitor_files = set()
+            for rank in range(self.n_envs):  # the reference creates every env's file at construction, finished episodes or not
+                path = os.path.join(str(mdir), f"{rank}.monitor.csv")
+                if rank not in written:
+                    with open(path, "a", encoding="utf-8") as f:
+                        if f.tell() == 0:
+                            f.write(header(rank))
+                    written.add(rank)
+                rows = keep[e[keep] == rank]
+                if len(rows):
+                    pos = np.searchsorted(keep, rows)
+                    jobs.append((path, np.ascontiguousarray(r[rows], np.float64), np.ascontiguousarray(l[rows], np.int32),
+                                 np.ascontiguousarray(ts_all[pos], np.float64)))
+        else:
+            path = os.path.join(str(mdir), "0.monitor.csv")
+            new = not os.path.exists(path)
+            with open(path, "a", encoding="utf-8") as f:
+                if new:
+                    f.write(header(0))
+                if len(keep) < seen:
+                    f.write(f"# {seen} episodes finished in this interval, {len(keep)} rows kept; interval mean r={sum_ret / count:.6f} l={sum_len / count:.3f}\n")
+            if len(keep):
+                jobs.append((path, np.ascontiguousarray(r[keep], np.float64), np.ascontiguousarray(l[keep], np.int32),
+                             np.ascontiguousarray(ts_all, np.float64)))
+        if not jobs:
             return
         # the rows themselves: formatted and appended natively (tma_monitor_append_rows) on a writer thread -- the ctypes call releases the
         # GIL, so 10^5 rows per iteration (4096 envs, ~30-step episodes) cost the training loop nothing
-        rr, ll = np.ascontiguousarray(r[keep], np.float64), np.ascontiguousarray(l[keep], np.int32)
-        ts = np.ascontiguousarray(t_begin + (t_end - t_begin) * (np.arange(len(keep)) + 1.0) / len(keep), np.float64)
         import threading
 
         def work():
-            _lib.check(_lib.lib().tma_monitor_append_rows(path.encode(), rr.ctypes.data_as(C.c_void_p), ll.ctypes.data_as(C.c_void_p),
-                                                          ts.ctypes.data_as(C.c_void_p), len(rr)))
+            try:
+                for path, rr, ll, ts in jobs:
+                    _lib.check(_lib.lib().tma_monitor_append_rows(path.encode(), rr.ctypes.data_as(C.c_void_p), ll.ctypes.data_as(C.c_void_p),
+                                                                  ts.ctypes.data_as(C.c_void_p), len(rr)))
+            except BaseException as exc:  # noqa: BLE001 -- handed to the training thread by _join_monitor_writer
+                self._monitor_error = exc
 
         self._monitor_thread = threading.Thread(target=work, name="tma-monitor-writer", daemon=False)
         self._monitor_thread.start()
 
-    def _join_monitor_writer(self) -> None:
+    def _join_monitor_writer(self, reraise: bool = True) -> None:
         th = getattr(self, "_monitor_thread", None)
         if th is not None:
             th.join()
             self._monitor_thread = None
+        err = getattr(self, "_monitor_error", None)
+        if err is not None and reraise:  # a failed row write surfaces in the training thread (an exception inside the thread is only printed)
+            self._monitor_error = None
+            raise RuntimeError(f"Monitor writer failed: {err}") from err
 
     # -- inference ------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
