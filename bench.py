@@ -59,7 +59,7 @@ def parse():
                     help="MFMA operand type of the hidden-layer GEMMs (bf16: hidden 128/192/256 only; BASELINE.json configs[2])")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=28.0, help="CPU-baseline budget over all five configs x {1 thread, all cores}")
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs / literal_batch_256 (N = 1 default runs include them)")
     ap.add_argument("--sweep", action="store_true", help="also run the env-count sweep of the step kernel (extra JSON field)")
     return ap.parse_args()
@@ -198,7 +198,7 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
 def attach_pmc_traffic(roof, name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summaries (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2
     corrected as MI355X_MICROARCH.md prescribes); newest round first."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
         if os.path.exists(path):
             with open(path) as f:
@@ -208,6 +208,8 @@ def attach_pmc_traffic(roof, name):
 
 
 def step_kernel_rooflines(out, args, env, model, world):
+    import ctypes as C
+
     import torch
 
     from three_mlagents_amd import _lib
@@ -249,6 +251,37 @@ def step_kernel_rooflines(out, args, env, model, world):
         "note": f"{N} envs move {N * lay / 1e6:.2f} MB per launch: launch-latency-bound, not HBM-bound (SURVEY.md 7.3-4); the training rollout uses the "
                 "fused multi-step kernel instead; see roofline_step_kernel_saturated for the HBM-bound regime",
     }
+    # the fused rollout chunk: policy + value forward, sampling, env step, buffer writes of one vector step (10 % of the headline iteration)
+    try:
+        T = model.n_steps
+        b_rb = model._rb
+
+        def collect_once():
+            _lib.check(L.tma_rollout_collect(eng._h, _lib.ptr(model.policy.params), C.byref(model.policy.dims), C.byref(b_rb), 0, T, T, args.seed & 0xFFFFFFFF,
+                                             (model._rollout_counter * T) & 0xFFFFFFFF, eng.env_offset & 0xFFFFFFFF, 0.99, 1, 0, model._stream()))
+            model._rollout_counter += 1
+
+        collect_once()
+        _, roll_us = timed_kernel_us(collect_once, 6, sync)
+        A_ = model.policy.act_dim
+        fwd_flops, _ = mlp_flops_per_sample(D, args.hidden, A_)
+        per_step_us = roll_us / T
+        tf = N * fwd_flops / (per_step_us * 1e-6) / 1e12
+        wbytes = N * (4 * D + 4 * (A_ if model.policy.continuous else 1) + 16)
+        peak = MFMA_BF16_PEAK_TFLOPS if args.mfma_dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        fused = {64: "tma::rollout_chunk2_h64_kernel", 256: "tma::rollout_chunk_wide_bf_kernel" if args.mfma_dtype == "bf16" else "tma::rollout_chunk_wide_f32_kernel"}
+        out["roofline_rollout_kernel"] = {
+            "kernel": f"{fused.get(args.hidden, 'per-step policy_fwd + step_kernel launches')}<{args.task}> (policy + value forward, sampling, env step with auto-reset, "
+                      f"buffer writes; up to one reset-ring window = {eng.ring_depth} vector steps per launch)",
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+            "us_per_vector_step": per_step_us, "collect_call_us": roll_us, "vector_steps_per_call": T, "flops_per_env_step_fwd": fwd_flops,
+            "buffer_bytes_per_vector_step": wbytes, "buffer_write_GBps": wbytes / (per_step_us * 1e-6) / 1e9,
+            "note": "HIP events around tma_rollout_collect over the whole rollout (chunk launches + MT19937 ring refills) / n_steps; flops = SURVEY.md 8d forward "
+                    "formula (both nets) x envs, bytes = 8d's rollout-buffer write (4D + 4A' + 16) x envs.  A vector step is ONE 16-env tile per CU running a "
+                    "dependent chain of ~84 MFMAs with a tanh between layers: bound by that chain's latency (DESIGN.md section 5), not by the pipe or by HBM; the "
+                    "rocprofv3 mean of the chunk kernel is in profiles/r04_bench_n1_kernel_stats.csv"}
+    except Exception as exc:  # noqa: BLE001
+        out["roofline_rollout_kernel"] = {"error": repr(exc)}
     # GAE over the rollout that was just collected (20 B per (t, env) in SB3's layout; the engine's flag bytes make it 18)
     try:
         T = model.n_steps
@@ -315,6 +348,9 @@ EXTRA_CONFIGS = [
          n_steps=2048, hidden=256, mfma="bf16"),
     dict(name="configs[0] Basic 8 envs, MLP(256,256) f32, the reference's literal batch 256", task="basic", n_envs=8, n_steps=1024, hidden=256, mfma="f32",
          batch=256),
+    # SURVEY.md 8d config (2), second half: the headline env with the reference's DEFAULT net and dtype (training.py:363-365)
+    dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 (reference default net)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="f32",
+         steps=4, warmup=1),
 ]
 
 
@@ -333,6 +369,8 @@ def run_extra(cfg, args, dev):
             attach_pmc_traffic(roof, {"ball3d": "gradbf_kernel", "push": "gradbf_push_kernel", "crawler": "gradbf_crawler_kernel"}.get(cfg["task"], "none"))
         elif cfg["task"] == "basic":
             attach_pmc_traffic(roof, "gradwide_basic_kernel")
+        elif cfg["task"] == "gridworld" and cfg["hidden"] == 256:
+            attach_pmc_traffic(roof, "gradwide_gridworld_kernel")
         res = {"config": cfg["name"], "task": cfg["task"], "envs_per_gpu": cfg["n_envs"], "n_steps": cfg["n_steps"], "hidden": cfg["hidden"],
                "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": warm,
                "env_steps_per_sec": steps * total / el, "ms_per_step": el / steps * 1e3, "rollout_ms": t_roll / steps * 1e3,
@@ -443,84 +481,153 @@ def harness_train_task(args, dev):
 # ------------------------------------------------------------------------------------------------------------------------
 # CPU leg (the oracle as the stated baseline; never the thing shipped)
 # ------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(args, seconds, batch):
-    """The same PPO iteration on the host cores: C oracle env (OpenMP over envs) + torch-CPU restatement of the SB3 policy / GAE / update.
-    A full iteration would take minutes, so two bounded legs are timed on samples of the SAME workload and composed with the GPU leg's
-    schedule (same n_envs, minibatch size, epochs): (a) rollout -- Tc vector steps of policy forward + sampling + env step over all
-    n_envs, then GAE; (b) update -- optimizer steps on minibatches of the GPU leg's batch size drawn from that rollout."""
+# the five BASELINE.json configs as the CPU legs see them (per-GPU shard sizes as in EXTRA_CONFIGS; the reference's default net 256x256 for
+# everything but the headline, which BASELINE.json names at 64x64); batch 0 -> the GPU leg's schedule (32 minibatches per epoch)
+CPU_CONFIGS = [
+    dict(name="configs[0] Basic 8 envs, MLP(256,256), batch 256 (the reference's literal config)", task="basic", n_envs=8, n_steps=1024, hidden=256, batch=256),
+    dict(name="configs[1] GridWorld 4096 envs, MLP(64,64) (headline)", task="gridworld", n_envs=4096, n_steps=1024, hidden=64, batch=0, headline=True),
+    dict(name="configs[2] Ball3D 4096 envs, MLP(256,256)", task="ball3d", n_envs=4096, n_steps=1024, hidden=256, batch=0),
+    dict(name="configs[3] Push 2048 envs (one GPU's shard of 8192), T=2048, MLP(256,256)", task="push", n_envs=2048, n_steps=2048, hidden=256, batch=0),
+    dict(name="configs[4] Crawler-shape 172/20, 2048 envs (one GPU's shard of 16384), T=2048, MLP(256,256)", task="crawler", n_envs=2048, n_steps=2048,
+         hidden=256, batch=0),
+]
+
+
+def _cpu_legs(cfg, threads, seconds, n_epochs, seed):
+    """One config on `threads` host threads (C oracle env: OpenMP over envs; torch-CPU restatement of SB3's policy / loss / Adam:
+    torch.set_num_threads), each leg time-boxed to about a quarter of `seconds`:
+      env_only  vector steps on a fixed action tape (auto-reset, Monitor sums, terminal observations included);
+      env_gae   the same steps + GAE over them (no policy);
+      rollout   policy forward + sampling + env step, then GAE -- what collect_rollouts does;
+      update    optimizer steps (forward, loss, backward, clip, Adam) on minibatches drawn from that rollout, scaled to the config's batch size.
+    `env_steps_per_s` composes rollout + n_epochs x minibatches x update into full PPO iterations (the metric of the GPU leg)."""
     import numpy as np
     import torch
 
     from oracle import oracle as orc
     from oracle import sb3_ref
 
-    cores = min(os.cpu_count() or 1, 32)  # threads actually used by both the OpenMP oracle and torch
-    torch.set_num_threads(cores)
-    N, D, A, H, T = args.n_envs, orc.obs_dim(args.task), orc.num_actions(args.task), args.hidden, args.n_steps
+    torch.set_num_threads(threads)
+    task, N, T, H = cfg["task"], cfg["n_envs"], cfg["n_steps"], cfg["hidden"]
+    D, A = orc.obs_dim(task), orc.num_actions(task)
+    cont = A == 0
+    Ad = orc.act_dim(task) if cont else A
     total = N * T
+    batch = cfg["batch"] or max(256, total // 32)
     n_mb = (total + batch - 1) // batch
-    Tc = max(8, min(T, -(-batch // N)))  # enough vector steps for one full minibatch of the GPU leg's size
-    log(f"cpu_baseline: {cores} threads, budget {seconds:.0f} s, rollout sample {Tc} x {N}, minibatch {batch}")
-    env = orc.OracleVecEnv(args.task, N, seed=args.seed, threads=cores)
-    sd = sb3_ref.init_policy(D, H, A, False, seed=args.seed)
-    obs = torch.from_numpy(env.reset())
-    # ---- leg (a): rollout sample ----
-    b_obs, b_act, b_lp, b_val, b_rew, b_done = [], [], [], [], [], []
-    env_only_t = 0.0
+    leg = max(0.3, seconds / 4.0)
+    env = orc.OracleVecEnv(task, N, seed=seed, threads=threads)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    # ---- env only (+ GAE) ----
+    Tmax = T
+    tape = (rng.uniform(-1.0, 1.0, size=(min(Tmax, 64), N, Ad)).astype(np.float32) if cont else orc.action_tape(seed + 2, N, Tmax, A))
+    obs = np.zeros((N, D), np.float32)
+    rew_all, term_all, trunc_all = np.zeros((Tmax, N), np.float32), np.zeros((Tmax, N), np.uint8), np.zeros((Tmax, N), np.uint8)
     t0 = time.perf_counter()
-    for _ in range(Tc):
+    n_env = 0
+    while n_env < Tmax and (time.perf_counter() - t0 < leg or n_env < 2):
+        env.step_fast(tape[n_env % len(tape)], obs, rew_all[n_env], term_all[n_env], trunc_all[n_env])  # (rows are contiguous views: no copies)
+        n_env += 1
+    t_env = time.perf_counter() - t0
+    rew, done = rew_all[:n_env], (term_all[:n_env] | trunc_all[:n_env]).astype(np.float32)
+    val = rng.normal(size=rew.shape).astype(np.float32)
+    es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
+    g0 = time.perf_counter()
+    orc.gae(rew, val, es, val[-1], done[-1].astype(np.uint8), threads=threads)
+    t_gae = time.perf_counter() - g0
+    # ---- rollout: policy forward + sampling + env step, then GAE ----
+    sd = sb3_ref.init_policy(D, H, Ad, cont, seed=seed)
+    ob = torch.from_numpy(env.reset())
+    b_obs, b_act, b_lp, b_val, b_rew, b_done = [], [], [], [], [], []
+    Tneed = max(2, min(T, -(-min(batch, 16384) // N)))  # enough rows for the update leg's sample
+    t0 = time.perf_counter()
+    n_roll = 0
+    while n_roll < T and (time.perf_counter() - t0 < leg or n_roll < Tneed):
         with torch.no_grad():
-            logits, values = sb3_ref.forward(sd, obs)
-            dist = torch.distributions.Categorical(logits=logits)
+            out, values = sb3_ref.forward(sd, ob)
+            dist = (torch.distributions.Normal(out, torch.ones_like(out) * sd["log_std"].exp()) if cont else torch.distributions.Categorical(logits=out))
             act = dist.sample()
-            lp = dist.log_prob(act)
-        e0 = time.perf_counter()
-        o = env.step(act.numpy().astype(np.int32))
-        env_only_t += time.perf_counter() - e0
-        b_obs.append(obs), b_act.append(act), b_lp.append(lp), b_val.append(values), b_rew.append(torch.from_numpy(o["rew32"]))
+            lp = dist.log_prob(act).sum(dim=1) if cont else dist.log_prob(act)
+        o = env.step(np.clip(act.numpy(), -1.0, 1.0).astype(np.float32) if cont else act.numpy().astype(np.int32))
+        b_obs.append(ob), b_act.append(act), b_lp.append(lp), b_val.append(values), b_rew.append(torch.from_numpy(o["rew32"]))
         b_done.append(torch.from_numpy((o["term"] | o["trunc"]).astype(np.float32)))
-        obs = torch.from_numpy(o["obs"])
+        ob = torch.from_numpy(o["obs"])
+        n_roll += 1
     with torch.no_grad():
-        _, last_v = sb3_ref.forward(sd, obs)
+        _, last_v = sb3_ref.forward(sd, ob)
     rew, val, done = torch.stack(b_rew).numpy(), torch.stack(b_val).numpy(), torch.stack(b_done).numpy()
     es = np.concatenate([np.zeros((1, N), np.float32), done[:-1]])
-    adv, ret = orc.gae(rew, val, es, last_v.numpy(), done[-1].astype(np.uint8))
+    adv, ret = orc.gae(rew, val, es, last_v.numpy(), done[-1].astype(np.uint8), threads=threads)
     t_roll = time.perf_counter() - t0
-    roll_per_env_step = t_roll / (Tc * N)
-    # ---- leg (b): optimizer steps at the GPU leg's minibatch size ----
+    roll_per_env_step = t_roll / (n_roll * N)
+    # ---- update: optimizer steps on minibatches of the rollout sample, scaled linearly to the config's batch size ----
     tr = sb3_ref.RefTrainer(sd)
     fo, fa, fl = torch.cat(b_obs), torch.cat(b_act), torch.cat(b_lp)
     fadv, fret = torch.from_numpy(adv).reshape(-1), torch.from_numpy(ret).reshape(-1)
     have = fo.shape[0]
-    bs = min(batch, have)
+    bs = min(batch, have, 16384 if threads > 1 else 4096)
     n_upd, t1 = 0, time.perf_counter()
     while True:
         idx = torch.randperm(have)[:bs]
         tr.step(fo[idx], fa[idx], fl[idx], fadv[idx], fret[idx], clip_range=0.2, ent_coef=0.01, vf_coef=0.5)
         n_upd += 1
-        if time.perf_counter() - t1 > max(2.0, seconds - t_roll) or n_upd >= args.n_epochs * n_mb:
+        if time.perf_counter() - t1 > leg or n_upd >= n_epochs * n_mb:
             break
     t_upd = (time.perf_counter() - t1) / n_upd * (batch / bs)
-    iter_s = total * roll_per_env_step + args.n_epochs * n_mb * t_upd
+    iter_s = total * roll_per_env_step + n_epochs * n_mb * t_upd
+    del env
+    return {"threads": threads, "env_only_steps_per_s": n_env * N / t_env, "env_gae_steps_per_s": n_env * N / (t_env + t_gae),
+            "rollout_env_steps_per_s": 1.0 / roll_per_env_step, "ppo_updates_per_sec": 1.0 / t_upd, "update_ms_per_minibatch": t_upd * 1e3,
+            "env_steps_per_s": total / iter_s, "batch_size": batch, "minibatches_per_epoch": n_mb,
+            "sample": f"env-only {n_env} x {N} steps ({t_env:.2f} s) + GAE ({t_gae * 1e3:.1f} ms); rollout {n_roll} x {N} steps incl. policy + GAE ({t_roll:.2f} s); "
+                      f"{n_upd} optimizer steps on {bs}-sample minibatches, scaled x{batch / bs:.0f} to batch {batch}"}
+
+
+def cpu_baseline(args, seconds, batch):
+    """The same PPO iterations on the host cores of this box: the build's C restatement of the reference's envs
+    (oracle/tma_oracle.c, bit-exact against fixtures generated from the reference) + the torch-CPU restatement of SB3's policy / GAE / update
+    (oracle/sb3_ref.py), for each of the five BASELINE.json configs, (a) on ONE thread and (b) on every logical CPU of the box.  A full
+    iteration would take minutes, so every leg is a bounded sample of the same workload (see `sample` in each entry) and full iterations are
+    composed from the legs with the GPU leg's schedule.  `value` is the headline config on all cores."""
+    cores_all = os.cpu_count() or 1
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         pass
+    log(f"cpu_baseline: 1 and {cores_all} threads, budget {seconds:.0f} s over {len(CPU_CONFIGS)} configs")
+    weights = [0.3 if c.get("headline") else 0.7 / (len(CPU_CONFIGS) - 1) for c in CPU_CONFIGS]
+    configs, head = [], None
+    for cfg, w in zip(CPU_CONFIGS, weights):
+        if cfg.get("headline"):  # the headline is whatever this run measured on the GPU (defaults = BASELINE configs[1])
+            cfg = dict(cfg, task=args.task, n_envs=args.n_envs, n_steps=args.n_steps, hidden=args.hidden, batch=batch)
+        entry = {"config": cfg["name"], "task": cfg["task"], "envs": cfg["n_envs"], "n_steps": cfg["n_steps"], "hidden": cfg["hidden"]}
+        try:
+            entry["single_thread"] = _cpu_legs(cfg, 1, seconds * w / 2, args.n_epochs, args.seed)
+            entry["all_cores"] = _cpu_legs(cfg, cores_all, seconds * w / 2, args.n_epochs, args.seed)
+            log(f"cpu {cfg['task']}: 1 thread {entry['single_thread']['env_steps_per_s']:.0f}, {cores_all} threads {entry['all_cores']['env_steps_per_s']:.0f} env-steps/s "
+                f"(env-only {entry['single_thread']['env_only_steps_per_s']:.3g} / {entry['all_cores']['env_only_steps_per_s']:.3g})")
+        except Exception as exc:  # noqa: BLE001
+            entry["error"] = repr(exc)
+        configs.append(entry)
+        if cfg.get("headline"):
+            head = entry
+    a = (head or {}).get("all_cores") or {}
+    one = (head or {}).get("single_thread") or {}
     return {
-        "value": total / iter_s, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+        "value": a.get("env_steps_per_s"), "unit": "env-steps/s", "cores": cores_all, "kind": "port", "cpu_model": cpu_model, "host_logical_cpus": cores_all,
+        "single_thread_value": one.get("env_steps_per_s"),
         "reference_python_calibration": "BASELINE.md section 3 (measured in the survey container, 2.6 GHz Xeon, one core): the reference's own Python envs run "
                                         "62-64 k raw env.step()/s/core for GridWorld (no policy, no VecEnv); through SB3's DummyVecEnv + PPO the reference "
                                         "trains at about 1-2 k env-steps/s.  The C port timed here is the build's restatement, not the reference's Python: "
-                                        "its env-only rate (env_only_steps_per_s) is what relates to the 62-64 k figure",
-        "sample": f"same schedule as the GPU leg ({args.task}, {N} envs x {T} steps, MLP {H}x{H}, {args.n_epochs} epochs x {n_mb} minibatches of {batch}), "
-                  f"composed from two timed legs: rollout {Tc} vector steps x {N} envs + GAE ({t_roll:.2f} s; C oracle env with OpenMP + torch-CPU "
-                  f"policy, {cores} threads) and {n_upd} optimizer steps on minibatches of {bs} samples ({t_upd * 1e3:.1f} ms each; torch-CPU autograd "
-                  f"restatement of SB3's loss / clip / Adam, {cores} threads); value = n_envs*n_steps / (n_envs*n_steps*t_rollout_per_env_step + "
-                  "n_epochs*n_minibatches*t_update)",
-        "rollout_env_steps_per_s": 1.0 / roll_per_env_step, "env_only_steps_per_s": Tc * N / max(env_only_t, 1e-9),
-        "update_ms_per_minibatch": t_upd * 1e3, "ppo_updates_per_sec": 1.0 / t_upd, "rollout_sample_env_steps": Tc * N, "update_sample_steps": n_upd,
+                                        "its single-thread env-only rate (configs[*].single_thread.env_only_steps_per_s) is what relates to the 62-64 k figure",
+        "sample": f"headline: {args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, {args.n_epochs} epochs x minibatches of {batch}; "
+                  f"all {cores_all} logical CPUs; " + str(a.get("sample")) + "; value = n_envs*n_steps / (n_envs*n_steps*t_rollout_per_env_step + n_epochs*n_minibatches*t_update)",
+        "rollout_env_steps_per_s": a.get("rollout_env_steps_per_s"), "env_only_steps_per_s": a.get("env_only_steps_per_s"),
+        "env_gae_steps_per_s": a.get("env_gae_steps_per_s"), "update_ms_per_minibatch": a.get("update_ms_per_minibatch"),
+        "ppo_updates_per_sec": a.get("ppo_updates_per_sec"), "configs": configs,
     }
 
 
@@ -550,6 +657,8 @@ def main():
     log(f"rank {rank}/{world}: engine ready, N={N} T={T} batch={batch}")
     if world > 1:
         model.dp_timing = {}  # HIP events around the collectives of the first minibatches / epochs of every train() call
+        if model._native_comm is not None:  # (native RCCL path: the library brackets its own ncclAllReduce calls)
+            model._native_comm.timing(model.dp_timing_samples)
     el, t_roll = time_iterations(model, args.steps, args.warmup)
     log(f"timed region done: {el:.3f} s for {args.steps} iterations")
     env_steps = world * total * args.steps
@@ -583,7 +692,9 @@ def main():
         timing = model.dp_timing_collect()
         model.dp_timing = None
         out["dp_timing"] = {
-            "backend": td.get_backend(), "grad_allreduce": timing["grad_allreduce_us"], "adv_sums_allreduce": timing["adv_allreduce_us"],
+            "backend": td.get_backend(), "allreduce_path": "native (libtma_hip.so: ncclAllReduce on the compute stream from inside tma_ppo_train_epoch_dp)"
+            if model._native_comm is not None else "callback (ctypes -> Python -> torch.distributed.all_reduce)",
+            "grad_allreduce": timing["grad_allreduce_us"], "adv_sums_allreduce": timing["adv_allreduce_us"],
             "grad_allreduces_per_iteration": updates // args.steps, "adv_sums_allreduces_per_iteration": args.n_epochs,
             "per_rank_rollout_ms": [float(t[0]) for t in per_rank], "per_rank_update_ms": [float(t[1]) for t in per_rank],
             "note": "durations are HIP events on rank 0's compute stream: from the end of the kernel that produced the tensor to the point where the "

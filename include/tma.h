@@ -106,6 +106,15 @@ int tma_monitor_append_rows(const char *path, const double *ret, const int32_t *
 /* Monitor aggregate since the last call: out[0]=sum of episode returns, out[1]=sum of lengths, out[2]=count.
  * Synchronises `stream`. */
 int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream);
+/* Two-phase pop for a training loop that keeps the GPU busy across iterations (round 4; the reference's Monitor / logger run on the host
+ * between rollouts, training.py:85-86,152-161 -- here they must not sit between two GPU iterations).  tma_env_detach_episode_log: HOST-side
+ * swap of the buffer set handed to kernels at launch -- kernels launched BEFORE the call wrote their Monitor aggregates and episode records
+ * into the set that is now detached, later launches write into the other, empty set; no stream is touched.  tma_env_pop_detached_episode_log:
+ * tma_env_pop_episode_log + tma_env_pop_episode_stats of the detached set on any stream ordered behind those earlier kernels (a side stream
+ * behind an event); empties it; synchronises only `stream`.  One detached set at a time (TMA_ERR_INVALID otherwise). */
+int tma_env_detach_episode_log(tma_env *env);
+int tma_env_pop_detached_episode_log(tma_env *env, double *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored,
+                                     int64_t *n_seen, double *stats3_host, void *stream);
 
 /* ---- GAE: replaces SB3 RolloutBuffer.compute_returns_and_advantage (3P, constructed at
  *      backend/mlagents/training.py:150; hyper-parameters training.py:383-384).  All [T][N] f32. ---- */
@@ -247,6 +256,29 @@ int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_ro
                            int64_t batch_size, int64_t prepared_batch, int stats_world, const tma_ppo_hparams *hp, float *grad, float *exp_avg,
                            float *exp_avg_sq, int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm,
                            double grad_scale, tma_allreduce_fn allreduce, void *ctx, void *workspace, void *stream);
+/* ---- RCCL communicator owned by the library (round 4): the collective of tma_ppo_train_epoch_dp without a host-language hop.
+ *      The reference has no distributed code (one process: backend/mlagents/training.py:71-89,150); north_star's only collective is the
+ *      per-minibatch SUM of the flat f32 policy gradient over the GPUs of a node.
+ * Rank 0 draws a unique id (128 opaque bytes, ncclGetUniqueId), the caller broadcasts it over whatever channel it has (the torch.distributed
+ * process group it rendezvoused with: any backend), every rank then calls tma_comm_create (ncclCommInitRank; collective over the ranks;
+ * device < 0: the calling thread's current device).  tma_comm_allreduce: in-place SUM of `count` elements (dtype 0 = f32, 1 = f64) enqueued
+ * on `stream` -- kernels queued on that stream before / after it are ordered before / after the collective, nothing else is needed.
+ * tma_comm_allreduce_cb has the tma_allreduce_fn signature: pass it to tma_ppo_train_epoch_dp with the communicator as ctx (after
+ * tma_comm_bind_stream(comm, the stream given to the epoch call)) and a data-parallel epoch runs without leaving native code.
+ * RCCL is bound at run time (dlopen librccl.so.1: inside a PyTorch process that is the copy PyTorch loaded); tma_comm_available() == 0 and
+ * TMA_ERR_HIP from the other entries when it cannot be.  tma_comm_timing(comm, n): bracket the next n all-reduces with HIP events on their
+ * stream; tma_comm_pop_timing waits for them and returns their durations in microseconds (bench.py dp_timing) and the number of
+ * all-reduces issued so far. */
+typedef struct tma_comm tma_comm;
+int tma_comm_available(void);
+int tma_comm_unique_id(unsigned char *id_out128);
+int tma_comm_create(const unsigned char *id128, int world, int rank, int device, tma_comm **out);
+int tma_comm_destroy(tma_comm *comm);
+int tma_comm_bind_stream(tma_comm *comm, void *stream);
+int tma_comm_allreduce(tma_comm *comm, void *buffer, int64_t count, int dtype, void *stream);
+int tma_comm_allreduce_cb(void *ctx, float *buffer, int64_t count);
+int tma_comm_timing(tma_comm *comm, int samples);
+int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out, int64_t *calls_out);
 /* How many epochs of tma_ppo_train_epoch_local on this workspace fell back from the persistent launch to per-minibatch launches.  Synchronises `stream`. */
 int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream);
 /* The minibatch order of the on-device permutation (the engine's stand-in for np.random.permutation in SB3's RolloutBuffer.get): writes, to
@@ -263,6 +295,13 @@ int tma_debug_last_grad_kernel_us(float *us_out);
 /* out8: sums since the last call of {policy_loss, value_sq_err, entropy, approx_kl, clipped, n_samples}, then the last
  * total grad norm and clip coefficient.  Synchronises `stream`. */
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream);
+/* The same in two phases, for a loop that must not wait for the update it has just queued: tma_ppo_stats_enqueue copies the raw slots into
+ * `staging_host` (tma_ppo_stats_staging_bytes() bytes of host memory; pinned memory makes the copy asynchronous) and clears them, ordered
+ * on `stream`, without waiting; after the caller has synchronised with that point of the stream tma_ppo_stats_fold(staging_host, out8)
+ * returns what tma_ppo_pop_stats would have. */
+int64_t tma_ppo_stats_staging_bytes(void);
+int tma_ppo_stats_enqueue(void *workspace, void *staging_host, void *stream);
+int tma_ppo_stats_fold(const void *staging_host, double *out8_host);
 
 /* ---- native rollout loop: SB3 OnPolicyAlgorithm.collect_rollouts driven by model.learn()
  *      (backend/mlagents/training.py:166-170; SURVEY.md §3.1 loop A) without a host round-trip per step ---- */

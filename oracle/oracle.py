@@ -48,6 +48,7 @@ def lib():
         L.orc_reset_from_seed.argtypes = [i32, u32, vp, vp]
         L.orc_legacy_step.argtypes = [i32, vp, vp, vp, vp, vp]
         L.orc_gae.argtypes = [vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]
+        L.orc_gae_threads.argtypes = [vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, i32]
         L.orc_mt_raw.argtypes = [u32, vp, i32]
         L.orc_mt_shuffle.argtypes = [u32, vp, i32, vp]
         L.orc_mt_uniform.argtypes = [u32, f64, f64, vp, i32]
@@ -197,7 +198,7 @@ class OracleVecEnv:
         return out
 
 
-def gae(rewards, values, episode_starts, last_values, dones, gamma=0.99, gae_lambda=0.95):
+def gae(rewards, values, episode_starts, last_values, dones, gamma=0.99, gae_lambda=0.95, threads=1):
     T, N = rewards.shape
     adv = np.zeros((T, N), np.float32)
     ret = np.zeros((T, N), np.float32)
@@ -207,5 +208,8 @@ def gae(rewards, values, episode_starts, last_values, dones, gamma=0.99, gae_lam
     lv = np.ascontiguousarray(last_values, np.float32)
     d = np.ascontiguousarray(dones, np.uint8)
     gl = np.float32(float(gamma) * float(gae_lambda))  # python-float product, then weak-cast to f32
-    lib().orc_gae(_p(r), _p(v), _p(es), _p(lv), _p(d), np.float32(gamma), gl, T, N, _p(adv), _p(ret))
+    if threads > 1:
+        lib().orc_gae_threads(_p(r), _p(v), _p(es), _p(lv), _p(d), np.float32(gamma), gl, T, N, _p(adv), _p(ret), int(threads))
+    else:
+        lib().orc_gae(_p(r), _p(v), _p(es), _p(lv), _p(d), np.float32(gamma), gl, T, N, _p(adv), _p(ret))
     return adv, ret

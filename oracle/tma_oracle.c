@@ -1036,9 +1036,23 @@ void orc_vec_episode_index(const orc_vec *v, uint32_t *out) { memcpy(out, v->epi
  * All float32, numpy op order: delta = r + gamma*next_v*nnt - v ; gae = delta + (gamma*lam)*nnt*gae
  * `gl` = float32(gamma*gae_lambda) with the product taken in float64 by the caller (python floats).
  * ======================================================================================= */
+static void gae_envs(const float *rewards, const float *values, const float *episode_starts, const float *last_values, const uint8_t *dones,
+                     float gamma, float gl, int T, int N, int i0, int i1, float *adv, float *ret);
 void orc_gae(const float *rewards, const float *values, const float *episode_starts, const float *last_values,
              const uint8_t *dones, float gamma, float gl, int T, int N, float *adv, float *ret) {
-    for (int i = 0; i < N; i++) {
+    gae_envs(rewards, values, episode_starts, last_values, dones, gamma, gl, T, N, 0, N, adv, ret);
+}
+/* the same per-env chains, env blocks dealt to `threads` OpenMP threads (bench.py's all-cores leg): identical arithmetic per element */
+void orc_gae_threads(const float *rewards, const float *values, const float *episode_starts, const float *last_values, const uint8_t *dones,
+                     float gamma, float gl, int T, int N, float *adv, float *ret, int threads) {
+    const int blk = 16, nb = (N + blk - 1) / blk;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int b = 0; b < nb; b++) gae_envs(rewards, values, episode_starts, last_values, dones, gamma, gl, T, N, b * blk, (b + 1) * blk < N ? (b + 1) * blk : N, adv, ret);
+}
+static void gae_envs(const float *rewards, const float *values, const float *episode_starts, const float *last_values, const uint8_t *dones,
+                     float gamma, float gl, int T, int N, int i0, int i1, float *adv, float *ret) {
+    for (int i = i0; i < i1; i++) {
         float last = 0.0f;
         for (int t = T - 1; t >= 0; t--) {
             float nnt, nv;

@@ -78,6 +78,10 @@ void orc_vec_episode_index(const orc_vec *v, uint32_t *out /*[n]*/);
 void orc_gae(const float *rewards, const float *values, const float *episode_starts, const float *last_values,
              const uint8_t *dones, float gamma, float gae_lambda_times_gamma, int T, int N, float *adv_out,
              float *ret_out);
+/* the same chains over env blocks on `threads` OpenMP threads (bit-identical; bench.py's all-cores CPU leg) */
+void orc_gae_threads(const float *rewards, const float *values, const float *episode_starts, const float *last_values,
+                     const uint8_t *dones, float gamma, float gae_lambda_times_gamma, int T, int N, float *adv_out,
+                     float *ret_out, int threads);
 
 #ifdef __cplusplus
 }

@@ -87,3 +87,27 @@ def test_monitor_rows_are_printed_like_python_prints_them(tmp_path):
     with pytest.raises(ValueError):
         _lib.check(_lib.lib().tma_monitor_append_rows(str(tmp_path / "no" / "such" / "dir.csv").encode(), r.ctypes.data_as(C.c_void_p),
                                                       length.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), 1))
+
+
+def test_comm_entry_points_validate_their_arguments():
+    """tma_comm_* (the library's RCCL communicator): argument errors are reported before RCCL or a GPU is touched."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    assert L.tma_comm_available() in (0, 1)
+    h = C.c_void_p()
+    ident = (C.c_ubyte * 128)()
+    for world, rank in ((0, 0), (2, 2), (2, -1)):
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_create(ident, world, rank, -1, C.byref(h)))
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_comm_create(None, 1, 0, -1, C.byref(h)))
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_comm_unique_id(None))
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_comm_allreduce(None, None, 4, 0, None))
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_comm_bind_stream(None, None))
+    assert L.tma_comm_allreduce_cb(None, None, 4) == 1 and L.tma_comm_destroy(None) == 0

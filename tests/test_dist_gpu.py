@@ -57,6 +57,84 @@ def test_rccl_backend_initialises_and_all_reduces():
     assert (rk, ws, backend) == (0, 1, "nccl") and total == float(sum(range(9350))) and mx == 3.5
 
 
+def _native_comm_single(port, q):
+    """World size 1, real RCCL twice in one process: torch.distributed's communicator (nccl backend) and the library's own (tma_comm_*)."""
+    os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    from three_mlagents_amd import _lib, dist
+
+    dist.init_from_env(backend="nccl", single_rank_group=True)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    comm = dist.NativeComm(dev)
+    g32 = torch.arange(9350, dtype=torch.float32, device=dev) * 0.5
+    g64 = torch.arange(64, dtype=torch.float64, device=dev) + 0.25
+    want32, want64 = g32.clone(), g64.clone()
+    comm.timing(3)
+    side = torch.cuda.Stream(dev)  # the collective runs on the stream it is given, ordered with the kernels queued there
+    with torch.cuda.stream(side):
+        g32.mul_(2.0)
+        comm.all_reduce_(g32, _lib.stream_ptr(dev))
+        g32.mul_(0.5)
+        comm.all_reduce_(g64, _lib.stream_ptr(dev))
+    side.synchronize()
+    us, calls = comm.pop_timing()
+    ok_collectives = bool(torch.equal(g32, want32) and torch.equal(g64, want64)) and len(us) == 2 and calls == 2 and all(u > 0 for u in us)
+    # the PPO data-parallel epoch loop with the native communicator (TMA_DP_PATH: the multi-GPU loop at world size 1) against the callback
+    # path into torch.distributed and against the single-GPU epoch call: same parameters, moments and statistics, bit for bit
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(mode):
+        for k in ("TMA_DP_PATH", "TMA_NATIVE_RCCL", "TMA_NO_NATIVE_RCCL"):
+            os.environ.pop(k, None)
+        if mode != "local":
+            os.environ["TMA_DP_PATH"] = "1"
+        if mode == "native":
+            os.environ["TMA_NATIVE_RCCL"] = "1"
+        env = make_vector_env("gridworld", n_envs=256, seed=5)
+        m = PPO("MlpPolicy", env, n_steps=64, batch_size=2048, n_epochs=3, seed=5, policy_kwargs={"net_arch": [64, 64]})
+        if mode == "native":
+            assert m._native_comm is not None
+            m._native_comm.timing(8)
+        m.collect_rollouts()
+        m.train()
+        st = m.pop_train_stats()
+        tim = m.dp_timing_collect() if mode == "native" else None
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, tim, m._native_comm is not None)
+        env.close()
+        return out
+
+    p_n, m_n, v_n, s_n, tim, used_n = run("native")
+    p_c, m_c, v_c, s_c, _, used_c = run("callback")
+    p_l, m_l, v_l, s_l, _, _ = run("local")
+    same = bool(torch.equal(p_n, p_c) and torch.equal(m_n, m_c) and torch.equal(v_n, v_c)) and all(s_n[k] == s_c[k] for k in s_c)
+    near_local = bool(torch.allclose(p_n, p_l, rtol=0, atol=1e-6))
+    q.put((ok_collectives, used_n, used_c, same, near_local, tim["grad_allreduce_us"]["calls_timed"], tim["grad_allreduce_us"]["allreduces_issued"],
+           tim["grad_allreduce_us"]["path"]))
+    comm.close()
+    import torch.distributed as td
+
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_native_rccl_communicator_at_world_size_one():
+    """include/tma.h tma_comm_*: the library's own RCCL communicator (ncclCommInitRank from a unique id, ncclAllReduce on the caller's stream)
+    next to torch.distributed's in one process; the data-parallel epoch loop with tma_comm_allreduce_cb as its collective -- no Python call
+    per minibatch -- gives the bits of the callback path (3 epochs x 8 minibatches = 24 all-reduces issued natively).  One GPU: world size 1;
+    more ranks need more devices (RCCL allows one rank per device), which only the driver's scaling run has."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_comm_single, args=(_free_port(), q))
+    p.start()
+    ok, used_n, used_c, same, near_local, timed, issued, path = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ok and used_n and not used_c and same and near_local
+    assert timed == 8 and issued == 1 + 24 and path.startswith("native")  # (1: the construction-time self-check)
+
+
 def _worker(rank, world, port, q, task, hidden, mfma, N, T):
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     from three_mlagents_amd import dist

@@ -69,6 +69,8 @@ SIGNATURES = {
     "tma_monitor_append_rows": (_i32, [C.c_char_p, _vp, _vp, _vp, _i64]),
     "tma_env_pop_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
+    "tma_env_detach_episode_log": (_i32, [_vp]),
+    "tma_env_pop_detached_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_f64), _vp]),
     "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
     "tma_gae_flags": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),
     "tma_policy_param_count": (_i32, [_pd, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -96,6 +98,18 @@ SIGNATURES = {
     "tma_ppo_train_epoch_dp": (_i32, [_vp, _pd, C.POINTER(Rollout), _u32, _u32, _i64, _i64, _i32, C.POINTER(PPOHParams), _vp, _vp, _vp, _i64, _f64, _f64, _f64,
                                       _f64, _f64, _f64, None, _vp, _vp, _vp]),  # (None: the AllReduceFn slot, filled in below)
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
+    "tma_ppo_stats_staging_bytes": (_i64, []),
+    "tma_ppo_stats_enqueue": (_i32, [_vp, _vp, _vp]),
+    "tma_ppo_stats_fold": (_i32, [_vp, C.POINTER(_f64)]),
+    "tma_comm_available": (_i32, []),
+    "tma_comm_unique_id": (_i32, [_vp]),
+    "tma_comm_create": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "tma_comm_destroy": (_i32, [_vp]),
+    "tma_comm_bind_stream": (_i32, [_vp, _vp]),
+    "tma_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "tma_comm_allreduce_cb": (_i32, [_vp, _vp, _i64]),
+    "tma_comm_timing": (_i32, [_vp, _i32]),
+    "tma_comm_pop_timing": (_i32, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
     "tma_rollout_collect": (_i32, [_vp, _vp, _pd, C.POINTER(RolloutBuffers), _i32, _i32, _i32, _u32, _u32, _u32, _f64, _i32, _i32, _vp]),
 }
 

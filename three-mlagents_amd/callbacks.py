@@ -54,6 +54,19 @@ class BaseCallback:
         self.num_timesteps = self.model.num_timesteps
         return self._on_step()
 
+    # Engine extension: the rollout runs natively in chunks of many vector steps, so the model reports them in bulk.  The default is SB3's
+    # contract replayed step by step (num_timesteps advances by `per_step`, then on_step(); False stops the rollout at that step); a callback
+    # that sets `takes_bulk_steps` implements bulk_steps() and is spared the per-step Python round trips (EvalCallback: 512 identical
+    # bookkeeping calls per rollout at 4096 envs).
+    takes_bulk_steps = False
+
+    def on_steps(self, n: int, per_step: int) -> tuple[int, bool]:
+        for k in range(int(n)):
+            self.model.num_timesteps += per_step
+            if not self.on_step():
+                return k + 1, False
+        return int(n), True
+
     def on_rollout_end(self) -> None:
         self._on_rollout_end()
 
@@ -93,6 +106,17 @@ class CallbackList(BaseCallback):
         for c in self.callbacks:
             ok = c.on_step() and ok
         return ok
+
+    def on_steps(self, n: int, per_step: int) -> tuple[int, bool]:
+        if not all(getattr(c, "takes_bulk_steps", False) for c in self.callbacks):
+            return super().on_steps(n, per_step)
+        start = self.model.num_timesteps
+        self.n_calls += int(n)
+        for c in self.callbacks:
+            c.bulk_steps(int(n), int(per_step), start)
+        self.model.num_timesteps = start + int(n) * int(per_step)
+        self.num_timesteps = self.model.num_timesteps
+        return int(n), True
 
     def _on_rollout_end(self) -> None:
         for c in self.callbacks:
@@ -200,33 +224,72 @@ class EvalCallback(BaseCallback):
                      ep_lengths=self.evaluations_length)
         self._dirty = False
 
+    takes_bulk_steps = True
+
     def _on_step(self) -> bool:
         if self.eval_freq > 0 and self.n_calls % self.eval_freq == 0:
-            key = self._policy_key()
-            fresh = not (self.deterministic and key == self._cached_key and None not in key[:2])
-            if fresh:
-                from .evaluation import evaluate_policy
-
-                rew, length = evaluate_policy(self.model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
-                                              return_episode_rewards=True)
-                self._cached = (np.asarray(rew, np.float64), np.asarray(length, np.int64))
-                self._cached_key = key
-                self.n_fresh_evaluations += 1
-            rewards, lengths = self._cached
-            self.evaluations_timesteps.append(self.num_timesteps)
-            self.evaluations_results.append(rewards)
-            self.evaluations_length.append(lengths)
-            self._dirty = True
-            if fresh:
-                self.last_mean_reward = float(np.mean(rewards))
-                self._flush(force=self.n_fresh_evaluations <= 1)
-                if self.verbose >= 1:
-                    print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
-                if self.last_mean_reward > self.best_mean_reward:
-                    self.best_mean_reward = self.last_mean_reward
-                    if self.best_model_save_path is not None:
-                        self.model.save(os.path.join(self.best_model_save_path, "best_model"))
+            self._tick()
         return True
+
+    def bulk_steps(self, n: int, per_step: int, start_timesteps: int) -> None:
+        """The n on_step() calls of a native rollout chunk at once: the calls that fall on the evaluation cadence do exactly what _on_step does
+        (same rows with the same timesteps, a fresh evaluation where the optimizer has stepped), the others do nothing but count."""
+        first = self.n_calls + 1
+        self.n_calls += n
+        if self.eval_freq <= 0:
+            return
+        c = -(-first // self.eval_freq) * self.eval_freq
+        while c < first + n:
+            self.num_timesteps = self.model.num_timesteps = start_timesteps + (c - first + 1) * per_step
+            self._tick()
+            c += self.eval_freq
+        self.num_timesteps = start_timesteps + n * per_step
+
+    def _evaluate_fresh(self):
+        """The deterministic evaluation (and the best-model zip) on the model's SIDE stream, behind the event the last update left: the compute
+        stream is already running the next rollout (queued before the callbacks are called), and nothing here writes what it reads."""
+        import contextlib
+
+        import torch
+
+        from .evaluation import evaluate_policy
+
+        model = self.model
+        side = model.side_stream() if hasattr(model, "side_stream") and getattr(self.eval_env, "device", None) == getattr(model, "device", None) else None
+        main = torch.cuda.current_stream(model.device) if side is not None else None
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if side is not None:
+                ev = getattr(model, "_update_done", None)
+                if ev is not None:
+                    side.wait_event(ev)
+                else:  # no update yet: the parameters were written by whatever the compute stream did before
+                    side.wait_stream(main)
+            rew, length = evaluate_policy(model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
+                                          return_episode_rewards=True)
+            self._cached = (np.asarray(rew, np.float64), np.asarray(length, np.int64))
+            mean = float(np.mean(self._cached[0]))
+            if mean > self.best_mean_reward and self.best_model_save_path is not None:
+                model.save(os.path.join(self.best_model_save_path, "best_model"))  # (reads the parameters: same stream, same reasoning)
+
+    def _tick(self) -> None:
+        key = self._policy_key()
+        fresh = not (self.deterministic and key == self._cached_key and None not in key[:2])
+        if fresh:
+            self._evaluate_fresh()
+            self._cached_key = key
+            self.n_fresh_evaluations += 1
+        rewards, lengths = self._cached
+        self.evaluations_timesteps.append(self.num_timesteps)
+        self.evaluations_results.append(rewards)
+        self.evaluations_length.append(lengths)
+        self._dirty = True
+        if fresh:
+            self.last_mean_reward = float(np.mean(rewards))
+            self._flush(force=self.n_fresh_evaluations <= 1)
+            if self.verbose >= 1:
+                print(f"Eval num_timesteps={self.num_timesteps}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(rewards)):.2f}")
+            if self.last_mean_reward > self.best_mean_reward:
+                self.best_mean_reward = self.last_mean_reward
 
     def _on_training_end(self) -> None:
         self._flush()

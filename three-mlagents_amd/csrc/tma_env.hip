@@ -549,6 +549,7 @@ int tma_env_destroy(tma_env *h) {
     (void)hipFree(h->v.log_len);
     (void)hipFree(h->v.log_env);
     (void)hipFree(h->v.log_n);
+    (void)hipFree(h->d_stats), (void)hipFree(h->d_log_ret), (void)hipFree(h->d_log_len), (void)hipFree(h->d_log_env), (void)hipFree(h->d_log_n);
     (void)hipFree(h->mt_scratch);
     (void)hipFree(h->rv.first_ep);
     (void)hipFree(h->rv.env_off);
@@ -696,6 +697,10 @@ int tma_env_episode_log(tma_env *h, int64_t capacity) {
     EnvView &v = h->v;
     (void)hipFree(v.log_ret), (void)hipFree(v.log_len), (void)hipFree(v.log_env), (void)hipFree(v.log_n);
     v.log_ret = nullptr, v.log_len = nullptr, v.log_env = nullptr, v.log_n = nullptr, v.log_cap = 0;
+    (void)hipFree(h->d_log_ret), (void)hipFree(h->d_log_len), (void)hipFree(h->d_log_env), (void)hipFree(h->d_log_n);  // (the spare set has the old capacity)
+    h->d_log_ret = nullptr, h->d_log_len = nullptr, h->d_log_env = nullptr, h->d_log_n = nullptr;
+    h->detached = false;  // (a detached, unpopped log goes with its buffers; the detached aggregates are cleared below)
+    if (h->d_stats) TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * 3 * (size_t)ceil_div(v.N, 256)));
     if (capacity == 0) return TMA_OK;
     TMA_HIP(hipMalloc(&v.log_ret, sizeof(double) * (size_t)capacity));
     TMA_HIP(hipMalloc(&v.log_len, sizeof(int32_t) * (size_t)capacity));
@@ -783,6 +788,66 @@ int tma_monitor_append_rows(const char *path, const double *ret, const int32_t *
     }
     fwrite(buf.data(), 1, used, f);
     fclose(f);
+    return TMA_OK;
+}
+
+// Two-phase pop for a training loop that must not drain the GPU between iterations.  tma_env_detach_episode_log is a HOST-side swap of the
+// buffer set the kernels are handed at launch: every step / rollout kernel launched before it wrote its Monitor aggregates and episode records
+// into the set that is now detached, every later launch writes into the other (empty) set.  tma_env_pop_detached_episode_log then reads the
+// detached set on ANY stream that is ordered behind those earlier kernels (e.g. a side stream that waited on an event recorded behind the
+// rollout) while the next rollout or the update runs on the compute stream; it empties the set and synchronises only `stream`.
+int tma_env_detach_episode_log(tma_env *h) {
+    if (!h) return fail(TMA_ERR_INVALID, "tma_env_detach_episode_log: null handle");
+    if (h->detached) return fail(TMA_ERR_INVALID, "tma_env_detach_episode_log: the previous detached set has not been popped");
+    TMA_HIP(hipSetDevice(h->device));
+    EnvView &v = h->v;
+    const size_t n_stat = (size_t)ceil_div(v.N, 256) * 3;
+    if (!h->d_stats) {
+        TMA_HIP(hipMalloc(&h->d_stats, sizeof(double) * n_stat));
+        TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * n_stat));
+    }
+    if (v.log_n && !h->d_log_n) {
+        TMA_HIP(hipMalloc(&h->d_log_ret, sizeof(double) * (size_t)v.log_cap));
+        TMA_HIP(hipMalloc(&h->d_log_len, sizeof(int32_t) * (size_t)v.log_cap));
+        TMA_HIP(hipMalloc(&h->d_log_env, sizeof(int32_t) * (size_t)v.log_cap));
+        TMA_HIP(hipMalloc(&h->d_log_n, sizeof(unsigned long long)));
+        TMA_HIP(hipMemset(h->d_log_n, 0, sizeof(unsigned long long)));
+    }
+    std::swap(v.stats, h->d_stats);
+    if (v.log_n) {
+        std::swap(v.log_ret, h->d_log_ret), std::swap(v.log_len, h->d_log_len), std::swap(v.log_env, h->d_log_env), std::swap(v.log_n, h->d_log_n);
+    }
+    h->detached = true;
+    return TMA_OK;
+}
+
+int tma_env_pop_detached_episode_log(tma_env *h, double *ret_host, int32_t *len_host, int32_t *env_host, int64_t max_records, int64_t *n_stored,
+                                     int64_t *n_seen, double *stats3_host, void *stream) {
+    if (!h || !n_stored || !n_seen || !stats3_host || max_records < 0 || (max_records > 0 && (!ret_host || !len_host || !env_host)))
+        return fail(TMA_ERR_INVALID, "tma_env_pop_detached_episode_log: null argument");
+    if (!h->detached) return fail(TMA_ERR_INVALID, "tma_env_pop_detached_episode_log: nothing is detached (tma_env_detach_episode_log)");
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nb = (size_t)ceil_div(h->v.N, 256);
+    std::vector<double> tmp(nb * 3);
+    unsigned long long seen = 0;
+    TMA_HIP(hipMemcpyAsync(tmp.data(), h->d_stats, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, s));
+    if (h->d_log_n) TMA_HIP(hipMemcpyAsync(&seen, h->d_log_n, sizeof(seen), hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipStreamSynchronize(s));
+    int64_t n = h->d_log_n ? (int64_t)std::min<unsigned long long>(seen, (unsigned long long)h->v.log_cap) : 0;
+    if (n > max_records) n = max_records;
+    if (n > 0) {
+        TMA_HIP(hipMemcpyAsync(ret_host, h->d_log_ret, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+        TMA_HIP(hipMemcpyAsync(len_host, h->d_log_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+        TMA_HIP(hipMemcpyAsync(env_host, h->d_log_env, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    if (h->d_log_n) TMA_HIP(hipMemsetAsync(h->d_log_n, 0, sizeof(unsigned long long), s));
+    TMA_HIP(hipMemsetAsync(h->d_stats, 0, sizeof(double) * nb * 3, s));
+    TMA_HIP(hipStreamSynchronize(s));
+    stats3_host[0] = stats3_host[1] = stats3_host[2] = 0.0;
+    for (size_t b = 0; b < nb; b++) stats3_host[0] += tmp[3 * b], stats3_host[1] += tmp[3 * b + 1], stats3_host[2] += tmp[3 * b + 2];
+    *n_stored = n, *n_seen = (int64_t)seen;
+    h->detached = false;
     return TMA_OK;
 }
 

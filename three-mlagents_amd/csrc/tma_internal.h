@@ -76,6 +76,11 @@ struct tma_env {
     int steps_since_refill;
     bool is_reset;
     bool small_window;  // test hook: use the short fast-path window so the fallback generator is exercised
+    // second set of Monitor aggregates / episode-log buffers (tma_env_detach_episode_log): what the kernels launched before the detach wrote
+    double *d_stats = nullptr, *d_log_ret = nullptr;
+    int32_t *d_log_len = nullptr, *d_log_env = nullptr;
+    unsigned long long *d_log_n = nullptr;
+    bool detached = false;  // the detached set holds data that has not been popped yet
 };
 
 template <class F>

@@ -2618,6 +2618,43 @@ int tma_debug_last_grad_kernel_us(float *us_out) {
     return TMA_OK;
 }
 
+// Two-phase form of tma_ppo_pop_stats for a loop that must not wait for the update it has just queued: _enqueue copies the raw statistic
+// slots into the caller's staging buffer (tma_ppo_stats_staging_bytes() bytes of HOST memory, pinned for a truly asynchronous copy) and clears
+// them, stream-ordered, and returns at once; once the caller knows that point of the stream has passed (an event, a later synchronisation),
+// _fold turns the staged slots into the eight values tma_ppo_pop_stats returns.
+int64_t tma_ppo_stats_staging_bytes(void) { return (int64_t)sizeof(double) * (MAX_GRAD_BLOCKS * 8 + 2) + 16; }
+
+int tma_ppo_stats_enqueue(void *workspace, void *staging_host, void *stream) {
+    if (!workspace || !staging_host) return fail(TMA_ERR_INVALID, "tma_ppo_stats_enqueue: null argument");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, workspace) == hipSuccess) (void)hipSetDevice(attr.device);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = static_cast<char *>(workspace);
+    double *tmp = static_cast<double *>(staging_host);
+    TMA_HIP(hipMemcpyAsync(tmp, ws + WS_STATS, sizeof(double) * MAX_GRAD_BLOCKS * 8, hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemcpyAsync(tmp + MAX_GRAD_BLOCKS * 8, ws + WS_NORM_OUT, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemcpyAsync(tmp + MAX_GRAD_BLOCKS * 8 + 2, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, s));
+    TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), s));
+    TMA_HIP(hipMemsetAsync(ws + WS_STATS, 0, sizeof(double) * MAX_GRAD_BLOCKS * 8, s));
+    return TMA_OK;
+}
+
+int tma_ppo_stats_fold(const void *staging_host, double *out8_host) {
+    if (!staging_host || !out8_host) return fail(TMA_ERR_INVALID, "tma_ppo_stats_fold: null argument");
+    const double *tmp = static_cast<const double *>(staging_host);
+    int persist_err = 0;
+    memcpy(&persist_err, tmp + MAX_GRAD_BLOCKS * 8 + 2, sizeof(int));
+    if (persist_err)
+        return fail(TMA_ERR_HIP, "the persistent epoch kernel could not place / synchronise its workgroups on one XCD; parameters of that epoch "
+                                      "were not updated (set TMA_NO_PERSIST=1 to use the per-minibatch launches)");
+    for (int q = 0; q < 6; q++) out8_host[q] = 0.0;
+    for (int b = 0; b < MAX_GRAD_BLOCKS; b++)
+        for (int q = 0; q < 6; q++) out8_host[q] += tmp[b * 8 + q];
+    out8_host[6] = tmp[MAX_GRAD_BLOCKS * 8];
+    out8_host[7] = tmp[MAX_GRAD_BLOCKS * 8 + 1];
+    return TMA_OK;
+}
+
 int tma_ppo_pop_stats(void *workspace, double *out8_host, void *stream) {
     if (!workspace || !out8_host) return fail(TMA_ERR_INVALID, "null argument");
     hipPointerAttribute_t attr;

@@ -81,3 +81,76 @@ def barrier() -> None:
 
     if is_initialized() and td.get_world_size() > 1:
         td.barrier()
+
+
+class NativeComm:
+    """RCCL communicator owned by libtma_hip.so (include/tma.h `tma_comm_*`): the gradient all-reduce of a data-parallel epoch is issued by
+    the native epoch loop itself, on the compute stream, with no Python / torch.distributed call per minibatch.  The 128-byte unique id is
+    drawn on rank 0 and broadcast over the torch.distributed group that already exists (any backend); a world of one needs no group."""
+
+    def __init__(self, device: torch.device):
+        import ctypes as C
+
+        import torch.distributed as td
+
+        from . import _lib
+
+        L = _lib.lib()
+        if not L.tma_comm_available():
+            raise RuntimeError("librccl.so.1 could not be bound by libtma_hip.so")
+        self.world, self.rank, self.device = world_size(), rank(), torch.device(device)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            _lib.check(L.tma_comm_unique_id(_lib.ptr(ident.numpy())))
+        if self.world > 1:
+            on_gpu = td.get_backend() == "nccl"
+            t = ident.to(self.device) if on_gpu else ident
+            td.broadcast(t, src=0)
+            ident = t.cpu()
+        handle = C.c_void_p()
+        _lib.check(L.tma_comm_create(_lib.ptr(ident.contiguous().numpy()), self.world, self.rank,
+                                     self.device.index if self.device.index is not None else -1, C.byref(handle)))
+        self._h, self._L = handle, L
+        self.callback = C.cast(L.tma_comm_allreduce_cb, _lib.AllReduceFn)  # the tma_allreduce_fn the epoch loop calls (ctx = the communicator)
+
+    @property
+    def ctx(self):
+        return self._h
+
+    def bind_stream(self, stream_ptr) -> None:
+        from . import _lib
+
+        _lib.check(self._L.tma_comm_bind_stream(self._h, stream_ptr))
+
+    def all_reduce_(self, t: torch.Tensor, stream_ptr) -> torch.Tensor:
+        """In-place SUM of a contiguous float32 / float64 device tensor, enqueued on `stream_ptr`."""
+        from . import _lib
+
+        code = {torch.float32: 0, torch.float64: 1}[t.dtype]
+        _lib.check(self._L.tma_comm_allreduce(self._h, _lib.ptr(t), t.numel(), code, stream_ptr))
+        return t
+
+    def timing(self, samples: int) -> None:
+        from . import _lib
+
+        _lib.check(self._L.tma_comm_timing(self._h, int(samples)))
+
+    def pop_timing(self, capacity: int = 4096) -> tuple[list[float], int]:
+        import ctypes as C
+
+        from . import _lib
+
+        buf, n, calls = (C.c_float * capacity)(), C.c_int(0), C.c_int64(0)
+        _lib.check(self._L.tma_comm_pop_timing(self._h, buf, capacity, C.byref(n), C.byref(calls)))
+        return [float(buf[i]) for i in range(n.value)], int(calls.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tma_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

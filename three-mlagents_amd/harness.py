@@ -29,7 +29,7 @@ from .vec_env import HipVecEnv
 
 POLICIES_DIR, RUNS_DIR = (Path(name) for name in ("policies", "runs"))
 ALGORITHMS = dict(ppo=PPO)  # the one algorithm north_star puts on the GPU
-EVAL_ENVS = int(os.environ.get("TMA_EVAL_ENVS", "64"))  # width of the evaluation vector (train_task / evaluate_model)
+EVAL_ENVS = int(os.environ.get("TMA_EVAL_ENVS", "128"))  # width of the evaluation vector (train_task / evaluate_model): up to one env per episode
 _SB3_NAMES = {"a2c", "dqn", "ppo", "sac", "td3"}  # what the reference's table accepts (training.py:31-37)
 
 # (name, type, default) -- the reference's request / result records (training.py:40-68); `device` is an engine-only extra

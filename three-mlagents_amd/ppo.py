@@ -54,6 +54,12 @@ def _hidden_from_net_arch(net_arch) -> int:
     return H
 
 
+def _dist_backend() -> str | None:
+    import torch.distributed as td
+
+    return td.get_backend() if td.is_available() and td.is_initialized() else None
+
+
 class HipActorCriticPolicy:
     """Parameters of SB3's ActorCriticPolicy(MlpPolicy) in one flat HBM buffer + the forward kernels."""
 
@@ -201,6 +207,7 @@ class PPO:
         self.dp_timing: dict | None = None
         self.dp_timing_samples = 64
         self._dp_events: dict[str, list] = {"grad_allreduce_us": [], "adv_allreduce_us": []}
+        self._native_comm = None  # dist.NativeComm (set by _setup_model when the job runs on the RCCL backend)
         if env is not None and _init_setup_model:
             self._setup_model()
 
@@ -255,6 +262,42 @@ class PPO:
         # rank has collected a rollout, not inside train()
         if self.world_size > 1 and self.normalize_advantage and not (T * N <= (1 << 22) and self.batch_size >= 256):
             raise ValueError("data-parallel PPO needs batch_size >= 256 per rank and n_steps * n_envs <= 2**22 per rank (global advantage statistics)")
+        # The collectives of the data-parallel update.  With the RCCL backend the library owns a communicator of its own (dist.NativeComm ->
+        # include/tma.h tma_comm_*) and the native epoch loop issues ncclAllReduce itself on the compute stream: no Python, no torch.distributed
+        # and no stream hand-off per minibatch.  Any other backend (gloo: the CPU / one-GPU tests), TMA_NO_NATIVE_RCCL=1 or a failed self-check keep
+        # the callback into torch.distributed.  TMA_NATIVE_RCCL=1 builds the communicator at world size 1 too (exercises real RCCL on one GPU).
+        self._native_comm = None
+        want_native = os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and _dist_backend() == "nccl")
+        if want_native and not os.environ.get("TMA_NO_NATIVE_RCCL"):
+            self._native_comm = self._make_native_comm()
+
+    def _make_native_comm(self):
+        """dist.NativeComm, checked against torch.distributed on a known vector before it is trusted with gradients; None (and one stderr
+        line) if RCCL cannot be bound or the check fails -- the callback path then carries the collectives."""
+        import sys
+
+        from . import dist as _dist
+
+        try:
+            comm = _dist.NativeComm(self.device)
+            probe = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.rank + 1)
+            mine = probe.clone()
+            comm.all_reduce_(mine, self._stream())
+            torch.cuda.current_stream(self.device).synchronize()
+            want = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.world_size * (self.world_size + 1) // 2)
+            ok = bool(torch.equal(mine, want))
+            if self.world_size > 1:  # every rank must take the same path
+                import torch.distributed as tdist
+
+                flag = torch.tensor([1.0 if ok else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
+                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+                ok = bool(flag.item() == 1.0)
+            if not ok:
+                raise RuntimeError("self-check of the native all-reduce against the expected sum failed")
+            return comm
+        except Exception as exc:  # noqa: BLE001
+            print(f"three-mlagents_amd: native RCCL communicator not used ({exc}); collectives go through torch.distributed", file=sys.stderr, flush=True)
+            return None
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
@@ -279,11 +322,13 @@ class PPO:
             _lib.check(L.tma_rollout_collect(eng._h, _lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rb), t, te, T,
                                              self.seed & 0xFFFFFFFF, (self._rollout_counter * T) & 0xFFFFFFFF, eng.env_offset & 0xFFFFFFFF,
                                              self.gamma, 1, 0, self._stream()))
-            for _ in range(te - t):
-                self.num_timesteps += self.n_envs * self.world_size
-                if callback is not None and not callback.on_step():
-                    keep_going = False
-                    break
+            if callback is not None:
+                # one call per native chunk (callbacks.BaseCallback.on_steps: a per-step loop unless the callback knows how to take the
+                # steps in bulk -- EvalCallback does; 1024 Python round trips per rollout are 2.5 ms at 4096 envs)
+                done_steps, keep_going = callback.on_steps(te - t, self.n_envs * self.world_size)
+                te = t + done_steps
+            else:
+                self.num_timesteps += (te - t) * self.n_envs * self.world_size
             t = te
         self._rollout_counter += 1  # sampling counters (rng_step0) are never reused, also after an interrupted rollout
         if not keep_going:
@@ -328,6 +373,7 @@ class PPO:
                 self._adam_step += n_mb
                 self._epoch_counter += 1
             self._n_updates += self.n_epochs
+            self._mark_update_done()
             return
         for _ in range(self.n_epochs):  # data parallel: per-minibatch calls around the collectives
             if can_prepare:  # one launch per epoch: sample offsets of the permutation + advantage partials of every minibatch
@@ -341,7 +387,10 @@ class PPO:
                         _lib.check(L.tma_ppo_epoch_adv_sums(_lib.ptr(self.workspace), C.byref(self.policy.dims), self.batch_size, total,
                                                             _lib.ptr(self._adv_sums), direction, self._stream()))
                         if direction == 0:
-                            self._timed_all_reduce(self._adv_sums, "adv_allreduce_us")
+                            if self._native_comm is not None:
+                                self._native_comm.all_reduce_(self._adv_sums, self._stream())
+                            else:
+                                self._timed_all_reduce(self._adv_sums, "adv_allreduce_us")
             # the minibatch loop itself is native (tma_ppo_train_epoch_dp): gradient launches, this callback, optimizer launches.  The callback is
             # the only host-language call per minibatch.  RCCL sum over xGMI, scaled by 1/world inside the optimizer arithmetic; with the nccl
             # backend the collective runs on the process group's own stream and is ordered against the compute stream through events on both
@@ -359,17 +408,38 @@ class PPO:
                 self._allreduce_cb = _lib.AllReduceFn(_cb)
             n_mb = (total + self.batch_size - 1) // self.batch_size
             self._allreduce_error = None
+            cb, ctx = self._allreduce_cb, None
+            if self._native_comm is not None:  # ncclAllReduce from inside the native loop, on the stream the kernels run on
+                self._native_comm.bind_stream(self._stream())
+                cb, ctx = self._native_comm.callback, self._native_comm.ctx
             rc = L.tma_ppo_train_epoch_dp(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view), perm_seed,
                                           self._epoch_counter & 0xFFFFFFFF, self.batch_size, self.batch_size if can_prepare else 0,
                                           self.world_size if global_stats else 0, C.byref(self._hp), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
                                           _lib.ptr(self.exp_avg_sq), self._adam_step + 1, self.learning_rate, 0.9, 0.999, 1e-5, self.max_grad_norm, scale,
-                                          self._allreduce_cb, None, _lib.ptr(self.workspace), self._stream())
+                                          cb, ctx, _lib.ptr(self.workspace), self._stream())
             if self._allreduce_error is not None:
                 raise self._allreduce_error
             _lib.check(rc)
             self._adam_step += n_mb
             self._epoch_counter += 1
         self._n_updates += self.n_epochs
+        self._mark_update_done()
+
+    def _mark_update_done(self) -> None:
+        """Event behind the last launch of train(): what a reader of the parameters on ANOTHER stream waits for (EvalCallback evaluates on a
+        side stream while the next rollout already runs on the compute stream)."""
+        ev = getattr(self, "_update_done", None)
+        if ev is None:
+            ev = self._update_done = torch.cuda.Event(enable_timing=False)
+        ev.record(torch.cuda.current_stream(self.device))
+
+    def side_stream(self):
+        """A second stream of the model's device for work that only READS what the compute stream produced earlier (deterministic evaluation,
+        the episode-log read-back): it runs beside the compute stream's next rollout / update instead of between two iterations."""
+        st = getattr(self, "_side_stream", None)
+        if st is None:
+            st = self._side_stream = torch.cuda.Stream(self.device)
+        return st
 
     def _timed_all_reduce(self, tensor: torch.Tensor, key: str) -> None:
         import torch.distributed as tdist
@@ -389,6 +459,15 @@ class PPO:
         recorded since the last call.  Synchronises the device."""
         torch.cuda.synchronize(self.device)
         out = {}
+        if self._native_comm is not None:
+            us, calls = self._native_comm.pop_timing()
+            us.sort()
+            out["grad_allreduce_us"] = {"calls_timed": len(us), "median_us": us[len(us) // 2] if us else None, "max_us": us[-1] if us else None,
+                                        "bytes": int(self.grad.numel() * 4), "path": "native: ncclAllReduce issued by libtma_hip.so on the compute stream",
+                                        "allreduces_issued": calls}
+            out["adv_allreduce_us"] = {"calls_timed": 0, "median_us": None, "max_us": None, "bytes": int(getattr(self, "_adv_sums", torch.empty(0)).numel() * 8),
+                                       "path": "native (f64, same communicator; not timed separately: one per epoch)"}
+            return out
         for key, evs in self._dp_events.items():
             us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
             out[key] = {"calls_timed": len(us), "median_us": us[len(us) // 2] if us else None, "max_us": us[-1] if us else None,
@@ -426,6 +505,30 @@ class PPO:
         if getattr(self.env, "monitor_dir", None) and self.rank == 0 and getattr(self.env.engine, "_log_cap", 0) == 0:
             self.env.engine.episode_log(self.monitor_log_capacity)  # per-episode Monitor rows (r, l, t)
         t_prev = 0.0
+        # Logging that does not drain the GPU (round 4).  Per logged iteration: the Monitor aggregates / episode records of the rollout are
+        # detached (a host-side buffer swap) and read back on a side stream behind the rollout WHILE the update runs; the update's statistic
+        # slots are copied to pinned memory and cleared stream-ordered; the row of iteration k (progress.csv / TensorBoard / logger_values /
+        # the verbose line) is finished one iteration later, when update k is long over -- so rollout k + 1 is queued before anything waits.
+        # TMA_SYNC_LOGGING=1 restores the synchronous order (pop, log, then the next rollout).
+        pipelined = not os.environ.get("TMA_SYNC_LOGGING")
+        eng = self.env.engine
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(self.device))
+        pending = None
+
+        def finish(p):
+            p["ev_train"].synchronize()
+            stats = self._fold_train_stats(p["staging"])
+            s_ret, s_len, cnt = p["ep"]
+            elapsed = max(ev0.elapsed_time(p["ev_train"]) * 1e-3, 1e-9)  # device timeline: learn() start -> the end of this iteration's update
+            stats.update({"time/fps": p["num_timesteps"] / elapsed, "time/iterations": p["iteration"], "time/total_timesteps": p["num_timesteps"],
+                          "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
+                          "rollout/episodes": cnt, "train/n_updates": p["n_updates"]})
+            self.logger_values = stats
+            self._write_progress(stats, p["num_timesteps"])
+            if self.verbose >= 1 and self.rank == 0:
+                print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+
         try:
             while self.num_timesteps < total_timesteps:
                 cb.on_rollout_start()
@@ -433,20 +536,42 @@ class PPO:
                     break
                 cb.on_rollout_end()
                 iteration += 1
+                logging = log_interval is not None and iteration % log_interval == 0
+                if logging and pipelined:
+                    eng.detach_episode_log()
+                    ev_roll = torch.cuda.Event()
+                    ev_roll.record(torch.cuda.current_stream(self.device))
                 self.train()
-                if log_interval is not None and iteration % log_interval == 0:
-                    s_ret, s_len, cnt = self.env.engine.pop_episode_stats()
+                if logging and pipelined:
+                    staging = self._stats_staging(iteration & 1)
+                    _lib.check(_lib.lib().tma_ppo_stats_enqueue(_lib.ptr(self.workspace), _lib.ptr(staging), self._stream()))
+                    ev_train = torch.cuda.Event(enable_timing=True)
+                    ev_train.record(torch.cuda.current_stream(self.device))
+                    side = self.side_stream()
+                    side.wait_event(ev_roll)
+                    ep, lr_, ll_, le_, seen = eng.pop_detached_episode_log(C.c_void_p(side.cuda_stream))  # waits for the ROLLOUT only
+                    now = time.time() - t0
+                    self._write_monitor(ep[0], ep[1], ep[2], t_prev, now, t0, log=(lr_, ll_, le_, seen))
+                    t_prev = now
+                    if pending is not None:
+                        finish(pending)
+                    pending = dict(ev_train=ev_train, staging=staging, ep=ep, iteration=iteration, num_timesteps=self.num_timesteps, n_updates=self._n_updates)
+                elif logging:
+                    s_ret, s_len, cnt = eng.pop_episode_stats()
                     stats = self.pop_train_stats()
                     fps = self.num_timesteps / max(time.time() - t0, 1e-9)
                     stats.update({"time/fps": fps, "time/iterations": iteration, "time/total_timesteps": self.num_timesteps,
                                   "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
                                   "rollout/episodes": cnt, "train/n_updates": self._n_updates})
                     self.logger_values = stats
-                    self._write_progress(stats)
+                    self._write_progress(stats, self.num_timesteps)
                     self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0)
                     t_prev = time.time() - t0
                     if self.verbose >= 1 and self.rank == 0:
                         print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
+            if pending is not None:
+                finish(pending)
+                pending = None
         except BaseException:
             # learn() is unwinding (an all-reduce error, KeyboardInterrupt, a callback that raised): on_training_end will not run, so what the
             # callbacks and the Monitor writer hold in memory goes to disk HERE -- SB3 writes evaluations.npz after every evaluation
@@ -462,7 +587,21 @@ class PPO:
         cb.on_training_end()
         return self
 
-    def _write_progress(self, stats: dict) -> None:
+    def _stats_staging(self, which: int) -> torch.Tensor:
+        bufs = getattr(self, "_staging_bufs", None)
+        if bufs is None:
+            n = int(_lib.lib().tma_ppo_stats_staging_bytes())
+            bufs = self._staging_bufs = [torch.zeros(n, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        return bufs[which]
+
+    def _fold_train_stats(self, staging: torch.Tensor) -> dict[str, float]:
+        out = (C.c_double * 8)()
+        _lib.check(_lib.lib().tma_ppo_stats_fold(_lib.ptr(staging), out))
+        n = max(out[5], 1.0)
+        return {"train/policy_gradient_loss": out[0] / n, "train/value_loss": out[1] / n, "train/entropy_loss": -out[2] / n,
+                "train/approx_kl": out[3] / n, "train/clip_fraction": out[4] / n, "train/grad_norm": out[6], "train/n_samples": out[5]}
+
+    def _write_progress(self, stats: dict, step: int | None = None) -> None:
         """Scalar log per iteration (the keys SB3's logger writes: rollout/*, train/*, time/*) under tensorboard_log: `progress.csv` and a
         TensorBoard event file in `<tb_log_name>_1/` (tb_events.py; SB3 sends the same scalars through its TensorBoard output format)."""
         if not self.tensorboard_log or self.rank != 0:
@@ -479,14 +618,14 @@ class PPO:
             from .tb_events import EventWriter
 
             self._tb_writer = EventWriter(os.path.join(self.tensorboard_log, "PPO_1"))
-        self._tb_writer.add_scalars(stats, self.num_timesteps)
+        self._tb_writer.add_scalars(stats, self.num_timesteps if step is None else int(step))
 
     monitor_log_capacity = 1 << 20  # episode records the device keeps between two log intervals
     monitor_max_rows = 100_000      # rows written per log interval (an evenly strided subsample beyond that)
 
     monitor_per_env_limit = 64      # up to this many envs: one `<rank>.monitor.csv` per env, as the reference writes them (training.py:84-86)
 
-    def _write_monitor(self, sum_ret: float, sum_len: float, count: float, t_begin: float, t_end: float, t_start: float) -> None:
+    def _write_monitor(self, sum_ret: float, sum_len: float, count: float, t_begin: float, t_end: float, t_start: float, log=None) -> None:
         """SB3 Monitor files under the directory make_vector_env passes (reference training.py:84-86: env `rank` of the vector is wrapped in
         `Monitor(env, monitor_dir / f"{rank}")` -> `<rank>.monitor.csv`): the JSON header line, `r,l,t`, then one row per finished episode.
         Up to `monitor_per_env_limit` envs every env gets its own file, as in the reference -- the device episode log carries the env index;
@@ -498,7 +637,9 @@ class PPO:
         if not mdir or self.rank != 0 or not count:
             return
         os.makedirs(mdir, exist_ok=True)
-        r, l, e, seen = self.env.engine.pop_episode_log()
+        if getattr(self.env.engine, "_log_cap", 0) <= 0:
+            return
+        r, l, e, seen = log if log is not None else self.env.engine.pop_episode_log()  # (log: what pop_detached_episode_log read on the side stream)
         n = len(r)
         keep = np.arange(n) if n <= self.monitor_max_rows else np.linspace(0, n - 1, self.monitor_max_rows).astype(np.int64)
         self._join_monitor_writer()  # (rows of the previous interval are on disk before this interval's header / comment lines)

@@ -195,6 +195,26 @@ class HipEnvEngine:
                                                       cap, C.byref(n), C.byref(seen), self._stream()))
         return r[:n.value].copy(), l[:n.value].copy(), e[:n.value].copy(), int(seen.value)
 
+    def detach_episode_log(self) -> None:
+        """Host-side swap of the Monitor aggregate / episode-log buffers (include/tma.h tma_env_detach_episode_log): what the kernels launched
+        so far wrote can then be read with pop_detached_episode_log on a side stream while later launches fill the other set."""
+        _lib.check(_lib.lib().tma_env_detach_episode_log(self._h))
+
+    def pop_detached_episode_log(self, stream_ptr=None):
+        """((sum of returns, sum of lengths, episodes), returns f64[n], lengths i32[n], env index i32[n], episodes seen) of the detached set;
+        synchronises only the given stream (default: the current one), which must be ordered behind the kernels that wrote the set."""
+        cap = max(int(getattr(self, "_log_cap", 0)), 0)
+        host = getattr(self, "_log_host", None)
+        if cap and (host is None or len(host[0]) != cap):
+            host = self._log_host = (np.empty(cap, np.float64), np.empty(cap, np.int32), np.empty(cap, np.int32))
+        r, l, e = host if cap else (np.empty(0, np.float64), np.empty(0, np.int32), np.empty(0, np.int32))
+        n, seen, st = C.c_int64(0), C.c_int64(0), (C.c_double * 3)()
+        _lib.check(_lib.lib().tma_env_pop_detached_episode_log(self._h, r.ctypes.data_as(C.c_void_p) if cap else None, l.ctypes.data_as(C.c_void_p) if cap else None,
+                                                               e.ctypes.data_as(C.c_void_p) if cap else None, cap, C.byref(n), C.byref(seen), st,
+                                                               stream_ptr if stream_ptr is not None else self._stream()))
+        k = n.value
+        return (float(st[0]), float(st[1]), int(st[2])), r[:k].copy(), l[:k].copy(), e[:k].copy(), int(seen.value)
+
     def pop_episode_stats(self) -> tuple[float, float, int]:
         out = (C.c_double * 3)()
         _lib.check(_lib.lib().tma_env_pop_episode_stats(self._h, out, self._stream()))

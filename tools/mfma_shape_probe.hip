@@ -1,0 +1,211 @@
+// mfma_shape_probe.hip -- would v_mfma_f32_32x32x16_bf16 shorten the H x H phases of ppo_grad_wide_bf_kernel?  
+//
+// The layer-2 forward phase of the 64-row-group kernel (tma_wide_bf16.h, P2) rebuilt stand-alone in both MFMA shapes, everything else equal:
+//   one block = 4 waves (one per SIMD, __launch_bounds__(256, 1)), wave w owns output columns [64 w, 64 w + 64) of a 64-row group, K = 256;
+//   A operands (the previous layer's activations) from a row-major bf16 LDS image with ds_read_b128, one half-step ahead;
+//   B operands (weights) from a fragment-major global image through a register ring (same bytes per group in both shapes);
+//   epilogue: + bias, tanh (exp2 + rcp, packed f32 as tma_tanh2), bf16 rounding, 8-byte stores into the transposed image and 2-byte stores
+//   into the row-major image -- per element exactly the product kernel's instruction mix.
+// 16x16x32: 128 MFMAs (16 cycles each) + 64 A-fragment reads per wave and group;  32x32x16: 64 MFMAs (32 cycles) + 32 A-fragment reads.
+// Prints microseconds per group for both (median of several launches) -- the ratio is what the shape is worth on this phase.
+//
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 tools/mfma_shape_probe.hip -o /tmp/mfma_shape_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CK(x)                                                                   \
+    do {                                                                        \
+        hipError_t e_ = (x);                                                    \
+        if (e_ != hipSuccess) {                                                 \
+            printf("%s: %s\n", #x, hipGetErrorString(e_));                      \
+            exit(1);                                                            \
+        }                                                                       \
+    } while (0)
+
+constexpr int H = 256, M = 64, LDA = H + 16;
+
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) {
+    const f32x2 t = x * 2.8853900817779268f;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(t[0]);
+    e[1] = __builtin_amdgcn_exp2f(t[1]);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
+}
+
+typedef const bf16x8 __attribute__((address_space(1))) *bf_gptr;
+__device__ __forceinline__ bf16x8 frag(const bf16_t *img, int idx, int lane) {
+    typedef const char __attribute__((address_space(1))) *gbyte_ptr;
+    const gbyte_ptr base = reinterpret_cast<gbyte_ptr>(reinterpret_cast<uintptr_t>(img + (int64_t)idx * 512));
+    return *reinterpret_cast<bf_gptr>(base + (uint32_t)lane * 16u);
+}
+__device__ __forceinline__ const bf16_t *launder(const bf16_t *p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const bf16_t *>(((uint64_t)hi << 32) | lo);
+}
+
+// epilogue of 4 consecutive rows (m0 .. m0 + 3) of column n: tanh, bf16, T-image quad + A-image scalars
+__device__ __forceinline__ void store4(bf16_t *Aout, bf16_t *Tout, int n, int m0, float v0, float v1, float v2, float v3) {
+    const f32x2 a = tanh2(f32x2{v0, v1}), b = tanh2(f32x2{v2, v3});
+    bf16x4 q;
+    q[0] = (bf16_t)a[0], q[1] = (bf16_t)a[1], q[2] = (bf16_t)b[0], q[3] = (bf16_t)b[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) Aout[(m0 + r) * LDA + n] = q[r];
+    *reinterpret_cast<bf16x4 *>(Tout + n * M + (((m0 >> 3) ^ (2 * ((n >> 1) & 3))) << 3) + (m0 & 7)) = q;
+}
+
+template <int SHAPE>  // 0: 16x16x32, 1: 32x32x16
+__global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict__ Wimg, const float *__restrict__ bias, int groups, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *Ain = reinterpret_cast<bf16_t *>(smem), *Aout = Ain + M * LDA, *Tout = Aout + M * LDA;
+    const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < M * LDA; e += 256) Ain[e] = (bf16_t)(0.01f * (float)((e * 37) % 61) - 0.3f);
+    __syncthreads();
+    float acc_sink = 0.0f;
+    constexpr int R = 8;  // ring slots (fragments of 1 KiB)
+    bf16x8 ring[R];
+    // stream of a group, both shapes: 64 fragments of this wave's 256 x 64 weight slice
+    //   16x16x32: two column halves; within a half k-step outer (8), column tile inner (2)  -> index (half, ks, jj)
+    //   32x32x16: two column tiles (32 wide); within a tile k-step outer (16)                -> index (tile, ks)
+    const bf16_t *W = Wimg + (int64_t)wave * 64 * 512;
+#pragma unroll
+    for (int s = 0; s < R; s++) ring[s] = frag(W, s, lane0);
+    for (int grp = 0; grp < groups; grp++) {
+        W = launder(W);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        if constexpr (SHAPE == 0) {
+            const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++) {
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const float b = bias[wave * 64 + 16 * (2 * jh + jj) + r16];
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) acc[jj][mt] = f32x4{b, b, b, b};
+                }
+                bf16x8 a[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) a[0][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * mt + r16) * LDA + 8 * g);
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                    for (int hb = 0; hb < 2; hb++) {
+                        const int nb_ks = hb ? ks + 1 : ks, nb_h = hb ? 0 : 1;
+                        if (nb_ks < 8) {
+#pragma unroll
+                            for (int mt = 0; mt < 2; mt++)
+                                a[hb ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * (nb_h * 2 + mt) + r16) * LDA + 32 * nb_ks + 8 * g);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++) {
+                            const int sp = jh * 16 + ks * 2 + jj;
+#pragma unroll
+                            for (int mt = 0; mt < 2; mt++)
+                                acc[jj][hb * 2 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[hb][mt], ring[sp % R], acc[jj][hb * 2 + mt], 0, 0, 0);
+                            if (hb) ring[sp % R] = frag(W, (sp + R) % 32 + 0, lane);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const int n = wave * 64 + 16 * (2 * jh + jj) + r16;
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) store4(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3]);
+                }
+            }
+        } else {
+            const int c32 = lane & 31, hi = lane >> 5;
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                f32x16 acc[2];
+                {
+                    const float b = bias[wave * 64 + 32 * jt + c32];
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) acc[rt][i] = b;
+                }
+                bf16x8 a[2][2];  // [buffer][row tile of 32]
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++) a[0][rt] = *reinterpret_cast<const bf16x8 *>(Ain + (32 * rt + c32) * LDA + 8 * hi);
+#pragma unroll
+                for (int ks = 0; ks < 16; ks++) {
+                    if (ks + 1 < 16) {
+#pragma unroll
+                        for (int rt = 0; rt < 2; rt++) a[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8 *>(Ain + (32 * rt + c32) * LDA + 16 * (ks + 1) + 8 * hi);
+                    }
+                    const int sp = jt * 16 + ks;
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][rt], ring[sp % R], acc[rt], 0, 0, 0);
+                    ring[sp % R] = frag(W, (sp + R) % 32, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int n = wave * 64 + 32 * jt + c32;
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)  // rows 32 rt + 8 q + 4 hi .. + 3
+                        store4(Aout, Tout, n, 32 * rt + 8 * q + 4 * hi, acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]);
+            }
+        }
+        __syncthreads();
+        acc_sink += (float)Aout[(lane0 % M) * LDA + wave];
+        __syncthreads();
+    }
+    if (acc_sink == 12345.678f) sink[0] = acc_sink;
+}
+
+int main() {
+    const int groups = 64, blocks = 256;
+    bf16_t *W;
+    float *bias, *sink;
+    CK(hipMalloc(&W, 4 * 64 * 512 * sizeof(bf16_t) + 65536));
+    CK(hipMalloc(&bias, H * 4));
+    CK(hipMalloc(&sink, 4));
+    std::vector<unsigned short> hw(4 * 64 * 512);
+    for (size_t i = 0; i < hw.size(); i++) hw[i] = (unsigned short)(0x3C00 + (i * 2654435761u >> 22) % 512 - ((i & 1) ? 0 : 0x8000 * 0));  // ~ +-0.01 .. 0.05
+    CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, H * 4));
+    const int smem = (3 * M * LDA) * 2 + 1024;
+    auto run = [&](auto kern, const char *name) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        std::vector<float> us;
+        for (int it = 0; it < 12; it++) {
+            CK(hipEventRecord(a));
+            kern<<<blocks, 256, smem>>>(W, bias, groups, sink);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (it >= 2) us.push_back(ms * 1e3f);
+        }
+        std::sort(us.begin(), us.end());
+        printf("%-10s %8.1f us per launch, %6.3f us per 64-row group (median of %zu)\n", name, us[us.size() / 2], us[us.size() / 2] / groups, us.size());
+        return us[us.size() / 2];
+    };
+    const float t0 = run(layer_kernel<0>, "16x16x32");
+    const float t1 = run(layer_kernel<1>, "32x32x16");
+    printf("ratio 32x32x16 / 16x16x32 = %.3f\n", t1 / t0);
+    return 0;
+}
