@@ -568,7 +568,8 @@ struct WideContLds {
     static constexpr int M = 32, H = 256, NTW = 4, KS2 = H / 32, LDA = H + 16, KP1 = (T::OBS + 31) & ~31, KS1 = KP1 / 32, LDX = KP1 + 16, NT3 = 2;
     // observation + terminal-observation images, two activation images per net, head fragments (policy NT3 x KS2, value KS2), sampled
     // actions [M][32] f32, env state [SW][M], bootstrap scratch
-    static constexpr int bytes() { return (2 * M * LDX + 4 * M * LDA + (NT3 + 1) * KS2 * 512) * 2 + (M * 32 + T::SW * M + 32 + 32 + 4) * 4; }
+    // ... and the per-joint terms of the multi-lane env step [M][NJ][5] f32 + a done flag per row
+    static constexpr int bytes() { return (2 * M * LDX + 4 * M * LDA + (NT3 + 1) * KS2 * 512) * 2 + (M * 32 + T::SW * M + 32 + 32 + 4 + M * T::NJ * 5 + 32) * 4; }
 };
 
 // one observation element to its global row and, as bf16, to its LDS image row (CrawlerTask::obs writes through operator[] / operator+)
@@ -615,6 +616,8 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
     uint32_t *stl = reinterpret_cast<uint32_t *>(actl + M * 32);        // [SW][M] env state words
     float *rw = reinterpret_cast<float *>(stl + T::SW * M);             // [32] reward of a truncated row before the bootstrap
     int *trf = reinterpret_cast<int *>(rw + 32), *flag = trf + 32;      // [32] row truncated in this step; [1] any of them
+    float *termsl = reinterpret_cast<float *>(flag + 4);                // [M][NJ][5] per-joint terms of the multi-lane env step (ChainTask::step_lanes)
+    int *dnf = reinterpret_cast<int *>(termsl + M * T::NJ * 5);         // [32] row finished an episode in this step
     const int64_t N = v.N;
     const int64_t row0 = (int64_t)blockIdx.x * M;
     float *act_out = reinterpret_cast<float *>(b.actions);
@@ -638,10 +641,14 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
     float b3v[NT3];
 #pragma unroll
     for (int q = 0; q < NT3; q++) b3v[q] = (16 * q + r16 < n_out) ? Q.b3[16 * q + r16] : 0.0f;
-    // ---- env state of the 32 owner lanes (policy head waves 0 / 1, lanes r16 < 4: row = 16 mt + 4 g + r16) -> LDS ----
-    const int my_row = mt * 16 + g * 4 + r16;
+    // ---- env state -> LDS.  The env step runs on EIGHT lanes per env (round 4: one owner lane ran twenty joints and 172 observation stores in
+    // sequence while the other seven waves waited -- and spilled 153 registers doing it): the four policy waves take eight envs each, lane
+    // `sub` of an env's group its joints sub, sub + 8, sub + 16 (T::step_lanes / T::obs_lanes, bit-identical to T::step / T::obs); lane 0 of a
+    // group is the env's owner (running return, episode counter, flags, reset). ----
+    const int my_row = (wave & 3) * 8 + (lane >> 3), sub = lane & 7;
     const int64_t i = row0 + my_row;
-    const bool owner = wave < 2 && r16 < 4 && i < N;
+    const bool grp_ok = wave < 4 && i < N;
+    const bool owner = grp_ok && sub == 0;
     double er = 0.0;
     uint32_t ce = 0;
     // (the state struct lives in LDS for the whole launch and T::step / T::obs work on it in place: next to the 128 weight registers a wave
@@ -785,40 +792,48 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
                     lpsum = gsum16(lpsum);
                     if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
                 }
-                bool tr_flag = false;
-                if (owner) {  // (the actions of row tile mt were written by this wave: LDS operations of one wave execute in order)
-                    const int64_t off = (int64_t)t * N + i;
-                    typename T::S &s = sl[my_row];
-                    double r;
-                    bool done;
-                    T::step(s, 0, actl + my_row * 32, r, done);
-                    const int steps = T::steps(s);
-                    const bool hit = steps >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
-                    const bool te = done && !hit, tr = hit;
-                    er += r;
-                    const float rew32 = (float)r;
-                    b.terminated[off] = (uint8_t)te;
-                    b.truncated[off] = (uint8_t)tr;
-                    if (te || tr) {
-                        if (tr) {
-                            T::obs(s, ObsImage{XTa + my_row * ldx});
-                            rw[my_row] = rew32;
-                        }
-                        sret += er, slen += (double)steps, scnt += 1.0;
-                        log_episode(v, i, er, steps);
-                        er = 0.0;
-                        ce += 1;
-                        T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
-                    }
-                    // next observation: buffer slot t + 1 and, as bf16, this row of the LDS image (every layer-1 read of this step's image is
-                    // behind hidden()'s barriers)
-                    T::obs(s, ObsDual{b.obs + ((int64_t)(t + 1) * N + i) * D, Xa + my_row * ldx});
-                    if (!tr) b.rewards[off] = rew32;  // truncated rows: the value head waves write reward + bootstrap below
-                    trf[my_row] = tr ? 1 : 0;
-                    tr_flag = tr;
-                }
-                if (__ballot(tr_flag) != 0ull && lane == 0) atomicOr(flag, 1);
             }
+        }
+        __syncthreads();  // the sampled actions of both row tiles (head waves 0 / 1) are in LDS
+        if (wave < 4) {
+            typename T::S &s = sl[my_row];
+            double r = 0.0;
+            bool done = false, tr_flag = false;
+            if (grp_ok) T::template step_lanes<8>(s, actl + my_row * 32, termsl + my_row * (T::NJ * 5), sub, r, done);
+            if (owner) {
+                const int64_t off = (int64_t)t * N + i;
+                const bool hit = T::steps(s) >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+                const bool te = done && !hit, tr = hit;
+                er += r;
+                const float rew32 = (float)r;
+                b.terminated[off] = (uint8_t)te;
+                b.truncated[off] = (uint8_t)tr;
+                if (tr) rw[my_row] = rew32;        // truncated rows: the value head waves write reward + bootstrap below
+                else b.rewards[off] = rew32;
+                trf[my_row] = tr ? 1 : 0;
+                dnf[my_row] = (te || tr) ? 1 : 0;
+                tr_flag = tr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool g_tr = grp_ok && trf[my_row] != 0, g_dn = grp_ok && dnf[my_row] != 0;
+            if (g_tr) T::template obs_lanes<8>(s, sub, ObsImage{XTa + my_row * ldx});  // terminal observation (only the bootstrap reads it)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (g_dn && sub == 0) {
+                const int steps = T::steps(s);
+                sret += er, slen += (double)steps, scnt += 1.0;
+                log_episode(v, i, er, steps);
+                er = 0.0;
+                ce += 1;
+                T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // next observation: buffer slot t + 1 and, as bf16, this row of the LDS image (every layer-1 read of this step's image is behind
+            // hidden()'s barriers); 8 lanes x <= 3 items of 8-12 floats
+            if (grp_ok) T::template obs_lanes<8>(s, sub, ObsDual{b.obs + ((int64_t)(t + 1) * N + i) * D, Xa + my_row * ldx});
+            if (__ballot(tr_flag) != 0ull && lane == 0) atomicOr(flag, 1);
         }
         __syncthreads();
         if (flag[0]) {  // (block-uniform) timeout bootstrap of this step: rewards = reward + gamma * V(terminal observation) where truncated
@@ -852,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
         v.ep_ret[i] = er;
         v.cur_ep[i] = ce;
     }
-    if (wave < 2) {
+    if (wave < 4) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sret += __shfl_down(sret, o, 64);

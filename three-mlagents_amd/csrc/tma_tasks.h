@@ -1252,6 +1252,103 @@ struct ChainTask {
         r = (double)rew;
         done = unhealthy || s.steps >= 1000;
     }
+    // step() spread over LANES lanes of ONE wave that share an env (the fused rollout chunk: 8 lanes per env instead of one owner lane running
+    // twenty joints in sequence next to idle neighbours).  Lane `sub` takes joints sub, sub + LANES, ...; the state struct `s` and the
+    // scratch `terms` ([NJ][5] floats) live in LDS.  Per joint the operations are step()'s; the five sums over the joints are taken by lane 0
+    // of the group in joint order from `terms` -- every stored value, the reward and the done flag equal step()'s bit for bit.
+    // All LANES lanes of the group must call it together; r / done are defined in lane sub == 0.
+    // Ordering: every lane reads the OLD neighbour angles before any lane stores a new one.  The lanes of a group execute the same
+    // instruction stream, and LDS operations of a wave complete in issue order, so what is needed is that the COMPILER keeps all loads of
+    // phase A ahead of the stores of phase B (wave_barrier + wavefront fence: no code motion across, no instruction emitted).
+    template <int LANES>
+    __device__ static void step_lanes(S &s, const float *act, float *terms, int sub, double &r, bool &done) {
+        const float dt = 0.05f, gear = 8.0f, kq = 4.0f, cq = 1.5f, kc = 1.0f;
+        constexpr int PER = (NJ + LANES - 1) / LANES;
+        float ql[PER], qj[PER], qr[PER], qdj[PER], aj[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int j = sub + LANES * u;
+            if (j < NJ) {
+                ql[u] = s.q[j == 0 ? NJ - 1 : j - 1];
+                qj[u] = s.q[j];
+                qr[u] = s.q[j + 1 < NJ ? j + 1 : 0];
+                qdj[u] = s.qd[j];
+                aj[u] = clipf(act[j], -1.0f, 1.0f);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int j = sub + LANES * u;
+            if (j < NJ) {
+                float lap = (ql[u] + qr[u]) - 2.0f * qj[u];
+                float acc = gear * aj[u];
+                acc = acc - kq * qj[u];
+                acc = acc - cq * qdj[u];
+                acc = acc + kc * lap;
+                float v = qdj[u] + dt * acc;
+                float p = qj[u] + dt * v;
+                if (p > 1.2f) {
+                    p = 1.2f;
+                    v = 0.0f;
+                }
+                if (p < -1.2f) {
+                    p = -1.2f;
+                    v = 0.0f;
+                }
+                s.q[j] = p;
+                s.qd[j] = v;
+                s.pa[j] = aj[u];
+                const float c = ccos(p), sn = csin(p);
+                const float side = (j & 1) ? -1.0f : 1.0f;
+                const float w = (j < NJ / 2) ? 1.0f : -1.0f;
+                float *t = terms + 5 * j;
+                t[0] = (side * v) * c, t[1] = (w * v) * c, t[2] = side * sn, t[3] = c, t[4] = aj[u] * aj[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) {
+            float thrust_x = 0.0f, thrust_y = 0.0f, asym = 0.0f, ctrl = 0.0f, lift = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const float *t = terms + 5 * j;
+                thrust_x = thrust_x + t[0];
+                thrust_y = thrust_y + t[1];
+                asym = asym + t[2];
+                lift = lift + t[3];
+                ctrl = ctrl + t[4];
+            }
+            float z = s.root[0], vx = s.root[1], vy = s.root[2], pitch = s.root[3], roll = s.root[4], pr = s.root[5], rr = s.root[6], x = s.root[7];
+            vx = vx + dt * (0.15f * thrust_x - 0.8f * vx);
+            vy = vy + dt * (0.15f * thrust_y - 0.8f * vy);
+            pr = pr + dt * (0.3f * asym - 6.0f * pitch - 1.2f * pr);
+            rr = rr + dt * (0.05f * thrust_y - 6.0f * roll - 1.2f * rr);
+            pitch = pitch + dt * pr;
+            roll = roll + dt * rr;
+            z = 0.25f + ZL * lift;
+            x = x + dt * vx;
+            s.root[0] = z, s.root[1] = vx, s.root[2] = vy, s.root[3] = pitch, s.root[4] = roll, s.root[5] = pr, s.root[6] = rr, s.root[7] = x;
+            s.steps += 1;
+            const bool unhealthy = (z < 0.38f) || (fabsf(pitch) > 1.0f) || (fabsf(roll) > 1.0f);
+            float rew = 1.0f + vx;
+            rew = rew - 0.5f * ctrl * 0.05f;
+            r = (double)rew;
+            done = unhealthy || s.steps >= 1000;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the observation row by the LANES lanes of the group: lane `sub` writes items sub, sub + LANES, ... (one source: obs_item)
+    template <int LANES, class O>
+    __device__ static void obs_lanes(const S &s, int sub, O o) {
+#pragma unroll
+        for (int u = 0; u < (OBS_ITEMS + LANES - 1) / LANES; u++) {
+            const int item = sub + LANES * u;
+            if (item < OBS_ITEMS) obs_item(s, item, o);
+        }
+    }
     // The observation row in ITEMS independent pieces: item 0 = the root block, item 1 + j = the block of joint j (LAYOUT 1: of body j).
     // obs() is the loop over the items; the fused rollout chunk gives every (row, item) pair to a thread of its own, so the 32 rows of a
     // block go out as coalesced stores by all 512 threads instead of 172 scattered stores per row by one owner lane -- one source, same bits.

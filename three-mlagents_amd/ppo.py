@@ -543,13 +543,16 @@ class PPO:
                     ev_roll.record(torch.cuda.current_stream(self.device))
                 self.train()
                 if logging and pipelined:
+                    # (order matters: device-to-host copies of every stream share one in-order copy queue, so the side stream's read-back goes
+                    #  in BEFORE the compute stream's statistics copy, which sits behind the whole update -- queued the other way round the
+                    #  read-back waited 21 ms for it)
+                    side = self.side_stream()
+                    side.wait_event(ev_roll)
+                    ep, lr_, ll_, le_, seen = eng.pop_detached_episode_log(C.c_void_p(side.cuda_stream))  # waits for the ROLLOUT only
                     staging = self._stats_staging(iteration & 1)
                     _lib.check(_lib.lib().tma_ppo_stats_enqueue(_lib.ptr(self.workspace), _lib.ptr(staging), self._stream()))
                     ev_train = torch.cuda.Event(enable_timing=True)
                     ev_train.record(torch.cuda.current_stream(self.device))
-                    side = self.side_stream()
-                    side.wait_event(ev_roll)
-                    ep, lr_, ll_, le_, seen = eng.pop_detached_episode_log(C.c_void_p(side.cuda_stream))  # waits for the ROLLOUT only
                     now = time.time() - t0
                     self._write_monitor(ep[0], ep[1], ep[2], t_prev, now, t0, log=(lr_, ll_, le_, seen))
                     t_prev = now

@@ -61,16 +61,25 @@ __device__ __forceinline__ const bf16_t *launder(const bf16_t *p) {
 }
 
 // epilogue of 4 consecutive rows (m0 .. m0 + 3) of column n: tanh, bf16, T-image quad + A-image scalars
-__device__ __forceinline__ void store4(bf16_t *Aout, bf16_t *Tout, int n, int m0, float v0, float v1, float v2, float v3) {
-    const f32x2 a = tanh2(f32x2{v0, v1}), b = tanh2(f32x2{v2, v3});
+// FLAGS (attribution variants of the same phase): 1 = B fragments stay in registers (no weight stream), 2 = no epilogue at all (the accumulators
+// are folded into a scalar), 4 = no tanh (conversion + stores only), 8 = no 2-byte stores into the row-major image (transposed image only)
+template <int FLAGS>
+__device__ __forceinline__ void store4(bf16_t *Aout, bf16_t *Tout, int n, int m0, float v0, float v1, float v2, float v3, float &sink) {
+    if constexpr (FLAGS & 2) {
+        sink += (v0 + v1) + (v2 + v3);
+        return;
+    }
+    const f32x2 a = (FLAGS & 4) ? f32x2{v0, v1} : tanh2(f32x2{v0, v1}), b = (FLAGS & 4) ? f32x2{v2, v3} : tanh2(f32x2{v2, v3});
     bf16x4 q;
     q[0] = (bf16_t)a[0], q[1] = (bf16_t)a[1], q[2] = (bf16_t)b[0], q[3] = (bf16_t)b[1];
+    if constexpr (!(FLAGS & 8)) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) Aout[(m0 + r) * LDA + n] = q[r];
+        for (int r = 0; r < 4; r++) Aout[(m0 + r) * LDA + n] = q[r];
+    }
     *reinterpret_cast<bf16x4 *>(Tout + n * M + (((m0 >> 3) ^ (2 * ((n >> 1) & 3))) << 3) + (m0 & 7)) = q;
 }
 
-template <int SHAPE>  // 0: 16x16x32, 1: 32x32x16
+template <int SHAPE, int FLAGS>  // SHAPE 0: 16x16x32, 1: 32x32x16
 __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict__ Wimg, const float *__restrict__ bias, int groups, float *sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t *Ain = reinterpret_cast<bf16_t *>(smem), *Aout = Ain + M * LDA, *Tout = Aout + M * LDA;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict_
 #pragma unroll
                             for (int mt = 0; mt < 2; mt++)
                                 acc[jj][hb * 2 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[hb][mt], ring[sp % R], acc[jj][hb * 2 + mt], 0, 0, 0);
-                            if (hb) ring[sp % R] = frag(W, (sp + R) % 32 + 0, lane);
+                            if (hb && !(FLAGS & 1)) ring[sp % R] = frag(W, (sp + R) % 32 + 0, lane);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -128,7 +137,70 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict_
                 for (int jj = 0; jj < 2; jj++) {
                     const int n = wave * 64 + 16 * (2 * jh + jj) + r16;
 #pragma unroll
-                    for (int mt = 0; mt < 4; mt++) store4(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3]);
+                    for (int mt = 0; mt < 4; mt++) store4<FLAGS>(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3], acc_sink);
+                }
+            }
+        } else if constexpr (SHAPE == 2) {
+            // 16x16x32 with the A fragments of a WHOLE k-step (four row tiles) read one k-step ahead (8 MFMAs = 128 cycles of cover instead of
+            // 2-4 MFMAs), and -- FLAGS & 32 -- the epilogue of the PREVIOUS column half issued in pieces between this half's k-steps
+            const int r16 = lane & 15, g = lane >> 4;
+            f32x4 prev[2][4];
+            int prev_n0 = -1;
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++) {
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const float b = bias[wave * 64 + 16 * (2 * jh + jj) + r16];
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) acc[jj][mt] = f32x4{b, b, b, b};
+                }
+                bf16x8 a[2][4];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) a[0][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * mt + r16) * LDA + 8 * g);
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) {
+                    if (ks + 1 < 8) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) a[(ks + 1) & 1][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * mt + r16) * LDA + 32 * (ks + 1) + 8 * g);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const int sp = jh * 16 + ks * 2 + jj;
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) acc[jj][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks & 1][mt], ring[sp % R], acc[jj][mt], 0, 0, 0);
+                        if (!(FLAGS & 1)) ring[sp % R] = frag(W, (sp + R) % 32 + 0, lane);
+                    }
+                    if constexpr ((FLAGS & 32) != 0) {
+                        if (jh == 1) {  // (the first half of a group carries the second half of the previous group: see below)
+                            const int jj = ks >> 2, mt = ks & 3;
+                            store4<FLAGS>(Aout, Tout, prev_n0 + 16 * jj, 16 * mt + 4 * g, prev[jj][mt][0], prev[jj][mt][1], prev[jj][mt][2], prev[jj][mt][3], acc_sink);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr ((FLAGS & 32) != 0) {
+                    if (jh == 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                            for (int mt = 0; mt < 4; mt++) prev[jj][mt] = acc[jj][mt];
+                        prev_n0 = wave * 64 + r16;
+                    } else {  // (probe only: the second half's epilogue is not deferred across the group boundary)
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++) {
+                            const int n = wave * 64 + 16 * (2 + jj) + r16;
+#pragma unroll
+                            for (int mt = 0; mt < 4; mt++) store4<FLAGS>(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3], acc_sink);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const int n = wave * 64 + 16 * (2 * jh + jj) + r16;
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) store4<FLAGS>(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3], acc_sink);
+                    }
                 }
             }
         } else {
@@ -155,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict_
                     const int sp = jt * 16 + ks;
 #pragma unroll
                     for (int rt = 0; rt < 2; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][rt], ring[sp % R], acc[rt], 0, 0, 0);
-                    ring[sp % R] = frag(W, (sp + R) % 32, lane);
+                    if (!(FLAGS & 1)) ring[sp % R] = frag(W, (sp + R) % 32, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int n = wave * 64 + 32 * jt + c32;
@@ -163,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict_
                 for (int rt = 0; rt < 2; rt++)
 #pragma unroll
                     for (int q = 0; q < 4; q++)  // rows 32 rt + 8 q + 4 hi .. + 3
-                        store4(Aout, Tout, n, 32 * rt + 8 * q + 4 * hi, acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]);
+                        store4<FLAGS>(Aout, Tout, n, 32 * rt + 8 * q + 4 * hi, acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3], acc_sink);
             }
         }
         __syncthreads();
@@ -201,11 +273,26 @@ int main() {
             if (it >= 2) us.push_back(ms * 1e3f);
         }
         std::sort(us.begin(), us.end());
-        printf("%-10s %8.1f us per launch, %6.3f us per 64-row group (median of %zu)\n", name, us[us.size() / 2], us[us.size() / 2] / groups, us.size());
+        printf("%-20s %8.1f us per launch, %6.3f us per 64-row group (median of %zu)\n", name, us[us.size() / 2], us[us.size() / 2] / groups, us.size());
         return us[us.size() / 2];
     };
-    const float t0 = run(layer_kernel<0>, "16x16x32");
-    const float t1 = run(layer_kernel<1>, "32x32x16");
+    const float t0 = run(layer_kernel<0, 0>, "16x16x32");
+    const float t1 = run(layer_kernel<1, 0>, "32x32x16");
     printf("ratio 32x32x16 / 16x16x32 = %.3f\n", t1 / t0);
+    // where the phase's time goes (16x16x32, then 32x32x16): one ingredient removed at a time
+    run(layer_kernel<0, 1>, "16 no-stream");
+    run(layer_kernel<0, 2>, "16 no-epilog");
+    run(layer_kernel<0, 3>, "16 mfma+lds");
+    run(layer_kernel<0, 4>, "16 no-tanh");
+    run(layer_kernel<0, 8>, "16 no-A-img");
+    run(layer_kernel<2, 0>, "16 deep-A");
+    run(layer_kernel<2, 3>, "16 deep-A mfma+lds");
+    run(layer_kernel<2, 32>, "16 deep-A +ilv");
+    run(layer_kernel<2, 40>, "16 deepA ilv noAimg");
+    run(layer_kernel<1, 1>, "32 no-stream");
+    run(layer_kernel<1, 2>, "32 no-epilog");
+    run(layer_kernel<1, 3>, "32 mfma+lds");
+    run(layer_kernel<1, 4>, "32 no-tanh");
+    run(layer_kernel<1, 8>, "32 no-A-img");
     return 0;
 }
