@@ -884,6 +884,243 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the Box-action chunk with the POLICY net only (the design of rollout_chunk_wide_f32_kernel below, applied to the Crawler / Ant
+// shapes).  Nothing in a vector step needs the value net, so it leaves the step loop: values of the chunk's n x N observation rows are ONE
+// tma_policy_values launch and the timeout bootstrap of its terminal-observation slots ONE tma_policy_bootstrap launch per chunk (rows are
+// independent in both kernels: the bits of one launch per step).  With one net per block every wave owns 32 columns instead of 64, and BOTH
+// weight slices fit its registers for the whole launch -- layer 1: KS1 x 2 fragments (48 registers at the 172-wide Crawler input), layer 2:
+// 8 x 2 (64) -- so a vector step reads no weight from memory at all (the two-net kernel re-streamed 48 KB of layer-1 fragments per net from L2
+// in three dependent round trips per step and spilled around the env step).  Per step: layer 1 -> barrier -> layer 2 -> barrier -> {mean
+// head, Gaussian sample, log-prob: waves 0 / 1} -> barrier -> env step on eight lanes per env (waves 0-3) -> barrier.
+// Forward arithmetic = policy_fwd_wide_kernel<true, 0, 4, true> per accumulator (same k order, same split-K head order): bit-identical to the
+// per-step composition and to the two-net chunk (TMA_CONT_TWO_NET=1 selects that one: the A/B switch).
+// ------------------------------------------------------------------------------------------
+template <class T>
+struct WideContPiLds {
+    static constexpr int M = 32, H = 256, KS2 = H / 32, LDA = H + 16, KP1 = (T::OBS + 31) & ~31, KS1 = KP1 / 32, LDX = KP1 + 16, NT3 = 2;
+    // observation image, two activation images, head fragments (NT3 x KS2), sampled actions [M][32] f32, env state [SW][M], per-joint terms
+    static constexpr int bytes() { return (M * LDX + 2 * M * LDA + NT3 * KS2 * 512) * 2 + (M * 32 + T::SW * M + 32 + 32 + M * T::NJ * 5) * 4; }
+};
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
+                                                                            float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,
+                                                                            uint32_t rng_step0, int det) {
+    extern __shared__ __attribute__((aligned(16))) char smem_wp[];
+    using W = WideContPiLds<T>;
+    constexpr int M = W::M, NTW = 2, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
+    static_assert(T::NACT == 0 && AD <= 32 && !T::USES_MT, "fused wide rollout, Box actions: <= 32 action dims, inline resets");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int n_base = wave * 16 * NTW, mt = wave & 1;  // mt: the row tile head wave 0 / 1 finishes
+    bf16_t *Xa = reinterpret_cast<bf16_t *>(smem_wp), *A1 = Xa + M * ldx, *A2 = A1 + M * lda;
+    bf16_t *W3l = A2 + M * lda;
+    float *actl = reinterpret_cast<float *>(W3l + NT3 * KS2 * 512);    // [M][32] sampled actions of this step
+    uint32_t *stl = reinterpret_cast<uint32_t *>(actl + M * 32);        // [SW][M] env state words
+    int *trf = reinterpret_cast<int *>(stl + T::SW * M), *dnf = trf + 32;  // [32] row truncated / finished an episode in this step
+    float *termsl = reinterpret_cast<float *>(dnf + 32);                // [M][NJ][5] per-joint terms of the multi-lane env step
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x * M;
+    float *act_out = reinterpret_cast<float *>(b.actions);
+    // ---- this wave's weights: both slices stay in registers for the whole launch ----
+    const Net Q = pi_net(params, L);
+    const BfNetPtr Wn = bf_net_ptr(params, L, true);
+    bf16x8 w1[NTW][KS1], w2[NTW][KS2];
+    float b1v[NTW], b2v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) w1[j][ks] = bf_frag(Wn.fW1, (wave * NTW + j) * KS1 + ks, lane);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) w2[j][ks] = bf_frag(Wn.fW2, (wave * NTW + j) * KS2 + ks, lane);
+        b1v[j] = Q.b1[n_base + 16 * j + r16];
+        b2v[j] = Q.b2[n_base + 16 * j + r16];
+    }
+    if (wave == 0) {  // head fragments -> LDS (fragment q * KS2 + ks, 1 KiB each)
+        for (int f = 0; f < NT3 * KS2; f++) *reinterpret_cast<bf16x8 *>(W3l + (f * 64 + lane) * 8) = bf_frag(Wn.fW3, f, lane);
+    }
+    const int n_out = L.A;
+    float b3v[NT3];
+#pragma unroll
+    for (int q = 0; q < NT3; q++) b3v[q] = (16 * q + r16 < n_out) ? Q.b3[16 * q + r16] : 0.0f;
+    // ---- env state -> LDS; eight lanes per env on waves 0-3 (see rollout_chunk_wide_cont_kernel) ----
+    const int my_row = (wave & 3) * 8 + (lane >> 3), sub = lane & 7;
+    const int64_t i = row0 + my_row;
+    const bool grp_ok = wave < 4 && i < N;
+    const bool owner = grp_ok && sub == 0;
+    double er = 0.0;
+    uint32_t ce = 0;
+    static_assert(sizeof(typename T::S) <= T::SW * 4, "state struct fits its LDS slot");
+    typename T::S *sl = reinterpret_cast<typename T::S *>(stl);
+    if (owner) {
+        T::unpack(v.st, N, i, sl[my_row]);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int e = threadIdx.x; e < M * ldx; e += blockDim.x) {  // observation image of step t0 (columns >= D stay zero for the whole launch)
+        const int row = e / ldx, c = e - row * ldx;
+        Xa[e] = (bf16_t)((row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f);
+    }
+    if (threadIdx.x < 32) trf[threadIdx.x] = 0, dnf[threadIdx.x] = 0;
+    __syncthreads();
+    const float *ls = params + L.log_std;
+    float lsd_v[2], sd_v[2];  // log_std and exp(log_std) of this lane's two action columns: constant over the launch
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        lsd_v[j] = (16 * j + r16 < AD) ? ls[16 * j + r16] : 0.0f;
+        sd_v[j] = expf(lsd_v[j]);
+    }
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        {  // layer 1: bf_hidden_layer's order per accumulator (k-step ascending); every operand already in registers / LDS
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; m2++) {
+                    const bf16x8 a = a_frag(Xa, ldx, 16 * m2 + r16, ks, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w1[j][ks], acc[j][m2]);
+                }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; m2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+        }
+        __syncthreads();
+        {
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; m2++) {
+                    const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
+                }
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; m2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+        }
+        __syncthreads();
+        if (wave < 2) {
+            // mean head of row tile mt in the summation order of bf_head (four partial sums over k-steps 2w', 2w' + 1, added to the bias)
+            f32x4 part[4][NT3], acc[NT3];
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++)
+#pragma unroll
+                for (int q = 0; q < NT3; q++) part[wq][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+                for (int wq = 0; wq < 4; wq++) {
+                    const int ks = wq * 2 + i2;
+                    const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                    for (int q = 0; q < NT3; q++) part[wq][q] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W3l + ((q * KS2 + ks) * 64 + lane) * 8), part[wq][q]);
+                }
+#pragma unroll
+            for (int q = 0; q < NT3; q++) {
+                acc[q] = f32x4{b3v[q], b3v[q], b3v[q], b3v[q]};
+#pragma unroll
+                for (int wq = 0; wq < 4; wq++) acc[q] += part[wq][q];
+            }
+            // DiagGaussian sample + log-prob: policy_fwd_wide_kernel<CONT>'s streams and arithmetic
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int lrow = mt * 16 + g * 4 + r;
+                const int64_t row = row0 + lrow;
+                const uint32_t gi = v.env_offset + (uint32_t)row;
+                const uint32_t rstep = rng_step0 + (uint32_t)t;
+                float lpsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = 16 * j + r16;
+                    if (col < AD) {
+                        const float mu = acc[j][r], lsd = lsd_v[j], sd = sd_v[j];
+                        const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
+                        const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
+                        const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+                        const float a = det ? mu : mu + sd * z;  // deterministic evaluation: the mean (policy_fwd_wide_kernel)
+                        const float d = a - mu;
+                        lpsum += -(d * d) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                        actl[lrow * 32 + col] = a;
+                        if (row < N) act_out[((int64_t)t * N + row) * AD + col] = a;
+                    }
+                }
+                lpsum = gsum16(lpsum);
+                if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
+            }
+        }
+        __syncthreads();  // the sampled actions of both row tiles are in LDS
+        if (wave < 4) {
+            typename T::S &s = sl[my_row];
+            double r = 0.0;
+            bool done = false;
+            if (grp_ok) T::template step_lanes<8>(s, actl + my_row * 32, termsl + my_row * (T::NJ * 5), sub, r, done);
+            if (owner) {
+                const int64_t off = (int64_t)t * N + i;
+                const bool hit = T::steps(s) >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+                const bool te = done && !hit, tr = hit;
+                er += r;
+                b.rewards[off] = (float)r;  // (the timeout bootstrap is added by the caller's batched tma_policy_bootstrap)
+                b.terminated[off] = (uint8_t)te;
+                b.truncated[off] = (uint8_t)tr;
+                trf[my_row] = tr ? 1 : 0;
+                dnf[my_row] = (te || tr) ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool g_tr = grp_ok && trf[my_row] != 0, g_dn = grp_ok && dnf[my_row] != 0;
+            if (g_tr) T::template obs_lanes<8>(s, sub, term_obs + ((int64_t)k * N + i) * D);  // terminal observation: slot (t - t0) of the chunk
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (g_dn && sub == 0) {
+                const int steps = T::steps(s);
+                sret += er, slen += (double)steps, scnt += 1.0;
+                log_episode(v, i, er, steps);
+                er = 0.0;
+                ce += 1;
+                T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (grp_ok) T::template obs_lanes<8>(s, sub, ObsDual{b.obs + ((int64_t)(t + 1) * N + i) * D, Xa + my_row * ldx});
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        T::pack(v.st, N, i, sl[my_row]);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    if (wave < 4) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sret += __shfl_down(sret, o, 64);
+            slen += __shfl_down(slen, o, 64);
+            scnt += __shfl_down(scnt, o, 64);
+        }
+        if (lane == 0 && scnt > 0.0) {
+            double *slot = v.stats + (row0 >> 8) * 3;
+            atomicAdd(slot + 0, sret);
+            atomicAdd(slot + 1, slen);
+            atomicAdd(slot + 2, scnt);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused rollout chunk for the reference's OWN default policy and dtype -- MLP(256, 256), f32 (backend/mlagents/training.py:363-365) -- on
 // the Discrete tasks with observations of up to 32 floats: ONE launch advances every env by n_steps vector steps.
 //
@@ -1106,6 +1343,21 @@ static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayou
 }
 
 template <class T>
+static int launch_chunk_wide_cont_pi(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n,
+                                     uint32_t rng_seed, uint32_t rng_step0, int det, hipStream_t s) {
+    if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && T::OBS <= 192) {
+        auto k = rollout_chunk_wide_cont_pi_kernel<T>;
+        const int smem = WideContPiLds<T>::bytes();
+        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    } else {
+        return fail(TMA_ERR_INVALID, "no policy-only fused wide rollout for this task");
+    }
+}
+
+template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
                              uint32_t rng_step0, float gamma, int det, hipStream_t s) {
     if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
@@ -1192,6 +1444,40 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     // ... and on the Crawler shape (Box actions, 172 observations): layer-1 fragments streamed per step, env state in LDS
     const bool fused_cont = d->continuous && (env->task == TMA_TASK_CRAWLER || env->task == TMA_TASK_ANT) && d->act_dim == tma_task_act_dim(env->task);
     const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && env->is_reset && d->obs_dim == tma_task_obs_dim(env->task) && (fused_disc || fused_cont);
+    // Box-action tasks (Crawler / Ant shapes), round 4: policy-only fused chunk + ONE batched value launch + ONE batched bootstrap launch per
+    // chunk of up to terminal_obs_slots steps (TMA_CONT_TWO_NET=1: the round-2 chunk with both nets in the step loop)
+    static const bool cont_two_net = getenv("TMA_CONT_TWO_NET") != nullptr;
+    if (fused_wide && fused_cont && !cont_two_net) {
+        TMA_HIP(hipSetDevice(env->device));
+        ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
+        const int K = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
+        const int D = d->obs_dim;
+        int t = t_begin;
+        while (t < t_end) {
+            int left = 0;
+            int rc = tma_env_steps_until_refill(env, &left);
+            if (rc) return rc;
+            int n = left < (t_end - t) ? left : (t_end - t);
+            if (n > K) n = K;  // one terminal-observation slot per step of the chunk
+            rc = dispatch_task(env->task, [&](auto task) {
+                using TT = decltype(task);
+                return launch_chunk_wide_cont_pi<TT>(env, params, L, cp, b->terminal_obs, t, n, rng_seed, rng_step0, det, (hipStream_t)stream);
+            });
+            if (rc) return rc;
+            rc = tma_policy_values(params, d, b->obs + (int64_t)t * N * D, (int64_t)n * N, b->values + (int64_t)t * N, stream);
+            if (rc) return rc;
+            rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, (int64_t)n * N, gamma, b->rewards + (int64_t)t * N, stream);
+            if (rc) return rc;
+            rc = tma_env_internal_after_steps(env, n, stream);
+            if (rc) return rc;
+            t += n;
+        }
+        if (compute_last_values && t_end == T) {
+            if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
+            return tma_policy_values(params, d, b->obs + (int64_t)T * N * D, N, b->last_values, stream);
+        }
+        return TMA_OK;
+    }
     if (fused_wide) {
         TMA_HIP(hipSetDevice(env->device));
         ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};

@@ -203,6 +203,68 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict_
                     }
                 }
             }
+        } else if constexpr (SHAPE == 3) {
+            // 32x32x16 with the epilogue of the PREVIOUS column tile software-pipelined into this tile's k loop, placed by sched_group_barrier:
+            // a 32-cycle MFMA blocks the vector issue for 8 cycles and leaves ~24, i.e. room for ~5 plain vector instructions (or 2 + 1
+            // transcendental) and a store behind every MFMA -- the 16x16x32 form leaves 8 cycles, which is why interleaving buys nothing there
+            const int c32 = lane & 31, hi = lane >> 5;
+            f32x16 prev[2];
+            int prev_n = -1;
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                f32x16 acc[2];
+                {
+                    const float b = bias[wave * 64 + 32 * jt + c32];
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) acc[rt][i] = b;
+                }
+                bf16x8 a[2][2];
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++) a[0][rt] = *reinterpret_cast<const bf16x8 *>(Ain + (32 * rt + c32) * LDA + 8 * hi);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; kk++) {
+                        const int ks = 2 * k2 + kk;
+                        if (ks + 1 < 16) {
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++) a[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8 *>(Ain + (32 * rt + c32) * LDA + 16 * (ks + 1) + 8 * hi);
+                        }
+                        const int sp = jt * 16 + ks;
+#pragma unroll
+                        for (int rt = 0; rt < 2; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][rt], ring[sp % R], acc[rt], 0, 0, 0);
+                        if (!(FLAGS & 1)) ring[sp % R] = frag(W, (sp + R) % 32, lane);
+                    }
+                    if (jt == 1) {  // piece k2 of the previous tile's epilogue: rows 32 rt + 8 q + 4 hi .. + 3 with (rt, q) = (k2 >> 2, k2 & 3)
+                        const int rt = k2 >> 2, q = k2 & 3;
+                        store4<FLAGS>(Aout, Tout, prev_n, 32 * rt + 8 * q + 4 * hi, prev[rt][4 * q], prev[rt][4 * q + 1], prev[rt][4 * q + 2], prev[rt][4 * q + 3], acc_sink);
+                    }
+                    // placement: MFMA, then its share of the vector / LDS work, four times
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (next A fragments)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // VALU (incl. transcendentals)
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // DS write
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (ring)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (jt == 0) {
+                    prev[0] = acc[0], prev[1] = acc[1];
+                    prev_n = wave * 64 + c32;
+                } else {  // (probe only: the second tile's epilogue is not deferred across the group boundary)
+                    const int n = wave * 64 + 32 + c32;
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            store4<FLAGS>(Aout, Tout, n, 32 * rt + 8 * q + 4 * hi, acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3], acc_sink);
+                }
+            }
         } else {
             const int c32 = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -289,6 +351,8 @@ int main() {
     run(layer_kernel<2, 3>, "16 deep-A mfma+lds");
     run(layer_kernel<2, 32>, "16 deep-A +ilv");
     run(layer_kernel<2, 40>, "16 deepA ilv noAimg");
+    run(layer_kernel<3, 0>, "32 pipelined-epi");
+    run(layer_kernel<3, 8>, "32 pipe-epi noAimg");
     run(layer_kernel<1, 1>, "32 no-stream");
     run(layer_kernel<1, 2>, "32 no-epilog");
     run(layer_kernel<1, 3>, "32 mfma+lds");
