@@ -7,7 +7,7 @@
 #  (3) SQ counters (MFMA busy cycles / instruction counts / wait cycles / LDS conflicts) of the three gradient kernels.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-R=${1:-r03}
+R=${1:-r04}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench.log > gpurun_out/${R}_bench_n1.json
 cp $(ls -t gpurun_out/${R}_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_n1_kernel_stats.csv
@@ -17,6 +17,10 @@ cp $(ls -t gpurun_out/${R}_bench_ball3d_bf16/*/*kernel_stats.csv | head -1) gpur
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_crawler_bf16 -- python bench.py --gpus 1 --steps 2 --warmup 1 --task crawler --n-envs 2048 --n-steps 2048 --hidden 256 --mfma-dtype bf16 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_crawler_bf16.log 2>&1
 grep -E "^\{" gpurun_out/${R}_bench_crawler_bf16.log > gpurun_out/${R}_bench_crawler_bf16_n1.json
 cp $(ls -t gpurun_out/${R}_bench_crawler_bf16/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_crawler_bf16_kernel_stats.csv
+# GridWorld 4096 envs with the reference's default net, MLP(256, 256) f32 (second half)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_bench_gridworld_f32w -- python bench.py --gpus 1 --steps 2 --warmup 1 --hidden 256 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_gridworld_f32w.log 2>&1
+grep -E "^\{" gpurun_out/${R}_bench_gridworld_f32w.log > gpurun_out/${R}_bench_gridworld_f32w_n1.json
+cp $(ls -t gpurun_out/${R}_bench_gridworld_f32w/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_gridworld_f32w_kernel_stats.csv
 # the reference's literal batch_size = 256: one persistent launch per epoch (ppo_epoch_h64p_kernel), 4096 envs x 256 steps = 4096 optimizer steps per launch
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_literal256 -- python tools/time_epoch256.py 4096 256 > gpurun_out/${R}_literal256.log 2>&1
 cp $(ls -t gpurun_out/${R}_literal256/*/*kernel_stats.csv | head -1) gpurun_out/${R}_literal256_kernel_stats.csv
@@ -27,6 +31,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_push_$c -- python tools/prof_grad_bf16.py push 256 bf16 > gpurun_out/${R}_pmc_gradbf_push_$c.log 2>&1
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradbf_crawler_$c -- python tools/prof_grad_bf16.py crawler 256 bf16 > gpurun_out/${R}_pmc_gradbf_crawler_$c.log 2>&1
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradwide_basic_$c -- python tools/prof_grad_bf16.py basic 256 f32 8 256 > gpurun_out/${R}_pmc_gradwide_basic_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_gradwide_gridworld_$c -- python tools/prof_grad_bf16.py gridworld 256 f32 > gpurun_out/${R}_pmc_gradwide_gridworld_$c.log 2>&1
 done
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES"
@@ -55,7 +60,8 @@ for tag, sub, alg, cmd in (("step", "step_kernel<tma::GridTask, 3>", 54 * 419430
                            ("gradbf", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py ball3d 256 bf16"),
                            ("gradbf_push", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py push 256 bf16"),
                            ("gradbf_crawler", "ppo_grad_wide_bf_kernel", None, "python tools/prof_grad_bf16.py crawler 256 bf16  (both launches of the two-pass layout: per-launch mean)"),
-                           ("gradwide_basic", "ppo_grad_wide_kernel", None, "python tools/prof_grad_bf16.py basic 256 f32 8 256  (256 samples per launch)")):
+                           ("gradwide_basic", "ppo_grad_wide_kernel", None, "python tools/prof_grad_bf16.py basic 256 f32 8 256  (256 samples per launch)"),
+                           ("gradwide_gridworld", "ppo_grad_wide_kernel", None, "python tools/prof_grad_bf16.py gridworld 256 f32  (the reference's default net on the headline env, 131072 samples per launch)")):
     fs, n1 = counters(f"{R}_pmc_{tag}_FETCH_SIZE", sub)
     ws, n2 = counters(f"{R}_pmc_{tag}_WRITE_SIZE", sub)
     if not fs or not ws:
@@ -103,7 +109,7 @@ PY
 python - "$R" <<'PY'
 import csv, sys
 R = sys.argv[1]
-for name in (f"gpurun_out/{R}_bench_n1_kernel_stats.csv", f"gpurun_out/{R}_bench_ball3d_bf16_kernel_stats.csv", f"gpurun_out/{R}_bench_crawler_bf16_kernel_stats.csv",
+for name in (f"gpurun_out/{R}_bench_n1_kernel_stats.csv", f"gpurun_out/{R}_bench_ball3d_bf16_kernel_stats.csv", f"gpurun_out/{R}_bench_crawler_bf16_kernel_stats.csv", f"gpurun_out/{R}_bench_gridworld_f32w_kernel_stats.csv",
              f"gpurun_out/{R}_literal256_kernel_stats.csv"):
     print(name)
     for r in list(csv.DictReader(open(name)))[:8]:
