@@ -384,11 +384,13 @@ def run_extra(cfg, args, dev):
         torch.cuda.empty_cache()
 
 
-def literal_batch_256(args, dev):
+def literal_batch_256(args, dev, hidden=None):
     """The reference's literal PPO schedule on the headline shape (training.py:379 batch_size=256 at 4096 envs x 1024 steps = 16 384
     optimizer steps per epoch): one full rollout + ONE epoch timed; the 10-epoch iteration is composed from them."""
     import torch
 
+    if hidden is not None:  # the same schedule on another net width (the reference's default 256 x 256: per-minibatch launches)
+        args = argparse.Namespace(**{**vars(args), "hidden": hidden})
     env, model = build_model(args.task, args.n_envs, args.n_steps, args.hidden, args.mfma_dtype, 256, 1, args.seed, dev)
     try:
         model.collect_rollouts()
@@ -727,6 +729,11 @@ def main():
                 log(f"literal batch 256: {out['literal_batch_256']['ppo_updates_per_sec']:.0f} optimizer steps/s")
             except Exception as exc:  # noqa: BLE001
                 out["literal_batch_256"] = {"error": str(exc)}
+            try:  # ... and with the reference's default net (training.py:363-365): literal in both the width and the batch size
+                out["literal_batch_256_h256"] = literal_batch_256(args, dev, hidden=256)
+                log(f"literal batch 256, 256x256: {out['literal_batch_256_h256']['ppo_updates_per_sec']:.0f} optimizer steps/s")
+            except Exception as exc:  # noqa: BLE001
+                out["literal_batch_256_h256"] = {"error": str(exc)}
             extras = []
             for cfg in EXTRA_CONFIGS:
                 try:

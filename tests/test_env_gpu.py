@@ -338,3 +338,52 @@ def test_episode_log_from_the_fused_rollout():
         assert abs(float(r.astype(np.float64).sum()) - s_ret) <= 1e-4 * max(1.0, abs(s_ret)) and int(l.sum()) == int(s_len)
         assert 0 <= e.min() and e.max() < 256 and 1 <= l.min() and l.max() <= 100
         env.close()
+
+
+def test_detached_episode_log_is_read_on_a_side_stream_while_the_next_rollout_runs():
+    """tma_env_detach_episode_log / tma_env_pop_detached_episode_log (round 4): a host-side swap of the Monitor aggregate / episode-log buffers --
+    what the kernels launched BEFORE the detach wrote is read back on a side stream behind an event while kernels launched after it fill the
+    other set; nothing is lost, nothing is counted twice, and the two halves equal one undivided run."""
+    import ctypes as C
+
+    import torch
+
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def rollouts(split):
+        env = make_vector_env("gridworld", n_envs=512, seed=7)
+        model = PPO("MlpPolicy", env, n_steps=128, batch_size=4096, n_epochs=1, seed=7, policy_kwargs={"net_arch": [64, 64]})
+        eng = env.engine
+        eng.episode_log(1 << 16)
+        model.collect_rollouts()
+        first = None
+        if split:
+            eng.detach_episode_log()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(eng.device))
+            with pytest.raises(ValueError):
+                eng.detach_episode_log()  # one detached set at a time
+        model.collect_rollouts()  # (queued before the first half is read)
+        if split:
+            side = torch.cuda.Stream(eng.device)
+            side.wait_event(ev)
+            first = eng.pop_detached_episode_log(C.c_void_p(side.cuda_stream))
+            with pytest.raises(ValueError):
+                eng.pop_detached_episode_log()  # nothing detached any more
+        s_ret, s_len, cnt = eng.pop_episode_stats()
+        r, l, e, seen = eng.pop_episode_log()
+        env.close()
+        return first, (s_ret, s_len, cnt), r, l, e, seen
+
+    first, st2, r2, l2, e2, seen2 = rollouts(True)
+    _, st, r, l, e, seen = rollouts(False)
+    (s_ret1, s_len1, cnt1), r1, l1, e1, seen1 = first
+    assert cnt1 == seen1 == len(r1) > 0 and st2[2] == seen2 == len(r2) > 0
+    assert cnt1 + st2[2] == st[2] == seen and s_len1 + st2[1] == st[1]
+    assert abs((s_ret1 + st2[0]) - st[0]) <= 1e-9 * max(1.0, abs(st[0]))
+    # per env the episodes of the two halves, in order, are the episodes of the undivided run (the log order across envs is execution order)
+    for env_i in range(0, 512, 37):
+        halves = [(float(a), int(b)) for a, b, c in zip(r1, l1, e1) if c == env_i] + [(float(a), int(b)) for a, b, c in zip(r2, l2, e2) if c == env_i]
+        whole = [(float(a), int(b)) for a, b, c in zip(r, l, e) if c == env_i]
+        assert halves == whole and len(whole) > 0

@@ -895,24 +895,27 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
 // Forward arithmetic = policy_fwd_wide_kernel<true, 0, 4, true> per accumulator (same k order, same split-K head order): bit-identical to the
 // per-step composition and to the two-net chunk (TMA_CONT_TWO_NET=1 selects that one: the A/B switch).
 // ------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int MROWS>
 struct WideContPiLds {
-    static constexpr int M = 32, H = 256, KS2 = H / 32, LDA = H + 16, KP1 = (T::OBS + 31) & ~31, KS1 = KP1 / 32, LDX = KP1 + 16, NT3 = 2;
+    static constexpr int M = MROWS, H = 256, KS2 = H / 32, LDA = H + 16, KP1 = (T::OBS + 31) & ~31, KS1 = KP1 / 32, LDX = KP1 + 16, NT3 = 2;
     // observation image, two activation images, head fragments (NT3 x KS2), sampled actions [M][32] f32, env state [SW][M], per-joint terms
     static constexpr int bytes() { return (M * LDX + 2 * M * LDA + NT3 * KS2 * 512) * 2 + (M * 32 + T::SW * M + 32 + 32 + M * T::NJ * 5) * 4; }
 };
 
-template <class T>
+// MROWS = 32 or 16 envs per block: 16 doubles the blocks (2048 envs: 128 instead of 64 of the 256 CUs) and halves a wave's MFMAs and
+// epilogue elements per step -- the shape the Crawler shard wants; 32 keeps two row tiles per weight fragment for larger vectors.
+template <class T, int MROWS>
 __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
                                                                             float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,
                                                                             uint32_t rng_step0, int det) {
     extern __shared__ __attribute__((aligned(16))) char smem_wp[];
-    using W = WideContPiLds<T>;
-    constexpr int M = W::M, NTW = 2, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
+    using W = WideContPiLds<T, MROWS>;
+    constexpr int M = W::M, MT2 = M / 16, NTW = 2, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
+    static_assert(MROWS == 32 || MROWS == 16, "one or two 16-row tiles per block");
     static_assert(T::NACT == 0 && AD <= 32 && !T::USES_MT, "fused wide rollout, Box actions: <= 32 action dims, inline resets");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int n_base = wave * 16 * NTW, mt = wave & 1;  // mt: the row tile head wave 0 / 1 finishes
+    const int n_base = wave * 16 * NTW, mt = MT2 == 2 ? (wave & 1) : 0;  // mt: the row tile head wave 0 / 1 finishes
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem_wp), *A1 = Xa + M * ldx, *A2 = A1 + M * lda;
     bf16_t *W3l = A2 + M * lda;
     float *actl = reinterpret_cast<float *>(W3l + NT3 * KS2 * 512);    // [M][32] sampled actions of this step
@@ -944,9 +947,10 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
 #pragma unroll
     for (int q = 0; q < NT3; q++) b3v[q] = (16 * q + r16 < n_out) ? Q.b3[16 * q + r16] : 0.0f;
     // ---- env state -> LDS; eight lanes per env on waves 0-3 (see rollout_chunk_wide_cont_kernel) ----
-    const int my_row = (wave & 3) * 8 + (lane >> 3), sub = lane & 7;
+    constexpr int EW = M / 8;  // waves that run the env step (eight envs each)
+    const int my_row = (wave % EW) * 8 + (lane >> 3), sub = lane & 7;
     const int64_t i = row0 + my_row;
-    const bool grp_ok = wave < 4 && i < N;
+    const bool grp_ok = wave < EW && i < N;
     const bool owner = grp_ok && sub == 0;
     double er = 0.0;
     uint32_t ce = 0;
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
         const int row = e / ldx, c = e - row * ldx;
         Xa[e] = (bf16_t)((row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f);
     }
-    if (threadIdx.x < 32) trf[threadIdx.x] = 0, dnf[threadIdx.x] = 0;
+    if (threadIdx.x < 32) trf[threadIdx.x] = 0, dnf[threadIdx.x] = 0;  // (slots beyond M stay unused)
     __syncthreads();
     const float *ls = params + L.log_std;
     float lsd_v[2], sd_v[2];  // log_std and exp(log_std) of this lane's two action columns: constant over the launch
@@ -974,13 +978,15 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k;
         {  // layer 1: bf_hidden_layer's order per accumulator (k-step ascending); every operand already in registers / LDS
-            f32x4 acc[NTW][2];
+            f32x4 acc[NTW][MT2];
 #pragma unroll
-            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int m2 = 0; m2 < MT2; m2++) acc[j][m2] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++)
 #pragma unroll
-                for (int m2 = 0; m2 < 2; m2++) {
+                for (int m2 = 0; m2 < MT2; m2++) {
                     const bf16x8 a = a_frag(Xa, ldx, 16 * m2 + r16, ks, g);
 #pragma unroll
                     for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w1[j][ks], acc[j][m2]);
@@ -988,19 +994,21 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
-                for (int m2 = 0; m2 < 2; m2++)
+                for (int m2 = 0; m2 < MT2; m2++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
         }
         __syncthreads();
         {
-            f32x4 acc[NTW][2];
+            f32x4 acc[NTW][MT2];
 #pragma unroll
-            for (int j = 0; j < NTW; j++) acc[j][0] = acc[j][1] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int m2 = 0; m2 < MT2; m2++) acc[j][m2] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
-                for (int m2 = 0; m2 < 2; m2++) {
+                for (int m2 = 0; m2 < MT2; m2++) {
                     const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
 #pragma unroll
                     for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
@@ -1008,12 +1016,12 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
-                for (int m2 = 0; m2 < 2; m2++)
+                for (int m2 = 0; m2 < MT2; m2++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
         }
         __syncthreads();
-        if (wave < 2) {
+        if (wave < MT2) {
             // mean head of row tile mt in the summation order of bf_head (four partial sums over k-steps 2w', 2w' + 1, added to the bias)
             f32x4 part[4][NT3], acc[NT3];
 #pragma unroll
@@ -1062,8 +1070,8 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
                 if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
             }
         }
-        __syncthreads();  // the sampled actions of both row tiles are in LDS
-        if (wave < 4) {
+        __syncthreads();  // the sampled actions of every row tile are in LDS
+        if (wave < EW) {
             typename T::S &s = sl[my_row];
             double r = 0.0;
             bool done = false;
@@ -1104,7 +1112,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
         v.ep_ret[i] = er;
         v.cur_ep[i] = ce;
     }
-    if (wave < 4) {
+    if (wave < EW) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sret += __shfl_down(sret, o, 64);
@@ -1346,10 +1354,20 @@ template <class T>
 static int launch_chunk_wide_cont_pi(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n,
                                      uint32_t rng_seed, uint32_t rng_step0, int det, hipStream_t s) {
     if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && T::OBS <= 192) {
-        auto k = rollout_chunk_wide_cont_pi_kernel<T>;
-        const int smem = WideContPiLds<T>::bytes();
-        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        // 16 envs per block while that still leaves CUs idle at 32 (up to 4096 envs: <= 256 blocks of 16), else 32 (TMA_CONT_ROWS=16/32 forces one)
+        static const int forced = getenv("TMA_CONT_ROWS") ? atoi(getenv("TMA_CONT_ROWS")) : 0;
+        const bool rows16 = forced ? forced == 16 : env->v.N <= 4096;
+        if (rows16) {
+            auto k = rollout_chunk_wide_cont_pi_kernel<T, 16>;
+            const int smem = WideContPiLds<T, 16>::bytes();
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(512), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        } else {
+            auto k = rollout_chunk_wide_cont_pi_kernel<T, 32>;
+            const int smem = WideContPiLds<T, 32>::bytes();
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        }
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     } else {

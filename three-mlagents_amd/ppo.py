@@ -512,6 +512,11 @@ class PPO:
         # TMA_SYNC_LOGGING=1 restores the synchronous order (pop, log, then the next rollout).
         pipelined = not os.environ.get("TMA_SYNC_LOGGING")
         eng = self.env.engine
+        if pipelined:  # (a learn() that unwound between a detach and its pop left a detached set behind: drop it)
+            try:
+                eng.pop_detached_episode_log()
+            except ValueError:
+                pass
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(self.device))
         pending = None
