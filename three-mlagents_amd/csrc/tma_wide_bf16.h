@@ -106,6 +106,11 @@ __device__ __forceinline__ bf16x8 a_frag(const bf16_t *A, int ld, int row, int k
 #define TMA_BF_TR_READS 1  // 0: row-major A images + ds_read_b128 everywhere (A/B builds).  Used for 32-row groups only: at 64-row groups the
                            // eight per-row-tile address registers of the transposed reads push the 510-register variant into spills (+3 %)
 #endif
+#ifndef TMA_BF_TR_MT4
+#define TMA_BF_TR_MT4 0  // 1: transposed reads (no row-major activation images) at 64-row groups too (A/B builds)
+#endif
+template <int MT>
+constexpr bool bf_tr_reads() { return TMA_BF_TR_READS && (MT == 2 || (MT == 4 && TMA_BF_TR_MT4)); }
 template <int MT>
 __device__ __forceinline__ bf16x8 a_frag_t(const bf16_t *T, int mt, int ks, int lane) {
     typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -124,7 +129,7 @@ __device__ __forceinline__ bf16x8 a_frag_t(const bf16_t *T, int mt, int ks, int 
 // A fragment of activations / deltas held in both images (A image + T image): the transposed read, or the row-major one
 template <int MT>
 __device__ __forceinline__ bf16x8 act_frag(const bf16_t *A, int ld, const bf16_t *T, int mt, int ks, int lane) {
-    if constexpr (TMA_BF_TR_READS && MT == 2) return a_frag_t<MT>(T, mt, ks, lane);
+    if constexpr (bf_tr_reads<MT>()) return a_frag_t<MT>(T, mt, ks, lane);
     else return a_frag(A, ld, 16 * mt + (lane & 15), ks, lane >> 4);
 }
 
@@ -634,7 +639,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                            if constexpr (!bf_tr_reads<MT>()) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
                         }
                     }
                     *t_quad<MT>(T1, n, mt, g) = q;
@@ -729,7 +734,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                                 q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                                 for (int r = r0; r < r0 + 2; r++) {
-                                    if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                                    if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                                 }
                             }
                             *t_quad<MT>(T2, n, mt, g) = q;
@@ -785,7 +790,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                            if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                         }
                     }
                     *t_quad<MT>(T2, n, mt, g) = q;
@@ -984,7 +989,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!(TMA_BF_TR_READS && MT == 2)) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
+                            if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                         }
                     }
                     *tq = q;

@@ -273,31 +273,37 @@ class PPO:
 
     def _make_native_comm(self):
         """dist.NativeComm, checked against torch.distributed on a known vector before it is trusted with gradients; None (and one stderr
-        line) if RCCL cannot be bound or the check fails -- the callback path then carries the collectives."""
+        line) if RCCL cannot be bound or the check fails -- the callback path then carries the collectives.  Every rank takes part in the
+        agreement (a MIN all-reduce of the local verdict over torch.distributed) whatever happened locally, so the ranks cannot end up on
+        different paths or leave each other waiting."""
         import sys
 
         from . import dist as _dist
 
+        comm, ok, why = None, False, ""
         try:
             comm = _dist.NativeComm(self.device)
             probe = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.rank + 1)
-            mine = probe.clone()
-            comm.all_reduce_(mine, self._stream())
+            comm.all_reduce_(probe, self._stream())
             torch.cuda.current_stream(self.device).synchronize()
             want = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.world_size * (self.world_size + 1) // 2)
-            ok = bool(torch.equal(mine, want))
-            if self.world_size > 1:  # every rank must take the same path
-                import torch.distributed as tdist
-
-                flag = torch.tensor([1.0 if ok else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
-                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-                ok = bool(flag.item() == 1.0)
-            if not ok:
-                raise RuntimeError("self-check of the native all-reduce against the expected sum failed")
-            return comm
+            ok = bool(torch.equal(probe, want))
+            why = "" if ok else "self-check of the native all-reduce against the expected sum failed"
         except Exception as exc:  # noqa: BLE001
-            print(f"three-mlagents_amd: native RCCL communicator not used ({exc}); collectives go through torch.distributed", file=sys.stderr, flush=True)
-            return None
+            why = str(exc)
+        if self.world_size > 1:
+            import torch.distributed as tdist
+
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            if ok and flag.item() != 1.0:
+                ok, why = False, "another rank could not use its native communicator"
+        if ok:
+            return comm
+        if comm is not None:
+            comm.close()
+        print(f"three-mlagents_amd: native RCCL communicator not used ({why}); collectives go through torch.distributed", file=sys.stderr, flush=True)
+        return None
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
