@@ -549,6 +549,10 @@ int tma_env_destroy(tma_env *h) {
     (void)hipFree(h->v.log_len);
     (void)hipFree(h->v.log_env);
     (void)hipFree(h->v.log_n);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_chunk) (void)hipEventDestroy(h->ev_chunk);
+    for (hipEvent_t e : h->ev_side)
+        if (e) (void)hipEventDestroy(e);
     (void)hipFree(h->d_stats), (void)hipFree(h->d_log_ret), (void)hipFree(h->d_log_len), (void)hipFree(h->d_log_env), (void)hipFree(h->d_log_n);
     (void)hipFree(h->mt_scratch);
     (void)hipFree(h->rv.first_ep);

@@ -81,6 +81,10 @@ struct tma_env {
     int32_t *d_log_len = nullptr, *d_log_env = nullptr;
     unsigned long long *d_log_n = nullptr;
     bool detached = false;  // the detached set holds data that has not been popped yet
+    // side stream + events of the policy-only fused rollout (tma_rollout_collect): the batched value / bootstrap launches of chunk c run beside
+    // the chunk kernel of chunk c + 1
+    hipStream_t side = nullptr;
+    hipEvent_t ev_chunk = nullptr, ev_side[2] = {nullptr, nullptr};
 };
 
 template <class F>

@@ -1468,28 +1468,60 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     if (fused_wide && fused_cont && !cont_two_net) {
         TMA_HIP(hipSetDevice(env->device));
         ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
-        const int K = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
         const int D = d->obs_dim;
-        int t = t_begin;
+        // The chunk kernel holds the registers of N / 16 (or N / 32) CUs and nothing of the others; the value pass of chunk c depends only on the
+        // observations chunk c left behind.  So it runs on a SIDE stream behind an event on chunk c, beside the chunk kernel of chunk c + 1 on the
+        // CUs that one leaves idle; the terminal-observation slots are split in two halves used alternately, so that chunk c + 1 does not overwrite
+        // what the bootstrap of chunk c still reads.  The call returns with `stream` waiting for the side stream.  (TMA_CONT_SERIAL=1: one stream.)
+        static const bool serial = getenv("TMA_CONT_SERIAL") != nullptr;
+        const int slots = b->terminal_obs_slots > 1 ? b->terminal_obs_slots : 1;
+        const bool overlap = !serial && slots >= 2;
+        const int K = overlap ? slots / 2 : slots;
+        hipStream_t mainS = (hipStream_t)stream, sideS = mainS;
+        if (overlap) {
+            if (!env->side) {
+                TMA_HIP(hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking));
+                TMA_HIP(hipEventCreateWithFlags(&env->ev_chunk, hipEventDisableTiming));
+                TMA_HIP(hipEventCreateWithFlags(&env->ev_side[0], hipEventDisableTiming));
+                TMA_HIP(hipEventCreateWithFlags(&env->ev_side[1], hipEventDisableTiming));
+            }
+            sideS = env->side;
+        }
+        int t = t_begin, half = 0;
+        bool used[2] = {false, false};  // ev_side[h] has been recorded behind a bootstrap that reads half h
         while (t < t_end) {
             int left = 0;
             int rc = tma_env_steps_until_refill(env, &left);
             if (rc) return rc;
             int n = left < (t_end - t) ? left : (t_end - t);
             if (n > K) n = K;  // one terminal-observation slot per step of the chunk
+            float *tobs = b->terminal_obs + (overlap ? (int64_t)half * K * N * D : 0);
+            if (overlap && used[half])  // the half about to be rewritten was read by the bootstrap launched two chunks ago
+                TMA_HIP(hipStreamWaitEvent(mainS, env->ev_side[half], 0));
             rc = dispatch_task(env->task, [&](auto task) {
                 using TT = decltype(task);
-                return launch_chunk_wide_cont_pi<TT>(env, params, L, cp, b->terminal_obs, t, n, rng_seed, rng_step0, det, (hipStream_t)stream);
+                return launch_chunk_wide_cont_pi<TT>(env, params, L, cp, tobs, t, n, rng_seed, rng_step0, det, mainS);
             });
             if (rc) return rc;
-            rc = tma_policy_values(params, d, b->obs + (int64_t)t * N * D, (int64_t)n * N, b->values + (int64_t)t * N, stream);
+            if (overlap) {
+                TMA_HIP(hipEventRecord(env->ev_chunk, mainS));
+                TMA_HIP(hipStreamWaitEvent(sideS, env->ev_chunk, 0));
+            }
+            rc = tma_policy_values(params, d, b->obs + (int64_t)t * N * D, (int64_t)n * N, b->values + (int64_t)t * N, sideS);
             if (rc) return rc;
-            rc = tma_policy_bootstrap(params, d, b->terminal_obs, b->truncated + (int64_t)t * N, (int64_t)n * N, gamma, b->rewards + (int64_t)t * N, stream);
+            rc = tma_policy_bootstrap(params, d, tobs, b->truncated + (int64_t)t * N, (int64_t)n * N, gamma, b->rewards + (int64_t)t * N, sideS);
             if (rc) return rc;
+            if (overlap) {
+                TMA_HIP(hipEventRecord(env->ev_side[half], sideS));
+                used[half] = true;
+                half ^= 1;
+            }
             rc = tma_env_internal_after_steps(env, n, stream);
             if (rc) return rc;
             t += n;
         }
+        for (int h = 0; h < 2; h++)
+            if (overlap && used[h]) TMA_HIP(hipStreamWaitEvent(mainS, env->ev_side[h], 0));
         if (compute_last_values && t_end == T) {
             if (!b->last_values) return fail(TMA_ERR_INVALID, "last_values is null");
             return tma_policy_values(params, d, b->obs + (int64_t)T * N * D, N, b->last_values, stream);
