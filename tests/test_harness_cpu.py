@@ -383,3 +383,56 @@ def test_reward_table_is_the_reference_float64_reward_set(task):
         assert np.array_equal(np.array([tab[float(x)] for x in r32]), r64)
     assert all(float(np.float32(v)) == k for k, v in tab.items())
     assert reward_table("ball3d") == {}
+
+
+def test_eval_callback_bulk_steps_equal_the_per_step_loop():
+    """callbacks.BaseCallback.on_steps (round 4): a native rollout chunk reports its vector steps in bulk.  EvalCallback.bulk_steps must leave
+    exactly what SB3's per-step protocol leaves -- the same rows at the same timesteps, a fresh evaluation exactly where the optimizer has stepped,
+    the same counters -- and a CallbackList with a callback that does not take bulk steps must fall back to the per-step loop (num_timesteps
+    advancing by n_envs per call, a False return stopping the rollout at that step)."""
+    from three_mlagents_amd.callbacks import BaseCallback, CallbackList, EvalCallback
+
+    class Model:
+        def __init__(self):
+            self.num_timesteps, self._n_updates, self._adam_step, self.policy = 0, 0, 0, object()
+
+        def get_env(self):
+            return None
+
+    def run(bulk, chunks=((7, 3), (12, 3), (5, 3)), eval_freq=4):
+        m = Model()
+        ev = EvalCallback(eval_env=None, eval_freq=eval_freq, n_eval_episodes=2, deterministic=True)
+        fresh_at = []
+
+        def fake_eval():
+            fresh_at.append((m.num_timesteps, m._n_updates))
+            ev._cached = (np.array([float(m._n_updates), 1.0]), np.array([3, 4]))
+
+        ev._evaluate_fresh = fake_eval
+        cb = CallbackList([ev])
+        cb.init_callback(m)
+        for n, per_step in chunks:
+            if bulk:
+                done, go = cb.on_steps(n, per_step)
+            else:
+                done, go = BaseCallback.on_steps(cb, n, per_step)
+            assert (done, go) == (n, True)
+            m._n_updates += 1  # the optimizer steps between rollouts
+            m._adam_step += 10
+        return m.num_timesteps, ev.n_calls, ev.num_timesteps, list(ev.evaluations_timesteps), [r.tolist() for r in ev.evaluations_results], fresh_at, ev.n_fresh_evaluations
+
+    assert run(True) == run(False)
+    ts, calls, _, rows, results, fresh, n_fresh = run(True)
+    assert ts == 24 * 3 and calls == 24 and rows == [12, 24, 36, 48, 60, 72] and n_fresh == 3  # one fresh evaluation per optimizer state
+    assert [r[0] for r in results] == [0.0, 1.0, 1.0, 1.0, 2.0, 2.0]
+
+    class Stopper(BaseCallback):  # an SB3-style user callback: no bulk_steps -> the whole list is driven per step
+        def _on_step(self):
+            return self.n_calls < 5
+
+    m = Model()
+    ev = EvalCallback(eval_env=None, eval_freq=2, n_eval_episodes=1)
+    ev._evaluate_fresh = lambda: setattr(ev, "_cached", (np.array([0.0]), np.array([1])))
+    cb = CallbackList([ev, Stopper()])
+    cb.init_callback(m)
+    assert cb.on_steps(10, 8) == (5, False) and m.num_timesteps == 40 and ev.n_calls == 5 and ev.evaluations_timesteps == [16, 32]
