@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 204
+#define TMA_VERSION 205
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 

@@ -361,3 +361,44 @@ def test_eval_callback_repeats_rows_while_the_policy_has_not_moved(tmp_path, mon
     # the schedule that was trained with is on record (deviation 10: batch_size follows the env count unless given / TMA_LITERAL_BATCH)
     assert meta["schedule"] == {"batch_size": 131072, "n_steps": 1024, "n_epochs": 10, "n_envs": 4096, "minibatches_per_epoch": 32,
                                 "reference_batch_size": 256, "literal_batch_env": False, "batch_size_from": "model_kwargs"}
+
+
+def test_pipelined_logging_leaves_the_files_of_the_synchronous_order(tmp_path, monkeypatch):
+    """PPO.learn queues rollout k + 1 before it has seen the statistics of update k (detached episode log read on a side stream, two-phase train
+    statistics, evaluation beside the next rollout, callbacks in bulk: DESIGN.md deviation 11).  Everything it writes must be what the
+    synchronous order (TMA_SYNC_LOGGING=1: pop, log, evaluate, then the next rollout) writes: every progress row except the clock, every Monitor
+    row except its timestamp, every evaluation, the parameters."""
+    import csv
+
+    import torch
+
+    from three_mlagents_amd import harness
+
+    def run(name, sync):
+        monkeypatch.chdir(tmp_path)
+        if sync:
+            monkeypatch.setenv("TMA_SYNC_LOGGING", "1")
+        else:
+            monkeypatch.delenv("TMA_SYNC_LOGGING", raising=False)
+        cfg = harness.TrainConfig("gridworld", total_timesteps=6 * 256 * 64, n_envs=256, eval_episodes=20, eval_freq=4096, run_name=name, verbose=0, seed=3)
+        res = harness.train_task(cfg, model_kwargs={"n_steps": 64, "batch_size": 2048, "n_epochs": 2, "policy_kwargs": {"net_arch": [64, 64]}})
+        root = tmp_path / "runs" / "gridworld" / name
+        with open(root / "tb" / "progress.csv") as f:
+            prog = list(csv.DictReader(f))
+        mon = [ln.split(",")[:2] for ln in (root / "monitor" / "0.monitor.csv").read_text().splitlines()[2:] if not ln.startswith("#")]
+        ev = np.load(root / "eval" / "evaluations.npz")
+        model = harness.load_model("gridworld", res.model_filename)
+        return prog, mon, {k: ev[k].copy() for k in ev.files}, model.policy.params.cpu(), res
+
+    prog_p, mon_p, ev_p, par_p, res_p = run("pipelined", False)
+    prog_s, mon_s, ev_s, par_s, res_s = run("sync", True)
+    assert len(prog_p) == len(prog_s) == 6
+    for a, b in zip(prog_p, prog_s):
+        for k in a:
+            if k != "time/fps":  # (rollout/ep_rew_mean is a sum of per-block double atomics: its last bit depends on their order in either mode)
+                x, y = float(a[k]), float(b[k])
+                assert (x != x and y != y) or abs(x - y) <= 1e-12 * max(1.0, abs(y)), (k, a[k], b[k])
+    # (one file for the vector: rows are in the order the kernels' atomics logged them, which varies from run to run within a vector step)
+    assert sorted(mon_p) == sorted(mon_s) and len(mon_p) > 100
+    assert all(np.array_equal(ev_p[k], ev_s[k]) for k in ev_s) and ev_p["results"].shape[1] == 20
+    assert torch.equal(par_p, par_s) and res_p.mean_reward == res_s.mean_reward

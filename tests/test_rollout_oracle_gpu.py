@@ -35,6 +35,9 @@ CASES = [
     # (Crawler episodes run to the 1000-step limit: a narrower vector long enough for every env to finish one, timeout bootstrap included)
     pytest.param("crawler", 512, 1040, 256, "bf16", 4096, id="crawler-512x1040-h256-bf16-shard2-unpinned"),
     pytest.param("ant", 512, 1040, 256, "bf16", 0, id="ant-105x8-512x1040-h256-bf16-unpinned"),
+    # ... and the configs[4] shard at its full size (round 4: the policy-only chunk on 16-env blocks, values / bootstrap on the side stream):
+    # 2048 envs x 2048 steps, every env through two time limits
+    pytest.param("crawler", 2048, 2048, 256, "bf16", 4096, id="crawler-2048x2048-h256-bf16-shard2-unpinned-config-size"),
     # the reference's default net and dtype (f32 256 x 256) at the headline size: the policy-only fused chunk + batched values / bootstrap
     pytest.param("gridworld", 4096, 256, 256, "f32", 0, id="gridworld-4096x256-h256-f32"),
     # the other fused H = 64 instantiations at the headline size

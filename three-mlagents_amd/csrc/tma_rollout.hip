@@ -293,23 +293,28 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
 // (13.5 us per vector step at 4096 envs); the forward arithmetic here is instruction for instruction that of policy_fwd_wide_kernel<BF>
 // (same k order per accumulator, same split-K head order), so actions, log-probs, values and rewards are bit-identical to it.
 // ------------------------------------------------------------------------------------------
+template <int MROWS>
 struct WideLds {
-    static constexpr int M = 32, H = 256, NTW = 4, KS2 = H / 32, LDA = H + 16, LDX = 48;  // LDX: 32 observation columns + 16 (A-image stride rule)
+    static constexpr int M = MROWS, H = 256, NTW = 4, KS2 = H / 32, LDA = H + 16, LDX = 48;  // LDX: 32 observation columns + 16 (A-image stride rule)
     // observation + terminal-observation images, two activation images per net, W1 fragments [8 waves][4][64 lanes][8], head fragments
     // [2 nets][8][64][8] (only the layer-2 fragments -- 128 registers a wave -- stay in registers), bootstrap scratch
     static constexpr int bytes() { return (2 * M * LDX + 4 * M * LDA + 8 * NTW * 512 + 2 * KS2 * 512) * 2 + (32 + 32 + 4) * 4; }
 };
 
-template <class T>
+// MROWS = 32 or 16 envs per block (round 4): 16 doubles the blocks -- 4096 envs fill all 256 CUs instead of 128, a 2048-env shard 128 instead
+// of 64 -- and halves a wave's MFMAs and epilogue elements per step; 32 keeps two row tiles per weight fragment for larger vectors.
+template <class T, int MROWS>
 __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
                                                                        uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    constexpr int M = WideLds::M, NTW = WideLds::NTW, KS2 = WideLds::KS2, lda = WideLds::LDA, ldx = WideLds::LDX, D = T::OBS;
+    using WL = WideLds<MROWS>;
+    constexpr int M = WL::M, MT2 = M / 16, NTW = WL::NTW, KS2 = WL::KS2, lda = WL::LDA, ldx = WL::LDX, D = T::OBS;
+    static_assert(MROWS == 32 || MROWS == 16, "one or two 16-row tiles per block");
     static_assert(D <= 32 && T::NACT > 0, "fused wide rollout: observations of up to 32 floats, Discrete actions");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const bool is_pi = wave < 4;
-    const int w4 = wave & 3, n_base = w4 * 16 * NTW, mt = w4 & 1;  // mt: the row tile the two head waves of a net (w4 < 2) finish
+    const int w4 = wave & 3, n_base = w4 * 16 * NTW, mt = MT2 == 2 ? (w4 & 1) : 0;  // mt: the row tile the head waves of a net (w4 < MT2) finish
     const int A = L.A;
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem_w), *XTa = Xa + M * ldx;
     bf16_t *A1 = XTa + M * ldx + (is_pi ? 0 : 2 * M * lda), *A2 = A1 + M * lda;  // per-net activation images
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
     // ---- env state of the 32 owner lanes (policy head waves 0 / 1, lanes r16 < 4: row = 16 mt + 4 g + r16) ----
     const int my_row = mt * 16 + g * 4 + r16;
     const int64_t i = row0 + my_row;
-    const bool owner = wave < 2 && r16 < 4 && i < N;
+    const bool owner = wave < MT2 && r16 < 4 && i < N;
     typename T::S s;
     double er = 0.0;
     uint32_t ce = 0;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
         // (one row tile at a time: 16 accumulator registers live instead of 32 -- the 128 weight registers leave little room at 256 per wave;
         //  the MFMA order per accumulator is unchanged)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; m2++) {
+        for (int m2 = 0; m2 < MT2; m2++) {
             f32x4 acc[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) acc[j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
         }
         __syncthreads();
 #pragma unroll
-        for (int m2 = 0; m2 < 2; m2++) {
+        for (int m2 = 0; m2 < MT2; m2++) {
             f32x4 acc[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) acc[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k;
         hidden(Xa);  // (two barriers inside: every wave of the block takes part)
-        if (w4 < 2) {
+        if (w4 < MT2) {
             const f32x4 acc = head();
             if (!is_pi) {
                 if (r16 == 0)
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
         if (flag[0]) {  // (block-uniform) timeout bootstrap of this step: rewards = reward + gamma * V(terminal observation) where truncated
             if (!is_pi) {
                 hidden(XTa);
-                if (w4 < 2) {
+                if (w4 < MT2) {
                     const f32x4 vt = head();
                     if (r16 == 0)
 #pragma unroll
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
         v.ep_ret[i] = er;
         v.cur_ep[i] = ce;
     }
-    if (wave < 2) {
+    if (wave < MT2) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sret += __shfl_down(sret, o, 64);
@@ -1379,10 +1384,20 @@ template <class T>
 static int launch_chunk_wide(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, int t0, int n, uint32_t rng_seed,
                              uint32_t rng_step0, float gamma, int det, hipStream_t s) {
     if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
-        auto k = rollout_chunk_wide_bf_kernel<T>;
-        const int smem = WideLds::bytes();
-        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
+        // 16 envs per block while 32 would leave CUs idle (up to 4096 envs: <= 256 blocks of 16), else 32 (TMA_WIDE_ROWS=16/32 forces one)
+        static const int forced = getenv("TMA_WIDE_ROWS") ? atoi(getenv("TMA_WIDE_ROWS")) : 0;
+        const bool rows16 = forced ? forced == 16 : env->v.N <= 4096;
+        if (rows16) {
+            auto k = rollout_chunk_wide_bf_kernel<T, 16>;
+            const int smem = WideLds<16>::bytes();
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
+        } else {
+            auto k = rollout_chunk_wide_bf_kernel<T, 32>;
+            const int smem = WideLds<32>::bytes();
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            k<<<dim3((unsigned)ceil_div(env->v.N, 32)), dim3(512), smem, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
+        }
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     } else if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && ((T::OBS + 31) / 32) % 2 == 0) {
