@@ -515,7 +515,11 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
 // ITS slab of the gradient with plain stores (no atomics; slab_reduce_kernel folds the blocks in a fixed order).
 // Activations of the row group live in block-shared LDS; __syncthreads separates the layers.
 // ------------------------------------------------------------------------------------------
-template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C>
+// HALF (round 4): row groups of 16 samples (one row tile) instead of 32 -- for minibatches too small to give every CU a 32-row group (the
+// reference's literal batch_size = 256: 8 groups per net = 16 workgroups; as half groups 32): the second row tile's MFMAs, LDS traffic and
+// epilogues are compiled out, the sample dimension of the weight-gradient GEMMs runs over 4 k-steps instead of 8.  Same operations per
+// element in the same order as the first row tile of a full group.
+template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C, bool HALF = false>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net,
@@ -524,6 +528,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     // of the dW1 MFMAs ([group][wave][tile][lane][8 floats]); PASS 2 re-gathers the observation rows and runs only those MFMAs
     // -- same operands, same order as PASS 1 (the recompute pass, kept for larger minibatches), hence the same bits.
     constexpr int M = 32, H = 64 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
+    constexpr int MG = HALF ? 16 : 32, MTN = HALF ? 1 : 2, SN = HALF ? 4 : 8;  // rows per group, row tiles, sample k-steps of the weight-gradient GEMMs
+    static_assert(!HALF || (PASS == 0 && KT1C > 0 && NQ1C == 0), "half groups: single-pass shapes with dW1 in registers");
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (same two measures as tma_wide_bf16.h: the weight pointers are laundered once per row group so LICM cannot hoist the
     // loop-invariant weight loads out of the group loop and spill them, and lane-derived addresses are re-derived per phase)
@@ -612,7 +618,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
         for (int s = 0; s < R; s++) ring[s] = sload(s);
     }
-    const int64_t n_groups = (mb.count + M - 1) / M;
+    const int64_t n_groups = (mb.count + MG - 1) / MG;
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
         f32x4 zc[NTW][2];  // PASS 2: cached dz1 operands of this wave, in flight under the gathers of P0
         if constexpr (PASS == 2) {
@@ -634,10 +640,10 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         TMA_RELANE();
         // ---- P0: gather sample metadata and the observation rows ----
         if (threadIdx.x < M) {
-            const int64_t j = grp * M + threadIdx.x;
+            const int64_t j = grp * MG + threadIdx.x;
             int64_t off = -1;
             float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
-            if (j < mb.count) {
+            if ((int)threadIdx.x < MG && j < mb.count) {
                 off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
                 if constexpr (PASS != 2) {
                     m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
@@ -747,11 +753,11 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 for (int ks = 0; ks < KSC; ks++) {
                     if (ks < KS1) {
                         const int k = 4 * ks + g;
-                        const float a0 = X[r16 * ldx + k], a1 = X[(16 + r16) * ldx + k];
+                        const float a0 = X[r16 * ldx + k], a1 = HALF ? 0.0f : X[(16 + r16) * ldx + k];
 #pragma unroll
                         for (int j = 0; j < NTW; j++) {
                             acc[j][0] = mfma16(a0, w1[ks][j], acc[j][0]);
-                            acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
+                            if constexpr (!HALF) acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
                         }
                     }
                 }
@@ -770,7 +776,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
-                for (int mt = 0; mt < 2; mt++)
+                for (int mt = 0; mt < MTN; mt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) h1[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
         }
@@ -784,7 +790,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             // explicit pipeline, fenced per fragment: A operands one fragment ahead (LDS), the ring slot reloaded right behind its use
             float a0[2][4], a1[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a0[0][i] = h1[r16 * ld + 4 * i + g], a1[0][i] = h1[(16 + r16) * ld + 4 * i + g];
+            for (int i = 0; i < 4; i++) a0[0][i] = h1[r16 * ld + 4 * i + g], a1[0][i] = HALF ? 0.0f : h1[(16 + r16) * ld + 4 * i + g];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const int s = S1 + j * NQ + q;
@@ -792,14 +798,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int k = 16 * (q + 1) + 4 * i + g;
-                        a0[(q + 1) & 1][i] = h1[r16 * ld + k], a1[(q + 1) & 1][i] = h1[(16 + r16) * ld + k];
+                        a0[(q + 1) & 1][i] = h1[r16 * ld + k], a1[(q + 1) & 1][i] = HALF ? 0.0f : h1[(16 + r16) * ld + k];
                     }
                 }
                 const f32x4 w4 = ring[s % R];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     c0 = mfma16(a0[q & 1][i], w4[i], c0);
-                    c1 = mfma16(a1[q & 1][i], w4[i], c1);
+                    if constexpr (!HALF) c1 = mfma16(a1[q & 1][i], w4[i], c1);
                 }
                 ring[s % R] = sload((s + R) % SL);
                 __builtin_amdgcn_sched_barrier(0);
@@ -807,7 +813,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c0[r]);
-                h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
+                if constexpr (!HALF) h2[(16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c1[r]);
             }
         }
         __syncthreads();
@@ -825,7 +831,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     w3[i][q] = col < NOUT ? Q.W3t[(int64_t)k * NOUT + col] : 0.0f;
                 }
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
+            for (int mt = 0; mt < MTN; mt++) {
                 f32x4 part[NT3];
 #pragma unroll
                 for (int q = 0; q < NT3; q++) part[q] = z4;
@@ -842,7 +848,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         __syncthreads();
         TMA_RELANE();
         // ---- P3b: loss: wave mt (0, 1) takes row tile mt ----
-        if (wave < 2) {
+        if (wave < MTN) {
             const int mt = wave;
             f32x4 out[NT3];
 #pragma unroll
@@ -877,18 +883,18 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 const int col = 16 * q + r16;
                 float bf[8];
 #pragma unroll
-                for (int sidx = 0; sidx < 8; sidx++) bf[sidx] = dz3[(4 * sidx + g) * ld3 + col];
+                for (int sidx = 0; sidx < SN; sidx++) bf[sidx] = dz3[(4 * sidx + g) * ld3 + col];
                 if (wave == 0) {
                     float c = 0.0f;
 #pragma unroll
-                    for (int sidx = 0; sidx < 8; sidx++) c += bf[sidx];
+                    for (int sidx = 0; sidx < SN; sidx++) c += bf[sidx];
                     ab3[q] += c;
                 }
 #pragma unroll
                 for (int i = 0; i < NTW; i++) {
                     const int krow = n_base + 16 * i + r16;
 #pragma unroll
-                    for (int sidx = 0; sidx < 8; sidx++) aW3[i][q] = mfma16(h2[(4 * sidx + g) * ld + krow], bf[sidx], aW3[i][q]);
+                    for (int sidx = 0; sidx < SN; sidx++) aW3[i][q] = mfma16(h2[(4 * sidx + g) * ld + krow], bf[sidx], aW3[i][q]);
                 }
             }
             f32x4 acc[NTW][2];
@@ -908,18 +914,18 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             for (int ns = 0; ns < NSC; ns++) {
                 if (ns < NS) {
                     const int n = 4 * ns + g;
-                    const float a0 = dz3[r16 * ld3 + n], a1 = dz3[(16 + r16) * ld3 + n];
+                    const float a0 = dz3[r16 * ld3 + n], a1 = HALF ? 0.0f : dz3[(16 + r16) * ld3 + n];
 #pragma unroll
                     for (int j = 0; j < NTW; j++) {
                         acc[j][0] = mfma16(a0, w3b[ns][j], acc[j][0]);
-                        acc[j][1] = mfma16(a1, w3b[ns][j], acc[j][1]);
+                        if constexpr (!HALF) acc[j][1] = mfma16(a1, w3b[ns][j], acc[j][1]);
                     }
                 }
             }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
-                for (int mt = 0; mt < 2; mt++)
+                for (int mt = 0; mt < MTN; mt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         float *pp = h2 + (mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16;
@@ -938,7 +944,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 const int col = n_base + 16 * j + r16;
                 float c = 0.0f;
 #pragma unroll
-                for (int sidx = 0; sidx < 8; sidx++) {
+                for (int sidx = 0; sidx < SN; sidx++) {
                     bf[j][sidx] = h2[(4 * sidx + g) * ld + col];
                     c += bf[j][sidx];
                 }
@@ -948,9 +954,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             for (int kt = 0; kt < KT2; kt++) {  // one A fragment (8 LDS reads) feeds all NTW column tiles
                 float av[8];
 #pragma unroll
-                for (int sidx = 0; sidx < 8; sidx++) av[sidx] = h1[(4 * sidx + g) * ld + kt * 16 + r16];
+                for (int sidx = 0; sidx < SN; sidx++) av[sidx] = h1[(4 * sidx + g) * ld + kt * 16 + r16];
 #pragma unroll
-                for (int sidx = 0; sidx < 8; sidx++)
+                for (int sidx = 0; sidx < SN; sidx++)
 #pragma unroll
                     for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma16(av[sidx], bf[j][sidx], aW2[kt][j]);
                 __builtin_amdgcn_sched_barrier(0);  // do not let the scheduler hoist later tiles' reads over this one (register budget)
@@ -960,7 +966,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 f32x4 c0 = z4, c1 = z4;
                 float a0[2][4], a1[2][4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) a0[0][i] = h2[r16 * ld + 4 * i + g], a1[0][i] = h2[(16 + r16) * ld + 4 * i + g];
+                for (int i = 0; i < 4; i++) a0[0][i] = h2[r16 * ld + 4 * i + g], a1[0][i] = HALF ? 0.0f : h2[(16 + r16) * ld + 4 * i + g];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const int s = S1 + NTW * NQ + j * NQ + q;
@@ -968,14 +974,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const int n = 16 * (q + 1) + 4 * i + g;
-                            a0[(q + 1) & 1][i] = h2[r16 * ld + n], a1[(q + 1) & 1][i] = h2[(16 + r16) * ld + n];
+                            a0[(q + 1) & 1][i] = h2[r16 * ld + n], a1[(q + 1) & 1][i] = HALF ? 0.0f : h2[(16 + r16) * ld + n];
                         }
                     }
                     const f32x4 w4 = ring[s % R];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         c0 = mfma16(a0[q & 1][i], w4[i], c0);
-                        c1 = mfma16(a1[q & 1][i], w4[i], c1);
+                        if constexpr (!HALF) c1 = mfma16(a1[q & 1][i], w4[i], c1);
                     }
                     ring[s % R] = sload((s + R) % SL);
                     __builtin_amdgcn_sched_barrier(0);
@@ -987,7 +993,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
         for (int j = 0; j < NTW; j++)
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int mt = 0; mt < MTN; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float *pp = h1 + (mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16;
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             float bf[8];
             float c = 0.0f;
 #pragma unroll
-            for (int sidx = 0; sidx < 8; sidx++) {
+            for (int sidx = 0; sidx < SN; sidx++) {
                 bf[sidx] = h1[(4 * sidx + g) * ld + col];
                 c += bf[sidx];
             }
@@ -1019,7 +1025,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 for (int kt = 0; kt < KT1A; kt++) {
                     const int krow = kt * 16 + r16;
 #pragma unroll
-                    for (int sidx = 0; sidx < 8; sidx++) {
+                    for (int sidx = 0; sidx < SN; sidx++) {
                         const float a = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
                         aW1[kt][j] = mfma16(a, bf[sidx], aW1[kt][j]);
                     }
@@ -1119,7 +1125,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     }
 }
 
-template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0>
+template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                double *__restrict__ stat_slots, int n_pi, float *__restrict__ dz1,
@@ -1130,8 +1136,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__re
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1);
-    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1 ? dz1 + dz1_net_stride : nullptr);
+    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C, HALF>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C, HALF>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1 ? dz1 + dz1_net_stride : nullptr);
 }
 
 #include "tma_wide_bf16.h"
@@ -2205,7 +2211,10 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
     if (wide_f32) {
         // column-parallel register-accumulating kernel + deterministic slab reduction
         const int smemw = grad_wide_smem_bytes(L);
-        const int64_t groups = ceil_div(mbi->count, 32);  // one row group per block while there are CUs to spare, then grid-stride
+        // small minibatches on single-pass shapes (D <= 32): 16-row half groups, so that the reference's literal batch_size = 256 runs on 32
+        // workgroups instead of 16 (TMA_NO_HALF_GROUPS=1: 32-row groups throughout)
+        const bool half = L.D <= 32 && mbi->count <= 1024 && getenv("TMA_NO_HALF_GROUPS") == nullptr;  // (at 2048 samples the doubled slab count costs more than the shorter groups save: 79.6 against 76.6 us per call)
+        const int64_t groups = ceil_div(mbi->count, half ? 16 : 32);  // one row group per block while there are CUs to spare, then grid-stride
         const int cap_pi = d->continuous ? 136 : 128, cap_vf = 256 - cap_pi;  // measured: the Categorical head leaves the two nets balanced
         const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
         const int64_t pairs = n_pi;  // slabs in use (the value net uses the first n_vf of them)
@@ -2229,8 +2238,8 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             constexpr int NTWc = decltype(ntw)::value;
             auto both = [&](auto cont) -> int {
                 constexpr bool C = decltype(cont)::value;
-                if (kt1 == 1) return launch(ppo_grad_wide_kernel<C, NTWc, 1>);
-                if (kt1 == 2) return launch(ppo_grad_wide_kernel<C, NTWc, 2>);
+                if (kt1 == 1) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 1, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 1>);
+                if (kt1 == 2) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 2, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 2>);
                 if (kt1 == 11) {
                     const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0, 11>, dz1_cache);
                     if (rc2) return rc2;
