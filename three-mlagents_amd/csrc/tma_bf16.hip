@@ -21,7 +21,9 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         // observations of up to 32 floats: 64-row groups (half the weight bytes, barriers and latency chains per sample); wider ones keep
         // 32-row groups (their observation images would not fit next to 64-row activation images)
         static const bool force_mt2 = getenv("TMA_BF_MT2") != nullptr;  // development switch: the 32-row-group kernel
-        const int MTc = (variant <= 1 && !force_mt2 && L.H != 192) ? 4 : 2;  // (H = 192: three column tiles per wave do not split in halves)
+        // ... and minibatches too small to give every block a 64-row group (the reference's literal batch_size = 256: 4 groups per net) take
+        // 32-row groups as well: twice the workgroups on a launch that is all latency
+        const int MTc = (variant <= 1 && !force_mt2 && L.H != 192 && M.count > 4096) ? 4 : 2;  // (H = 192: three column tiles per wave do not split in halves)
         const int smemw = grad_wide_bf_smem_bytes(L.D, L.H, MTc);
         // 256 blocks = one per CU.  A policy-net row group costs 1.15-1.3x a value-net one (the loss), so the policy net gets
         // 136 or 144 of the blocks; with fewer row groups than that, one block per group.
