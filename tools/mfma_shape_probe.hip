@@ -79,6 +79,69 @@ __device__ __forceinline__ void store4(bf16_t *Aout, bf16_t *Tout, int n, int m0
     *reinterpret_cast<bf16x4 *>(Tout + n * M + (((m0 >> 3) ^ (2 * ((n >> 1) & 3))) << 3) + (m0 & 7)) = q;
 }
 
+// The same phase on EIGHT waves (two per SIMD, 32 columns each, 256 registers a wave at most): what a second wave per SIMD would buy this phase
+// if the product kernel's registers allowed it (its dW2 slice alone is 256 registers a wave at four waves, 128 at eight)
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void layer_kernel_w8(const bf16_t *__restrict__ Wimg, const float *__restrict__ bias, int groups, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *Ain = reinterpret_cast<bf16_t *>(smem), *Aout = Ain + M * LDA, *Tout = Aout + M * LDA;
+    const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = threadIdx.x; e < M * LDA; e += 512) Ain[e] = (bf16_t)(0.01f * (float)((e * 37) % 61) - 0.3f);
+    __syncthreads();
+    float acc_sink = 0.0f;
+    constexpr int R = 4;
+    bf16x8 ring[R];
+    const bf16_t *W = Wimg + (int64_t)(wave & 3) * 64 * 512 + (wave >> 2) * 16 * 512;
+#pragma unroll
+    for (int s = 0; s < R; s++) ring[s] = frag(W, s, lane0);
+    for (int grp = 0; grp < groups; grp++) {
+        W = launder(W);
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int r16 = lane & 15, g = lane >> 4;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const float b = bias[wave * 32 + 16 * jj + r16];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) acc[jj][mt] = f32x4{b, b, b, b};
+        }
+        bf16x8 a[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) a[0][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * mt + r16) * LDA + 8 * g);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+                const int nb_ks = hb ? ks + 1 : ks, nb_h = hb ? 0 : 1;
+                if (nb_ks < 8) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+                        a[hb ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(Ain + (16 * (nb_h * 2 + mt) + r16) * LDA + 32 * nb_ks + 8 * g);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const int sp = ks * 2 + jj;
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+                        acc[jj][hb * 2 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[hb][mt], ring[sp % R], acc[jj][hb * 2 + mt], 0, 0, 0);
+                    if (hb && !(FLAGS & 1)) ring[sp % R] = frag(W, (sp + R) % 16, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int n = wave * 32 + 16 * jj + r16;
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) store4<FLAGS>(Aout, Tout, n, 16 * mt + 4 * g, acc[jj][mt][0], acc[jj][mt][1], acc[jj][mt][2], acc[jj][mt][3], acc_sink);
+        }
+        __syncthreads();
+        acc_sink += (float)Aout[(lane0 % M) * LDA + wave];
+        __syncthreads();
+    }
+    if (acc_sink == 12345.678f) sink[0] = acc_sink;
+}
+
 template <int SHAPE, int FLAGS>  // SHAPE 0: 16x16x32, 1: 32x32x16
 __global__ __launch_bounds__(256, 1) void layer_kernel(const bf16_t *__restrict__ Wimg, const float *__restrict__ bias, int groups, float *sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,6 +382,24 @@ int main() {
     CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, H * 4));
     const int smem = (3 * M * LDA) * 2 + 1024;
+    auto run8 = [&](auto kern, const char *name) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        std::vector<float> us;
+        for (int it = 0; it < 12; it++) {
+            CK(hipEventRecord(a));
+            kern<<<blocks, 512, smem>>>(W, bias, groups, sink);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (it >= 2) us.push_back(ms * 1e3f);
+        }
+        std::sort(us.begin(), us.end());
+        printf("%-20s %8.1f us per launch, %6.3f us per 64-row group (median of %zu)\n", name, us[us.size() / 2], us[us.size() / 2] / groups, us.size());
+    };
     auto run = [&](auto kern, const char *name) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         hipEvent_t a, b;
@@ -353,6 +434,9 @@ int main() {
     run(layer_kernel<2, 40>, "16 deepA ilv noAimg");
     run(layer_kernel<3, 0>, "32 pipelined-epi");
     run(layer_kernel<3, 8>, "32 pipe-epi noAimg");
+    run8(layer_kernel_w8<0>, "16 eight waves");
+    run8(layer_kernel_w8<2>, "16 8w no-epilog");
+    run8(layer_kernel_w8<8>, "16 8w no-A-img");
     run(layer_kernel<1, 1>, "32 no-stream");
     run(layer_kernel<1, 2>, "32 no-epilog");
     run(layer_kernel<1, 3>, "32 mfma+lds");
