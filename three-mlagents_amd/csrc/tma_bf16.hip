@@ -29,7 +29,9 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         // 136 or 144 of the blocks; with fewer row groups than that, one block per group.
         const int64_t groups = ceil_div(M.count, 16 * MTc);
         static const int npi_env = getenv("TMA_BF_NPI") ? atoi(getenv("TMA_BF_NPI")) : 0;  // development switch: policy-net block count
-        const int cap_pi = npi_env > 0 ? npi_env : (L.cont ? 144 : 136), cap_vf = 256 - cap_pi;  // (Categorical loss is cheaper than the DiagGaussian one)
+        const bool eight = getenv("TMA_BF_NW4") == nullptr && MTc == 4 && variant == 0 && !L.cont && L.H == 256;
+        // (Categorical loss is cheaper than the DiagGaussian one; the eight-wave kernel shares a tile's loss between two waves: swept 124 .. 160, best 136 .. 140)
+        const int cap_pi = npi_env > 0 ? npi_env : (L.cont ? 144 : (eight ? 140 : 136)), cap_vf = 256 - cap_pi;
         const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
         if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab
             const int zrc = tma_launch_slab_zero_w1(slabs, n_pi, L, s);
@@ -40,6 +42,23 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
             k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
             return TMA_OK;
         };
+        // eight-wave variant (two waves per SIMD, 32 columns each; tma_wide_bf16.h): 64-row groups of the Discrete layouts with observations of up to
+        // 16 floats at H = 256 -- GridWorld, Push, Ball3D, WallJump (measured round 4, one box: 285 -> 246-255 us per 131 072 samples; TMA_BF_NW4=1
+        // selects the four-wave kernel)
+        static const bool nw8 = getenv("TMA_BF_NW4") == nullptr;
+        if (nw8 && MTc == 4 && variant == 0 && !L.cont && L.H == 256) {
+            const int smem8 = smemw + (L.H / 32) * 1024 + 4 * 4 * 5 * 8;  // + the head fragments + the statistics of four more waves
+            auto launch8 = [&](auto k) -> int {
+                TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
+                k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, nullptr, DZ1_CAP * L.H);
+                return TMA_OK;
+            };
+            const int rc8 = launch8(ppo_grad_wide_bf_kernel<false, 2, 4, 1, 1, 0, 8>);
+            if (rc8) return rc8;
+            TMA_LAUNCH_CHECK();
+            *n_pi_out = n_pi, *n_vf_out = n_vf;
+            return TMA_OK;
+        }
         // two-pass layouts: minibatches that fit the dz1 cache take PASS 0 (which leaves dz1 there) + PASS 2 (dW1 from the cache)
         // instead of PASS 0 + PASS 1 (dW1 from a recomputed forward / backward chain); the results are bit-identical
         bf16_t *const dz1_cache = (bf_two_pass(L) && M.count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))  // (env: test hook for the fallback)

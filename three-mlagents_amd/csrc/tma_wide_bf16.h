@@ -301,19 +301,25 @@ constexpr int bf_ring_slots(int stream_len, int cap) {
 // minibatch is then walked twice: PASS 0 accumulates everything except dW1, PASS 1 recomputes the forward / backward chain and
 // keeps only dW1 (2*KS1C k-tiles) in registers -- 1.8x the MFMA work instead of a 0.4 MB read-modify-write of the slab per row
 // group.  (Every store of PASS 0's quantities is compiled out of PASS 1, so the MFMAs that feed only them disappear as dead code.)
-template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C, int PASS>
+// NW = 8 (round 4, 64-row groups of single-k-step layouts only): two waves per SIMD, 32 columns each (NTW = 2).  The dW2 slice of a wave halves to
+// 128 accumulator registers; what does not halve with it has to shrink for 256 registers a wave to hold: the head fragments wait in LDS
+// (8 KB, read back where the head multiplies: only the four head waves need them) and the hidden-layer bias gradients are per-lane sums
+// instead of ones^T . dz accumulator tiles.  One wave's epilogue / loss / LDS waits then run beside its SIMD partner's MFMAs.
+template <bool CONT, bool IS_PI, int NTW, int MT, int KT1C, int KS1C, int PASS, int NW = 4>
 __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                   const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                   double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net,
                                                   bf16_t *__restrict__ dz1c) {
-    constexpr int M = 16 * MT, MK = MT / 2, H = 64 * NTW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
+    static_assert(NW == 4 || (NW == 8 && MT == 4 && KS1C == 1 && PASS == 0 && !CONT), "eight waves: 64-row groups, one layer-1 k-step, Discrete heads");
+    constexpr bool W8 = NW == 8;
+    constexpr int M = 16 * MT, MK = MT / 2, H = 16 * NTW * NW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
     // weight stream of a row group: [layer-1 fragments when KS1C > 1: k-step outer, tile inner] [layer-2 forward] [layer-2 input-gradient]
     constexpr int S1 = KS1C > 1 ? KS1C * NTW : 0, SL = S1 + 2 * KS2 * NTW;
     // largest divisor of SL not above four k-steps of fragments (slots are static registers); 64-row groups: two k-steps (each k-step is
     // twice the MFMA work, and the accumulators of four row tiles need the registers)
     constexpr int R = bf_ring_slots(SL, (MT == 4 ? 2 : 4) * NTW);
     constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
-    constexpr int NX = PF ? 2 * MT * KS1C : 1;
+    constexpr int NX = PF ? 2 * MT * KS1C * 4 / NW : 1;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
     // Every lane-derived LDS / global address in the group loop is loop-invariant; hoisted, there are far more of them than
     // registers and they come back as scratch reloads -- each one an s_waitcnt vmcnt(0) that drains the weight prefetch.
@@ -359,7 +365,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     float *hpart = scratch + 128;              // MT = 2: [4 waves][MT][2][64 lanes][4] split-K partial head outputs (MT = 4: none)
     float *bias = hpart + (MT == 4 ? 0 : 4 * MT * 2 * 256);  // b1[H], b2[H], b3[32] (zero padded): LDS copies, no global load in front of a phase
     double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [4 waves][4][5] loss statistics (lanes r16 == 0)
-    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + 4 * 4 * 5), *row_off_next = row_off + M;
+    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + NW * 4 * 5), *row_off_next = row_off + M;
+    bf16_t *W3lds = reinterpret_cast<bf16_t *>(row_off_next + M);  // W8: [KS2 * NT3] head fragments of 1 KiB (grad_wide_bf_smem_bytes adds them)
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
     const float invB = 1.0f / (float)mb.count;
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
@@ -390,11 +397,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     const bf16_t one_bf = (bf16_t)1.0f;
     const bf16x8 ones8 = bf16x8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
     f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
-    f32x4 aB1[NTW], aB2[NTW];  // hidden-layer bias gradients: column sums of dz as ones^T . dz on the MFMA (every row of the tile holds the sum)
+    f32x4 aB1[W8 ? 1 : NTW], aB2[W8 ? 1 : NTW];  // hidden-layer bias gradients: column sums of dz as ones^T . dz on the MFMA (every row of the tile holds the sum)
+    float sB1[NTW], sB2[NTW];  // W8: the same sums per lane (this lane's 16 rows of the column), folded over the four lane groups at the end
     float ab3 = 0.0f, dlsd[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
-        aB1[j] = aB2[j] = z4;
+        if (!W8 || j == 0) aB1[W8 ? 0 : j] = aB2[W8 ? 0 : j] = z4;
+        sB1[j] = sB2[j] = 0.0f;
 #pragma unroll
         for (int i = 0; i < KT1A; i++) aW1[i][j] = z4;
 #pragma unroll
@@ -404,7 +413,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     }
     for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
         bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
-    if (threadIdx.x < 4 * 4 * 5) stat_lds[threadIdx.x] = 0.0;
+    if (threadIdx.x < NW * 4 * 5) stat_lds[threadIdx.x] = 0.0;
     // ---- weight operands: ring over the two H x H streams, resident small fragments ----
     int nt0l = nt0;  // laundered copy (see the asm in the group loop): keeps the fragment address arithmetic scalar and inside the loop
     auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
@@ -430,11 +439,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
         for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
     }
+    if constexpr (W8) {  // head fragments -> LDS, once per launch (the group loop's first barrier is ahead of their first use)
+        for (int f = wave; f < KS2 * NT3; f += NW) *reinterpret_cast<bf16x8 *>(W3lds + (f * 64 + lane0) * 8) = bf_frag(W.fW3, f, lane0);
+    }
     // ---- prefetch registers for the next group's samples ----
     float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
-    const int mrow = wave * (M / 4) + lane0;  // sample row whose metadata this lane gathers (lanes < M/4 of every wave: the Feistel
-    const bool mlane = lane0 < M / 4;         // permutation arithmetic is spread over the four waves instead of skewing wave 0)
+    const int mrow = wave * (M / NW) + lane0;  // sample row whose metadata this lane gathers (lanes < M/NW of every wave: the Feistel
+    const bool mlane = lane0 < M / NW;         // permutation arithmetic is spread over the waves instead of skewing wave 0)
     int32_t noff = -1;  // cached buffer offset of this lane's row in the NEXT group, loaded one phase before fetch_meta needs it
     auto fetch_off = [&](int64_t grp) {  // (cache present) issue only; j beyond the minibatch reads a clamped entry that fetch_meta ignores
         if (mb.offs && mlane) {
@@ -463,7 +475,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             const int tid = wave * 64 + lane;
 #pragma unroll
             for (int i = 0; i < NX; i++) {
-                const int e = tid + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const int e = tid + 64 * NW * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
                 const int64_t off = row_off_next[row];
                 const bool ok = off >= 0 && c < D;
                 px[i] = rb.obs[ok ? off * D + c : 0];
@@ -506,7 +518,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             const int tid = wave * 64 + lane;
 #pragma unroll
             for (int i = 0; i < NX; i++) {
-                const int e = tid + 256 * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
+                const int e = tid + 64 * NW * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
                 const bool ok = row_off_next[row] >= 0 && c < D;  // row_off_next still names THIS group's rows (next fetch_meta: end of P2)
                 const bf16_t v = (bf16_t)(ok ? px[i] : 0.0f);
                 Xa[row * ldx + c] = v;
@@ -675,9 +687,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int q = 0; q < NT3; q++) *reinterpret_cast<f32x4 *>(hpart + (((wave * MT + mt) * 2 + q) * 64 + lane) * 4) = part[q];
             }
         };
-        bf16x8 w3all[MT == 4 ? KS2 * NT3 : 1];  // MT = 4: every head fragment (this wave runs the whole head of its row tile)
+        bf16x8 w3all[(MT == 4 && !W8) ? KS2 * NT3 : 1];  // MT = 4: every head fragment (this wave runs the whole head of its row tile)
         if (!(dbg & 32)) {
-            if constexpr (MT == 4) {
+            if constexpr (W8) {
+                // (head fragments wait in LDS)
+            } else if constexpr (MT == 4) {
 #pragma unroll
                 for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
@@ -815,8 +829,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             // ---- P3 (64-row groups): wave w owns row tile w -- whole head (the split-K summation order of bf_head, so the rollout's
             // log-probabilities still match bit for bit), loss, and both bf16 images of dz3, with no block barrier in between ----
             TMA_TICK(4);
+            // Eight waves: waves w and w + 4 share row tile w -- both run its head (8 MFMAs), each takes two of the four rows of every lane
+            // group through the loss (the expensive part: exp / log per row), then a barrier, then waves 0-3 build the row-major and
+            // waves 4-7 the transposed bf16 image of dz3
             if (!(dbg & 4)) {
-                const int mt = wave;
+                const int mt = W8 ? (wave & 3) : wave, r_lo = W8 ? 2 * (wave >> 2) : 0, r_hi = W8 ? r_lo + 2 : 4;
                 f32x4 part[4][NT3];
 #pragma unroll
                 for (int w = 0; w < 4; w++)
@@ -830,7 +847,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         if (ks < KS2) {
                             const bf16x8 a = act_frag<MT>(A2, lda, T2, mt, ks, lane);
 #pragma unroll
-                            for (int q = 0; q < NT3; q++) part[w][q] = mfma_bf(a, w3all[ks * NT3 + q], part[w][q]);
+                            for (int q = 0; q < NT3; q++)
+                                part[w][q] = mfma_bf(a, W8 ? *reinterpret_cast<const bf16x8 *>(W3lds + ((q * KS2 + ks) * 64 + lane) * 8) : w3all[ks * NT3 + q], part[w][q]);
                         }
                     }
                 f32x4 out[NT3];
@@ -845,10 +863,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 float *dzt = dz3 + mt * 16 * ld3;
                 if constexpr (IS_PI) {
                     policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                           lane);
+                                           lane, r_lo, r_hi);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
+                        if (r < r_lo || r >= r_hi) continue;
                         const int row = g * 4 + r;
                         const bool valid = row_off[mt * 16 + row] >= 0;
                         const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
@@ -860,9 +879,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     double *sl = stat_lds + (wave * 4 + g) * 5;
                     sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
                 }
+                if constexpr (W8) __syncthreads();  // (block-uniform: dbg is) both halves of every tile's dz3 are in LDS
                 // dz3 of this tile as bf16, row-major (Z3a) and transposed (Z3t); the f32 column sums feed the head bias gradient.
-                // (dzt was written by this wave: LDS operations of one wave execute in order, no barrier needed)
-                {
+                // (four waves: dzt was written by this wave -- LDS operations of one wave execute in order, no barrier needed)
+                if (!W8 || wave < 4) {
                     bf16x8 v;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
@@ -871,7 +891,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     }
                     *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
                 }
-                {
+                if (!W8 || wave >= 4) {
                     const int a = lane & 31, half = lane >> 5;
                     bf16x8 v;
                     float c = 0.0f;
@@ -992,6 +1012,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                         }
                     }
+                    if constexpr (W8 && MAIN) sB2[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);  // (the bf16 deltas the weight gradient uses)
                     *tq = q;
                 }
             }
@@ -1013,7 +1034,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T2, n_base + 16 * j + r16, kk, g);
-            if constexpr (MAIN) {  // db2 += ones^T . dz2 (the bf16 deltas the weight gradient uses, f32 accumulate)
+            if constexpr (MAIN && !W8) {  // db2 += ones^T . dz2 (the bf16 deltas the weight gradient uses, f32 accumulate)
 #pragma unroll
                 for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1094,6 +1115,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                                 const f32x2 dz = delta2(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                                 q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                             }
+                            if constexpr (W8 && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
                             *tq = q;
                         }
                     }
@@ -1158,7 +1180,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T1, n_base + 16 * j + r16, kk, g);
-            if constexpr (MAIN) {  // db1 += ones^T . dz1
+            if constexpr (MAIN && !W8) {  // db1 += ones^T . dz1
 #pragma unroll
                 for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1241,7 +1263,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
         }
         if constexpr (MAIN) {
-            if (g == 0) gb1[col] = aB1[j][0], gb2[col] = aB2[j][0];  // (rows of the ones^T . dz tiles are identical)
+            if constexpr (W8) {  // fold the four lane groups' partial sums (rows 4 g .. 4 g + 3 of every row tile) in a fixed order
+                float v1 = sB1[j], v2 = sB2[j];
+                v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
+                v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
+                if (g == 0) gb1[col] = v1, gb2[col] = v2;
+            } else {
+                if (g == 0) gb1[col] = aB1[j][0], gb2[col] = aB2[j][0];  // (rows of the ones^T . dz tiles are identical)
+            }
 #pragma unroll
             for (int q = 0; q < NT3; q++)
 #pragma unroll
@@ -1259,8 +1288,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         float v0 = dlsd[0], v1 = dlsd[1];
         v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
         v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
-        if constexpr (MT == 4) {  // every wave holds the column sums of its row tile
-            if (lane < 32) scratch[wave * 32 + lane] = v;
+        if constexpr (MT == 4) {  // every (head) wave holds the column sums of its row tile
+            if (lane < 32 && (W8 ? wave >= 4 : true)) scratch[(wave & 3) * 32 + lane] = v;
         } else if (wave >= 2) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
             if (lane < 32) scratch[(wave - 2) * 32 + lane] = v;
         }
@@ -1285,14 +1314,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     __syncthreads();
     if (MAIN && threadIdx.x < 5) {
         double ssum = 0.0;
-        for (int w = 0; w < 4 * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
+        for (int w = 0; w < NW * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
         const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
         if (q >= 0) stat_slot[q] += ssum;
     }
 }
 
-template <bool CONT, int NTW, int MT, int KT1C, int KS1C, int PASS>
-__global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+template <bool CONT, int NTW, int MT, int KT1C, int KS1C, int PASS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void ppo_grad_wide_bf_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                   const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                   double *__restrict__ stat_slots, int n_pi, bf16_t *__restrict__ dz1,
                                                                   int64_t dz1_net_stride) {
@@ -1303,7 +1332,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_bf_kernel(const float *_
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b, dz1);
-    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C, PASS>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b,
-                                                                   dz1 ? dz1 + dz1_net_stride : nullptr);
+    if (is_pi) grad_wide_bf_body<CONT, true, NTW, MT, KT1C, KS1C, PASS, NW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b, dz1);
+    else grad_wide_bf_body<CONT, false, NTW, MT, KT1C, KS1C, PASS, NW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem_bf, nb, b,
+                                                                       dz1 ? dz1 + dz1_net_stride : nullptr);
 }
