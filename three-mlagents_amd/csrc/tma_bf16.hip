@@ -59,6 +59,24 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
             *n_pi_out = n_pi, *n_vf_out = n_vf;
             return TMA_OK;
         }
+        // ... and the Crawler width (Box head, 161 .. 192 observations, two launches): 32-row groups on eight waves
+        if (nw8 && variant == 3 && L.cont && L.H == 256) {
+            bf16_t *const dz1c8 = (bf_two_pass(L) && M.count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
+                ? reinterpret_cast<bf16_t *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
+            const int smem8 = smemw + 4 * 4 * 5 * 8;  // + the statistics of four more waves
+            auto launch8 = [&](auto k, bf16_t *dz1) -> int {
+                TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
+                k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
+                return TMA_OK;
+            };
+            int rc8 = launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 6, 0, 8>, dz1c8);
+            if (rc8) return rc8;
+            rc8 = dz1c8 ? launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 6, 2, 8>, dz1c8) : launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 6, 1, 8>, nullptr);
+            if (rc8) return rc8;
+            TMA_LAUNCH_CHECK();
+            *n_pi_out = n_pi, *n_vf_out = n_vf;
+            return TMA_OK;
+        }
         // two-pass layouts: minibatches that fit the dz1 cache take PASS 0 (which leaves dz1 there) + PASS 2 (dW1 from the cache)
         // instead of PASS 0 + PASS 1 (dW1 from a recomputed forward / backward chain); the results are bit-identical
         bf16_t *const dz1_cache = (bf_two_pass(L) && M.count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))  // (env: test hook for the fallback)

@@ -310,8 +310,13 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                                                   const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                   double *__restrict__ stat_slot, char *smem, int n_blocks_net, int block_net,
                                                   bf16_t *__restrict__ dz1c) {
-    static_assert(NW == 4 || (NW == 8 && MT == 4 && KS1C == 1 && PASS == 0 && !CONT), "eight waves: 64-row groups, one layer-1 k-step, Discrete heads");
+    static_assert(NW == 4 || (NW == 8 && ((MT == 4 && KS1C == 1 && PASS == 0 && !CONT) || (MT == 2 && KS1C > 2 && KT1C == 0))),
+                  "eight waves: 64-row groups of the single-k-step Discrete layouts, or 32-row groups of the wide-observation two-pass layouts");
     constexpr bool W8 = NW == 8;
+#ifndef TMA_BF_W8_BIAS_VALU
+#define TMA_BF_W8_BIAS_VALU 1
+#endif
+    constexpr bool BV = W8 && TMA_BF_W8_BIAS_VALU;  // hidden-layer bias gradients as per-lane sums (A/B: 0 = the ones^T . dz accumulator tiles, 12 more registers)
     constexpr int M = 16 * MT, MK = MT / 2, H = 16 * NTW * NW, KS2 = H / 32, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, lda = H + 16, ldz = 48, ld3 = 34;
     // weight stream of a row group: [layer-1 fragments when KS1C > 1: k-step outer, tile inner] [layer-2 forward] [layer-2 input-gradient]
     constexpr int S1 = KS1C > 1 ? KS1C * NTW : 0, SL = S1 + 2 * KS2 * NTW;
@@ -397,12 +402,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     const bf16_t one_bf = (bf16_t)1.0f;
     const bf16x8 ones8 = bf16x8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
     f32x4 aW2[KT2][NTW], aW1[KT1A][NTW], aW3[NTW][NT3];
-    f32x4 aB1[W8 ? 1 : NTW], aB2[W8 ? 1 : NTW];  // hidden-layer bias gradients: column sums of dz as ones^T . dz on the MFMA (every row of the tile holds the sum)
+    f32x4 aB1[BV ? 1 : NTW], aB2[BV ? 1 : NTW];  // hidden-layer bias gradients: column sums of dz as ones^T . dz on the MFMA (every row of the tile holds the sum)
     float sB1[NTW], sB2[NTW];  // W8: the same sums per lane (this lane's 16 rows of the column), folded over the four lane groups at the end
     float ab3 = 0.0f, dlsd[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
-        if (!W8 || j == 0) aB1[W8 ? 0 : j] = aB2[W8 ? 0 : j] = z4;
+        if (!BV || j == 0) aB1[BV ? 0 : j] = aB2[BV ? 0 : j] = z4;
         sB1[j] = sB2[j] = 0.0f;
 #pragma unroll
         for (int i = 0; i < KT1A; i++) aW1[i][j] = z4;
@@ -439,7 +444,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
         for (int j = 0; j < NTW; j++) w1r[j] = bf_frag(W.fW1, nt0 + j, lane);
     }
-    if constexpr (W8) {  // head fragments -> LDS, once per launch (the group loop's first barrier is ahead of their first use)
+    if constexpr (W8 && MT == 4) {  // head fragments -> LDS, once per launch (the group loop's first barrier is ahead of their first use)
         for (int f = wave; f < KS2 * NT3; f += NW) *reinterpret_cast<bf16x8 *>(W3lds + (f * 64 + lane0) * 8) = bf_frag(W.fW3, f, lane0);
     }
     // ---- prefetch registers for the next group's samples ----
@@ -531,8 +536,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             // address arithmetic -- the element-indexed form of this loop was instruction-bound, 9k cycles per group), all loads
             // of a column chunk are in flight before the first is converted, and a thread's 8 rows of one column are exactly
             // one 16-byte chunk of the T image (one ds_write_b128, conflict-free under the chunk swizzle).
-            static_assert(MT == 2, "direct gather: 8 rows per wave = one T-image chunk");
-            constexpr int RW = 8;
+            static_assert(MT == 2, "direct gather: 8 rows per wave = one T-image chunk (four waves), 4 rows = half a chunk (eight)");
+            constexpr int RW = M / NW;
             typedef const float __attribute__((address_space(1))) *gf_ptr;
             gf_ptr rbase[RW];
             bool rok[RW];
@@ -559,13 +564,17 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int k = 0; k < KCC; k++) {
                     const int c = c0 + 64 * k + lane;
                     if (c < Kp1) {
-                        bf16x8 col;
+                        bf16_t col[RW];
 #pragma unroll
                         for (int i = 0; i < RW; i++) {
                             col[i] = (bf16_t)((rok[i] && c < D) ? t[k][i] : 0.0f);
                             Xa[(wave * RW + i) * ldx + c] = col[i];
                         }
-                        *reinterpret_cast<bf16x8 *>(Xt + t_off<MT>(c, wave * RW)) = col;
+                        if constexpr (RW == 8) {
+                            *reinterpret_cast<bf16x8 *>(Xt + t_off<MT>(c, wave * RW)) = bf16x8{col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]};
+                        } else {
+                            *reinterpret_cast<bf16x4 *>(Xt + t_off<MT>(c, wave * RW)) = bf16x4{col[0], col[1], col[2], col[3]};
+                        }
                     }
                 }
             }
@@ -665,8 +674,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         // split-K head over the four waves.  KS2 % 4 == 0 (H = 128 / 256): wave w takes the k-steps of ITS OWN h2 columns
         // (ks = w*HK .. w*HK + HK - 1), so its partial product needs no barrier after the layer-2 epilogue; H = 192: ks = w, w + 4.
         constexpr int HK = (KS2 + 3) / 4;
-        constexpr bool OWNK = KS2 % 4 == 0;
-        auto head_ks = [&](int i) { return OWNK ? wave * HK + i : wave + 4 * i; };
+        constexpr bool BLOCKK = KS2 % 4 == 0;  // bf_head's rule: partial w covers k-steps w*HK .. (else w, w + 4)
+        constexpr bool OWNK = BLOCKK && !W8;   // ... which are this wave's own h2 columns when four waves hold 64 columns each: no barrier in front
+        auto head_ks = [&](int i) { return BLOCKK ? wave * HK + i : wave + 4 * i; };
         bf16x8 w3f[HK * NT3];
         auto head_partial = [&]() {
 #pragma unroll
@@ -689,7 +699,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         };
         bf16x8 w3all[(MT == 4 && !W8) ? KS2 * NT3 : 1];  // MT = 4: every head fragment (this wave runs the whole head of its row tile)
         if (!(dbg & 32)) {
-            if constexpr (W8) {
+            if constexpr (W8 && MT == 4) {
                 // (head fragments wait in LDS)
             } else if constexpr (MT == 4) {
 #pragma unroll
@@ -698,9 +708,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     for (int q = 0; q < NT3; q++) w3all[ks * NT3 + q] = bf_frag(W.fW3, q * KS2 + ks, lane);
             } else {
 #pragma unroll
-                for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase
+                for (int i = 0; i < HK; i++)  // this wave's head fragments: in flight behind the whole layer-2 phase (eight waves: the four head waves')
 #pragma unroll
-                    for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + (head_ks(i) < KS2 ? head_ks(i) : 0), lane);
+                    for (int q = 0; q < NT3; q++) w3f[i * NT3 + q] = bf_frag(W.fW3, q * KS2 + ((wave < 4 && head_ks(i) < KS2) ? head_ks(i) : 0), lane);
             }
             if constexpr (MT == 4) {
                 static_assert(NTW % 2 == 0 && S1 == 0, "64-row groups: even column-tile count, single layer-1 k-step");
@@ -843,7 +853,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int i = 0; i < HK; i++)
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
-                        const int ks = OWNK ? w * HK + i : w + 4 * i;
+                        const int ks = BLOCKK ? w * HK + i : w + 4 * i;
                         if (ks < KS2) {
                             const bf16x8 a = act_frag<MT>(A2, lda, T2, mt, ks, lane);
 #pragma unroll
@@ -907,7 +917,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         } else {
         if constexpr (!OWNK) {
-            if (!(dbg & 4)) head_partial();
+            if (!(dbg & 4) && (!W8 || wave < 4)) head_partial();
             __syncthreads();
         }
         TMA_TICK(4);
@@ -915,7 +925,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2*(wave >> 1) .. +1 of each lane group) ----
         static_assert(MT == 2 || MT == 4, "the loss / dz3 split below assumes two row tiles and four waves");
         if (!(dbg & 4)) {
-            const int mt = wave & 1, r_lo = 2 * (wave >> 1);
+            const int mt = wave & 1, r_lo = W8 ? (wave >> 1) : 2 * (wave >> 1), r_n = W8 ? 1 : 2;  // (eight waves: one row of every lane group each)
             f32x4 out[NT3];
 #pragma unroll
             for (int q = 0; q < NT3; q++) {
@@ -928,11 +938,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                       lane, r_lo, r_lo + 2);
+                                       lane, r_lo, r_lo + r_n);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (r < r_lo || r >= r_lo + 2) continue;
+                    if (r < r_lo || r >= r_lo + r_n) continue;
                     const int row = g * 4 + r;
                     const bool valid = row_off[mt * 16 + row] >= 0;
                     const float diff = out[0][r] - meta[(mt * 16 + row) * 4 + 2];
@@ -959,7 +969,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     v[j] = (bf16_t)(a < 16 * NT3 ? dzt[r16 * ld3 + a] : 0.0f);
                 }
                 *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
-            } else {  // Z3t[a][m]: lane = (a, 8-sample half of the tile); the f32 column sum feeds the head bias gradient
+            } else if (!W8 || wave < 4) {  // Z3t[a][m]: lane = (a, 8-sample half of the tile); the f32 column sum feeds the head bias gradient
                 const int a = lane & 31, half = lane >> 5;
                 bf16x8 v;
                 float c = 0.0f;
@@ -1012,7 +1022,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
                         }
                     }
-                    if constexpr (W8 && MAIN) sB2[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);  // (the bf16 deltas the weight gradient uses)
+                    if constexpr (BV && MAIN) sB2[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);  // (the bf16 deltas the weight gradient uses)
                     *tq = q;
                 }
             }
@@ -1034,7 +1044,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T2, n_base + 16 * j + r16, kk, g);
-            if constexpr (MAIN && !W8) {  // db2 += ones^T . dz2 (the bf16 deltas the weight gradient uses, f32 accumulate)
+            if constexpr (MAIN && !BV) {  // db2 += ones^T . dz2 (the bf16 deltas the weight gradient uses, f32 accumulate)
 #pragma unroll
                 for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1115,7 +1125,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                                 const f32x2 dz = delta2(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                                 q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                             }
-                            if constexpr (W8 && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
+                            if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
                             *tq = q;
                         }
                     }
@@ -1170,6 +1180,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const f32x2 dz = delta2(f32x2{dh1[j][mt][r0], dh1[j][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                     q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                 }
+                if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
                 *tq = q;
             }
         }
@@ -1180,7 +1191,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int kk = 0; kk < MK; kk++) zb[j][kk] = t_frag<MT>(T1, n_base + 16 * j + r16, kk, g);
-            if constexpr (MAIN && !W8) {  // db1 += ones^T . dz1
+            if constexpr (MAIN && !BV) {  // db1 += ones^T . dz1
 #pragma unroll
                 for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1263,7 +1274,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
         }
         if constexpr (MAIN) {
-            if constexpr (W8) {  // fold the four lane groups' partial sums (rows 4 g .. 4 g + 3 of every row tile) in a fixed order
+            if constexpr (BV) {  // fold the four lane groups' partial sums (rows 4 g .. 4 g + 3 of every row tile) in a fixed order
                 float v1 = sB1[j], v2 = sB2[j];
                 v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
                 v2 += __shfl_xor(v2, 16, 64), v2 += __shfl_xor(v2, 32, 64);
@@ -1290,7 +1301,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
         if constexpr (MT == 4) {  // every (head) wave holds the column sums of its row tile
             if (lane < 32 && (W8 ? wave >= 4 : true)) scratch[(wave & 3) * 32 + lane] = v;
-        } else if (wave >= 2) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
+        } else if (wave >= 2 && wave < 4) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
             if (lane < 32) scratch[(wave - 2) * 32 + lane] = v;
         }
         __syncthreads();
@@ -1306,7 +1317,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             if (wave == 0 && lane < 32) {
                 float s = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 4; w++) s += scratch[w * 32 + lane];
+                for (int w = 0; w < NW; w++) s += scratch[w * 32 + lane];  // (eight waves: rows 4 .. 7 lie in the dead head-partial area behind the scratch)
                 if (lane < A) slab[L.log_std + lane] = s;
             }
         }
