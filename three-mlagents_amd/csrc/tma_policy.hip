@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
 // reference's literal batch_size = 256: 8 groups per net = 16 workgroups; as half groups 32): the second row tile's MFMAs, LDS traffic and
 // epilogues are compiled out, the sample dimension of the weight-gradient GEMMs runs over 4 k-steps instead of 8.  Same operations per
 // element in the same order as the first row tile of a full group.
-template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C, bool HALF = false>
+// NW = 8 (round 4, single-pass shapes): two waves per SIMD, 32 columns each -- the dW2 slice of a wave is 128 accumulator registers instead of 256,
+// and one wave's LDS waits and epilogues run beside its SIMD partner's MFMAs (the f32 MFMA pipe was 60 % busy with one wave per SIMD).
+template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C, bool HALF = false, int NW = 4>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
                                                double *__restrict__ stat_slot, float *smem, int n_blocks_net, int block_net,
@@ -527,7 +529,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     // dz1c (two-pass widths, minibatches that fit the workspace cache): PASS 0 leaves every row group's dz1 there as the B operands
     // of the dW1 MFMAs ([group][wave][tile][lane][8 floats]); PASS 2 re-gathers the observation rows and runs only those MFMAs
     // -- same operands, same order as PASS 1 (the recompute pass, kept for larger minibatches), hence the same bits.
-    constexpr int M = 32, H = 64 * NTW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
+    static_assert(NW == 4 || (NW == 8 && PASS == 0 && KT1C > 0 && NQ1C == 0), "eight waves: single-pass shapes with dW1 in registers");
+    constexpr int M = 32, RW = M / NW, H = 16 * NTW * NW, KT2 = H / 16, NT3 = (IS_PI && CONT) ? 2 : 1, ld = H + 2, ld3 = 34;
     constexpr int MG = HALF ? 16 : 32, MTN = HALF ? 1 : 2, SN = HALF ? 4 : 8;  // rows per group, row tiles, sample k-steps of the weight-gradient GEMMs
     static_assert(!HALF || (PASS == 0 && KT1C > 0 && NQ1C == 0), "half groups: single-pass shapes with dW1 in registers");
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -551,7 +554,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     int64_t *row_off = reinterpret_cast<int64_t *>(meta + M * 4);
     float *scratch = reinterpret_cast<float *>(row_off + M);  // 64 floats
     float *hpart = scratch + 64;  // [4 waves][2 tiles][2][64 lanes][4]: split-K partial head outputs
-    float *bias = hpart + 4 * 2 * 2 * 256;  // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
+    float *bias = hpart + NW * 2 * 2 * 256;  // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
@@ -659,11 +662,11 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             // lane offset, no 64-bit per-lane address arithmetic) and a whole batch of loads is in flight before the first store.
             // (The element-indexed form of this loop -- e = tid + 256 i, row = e / D -- was instruction-bound at Crawler width.)
             typedef const float __attribute__((address_space(1))) *gf_ptr;
-            gf_ptr rbase[8];
-            bool rok[8];
+            gf_ptr rbase[RW];
+            bool rok[RW];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int64_t off = row_off[wave * 8 + i];
+            for (int i = 0; i < RW; i++) {
+                const int64_t off = row_off[wave * RW + i];
                 const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)off >> 32));
                 const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
                 rok[i] = offu >= 0;
@@ -671,13 +674,13 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
             const int Dp = (D + 3) & ~3;
             for (int c0 = 0; c0 < Dp; c0 += 192) {
-                float t[3][8];
+                float t[3][RW];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const int c = c0 + 64 * k + lane;
                     if (c0 + 64 * k < Dp) {  // (uniform) narrow observations: one column chunk
 #pragma unroll
-                        for (int i = 0; i < 8; i++) t[k][i] = rbase[i][c < D ? c : 0];
+                        for (int i = 0; i < RW; i++) t[k][i] = rbase[i][c < D ? c : 0];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -686,7 +689,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     const int c = c0 + 64 * k + lane;
                     if (c0 + 64 * k < Dp && c < Dp) {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) X[(wave * 8 + i) * ldx + c] = (rok[i] && c < D) ? t[k][i] : 0.0f;
+                        for (int i = 0; i < RW; i++) X[(wave * RW + i) * ldx + c] = (rok[i] && c < D) ? t[k][i] : 0.0f;
                     }
                 }
             }
@@ -821,7 +824,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         // ---- P3a: split-K head: wave w multiplies k-steps [w*H/16, (w+1)*H/16) of h2 for both row tiles; all of its weight loads
         // go out together (one L2 round trip per group instead of a dependent load per k-step on two waves) ----
         {
-            constexpr int HKS = H / 16;  // k-steps of 4 per wave
+            constexpr int HKS = H / (4 * NW);  // k-steps of 4 per wave
             float w3[HKS][NT3];
 #pragma unroll
             for (int i = 0; i < HKS; i++)
@@ -857,7 +860,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 const float b = bias[2 * H + col];
                 out[q] = f32x4{b, b, b, b};
 #pragma unroll
-                for (int w = 0; w < 4; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * 2 + mt) * 2 + q) * 64 + lane) * 4);
+                for (int w = 0; w < NW; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * 2 + mt) * 2 + q) * 64 + lane) * 4);
             }
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
@@ -1125,8 +1128,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     }
 }
 
-template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0, bool HALF = false>
-__global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
+template <bool CONT, int NTW, int KT1C, int PASS = 0, int NQ1C = 0, bool HALF = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void ppo_grad_wide_kernel(const float *__restrict__ params, PLayout L, Rollout rb, Minibatch mb, HParams hp,
                                                                const float *__restrict__ ws_adv, float *__restrict__ slabs,
                                                                double *__restrict__ stat_slots, int n_pi, float *__restrict__ dz1,
                                                                int64_t dz1_net_stride) {
@@ -1136,8 +1139,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_wide_kernel(const float *__re
     const int b = is_pi ? blockIdx.x : blockIdx.x - n_pi, nb = is_pi ? n_pi : (int)gridDim.x - n_pi;
     float *slab = slabs + (int64_t)b * L.P;
     double *slot = stat_slots + (int64_t)b * 8;
-    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C, HALF>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1);
-    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C, HALF>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1 ? dz1 + dz1_net_stride : nullptr);
+    if (is_pi) grad_wide_body<CONT, true, NTW, KT1C, PASS, NQ1C, HALF, NW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1);
+    else grad_wide_body<CONT, false, NTW, KT1C, PASS, NQ1C, HALF, NW>(params, L, rb, mb, hp, ws_adv, slab, slot, smem, nb, b, dz1 ? dz1 + dz1_net_stride : nullptr);
 }
 
 #include "tma_wide_bf16.h"
@@ -1153,9 +1156,9 @@ __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
     }
 }
 
-static int grad_wide_smem_bytes(const PLayout &L) {
+static int grad_wide_smem_bytes(const PLayout &L, int nw = 4) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + 4 * 2 * 2 * 256 + 2 * L.H + 32) * 4;
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + nw * 2 * 2 * 256 + 2 * L.H + 32) * 4;
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
@@ -2231,6 +2234,13 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
             return TMA_OK;
         };
+        const bool eight = L.H == 256 && (kt1 == 1 || kt1 == 2) && getenv("TMA_WIDE_NW4") == nullptr;
+        const int smem8 = grad_wide_smem_bytes(L, 8);
+        auto launch8 = [&](auto k) -> int {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, nullptr, DZ1_CAP * L.H);
+            return TMA_OK;
+        };
         // (as on the bf16 path) minibatches that fit the dz1 cache: chain pass + dW1 from the cached operands; else chain + recompute
         float *const dz1_cache = (f32_two_pass(L) && kt1 == 11 && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
             ? reinterpret_cast<float *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
@@ -2238,6 +2248,10 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             constexpr int NTWc = decltype(ntw)::value;
             auto both = [&](auto cont) -> int {
                 constexpr bool C = decltype(cont)::value;
+                if constexpr (NTWc == 4) {  // H = 256, single-pass shapes: eight waves of 32 columns (TMA_WIDE_NW4=1: four of 64)
+                    if (eight && kt1 == 1) return half ? launch8(ppo_grad_wide_kernel<C, 2, 1, 0, 0, true, 8>) : launch8(ppo_grad_wide_kernel<C, 2, 1, 0, 0, false, 8>);
+                    if (eight && kt1 == 2) return half ? launch8(ppo_grad_wide_kernel<C, 2, 2, 0, 0, true, 8>) : launch8(ppo_grad_wide_kernel<C, 2, 2, 0, 0, false, 8>);
+                }
                 if (kt1 == 1) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 1, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 1>);
                 if (kt1 == 2) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 2, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 2>);
                 if (kt1 == 11) {
