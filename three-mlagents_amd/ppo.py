@@ -281,6 +281,22 @@ class PPO:
         from . import dist as _dist
 
         comm, ok, why = None, False, ""
+
+        def agree(mine: bool) -> bool:  # MIN over the ranks of a local verdict (torch.distributed, the group that already works)
+            if self.world_size == 1:
+                return mine
+            import torch.distributed as tdist
+
+            flag = torch.tensor([1.0 if mine else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            return flag.item() == 1.0
+
+        # first agreement BEFORE any native collective step: a rank that cannot bind RCCL must not leave the others inside the unique-id
+        # broadcast or ncclCommInitRank
+        if not agree(bool(_lib.lib().tma_comm_available())):
+            print("three-mlagents_amd: native RCCL communicator not used (librccl.so.1 could not be bound on every rank); collectives go through "
+                  "torch.distributed", file=sys.stderr, flush=True)
+            return None
         try:
             comm = _dist.NativeComm(self.device)
             probe = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.rank + 1)
@@ -291,13 +307,8 @@ class PPO:
             why = "" if ok else "self-check of the native all-reduce against the expected sum failed"
         except Exception as exc:  # noqa: BLE001
             why = str(exc)
-        if self.world_size > 1:
-            import torch.distributed as tdist
-
-            flag = torch.tensor([1.0 if ok else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
-            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-            if ok and flag.item() != 1.0:
-                ok, why = False, "another rank could not use its native communicator"
+        if not agree(ok) and ok:
+            ok, why = False, "another rank could not use its native communicator"
         if ok:
             return comm
         if comm is not None:
