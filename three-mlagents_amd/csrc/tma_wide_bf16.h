@@ -30,7 +30,23 @@ __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return _
 // the epilogues of this kernel are instruction-issue-bound.  Component for component the same IEEE operations as
 // tma_tanh and as dz = dh * (1 - h * h), hence the same bits.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// PK = false: one element per instruction (opaque values between the steps keep the compiler from re-packing them).  Beside ANOTHER wave's MFMAs
+// on the same SIMD -- the eight-wave kernels -- packed f32 VALU costs more than it saves (MI355X_MICROARCH.md, 'price of one filler beside MFMAs';
+// measured round 4: 250 -> 245 us on the Ball3D shape), at one wave per SIMD it is the cheaper form (round 3: 266 -> 261 us).
+template <bool PK = true>
 __device__ __forceinline__ f32x2 tma_tanh2(f32x2 x) {
+    if constexpr (!PK) {
+        f32x2 o;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float t = x[i] * 2.8853900817779268f;
+            asm volatile("" : "+v"(t));
+            float d = __builtin_amdgcn_exp2f(t) + 1.0f;
+            asm volatile("" : "+v"(d));
+            o[i] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(d), 1.0f);
+        }
+        return o;
+    }
     const f32x2 t = x * 2.8853900817779268f;
     f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(t[0]);
@@ -41,7 +57,20 @@ __device__ __forceinline__ f32x2 tma_tanh2(f32x2 x) {
     r[1] = __builtin_amdgcn_rcpf(d[1]);
     return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
 }
+template <bool PK = true>
 __device__ __forceinline__ f32x2 delta2(f32x2 dh, f32x2 h) {
+    if constexpr (!PK) {
+        f32x2 o;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float hh = h[i] * h[i];
+            asm volatile("" : "+v"(hh));
+            float om = 1.0f - hh;
+            asm volatile("" : "+v"(om));
+            o[i] = dh[i] * om;
+        }
+        return o;
+    }
     const f32x2 hh = h * h;
     const f32x2 om = 1.0f - hh;
     return dh * om;
@@ -656,7 +685,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     bf16x4 q;
 #pragma unroll
                     for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
+                        const f32x2 th = tma_tanh2<!W8>(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
                         q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
@@ -754,7 +783,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             bf16x4 q;
 #pragma unroll
                             for (int r0 = 0; r0 < 4; r0 += 2) {
-                                const f32x2 th = tma_tanh2(f32x2{acc[jj][mt][r0], acc[jj][mt][r0 + 1]});
+                                const f32x2 th = tma_tanh2<!W8>(f32x2{acc[jj][mt][r0], acc[jj][mt][r0 + 1]});
                                 q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                                 for (int r = r0; r < r0 + 2; r++) {
@@ -810,7 +839,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     bf16x4 q;
 #pragma unroll
                     for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
+                        const f32x2 th = tma_tanh2<!W8>(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
                         q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
@@ -1015,7 +1044,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     bf16x4 q;
 #pragma unroll
                     for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 dz = delta2(f32x2{dh[r0], dh[r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                        const f32x2 dz = delta2<!W8>(f32x2{dh[r0], dh[r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                         q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
 #pragma unroll
                         for (int r = r0; r < r0 + 2; r++) {
@@ -1122,7 +1151,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             bf16x4 q;
 #pragma unroll
                             for (int r0 = 0; r0 < 4; r0 += 2) {
-                                const f32x2 dz = delta2(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                                const f32x2 dz = delta2<!W8>(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                                 q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                             }
                             if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
@@ -1177,7 +1206,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 bf16x4 q;
 #pragma unroll
                 for (int r0 = 0; r0 < 4; r0 += 2) {
-                    const f32x2 dz = delta2(f32x2{dh1[j][mt][r0], dh1[j][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
+                    const f32x2 dz = delta2<!W8>(f32x2{dh1[j][mt][r0], dh1[j][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
                     q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
                 }
                 if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
