@@ -100,12 +100,15 @@ __device__ __forceinline__ bf16x8 bf_frag(const bf16_t *__restrict__ img, int id
 }
 
 // ---- T image addressing: row `r` holds M bf16 (M/8 chunks of 16 bytes); chunk c is stored at position c ^ t_swz<MT>(r).
-// MT = 2 (64-byte rows): swz = (-(r >> 2)) & 3;  MT = 4 (128-byte rows): swz = 2 * ((r >> 1) & 3).  With either, the four
+// MT = 2 (64-byte rows): swz = (-(r >> 2)) & 3;  MT = 4 (128-byte rows): swz = r & 7.  With either, the four
 // 16-lane groups of a ds_read_b128 whose lanes read (row = r0 + (l&15), chunk = c0 + (l>>4)) cover 64 distinct banks.
+// (MT = 4, rounds 1-3: swz = 2 * ((r >> 1) & 3) -- just as free of conflicts for those reads, but the epilogues' ds_write_b64 quads (16
+// consecutive rows per lane group, banks taken modulo 32 for stores) then landed on FOUR positions: 16 LDS cycles an instruction instead
+// of 8, and the 16-byte stores of the observation / dz3 images 16 instead of 8 -- a third of the kernel's SQ_LDS_BANK_CONFLICT count.)
 template <int MT>
 __device__ __forceinline__ int t_swz(int r) {
     if constexpr (MT == 2) return (-(r >> 2)) & 3;
-    else return 2 * ((r >> 1) & 3);
+    else return r & 7;
 }
 template <int MT>
 __device__ __forceinline__ int t_off(int r, int m) {  // element offset of T[r][m]
