@@ -270,7 +270,7 @@ __device__ __forceinline__ void grad_h64_body(const float *__restrict__ params, 
 // h1, h2, dz3, dz2, dz1 and the observation tile in [sample][feature] form, which the weight-gradient MFMAs (dW += x^T . dz, the
 // contraction runs over SAMPLES there) read back transposed, off the dependent path.
 // Observations and per-sample scalars go straight from global memory to registers, one tile ahead.
-// Activation tiles: [16][68] floats with the column index XOR-ed by 16 * (row & 1): the b128 stores of the chain (lane (g, s) holds
+// Activation tiles: [16][64] floats with a column swizzle (tsw, tma_h64_tile.h): the b128 stores of the chain (lane (g, s) holds
 // four consecutive features of sample s) and the transposed b32 reads of the weight-gradient operands are both conflict-free.
 // ------------------------------------------------------------------------------------------
 

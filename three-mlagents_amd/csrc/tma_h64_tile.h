@@ -45,9 +45,14 @@ struct TileTicks {
 struct TileTicks {};
 #define H64_TICK(i) do {} while (0)
 #endif
-constexpr int LDT = 68;
+constexpr int LDT = 64;
 constexpr int T_PER_WAVE = 2 * 16 * LDT + 256 + 256;  // slot A, slot B, dz3 [16][16], X [16][16]
-__device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ ((row & 1) << 4)); }
+// Column swizzle of the [16][64] tiles: XOR with 16 (row & 1) + 4 ((row >> 1) & 3) + 32 (row >> 3).  Banks by the per-instruction rules of
+// MI355X_MICROARCH.md (LDS table): the chain's b128 stores (8 consecutive rows per lane group, modulo 32) land on eight distinct 16-byte
+// slots, the transposed b32 reads of the weight-gradient operands (rows 4s + g of two lane groups per half wave, modulo 32) on the two
+// halves of the bank row, and the b128 read-back of a tile (non-contiguous 16-lane groups, modulo 64) on 16 distinct slots: all
+// conflict-free.  (Rounds 1-3: rows of 68 floats, XOR 16 (row & 1) -- the transposed reads, 72 per tile, were 2-way: 4 LDS cycles instead of 2.)
+__device__ __forceinline__ int tsw(int row, int col) { return row * LDT + (col ^ (((row & 1) << 4) | (((row >> 1) & 3) << 2) | ((row >> 3) << 5))); }
 
 // ---- The two SMALL weight gradients of a tile on v_mfma_f32_4x4x1_16b_f32 (round 3).  dW1 = X^T . dz1 has D <= 8 useful rows and dW3 = h2^T . dz3
 // has n_out <= 8 useful columns; as 16x16x4 MFMAs each is 16 instructions of 32 cycles with 3/4 (GridWorld: D = 4, 5 actions) of every tile
