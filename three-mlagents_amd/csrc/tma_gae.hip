@@ -174,6 +174,9 @@ __global__ __launch_bounds__(GP_PROD + 64) void gae_pc_kernel(const float *__res
     __syncthreads();
     float last = 0.0f;
     const bool chain_lane = tid < GP_ENVS && i0 + tid < N;
+#ifndef TMA_GAE_NO_PRIO
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);  // the chain wave shares its SIMD with a producer wave: its dependent mul / add pairs go first
+#endif
     for (int k = 0; k < n_chunks; k++) {
         if (wave > 0) {
             float r[PER], v[PER], vn[PER], nn[PER];
