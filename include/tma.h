@@ -59,6 +59,8 @@ typedef struct tma_env tma_env;
  * separate refill kernel every ring_depth steps). */
 int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, uint32_t env_offset, int ring_depth,
                    tma_env **out);
+/* destroy drains the device; the handle's device blocks (up to 64 MiB each, 512 MiB per process) are kept for the next tma_env_create that asks
+ * for the same sizes -- the callers this replaces build and close a vector env per training run and per evaluation */
 int tma_env_destroy(tma_env *h);
 /* VecEnv.seed(seed): env i -> seed + i at the next reset (SB3 DummyVecEnv) */
 int tma_env_seed(tma_env *h, uint32_t seed_base);

@@ -376,10 +376,11 @@ def test_pipelined_logging_leaves_the_files_of_the_synchronous_order(tmp_path, m
 
     def run(name, sync):
         monkeypatch.chdir(tmp_path)
-        if sync:
-            monkeypatch.setenv("TMA_SYNC_LOGGING", "1")
-        else:
-            monkeypatch.delenv("TMA_SYNC_LOGGING", raising=False)
+        for var in ("TMA_SYNC_LOGGING", "TMA_SYNC_EVAL"):  # (TMA_SYNC_EVAL=1: EvalCallback waits for every evaluation where it starts it)
+            if sync:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
         cfg = harness.TrainConfig("gridworld", total_timesteps=6 * 256 * 64, n_envs=256, eval_episodes=20, eval_freq=4096, run_name=name, verbose=0, seed=3)
         res = harness.train_task(cfg, model_kwargs={"n_steps": 64, "batch_size": 2048, "n_epochs": 2, "policy_kwargs": {"net_arch": [64, 64]}})
         root = tmp_path / "runs" / "gridworld" / name
@@ -388,10 +389,17 @@ def test_pipelined_logging_leaves_the_files_of_the_synchronous_order(tmp_path, m
         mon = [ln.split(",")[:2] for ln in (root / "monitor" / "0.monitor.csv").read_text().splitlines()[2:] if not ln.startswith("#")]
         ev = np.load(root / "eval" / "evaluations.npz")
         model = harness.load_model("gridworld", res.model_filename)
-        return prog, mon, {k: ev[k].copy() for k in ev.files}, model.policy.params.cpu(), res
+        import io
+        import zipfile
 
-    prog_p, mon_p, ev_p, par_p, res_p = run("pipelined", False)
-    prog_s, mon_s, ev_s, par_s, res_s = run("sync", True)
+        with zipfile.ZipFile(root / "best_model" / "best_model.zip") as z:  # written from the snapshot the deferred evaluation ran on
+            best = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+            best_opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+            best_steps = __import__("json").loads(z.read("data").decode())["num_timesteps"]
+        return prog, mon, {k: ev[k].copy() for k in ev.files}, model.policy.params.cpu(), res, (best, best_opt, best_steps)
+
+    prog_p, mon_p, ev_p, par_p, res_p, best_p = run("pipelined", False)
+    prog_s, mon_s, ev_s, par_s, res_s, best_s = run("sync", True)
     assert len(prog_p) == len(prog_s) == 6
     for a, b in zip(prog_p, prog_s):
         for k in a:
@@ -402,3 +410,7 @@ def test_pipelined_logging_leaves_the_files_of_the_synchronous_order(tmp_path, m
     assert sorted(mon_p) == sorted(mon_s) and len(mon_p) > 100
     assert all(np.array_equal(ev_p[k], ev_s[k]) for k in ev_s) and ev_p["results"].shape[1] == 20
     assert torch.equal(par_p, par_s) and res_p.mean_reward == res_s.mean_reward
+    # the best model: the same evaluation won in both orders, and the zip holds the parameters / optimizer moments / step counters of THAT policy
+    assert best_p[2] == best_s[2] and best_p[0].keys() == best_s[0].keys() and all(torch.equal(best_p[0][k], best_s[0][k]) for k in best_s[0])
+    st_p, st_s = best_p[1].get("state", {}), best_s[1].get("state", {})
+    assert st_p.keys() == st_s.keys() and all(torch.equal(torch.as_tensor(st_p[i][k]), torch.as_tensor(st_s[i][k])) for i in st_s for k in st_s[i])

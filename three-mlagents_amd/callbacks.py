@@ -83,6 +83,10 @@ class BaseCallback:
         """Write out whatever the callback buffers in memory; PPO.learn calls it when training unwinds on an exception (on_training_end does
         not run then).  Engine extension of the SB3 protocol: SB3's own callbacks write as they go."""
 
+    def on_update_queued(self) -> None:
+        """Engine extension: PPO.learn calls it right after train() has QUEUED an update -- the GPU is busy for the length of the update, host work
+        done here costs no wall time (EvalCallback collects its deferred evaluation)."""
+
 
 class CallbackList(BaseCallback):
     def __init__(self, callbacks):
@@ -129,6 +133,10 @@ class CallbackList(BaseCallback):
     def flush(self) -> None:
         for c in self.callbacks:
             c.flush()
+
+    def on_update_queued(self) -> None:
+        for c in self.callbacks:
+            c.on_update_queued()
 
 
 class _Duck(BaseCallback):
@@ -204,6 +212,7 @@ class EvalCallback(BaseCallback):
         self.n_fresh_evaluations = 0
         self._cached_key, self._cached = None, None
         self._dirty = False
+        self._pending = None  # a deferred evaluation in flight on the model's side stream (_evaluate_fresh)
 
     def _policy_key(self):
         m = self.model
@@ -214,6 +223,10 @@ class EvalCallback(BaseCallback):
     def _flush(self, force: bool = True) -> None:
         import time as _time
 
+        if self._pending is not None:  # rows of the evaluation in flight have no results yet
+            if not force:
+                return
+            self._complete_pending()
         now = _time.monotonic()
         if not force and now - getattr(self, "_last_flush", -1e9) < self.flush_interval_s:
             return
@@ -264,6 +277,20 @@ class EvalCallback(BaseCallback):
                     side.wait_event(ev)
                 else:  # no update yet: the parameters were written by whatever the compute stream did before
                     side.wait_stream(main)
+            if side is not None and hasattr(model, "freeze_for_save") and not os.environ.get("TMA_SYNC_EVAL"):
+                # DEFERRED: queue the evaluation (reset + the first chunk: one episode per env at the reference's 100 episodes) on a snapshot of the
+                # parameters and return; the result is collected when the next fresh evaluation starts, at a flush or at training end -- the host
+                # goes straight on to queue train() instead of waiting here for the previous update AND the episodes (TMA_SYNC_EVAL=1: wait).
+                from .evaluation import evaluate_policy_begin
+
+                frozen = model.freeze_for_save() if self.best_model_save_path is not None else {"params": model.policy.params.clone()}
+                snap = torch.cuda.Event(enable_timing=False)
+                snap.record(side)
+                main.wait_event(snap)  # train() may overwrite the live buffers once the clones exist
+                state = evaluate_policy_begin(model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
+                                              params=frozen["params"], assume_clean_log=True)
+                self._pending = {"state": state, "frozen": frozen, "side": side, "rows": [], "timesteps": self.num_timesteps}
+                return
             rew, length = evaluate_policy(model, self.eval_env, n_eval_episodes=self.n_eval_episodes, deterministic=self.deterministic,
                                           return_episode_rewards=True)
             self._cached = (np.asarray(rew, np.float64), np.asarray(length, np.int64))
@@ -271,13 +298,45 @@ class EvalCallback(BaseCallback):
             if mean > self.best_mean_reward and self.best_model_save_path is not None:
                 model.save(os.path.join(self.best_model_save_path, "best_model"))  # (reads the parameters: same stream, same reasoning)
 
+    def _complete_pending(self) -> None:
+        """Collect the deferred evaluation: its rows get their results, best_model.zip is written from the snapshot the evaluation ran on."""
+        p = self._pending
+        if p is None:
+            return
+        self._pending = None
+        import torch
+
+        from .evaluation import evaluate_policy_finish
+
+        with torch.cuda.stream(p["side"]):  # (the stream the chunk was queued on: the pop synchronises only that one)
+            rew, length = evaluate_policy_finish(p["state"], return_episode_rewards=True)
+            self._cached = (np.asarray(rew, np.float64), np.asarray(length, np.int64))
+            for i in p["rows"]:
+                self.evaluations_results[i], self.evaluations_length[i] = self._cached
+            self.last_mean_reward = float(np.mean(self._cached[0]))
+            if self.last_mean_reward > self.best_mean_reward:
+                if self.best_model_save_path is not None:
+                    self.model.save(os.path.join(self.best_model_save_path, "best_model"), _frozen=p["frozen"])
+                self.best_mean_reward = self.last_mean_reward
+        if self.verbose >= 1:
+            print(f"Eval num_timesteps={p['timesteps']}, episode_reward={self.last_mean_reward:.2f} +/- {float(np.std(self._cached[0])):.2f}")
+        self._flush(force=self.n_fresh_evaluations <= 1)
+
     def _tick(self) -> None:
         key = self._policy_key()
         fresh = not (self.deterministic and key == self._cached_key and None not in key[:2])
         if fresh:
+            self._complete_pending()
             self._evaluate_fresh()
             self._cached_key = key
             self.n_fresh_evaluations += 1
+        if self._pending is not None:  # the row keeps SB3's cadence and timestep; its results arrive with _complete_pending
+            self.evaluations_timesteps.append(self.num_timesteps)
+            self.evaluations_results.append(None)
+            self.evaluations_length.append(None)
+            self._pending["rows"].append(len(self.evaluations_timesteps) - 1)
+            self._dirty = True
+            return
         rewards, lengths = self._cached
         self.evaluations_timesteps.append(self.num_timesteps)
         self.evaluations_results.append(rewards)
@@ -296,3 +355,6 @@ class EvalCallback(BaseCallback):
 
     def flush(self) -> None:
         self._flush()
+
+    def on_update_queued(self) -> None:
+        self._complete_pending()

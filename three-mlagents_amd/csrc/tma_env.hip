@@ -16,7 +16,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 namespace tma {
@@ -27,6 +30,81 @@ char *err_buf() {
 }
 
 enum { ACT_I32 = 0, ACT_I64 = 1, ACT_F32 = 2, ACT_TAPE = 3 };
+
+// ------------------------------------------------------------------------------------------
+// Device buffers of an env handle come from a small size-keyed cache: a handle owns ~25 allocations, hipMalloc / hipFree cost 50-150 us
+// each (hipFree also drains the device), and the callers this library replaces build and close a vector env per training run and per
+// evaluation (training.py:71-89, 227-247) -- 3 ms of a 90 ms train_task call went into closing its two envs.  Freed blocks of up to 64 MiB
+// are kept (at most 512 MiB per process) and handed to the next request of exactly that size on that device; tma_env_destroy drains the
+// device first, so no kernel of the old handle can still touch a block when it is handed out again.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;
+    std::unordered_map<void *, std::pair<int, size_t>> live;
+    size_t cached_bytes = 0;
+};
+BlockCache &block_cache() {
+    static BlockCache *c = new BlockCache;  // (never destroyed: the HIP runtime may be gone by the time statics are)
+    return *c;
+}
+constexpr size_t CACHE_BLOCK_MAX = 64u << 20, CACHE_TOTAL_MAX = 512u << 20;
+}  // namespace
+
+template <class P>
+hipError_t env_malloc(P **p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    BlockCache &c = block_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_blocks.find({dev, bytes});
+        if (it != c.free_blocks.end()) {
+            *p = static_cast<P *>(it->second);
+            c.cached_bytes -= bytes;
+            c.free_blocks.erase(it);
+            c.live[*p] = {dev, bytes};
+            return hipSuccess;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {  // out of memory with blocks parked in the cache: give them back and try once more
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            for (auto &kv : c.free_blocks) (void)hipFree(kv.second);
+            c.free_blocks.clear();
+            c.cached_bytes = 0;
+        }
+        (void)hipGetLastError();
+        e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return e;
+    }
+    *p = static_cast<P *>(q);
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.live[q] = {dev, bytes};
+    return hipSuccess;
+}
+
+void env_free(void *p) {
+    if (!p) return;
+    BlockCache &c = block_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const auto key = it->second;
+            c.live.erase(it);
+            if (key.second <= CACHE_BLOCK_MAX && c.cached_bytes + key.second <= CACHE_TOTAL_MAX) {
+                c.free_blocks.insert({key, p});
+                c.cached_bytes += key.second;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
 
 // ------------------------------------------------------------------------------------------
 // step kernel: n_steps vector steps with the state held in registers.
@@ -504,14 +582,14 @@ static int env_alloc(tma_env *h, int task, int64_t num_envs, int ring_depth) {
     const TaskMeta &m = kMeta[task];
     EnvView &v = h->v;
     const size_t n = (size_t)num_envs;
-    TMA_HIP(hipMalloc(&v.st, sizeof(uint32_t) * n * m.sw));
+    TMA_HIP(env_malloc(&v.st, sizeof(uint32_t) * n * m.sw));
     TMA_HIP(hipMemset(v.st, 0, sizeof(uint32_t) * n * m.sw));
-    if (m.uses_mt) TMA_HIP(hipMalloc(&v.ring, sizeof(uint32_t) * n * m.rw * ring_depth));
-    TMA_HIP(hipMalloc(&v.cur_ep, sizeof(uint32_t) * n));
-    TMA_HIP(hipMalloc(&v.filled_hi, sizeof(uint32_t) * n));
-    TMA_HIP(hipMalloc(&v.ep_ret, sizeof(double) * n));
+    if (m.uses_mt) TMA_HIP(env_malloc(&v.ring, sizeof(uint32_t) * n * m.rw * ring_depth));
+    TMA_HIP(env_malloc(&v.cur_ep, sizeof(uint32_t) * n));
+    TMA_HIP(env_malloc(&v.filled_hi, sizeof(uint32_t) * n));
+    TMA_HIP(env_malloc(&v.ep_ret, sizeof(double) * n));
     const size_t n_stat = (size_t)ceil_div(num_envs, 256) * 3;
-    TMA_HIP(hipMalloc(&v.stats, sizeof(double) * n_stat));
+    TMA_HIP(env_malloc(&v.stats, sizeof(double) * n_stat));
     TMA_HIP(hipMemset(v.cur_ep, 0, sizeof(uint32_t) * n));
     TMA_HIP(hipMemset(v.filled_hi, 0, sizeof(uint32_t) * n));
     TMA_HIP(hipMemset(v.ep_ret, 0, sizeof(double) * n));
@@ -522,14 +600,14 @@ static int env_alloc(tma_env *h, int task, int64_t num_envs, int ring_depth) {
         // fallback-list capacity = items per refill round: 2^20, or a quarter of the largest possible refill beyond 4 M items
         const int64_t max_items = num_envs * (int64_t)(ring_depth + 1);
         rv.fb_cap = (int)std::min<int64_t>(std::max<int64_t>(FB_CAP, ceil_div(max_items, 4)), (int64_t)INT_MAX);
-        TMA_HIP(hipMalloc(&rv.first_ep, sizeof(uint32_t) * n));
-        TMA_HIP(hipMalloc(&rv.env_off, sizeof(uint32_t) * n));
-        TMA_HIP(hipMalloc(&rv.block_sum, sizeof(uint32_t) * rv.nb));
-        TMA_HIP(hipMalloc(&rv.block_off, sizeof(uint32_t) * rv.nb));
-        TMA_HIP(hipMalloc(&rv.total, sizeof(uint32_t) * 2));
-        TMA_HIP(hipMalloc(&rv.fb_env, sizeof(uint32_t) * (size_t)rv.fb_cap));
-        TMA_HIP(hipMalloc(&rv.fb_ep, sizeof(uint32_t) * (size_t)rv.fb_cap));
-        TMA_HIP(hipMalloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)FB_BLOCKS * 256));
+        TMA_HIP(env_malloc(&rv.first_ep, sizeof(uint32_t) * n));
+        TMA_HIP(env_malloc(&rv.env_off, sizeof(uint32_t) * n));
+        TMA_HIP(env_malloc(&rv.block_sum, sizeof(uint32_t) * rv.nb));
+        TMA_HIP(env_malloc(&rv.block_off, sizeof(uint32_t) * rv.nb));
+        TMA_HIP(env_malloc(&rv.total, sizeof(uint32_t) * 2));
+        TMA_HIP(env_malloc(&rv.fb_env, sizeof(uint32_t) * (size_t)rv.fb_cap));
+        TMA_HIP(env_malloc(&rv.fb_ep, sizeof(uint32_t) * (size_t)rv.fb_cap));
+        TMA_HIP(env_malloc(&h->mt_scratch, sizeof(uint32_t) * 624 * (size_t)FB_BLOCKS * 256));
     }
     return TMA_OK;
 }
@@ -539,29 +617,30 @@ extern "C" {
 int tma_env_destroy(tma_env *h) {
     if (!h) return TMA_OK;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->v.st);
-    (void)hipFree(h->v.ring);
-    (void)hipFree(h->v.cur_ep);
-    (void)hipFree(h->v.filled_hi);
-    (void)hipFree(h->v.ep_ret);
-    (void)hipFree(h->v.stats);
-    (void)hipFree(h->v.log_ret);
-    (void)hipFree(h->v.log_len);
-    (void)hipFree(h->v.log_env);
-    (void)hipFree(h->v.log_n);
+    (void)hipDeviceSynchronize();  // the blocks go back to the cache: no kernel of this handle may still be running when one is handed out again
+    env_free(h->v.st);
+    env_free(h->v.ring);
+    env_free(h->v.cur_ep);
+    env_free(h->v.filled_hi);
+    env_free(h->v.ep_ret);
+    env_free(h->v.stats);
+    env_free(h->v.log_ret);
+    env_free(h->v.log_len);
+    env_free(h->v.log_env);
+    env_free(h->v.log_n);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_chunk) (void)hipEventDestroy(h->ev_chunk);
     for (hipEvent_t e : h->ev_side)
         if (e) (void)hipEventDestroy(e);
-    (void)hipFree(h->d_stats), (void)hipFree(h->d_log_ret), (void)hipFree(h->d_log_len), (void)hipFree(h->d_log_env), (void)hipFree(h->d_log_n);
-    (void)hipFree(h->mt_scratch);
-    (void)hipFree(h->rv.first_ep);
-    (void)hipFree(h->rv.env_off);
-    (void)hipFree(h->rv.block_sum);
-    (void)hipFree(h->rv.block_off);
-    (void)hipFree(h->rv.total);
-    (void)hipFree(h->rv.fb_env);
-    (void)hipFree(h->rv.fb_ep);
+    env_free(h->d_stats), env_free(h->d_log_ret), env_free(h->d_log_len), env_free(h->d_log_env), env_free(h->d_log_n);
+    env_free(h->mt_scratch);
+    env_free(h->rv.first_ep);
+    env_free(h->rv.env_off);
+    env_free(h->rv.block_sum);
+    env_free(h->rv.block_off);
+    env_free(h->rv.total);
+    env_free(h->rv.fb_env);
+    env_free(h->rv.fb_ep);
     delete h;
     return TMA_OK;
 }
@@ -699,17 +778,17 @@ int tma_env_episode_log(tma_env *h, int64_t capacity) {
     TMA_HIP(hipSetDevice(h->device));
     TMA_HIP(hipDeviceSynchronize());  // no step kernel may hold the old view
     EnvView &v = h->v;
-    (void)hipFree(v.log_ret), (void)hipFree(v.log_len), (void)hipFree(v.log_env), (void)hipFree(v.log_n);
+    env_free(v.log_ret), env_free(v.log_len), env_free(v.log_env), env_free(v.log_n);
     v.log_ret = nullptr, v.log_len = nullptr, v.log_env = nullptr, v.log_n = nullptr, v.log_cap = 0;
-    (void)hipFree(h->d_log_ret), (void)hipFree(h->d_log_len), (void)hipFree(h->d_log_env), (void)hipFree(h->d_log_n);  // (the spare set has the old capacity)
+    env_free(h->d_log_ret), env_free(h->d_log_len), env_free(h->d_log_env), env_free(h->d_log_n);  // (the spare set has the old capacity)
     h->d_log_ret = nullptr, h->d_log_len = nullptr, h->d_log_env = nullptr, h->d_log_n = nullptr;
     h->detached = false;  // (a detached, unpopped log goes with its buffers; the detached aggregates are cleared below)
     if (h->d_stats) TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * 3 * (size_t)ceil_div(v.N, 256)));
     if (capacity == 0) return TMA_OK;
-    TMA_HIP(hipMalloc(&v.log_ret, sizeof(double) * (size_t)capacity));
-    TMA_HIP(hipMalloc(&v.log_len, sizeof(int32_t) * (size_t)capacity));
-    TMA_HIP(hipMalloc(&v.log_env, sizeof(int32_t) * (size_t)capacity));
-    TMA_HIP(hipMalloc(&v.log_n, sizeof(unsigned long long)));
+    TMA_HIP(env_malloc(&v.log_ret, sizeof(double) * (size_t)capacity));
+    TMA_HIP(env_malloc(&v.log_len, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(env_malloc(&v.log_env, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(env_malloc(&v.log_n, sizeof(unsigned long long)));
     TMA_HIP(hipMemset(v.log_n, 0, sizeof(unsigned long long)));
     v.log_cap = capacity;
     return TMA_OK;
@@ -807,14 +886,14 @@ int tma_env_detach_episode_log(tma_env *h) {
     EnvView &v = h->v;
     const size_t n_stat = (size_t)ceil_div(v.N, 256) * 3;
     if (!h->d_stats) {
-        TMA_HIP(hipMalloc(&h->d_stats, sizeof(double) * n_stat));
+        TMA_HIP(env_malloc(&h->d_stats, sizeof(double) * n_stat));
         TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * n_stat));
     }
     if (v.log_n && !h->d_log_n) {
-        TMA_HIP(hipMalloc(&h->d_log_ret, sizeof(double) * (size_t)v.log_cap));
-        TMA_HIP(hipMalloc(&h->d_log_len, sizeof(int32_t) * (size_t)v.log_cap));
-        TMA_HIP(hipMalloc(&h->d_log_env, sizeof(int32_t) * (size_t)v.log_cap));
-        TMA_HIP(hipMalloc(&h->d_log_n, sizeof(unsigned long long)));
+        TMA_HIP(env_malloc(&h->d_log_ret, sizeof(double) * (size_t)v.log_cap));
+        TMA_HIP(env_malloc(&h->d_log_len, sizeof(int32_t) * (size_t)v.log_cap));
+        TMA_HIP(env_malloc(&h->d_log_env, sizeof(int32_t) * (size_t)v.log_cap));
+        TMA_HIP(env_malloc(&h->d_log_n, sizeof(unsigned long long)));
         TMA_HIP(hipMemset(h->d_log_n, 0, sizeof(unsigned long long)));
     }
     std::swap(v.stats, h->d_stats);

@@ -44,13 +44,16 @@ class _EvalBuffers:
                                       _lib.ptr(self.terminated), _lib.ptr(self.truncated), _lib.ptr(self.terminal_obs), _lib.ptr(self.last_values), N, self.tobs_slots)
 
 
-def evaluate_policy(model, env, n_eval_episodes: int = 10, deterministic: bool = True, return_episode_rewards: bool = False, warn: bool = True,
-                    max_steps: int = 10_000_000, chunk_steps: int | None = None):
+def evaluate_policy_begin(model, env, n_eval_episodes: int = 10, deterministic: bool = True, max_steps: int = 10_000_000,
+                          chunk_steps: int | None = None, params: torch.Tensor | None = None, assume_clean_log: bool = False) -> dict:
+    """First half of evaluate_policy: reset + the FIRST native rollout chunk, enqueued on the current stream; nothing here waits for the GPU
+    when the env's episode log is known to be empty (`assume_clean_log` and the env was last used by a finished evaluation), so a caller
+    may queue it on a side stream and collect the result later (callbacks.EvalCallback).  `params`: the flat parameter buffer to evaluate
+    (default: the model's live one) -- a snapshot lets the optimizer move on while the chunk runs."""
     eng = env.engine
     if getattr(model, "env", None) is env:  # the training env: its episode log feeds the Monitor file -- leave it alone
-        return evaluate_policy_stepwise(model, env, n_eval_episodes, deterministic, return_episode_rewards, warn, max_steps)
+        return {"stepwise": evaluate_policy_stepwise(model, env, n_eval_episodes, deterministic, True, True, max_steps)}
     n = eng.num_envs
-    targets = _targets(n_eval_episodes, n)
     pol = model.policy
     if pol.device != eng.device:
         raise ValueError(f"policy lives on {pol.device}, the evaluation env on {eng.device}")
@@ -65,33 +68,60 @@ def evaluate_policy(model, env, n_eval_episodes: int = 10, deterministic: bool =
     cap = max(4096, K * n)  # at most one episode per env and step can finish inside a chunk
     if getattr(eng, "_log_cap", 0) < cap:
         eng.episode_log(cap)
-    L = _lib.lib()
-    stream = _lib.stream_ptr(eng.device)
+        eng._eval_log_clean = False
     eng.reset(bufs.obs[0])
-    eng.pop_episode_log()       # (drop what an earlier user of the env left)
-    eng.pop_episode_stats()
-    counts, t_end = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
-    found: list[tuple[int, int, float, int]] = []
-    seed = (model.seed ^ 0xE7A1) & 0xFFFFFFFF
-    steps = 0
-    while (counts < targets).any() and steps < max_steps:
-        _lib.check(L.tma_rollout_collect(eng._h, _lib.ptr(pol.params), C.byref(pol.dims), C.byref(bufs.rb), 0, K, K, seed, steps & 0xFFFFFFFF,
-                                         eng.env_offset & 0xFFFFFFFF, float(getattr(model, "gamma", 0.99)), 0, 1 if deterministic else 0, stream))
-        bufs.obs[0].copy_(bufs.obs[K])  # the next chunk continues from the last observation
-        steps += K
-        r, l, e, seen = eng.pop_episode_log()  # synchronises the stream: ONE host round trip per chunk
-        if seen > len(r):
-            raise RuntimeError(f"evaluation episode log overflowed ({seen} episodes in one chunk of {K} steps, capacity {len(r)})")
-        for ret, length, i in zip(r.tolist(), l.tolist(), e.tolist()):  # per env in the order the episodes finished
-            if counts[i] < targets[i]:
-                t_end[i] += int(length)  # the evaluation started from reset(): episode k of env i ends at the sum of its first k lengths
-                found.append((int(t_end[i]), int(i), float(ret), int(length)))
-                counts[i] += 1
-    found.sort()  # by finishing step, then env: the order a per-step loop sees them (evaluate_policy_stepwise)
-    rewards, lengths = [f[2] for f in found], [f[3] for f in found]
+    if not (assume_clean_log and getattr(eng, "_eval_log_clean", False)):  # (HipEnvEngine.step clears the mark)
+        eng.pop_episode_log()       # (drop what an earlier user of the env left; synchronises the stream)
+        eng.pop_episode_stats()
+    eng._eval_log_clean = False
+    st = {"model": model, "env": env, "bufs": bufs, "K": K, "n": n, "targets": _targets(n_eval_episodes, n), "counts": np.zeros(n, dtype=np.int64),
+          "t_end": np.zeros(n, dtype=np.int64), "found": [], "seed": (model.seed ^ 0xE7A1) & 0xFFFFFFFF, "steps": 0, "max_steps": max_steps,
+          "deterministic": deterministic, "params": pol.params if params is None else params, "gamma": float(getattr(model, "gamma", 0.99)), "queued": False}
+    _eval_chunk(st)
+    return st
+
+
+def _eval_chunk(st: dict) -> None:
+    eng, bufs, K, pol = st["env"].engine, st["bufs"], st["K"], st["model"].policy
+    _lib.check(_lib.lib().tma_rollout_collect(eng._h, _lib.ptr(st["params"]), C.byref(pol.dims), C.byref(bufs.rb), 0, K, K, st["seed"], st["steps"] & 0xFFFFFFFF,
+                                             eng.env_offset & 0xFFFFFFFF, st["gamma"], 0, 1 if st["deterministic"] else 0, _lib.stream_ptr(eng.device)))
+    bufs.obs[0].copy_(bufs.obs[K])  # the next chunk continues from the last observation
+    st["steps"] += K
+    st["queued"] = True
+
+
+def evaluate_policy_finish(st: dict, return_episode_rewards: bool = False):
+    """Second half: pop the episode log of the chunk in flight (ONE host round trip per chunk, on the current stream -- the stream the chunk was
+    queued on), run further chunks while episodes are missing."""
+    if "stepwise" in st:
+        rewards, lengths = st["stepwise"]
+    else:
+        eng, counts, targets, t_end, found = st["env"].engine, st["counts"], st["targets"], st["t_end"], st["found"]
+        while True:
+            if not st["queued"]:
+                if not ((counts < targets).any() and st["steps"] < st["max_steps"]):
+                    break
+                _eval_chunk(st)
+            r, l, e, seen = eng.pop_episode_log()  # synchronises the stream
+            st["queued"] = False
+            if seen > len(r):
+                raise RuntimeError(f"evaluation episode log overflowed ({seen} episodes in one chunk of {st['K']} steps, capacity {len(r)})")
+            for ret, length, i in zip(r.tolist(), l.tolist(), e.tolist()):  # per env in the order the episodes finished
+                if counts[i] < targets[i]:
+                    t_end[i] += int(length)  # the evaluation started from reset(): episode k of env i ends at the sum of its first k lengths
+                    found.append((int(t_end[i]), int(i), float(ret), int(length)))
+                    counts[i] += 1
+        eng._eval_log_clean = True  # every record of every chunk has been popped
+        found.sort()  # by finishing step, then env: the order a per-step loop sees them (evaluate_policy_stepwise)
+        rewards, lengths = [f[2] for f in found], [f[3] for f in found]
     if return_episode_rewards:
         return rewards, lengths
     return float(np.mean(rewards)), float(np.std(rewards))
+
+
+def evaluate_policy(model, env, n_eval_episodes: int = 10, deterministic: bool = True, return_episode_rewards: bool = False, warn: bool = True,
+                    max_steps: int = 10_000_000, chunk_steps: int | None = None):
+    return evaluate_policy_finish(evaluate_policy_begin(model, env, n_eval_episodes, deterministic, max_steps, chunk_steps), return_episode_rewards)
 
 
 def evaluate_policy_stepwise(model, env, n_eval_episodes: int = 10, deterministic: bool = True, return_episode_rewards: bool = False,

@@ -564,6 +564,7 @@ class PPO:
                     ev_roll = torch.cuda.Event()
                     ev_roll.record(torch.cuda.current_stream(self.device))
                 self.train()
+                cb.on_update_queued()  # (EvalCallback collects its deferred evaluation here: host work under the update the GPU is now running)
                 if logging and pipelined:
                     # (order matters: device-to-host copies of every stream share one in-order copy queue, so the side stream's read-back goes
                     #  in BEFORE the compute stream's statistics copy, which sits behind the whole update -- queued the other way round the
@@ -770,7 +771,16 @@ class PPO:
         data.update(sb3_format.data_members(obs_space, act_space))
         return data
 
-    def save(self, path, exclude=None, include=None) -> None:
+    def freeze_for_save(self) -> dict:
+        """Everything save() reads, as of NOW in stream order: device clones of the parameter buffer (weight images included: a deferred evaluation
+        runs on it) and of the optimizer moments, queued on the current stream, plus the host-side members.  save(path, _frozen=...) writes the zip
+        from it later -- EvalCallback's best_model.zip of an evaluation whose result arrives after train() has already moved the live buffers."""
+        has_moments = getattr(self, "exp_avg", None) is not None
+        return {"params": self.policy.params.clone(), "exp_avg": self.exp_avg.clone() if has_moments else None,
+                "exp_avg_sq": self.exp_avg_sq.clone() if has_moments else None, "adam_step": self._adam_step if has_moments else 0,
+                "data": json.dumps(self._data(), indent=2, default=str)}
+
+    def save(self, path, exclude=None, include=None, _frozen: dict | None = None) -> None:
         path = str(path)
         if not os.path.splitext(path)[1]:
             path += ".zip"
@@ -783,15 +793,17 @@ class PPO:
 
         from . import sb3_format
 
-        sd = self.policy.state_dict()
+        fz = _frozen
+        sd = self.policy.state_dict() if fz is None else self.policy.named_from_flat(fz["params"][: self.policy.n_trainable])
         order = sb3_format.parameter_order(self.policy.continuous)
         sd = {k: sd[k] for k in order}  # torch's registration order of an ActorCriticPolicy: also the optimizer's parameter indices
-        has_moments = getattr(self, "exp_avg", None) is not None  # (a model loaded without an env has a policy but no optimizer state)
-        opt = sb3_format.adam_state_dict(order, self.policy.named_from_flat(self.exp_avg) if has_moments else {},
-                                         self.policy.named_from_flat(self.exp_avg_sq) if has_moments else {}, self._adam_step if has_moments else 0,
-                                         self.learning_rate)
+        exp_avg, exp_avg_sq = (getattr(self, "exp_avg", None), getattr(self, "exp_avg_sq", None)) if fz is None else (fz["exp_avg"], fz["exp_avg_sq"])
+        has_moments = exp_avg is not None  # (a model loaded without an env has a policy but no optimizer state)
+        adam_step = (self._adam_step if fz is None else fz["adam_step"]) if has_moments else 0
+        opt = sb3_format.adam_state_dict(order, self.policy.named_from_flat(exp_avg) if has_moments else {},
+                                         self.policy.named_from_flat(exp_avg_sq) if has_moments else {}, adam_step, self.learning_rate)
         with zipfile.ZipFile(path, "w") as z:  # stored, not deflated: what SB3's save_to_zip_file writes (and EvalCallback saves a zip per new best)
-            z.writestr("data", json.dumps(self._data(), indent=2, default=str))
+            z.writestr("data", json.dumps(self._data(), indent=2, default=str) if fz is None else fz["data"])
             z.writestr("policy.pth", _pth(sd))
             z.writestr("policy.optimizer.pth", _pth(opt))
             z.writestr("pytorch_variables.pth", _pth({}))

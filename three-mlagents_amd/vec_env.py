@@ -125,6 +125,7 @@ class HipEnvEngine:
     def step(self, actions: torch.Tensor | None, *, n_steps: int = 1, tape_seed: int = 0, tape_t0: int = 0, outputs: dict | None = None,
              want_terminal_obs: bool = True, want_episode: bool = True) -> dict[str, torch.Tensor]:
         """One launch of `n_steps` vector steps.  `actions` None -> device-generated tape."""
+        self._eval_log_clean = False  # (evaluation.evaluate_policy_begin: episodes finished here land in the log a deferred evaluation would count)
         b = outputs if outputs is not None else self._out(n_steps)
         dtype = 0
         aptr = None
