@@ -470,7 +470,7 @@ def harness_train_task(args, dev):
                "eval_episodes": out.eval_episodes}
         if rep == 1:
             res = {"workload": f"train_task({args.task}, n_envs={args.n_envs}, total_timesteps={total}, batch_size={batch}, MLP {args.hidden}x{args.hidden}): PPO "
-                               "iterations + EvalCallback (eval_freq 10000 // n_envs vector steps, 100 episodes on a 64-env device eval vector) + Monitor rows + tb / "
+                               "iterations + EvalCallback (eval_freq 10000 // n_envs vector steps, 100 episodes on a 128-env device eval vector, queued on a parameter snapshot and collected under the next update) + Monitor rows + tb / "
                                "progress files + policy zip + final evaluation + metadata.json, next to the same iterations through PPO directly (construction "
                                "included on both sides)", **leg}
         elif rep == 2:
