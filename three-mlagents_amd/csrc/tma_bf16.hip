@@ -10,8 +10,22 @@
 #include <type_traits>
 
 namespace tma {
+#ifdef TMA_BF_PHASE_TICKS
+__device__ unsigned long long g_bf_ticks[2][16];
+#endif
 #include "tma_wide_bf16.h"
 }  // namespace tma
+
+#ifdef TMA_BF_PHASE_TICKS
+// diagnostic build only: read (reset != 0: clear) the per-phase cycle sums of the bf16 gradient kernel
+extern "C" int tma_debug_bf_ticks(unsigned long long *out32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(tma::g_bf_ticks), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(tma::g_bf_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 using namespace tma;
 

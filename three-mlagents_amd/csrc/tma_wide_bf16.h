@@ -363,13 +363,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // TMA_RELANE at the head of a phase re-derives lane / r16 / g from an opaque copy, so the addresses of that phase are
     // computed there (a few VALU instructions) and die with it.
     int lane = lane0, r16 = lane0 & 15, g = lane0 >> 4;
-#ifdef TMA_BF_PHASE_TICKS
-    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define TMA_TICK(i)                                    \
-    do {                                               \
-        const long long tn = clock64();                \
-        tph[i] += tn - tlast;                          \
-        tlast = tn;                                    \
+#ifdef TMA_BF_PHASE_TICKS  // diagnostic build (make libtma_hip_bfticks.so, tools/bf_ticks.py): cycles per phase, wave 0 of block 0 of each net
+    // (sums are kept in LDS and copied out once at the end: a global atomic per stamp stays in vmcnt for ~1 k cycles and every counted wait
+    //  for a weight fragment behind it would wait for it too)
+    __shared__ unsigned long long tick_lds[16];
+    if (threadIdx.x < 16) tick_lds[threadIdx.x] = 0;
+    long long tlast = clock64();
+    const bool tick_on = threadIdx.x == 0 && block_net == 0;
+#define TMA_TICK(i)                                                        \
+    do {                                                                   \
+        const long long tn = clock64();                                    \
+        if (tick_on) tick_lds[i] += (unsigned long long)(tn - tlast);      \
+        tlast = clock64();                                                 \
     } while (0)
 #else
 #define TMA_TICK(i)
@@ -1273,13 +1278,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             }
         }
         __syncthreads();
+        TMA_TICK(9);
     }
-#ifdef TMA_BF_PHASE_TICKS
     TMA_TICK(8);
-    if (threadIdx.x == 0 && block_net == 0 && mb.offs) {  // phase cycle counts of pair 0 -> tail of the offsets cache (debug builds only)
-        long long *dbg_out = reinterpret_cast<long long *>(const_cast<int32_t *>(mb.offs) + (1 << 22) - 64) + (IS_PI ? 0 : 12);
-        for (int i = 0; i < 12; i++) dbg_out[i] = tph[i];
-    }
+#ifdef TMA_BF_PHASE_TICKS
+    if (tick_on)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_bf_ticks[IS_PI ? 0 : 1][i], tick_lds[i]);
 #endif
 #undef TMA_RELANE
 #undef TMA_TICK
