@@ -1,0 +1,15 @@
+#!/bin/bash
+# The A/B switches of the library select the kernels of earlier rounds; each must keep passing the tests of the paths it touches.
+# Run on the GPU box: bash tools/test_switches.sh
+run() { echo "== $1"; env $1 python -m pytest $2 -m gpu -q -x 2>&1 | tail -1; }
+run "TMA_SYNC_EVAL=1" "tests/test_dropin_gpu.py"
+run "TMA_SYNC_LOGGING=1" "tests/test_dropin_gpu.py"
+run "TMA_BF_NW4=1" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
+run "TMA_WIDE_NW4=1" "tests/test_ppo_gpu.py"
+run "TMA_NO_HALF_GROUPS=1" "tests/test_ppo_gpu.py"
+run "TMA_CONT_TWO_NET=1" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
+run "TMA_CONT_SERIAL=1" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
+run "TMA_WIDE_ROWS=32" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
+run "TMA_CONT_ROWS=32" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
+run "TMA_NO_DZ1_CACHE=1" "tests/test_bf16_gpu.py"
+run "TMA_NO_NATIVE_RCCL=1" "tests/test_dist_gpu.py"
