@@ -10,8 +10,10 @@ Nothing is skipped inside the timed region.  `value` = env-steps of all ranks / 
 Run:  python bench.py [--gpus N --steps K --warmup W]
   N > 1 started as a plain process: this file starts N ranks itself (a child `python -m torch.distributed.run`, one rank per GPU,
   before this process makes any GPU call) and exits with the child's status; started under torch.distributed.run it is one rank.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline`, and (N = 1) `extra_configs` -- the
-other single-GPU BASELINE.json configs, time-boxed -- and `literal_batch_256`, the reference's literal batch_size on the headline shape.
+Prints ONE compact JSON line (< 4 KB) on rank 0: the contract keys, `roofline` (dominant kernel), `cpu_baseline` and one-number summaries of
+the other legs.  The full objects -- (N = 1) `extra_configs`, the other single-GPU BASELINE.json configs, time-boxed; `literal_batch_256`, the
+reference's literal batch_size on the headline shape; the harness leg; the per-config CPU table; the step / GAE / rollout rooflines -- go
+to `bench_extras.json` beside this file (and to gpurun_out/ when present); the line's `extras_path` names it.
 """
 from __future__ import annotations
 
@@ -640,6 +642,123 @@ def cpu_baseline(args, seconds, batch):
         "ppo_updates_per_sec": a.get("ppo_updates_per_sec"), "configs": configs,
     }
 
+# ------------------------------------------------------------------------------------------------------------------------
+# output: ONE compact JSON line (the driver keeps only the last ~8 KB of stdout) + everything else in a side file
+# ------------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _r(v, sig=5):
+    """Floats to `sig` significant digits (the line is a record, not a checksum); containers recursively."""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roof_short(r, extra=()):
+    if not isinstance(r, dict):
+        return None
+    if "error" in r:
+        return {"error": str(r["error"])[:120]}
+    o = _pick(r, ("kernel", "bound", "launch_us", "achieved", "peak", "unit", "frac", "traffic", *extra))
+    if "kernel" in o:
+        o["kernel"] = o["kernel"].split(" (")[0][:64]
+    if r.get("traffic_source"):
+        o["traffic_source"] = r["traffic_source"].split(" (")[0][:64]
+    return o
+
+
+def write_extras(out):
+    """Everything the line leaves out (extra configs, literal-batch legs, harness timing, the CPU table, the per-kernel notes), as
+    indented JSON beside bench.py -- and under gpurun_out/ when that scratch directory exists, so a gpurun call brings it home."""
+    name = os.environ.get("TMA_BENCH_EXTRAS", "bench_extras.json" if out.get("n_gpus", 1) == 1 else f"bench_extras_n{out.get('n_gpus')}.json")
+    written = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, os.path.basename(name)), "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.relpath(os.path.join(d, os.path.basename(name)), ROOT)
+        except OSError as exc:
+            log(f"could not write {d}/{name}: {exc}")
+    return written
+
+
+def compact_line(out, extras_path=None, limit=LINE_LIMIT):
+    """The contract's one JSON line, bounded to `limit` bytes: the contract keys, `config`, `roofline` (dominant kernel), `cpu_baseline`,
+    and one-number summaries of the other legs; the full objects live in `extras_path`.  Optional blocks are dropped last-first if a
+    run's strings ever push the line over the limit (the contract keys, roofline and cpu_baseline are never dropped)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = out.get("config", {})
+    line["config"] = {**_pick(cfg, ("envs_per_gpu", "n_steps", "batch_size", "n_epochs", "hidden")),
+                      "workload": str(cfg.get("workload", ""))[:260], "parallelism": str(cfg.get("parallelism", "")).split(":")[0][:40]}
+    line.update(_pick(out, ("ppo_updates_per_sec", "rollout_ms", "update_ms")))
+    line["roofline"] = _roof_short(out.get("roofline"), ("samples_per_launch", "flops_per_sample_fwd_bwd"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = ({"error": str(cb["error"])[:160]} if "error" in cb else
+                                {**_pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cpus", "single_thread_value", "all_cores_value",
+                                              "env_only_steps_per_s")), "sample": str(cb.get("sample", ""))[:200]})
+    optional = []  # (key, value) in the order they are dropped if the line is too long: last first
+    if isinstance(out.get("dp_timing"), dict):
+        dp = out["dp_timing"]
+
+        def med(x):
+            return _pick(x, ("calls_timed", "median_us", "max_us", "bytes")) if isinstance(x, dict) else x
+
+        optional.append(("dp_timing", {"backend": dp.get("backend"), "allreduce_path": str(dp.get("allreduce_path", "")).split(" (")[0],
+                                       "grad_allreduce": med(dp.get("grad_allreduce")), "adv_sums_allreduce": med(dp.get("adv_sums_allreduce")),
+                                       "grad_allreduces_per_iteration": dp.get("grad_allreduces_per_iteration"),
+                                       "per_rank_update_ms": dp.get("per_rank_update_ms"), "per_rank_rollout_ms": dp.get("per_rank_rollout_ms")}))
+    roofs = {}
+    for key, short in (("roofline_step_kernel_saturated", "step_saturated"), ("roofline_step_kernel", "step_4096"), ("roofline_gae_kernel", "gae"),
+                       ("roofline_rollout_kernel", "rollout")):
+        r = out.get(key)
+        if isinstance(r, dict):
+            roofs[short] = ({"error": str(r["error"])[:80]} if "error" in r else
+                            _pick(r, ("bound", "launch_us", "us_per_vector_step", "achieved", "unit", "frac", "traffic")))
+    if roofs:
+        optional.append(("other_rooflines", roofs))
+    if isinstance(out.get("extra_configs"), list):
+        optional.append(("extra_configs", [
+            ({"config": str(e.get("config", ""))[:48], "error": str(e["error"])[:80]} if "error" in e else
+             {"config": str(e.get("config", "")).split(",")[0][:48], **_pick(e, ("task", "envs_per_gpu", "hidden", "dtype", "env_steps_per_sec", "ms_per_step")),
+              "grad_us": (e.get("roofline") or {}).get("launch_us"), "frac": (e.get("roofline") or {}).get("frac")}) for e in out["extra_configs"]]))
+    lit = {}
+    for key, short in (("literal_batch_256", "h64"), ("literal_batch_256_h256", "h256")):
+        r = out.get(key)
+        if isinstance(r, dict):
+            lit[short] = {"error": str(r["error"])[:80]} if "error" in r else _pick(r, ("ppo_updates_per_sec", "us_per_optimizer_step", "env_steps_per_sec_10_epochs_composed"))
+    if lit:
+        optional.append(("literal_batch_256", lit))
+    h = out.get("harness_train_task")
+    if isinstance(h, dict):
+        optional.append(("harness_train_task", {"error": str(h["error"])[:80]} if "error" in h else
+                         _pick(h, ("train_task_seconds", "direct_ppo_seconds", "overhead_frac", "steady_state_overhead_frac"))))
+    if isinstance(out.get("thresholds"), dict):
+        optional.append(("thresholds", out["thresholds"]))
+    if isinstance(out.get("train_stats"), dict):
+        optional.append(("train_stats", _pick(out["train_stats"], ("train/approx_kl", "train/clip_fraction", "train/explained_variance"))))
+    line["extras_path"] = extras_path
+    for k, v in optional:
+        line[k] = v
+    text = json.dumps(_r(line), separators=(",", ":"))
+    while len(text) >= limit and optional:
+        k, _ = optional.pop()
+        line.pop(k, None)
+        line["dropped_to_fit"] = line.get("dropped_to_fit", []) + [k]
+        text = json.dumps(_r(line), separators=(",", ":"))
+    return text
+
 
 def main():
     args = parse()
@@ -756,7 +875,8 @@ def main():
             import env_sweep
 
             out["env_sweep"] = [env_sweep.run(args.task, n, 32, 3, pl) for n in (4096, 65536, 1 << 20, 1 << 22) for pl in (1, 32)]
-        print(json.dumps(out), flush=True)
+        extras_path = write_extras(out)
+        print(compact_line(out, extras_path), flush=True)
     dist.barrier()
 
 
