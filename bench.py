@@ -200,7 +200,7 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
 def attach_pmc_traffic(roof, name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summaries (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2
     corrected as MI355X_MICROARCH.md prescribes); newest round first."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
         if os.path.exists(path):
             with open(path) as f:
@@ -718,6 +718,7 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
         optional.append(("dp_timing", {"backend": dp.get("backend"), "allreduce_path": str(dp.get("allreduce_path", "")).split(" (")[0],
                                        "grad_allreduce": med(dp.get("grad_allreduce")), "adv_sums_allreduce": med(dp.get("adv_sums_allreduce")),
                                        "grad_allreduces_per_iteration": dp.get("grad_allreduces_per_iteration"),
+                                       "adv_sums_allreduces_per_iteration": dp.get("adv_sums_allreduces_per_iteration"),
                                        "per_rank_update_ms": dp.get("per_rank_update_ms"), "per_rank_rollout_ms": dp.get("per_rank_rollout_ms")}))
     roofs = {}
     for key, short in (("roofline_step_kernel_saturated", "step_saturated"), ("roofline_step_kernel", "step_4096"), ("roofline_gae_kernel", "gae"),
@@ -751,12 +752,17 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
     line["extras_path"] = extras_path
     for k, v in optional:
         line[k] = v
-    text = json.dumps(_r(line), separators=(",", ":"))
+    exact = {k: line[k] for k in ("value", "ms_per_step") if k in line}  # (a reader checks value against ms_per_step: these two are not rounded)
+
+    def dump():
+        return json.dumps({**_r(line), **exact}, separators=(",", ":"))
+
+    text = dump()
     while len(text) >= limit and optional:
         k, _ = optional.pop()
         line.pop(k, None)
         line["dropped_to_fit"] = line.get("dropped_to_fit", []) + [k]
-        text = json.dumps(_r(line), separators=(",", ":"))
+        text = dump()
     return text
 
 

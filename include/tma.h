@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 205
+#define TMA_VERSION 206
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -78,6 +78,12 @@ int tma_env_reset(tma_env *h, float *obs_out, void *stream);
 int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tape_seed, uint32_t tape_t0, int n_steps,
                  float *obs_out, float *rew_out, uint8_t *term_out, uint8_t *trunc_out, float *term_obs_out,
                  double *ep_ret_out, int32_t *ep_len_out, void *stream);
+/* Seam S1 (backend/mlagents/envs.py:125-152): the reference's single env returns `float(reward)` of the value the task computed in float64
+ * (Basic 0.09000000000000001, Bicycle / BrickBreak / Glider rewards out of float64 physics); `rew_out` carries its float32 rounding, which is
+ * what SB3's VecEnv keeps.  tma_env_set_reward64(env, plane): every tma_env_step launched afterwards ALSO stores the float64 reward at
+ * plane[k * num_envs + i] (device memory owned by the caller, n_steps * num_envs doubles); NULL turns it off.  The fused rollout kernels
+ * (tma_rollout_collect) do not write it: they replace SB3's float32 buffer, not the Gymnasium single-env surface. */
+int tma_env_set_reward64(tma_env *env, double *plane);
 /* `reps` consecutive single-step launches with the same action buffer and output planes, issued from native code with no
  * host-language round trip in between (launch-latency measurements; semantics = calling tma_env_step `reps` times) */
 int tma_env_step_repeat(tma_env *h, const void *actions, int action_dtype, int reps, float *obs_out, float *rew_out, uint8_t *term_out,
@@ -108,6 +114,10 @@ int tma_monitor_append_rows(const char *path, const double *ret, const int32_t *
 /* Monitor aggregate since the last call: out[0]=sum of episode returns, out[1]=sum of lengths, out[2]=count.
  * Synchronises `stream`. */
 int tma_env_pop_episode_stats(tma_env *h, double *out3_host, void *stream);
+/* Empty the episode log and the Monitor aggregate ordered on `stream` (two hipMemsetAsync), without reading them and without synchronising:
+ * what a deterministic evaluation does before its first chunk (SB3's evaluate_policy starts from fresh Monitor state by construction,
+ * backend/mlagents/training.py:240-247) -- whatever an earlier user of the env left, kernels launched on `stream` after this call start from zero. */
+int tma_env_clear_episode_log(tma_env *env, void *stream);
 /* Two-phase pop for a training loop that keeps the GPU busy across iterations (round 4; the reference's Monitor / logger run on the host
  * between rollouts, training.py:85-86,152-161 -- here they must not sit between two GPU iterations).  tma_env_detach_episode_log: HOST-side
  * swap of the buffer set handed to kernels at launch -- kernels launched BEFORE the call wrote their Monitor aggregates and episode records

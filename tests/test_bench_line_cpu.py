@@ -24,7 +24,7 @@ def test_line_is_bounded_and_round_trips():
     line = json.loads(text)
     for k in CONTRACT:
         assert k in line, k
-    assert line["value"] == float(f"{out['value']:.5g}") and line["n_gpus"] == 1 and line["config"]["workload"].startswith("gridworld")
+    assert line["value"] == out["value"] and line["ms_per_step"] == out["ms_per_step"] and line["n_gpus"] == 1 and line["config"]["workload"].startswith("gridworld")
     roof, cpu = line["roofline"], line["cpu_baseline"]
     for k in ("kernel", "bound", "launch_us", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k

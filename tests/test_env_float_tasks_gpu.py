@@ -137,3 +137,61 @@ def test_train_a_few_iterations_on_a_float_task():
     obs = env.reset()
     a, _ = m.predict(obs if isinstance(obs, np.ndarray) else obs.cpu().numpy(), deterministic=True)
     assert a.shape[0] == 64 and set(np.unique(a)).issubset({0, 1, 2})
+
+
+@pytest.mark.parametrize("task", TASKS + ["ball3d", "push", "basic"])
+def test_reward64_plane_matches_the_reference_float64_rewards(golden, task):
+    """tma_env_set_reward64 (seam S1, backend/mlagents/envs.py:125-152: `float(reward)` of the task's float64): the plane the step kernel fills
+    beside its float32 reward, against `rewards_f64` of the reference-generated fixtures over the whole multi-episode trajectories.  The
+    float64-physics tasks go through the device's sin / cos / atan2 (last-bit differences against the host libm): 1e-9 relative / 1e-12
+    absolute and a bounded count of inexact elements; Ball3D (float32 rewards), Push and Basic (finite float64 sets) are exact."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    g = golden(task)
+    n, T, base = [int(x) for x in g["meta"][:3]]
+    eng = _engine(task, n, seed=base, ring_depth=8)
+    plane = torch.full((1, n), float("nan"), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, C.c_void_p(plane.data_ptr())))
+    eng.reset()
+    actions = torch.from_numpy(g["actions"]).cuda()
+    inexact = 0
+    for t in range(T):
+        o = eng.step(actions[t])
+        r64, ref = plane[0].cpu().numpy(), g["rewards_f64"][t]
+        if task in TASKS:
+            assert np.allclose(r64, ref, rtol=1e-9, atol=1e-12), (task, t, np.abs(r64 - ref).max())
+            inexact += int((r64 != ref).sum())
+        else:
+            assert np.array_equal(r64, ref), (task, t)
+        assert np.array_equal(r64.astype(np.float32), o["rew"][0].cpu().numpy()), (task, t)  # the float32 plane is its rounding
+    assert inexact <= 64 + n * T // 500, (task, inexact, n * T)
+    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, None))
+    plane.fill_(7.0)
+    eng.step(actions[0])
+    assert bool((plane == 7.0).all())  # NULL turns it off
+    eng.close()
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_single_env_returns_the_kernels_float64_reward(golden, task):
+    """HipSingleEnv.step of a float64-physics task hands back the kernel's own float64 (not a decimal rounding of its float32)."""
+    from three_mlagents_amd.tasks import make_env
+
+    g = golden(task)
+    base = int(g["meta"][2])
+    env = make_env(task)
+    try:
+        env.reset(seed=base)
+        differs = 0
+        for t in range(200):
+            _, r, te, tr, _ = env.step(g["actions"][t, 0])
+            ref = float(g["rewards_f64"][t, 0])
+            assert isinstance(r, float) and abs(r - ref) <= 1e-12 + 1e-9 * abs(ref), (task, t, r, ref)
+            differs += int(r != float(np.float32(r)))
+            if te or tr:
+                env.reset()
+        assert differs > 50  # float64 values, not widened float32s
+    finally:
+        env.close()

@@ -56,6 +56,7 @@ SIGNATURES = {
     "tma_env_create": (_i32, [_i32, _i64, _i32, _u32, _u32, _i32, C.POINTER(_vp)]),
     "tma_env_destroy": (_i32, [_vp]),
     "tma_env_seed": (_i32, [_vp, _u32]),
+    "tma_env_set_reward64": (_i32, [_vp, _vp]),
     "tma_env_reset": (_i32, [_vp, _vp, _vp]),
     "tma_env_step": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tma_env_step_repeat": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "tma_monitor_append_rows": (_i32, [C.c_char_p, _vp, _vp, _vp, _i64]),
     "tma_env_pop_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "tma_env_pop_episode_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),
+    "tma_env_clear_episode_log": (_i32, [_vp, _vp]),
     "tma_env_detach_episode_log": (_i32, [_vp]),
     "tma_env_pop_detached_episode_log": (_i32, [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_f64), _vp]),
     "tma_gae": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _i64, _vp, _vp, _vp]),

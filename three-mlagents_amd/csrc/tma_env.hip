@@ -15,6 +15,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
                                                    int n_steps, float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                    uint8_t *__restrict__ term_out, uint8_t *__restrict__ trunc_out,
                                                    float *__restrict__ term_obs_out, double *__restrict__ ep_ret_out,
-                                                   int32_t *__restrict__ ep_len_out) {
+                                                   int32_t *__restrict__ ep_len_out, double *__restrict__ rew64_out) {
     extern __shared__ __attribute__((aligned(16))) float obs_tile[];
     using OS = ObsStaging<T>;
     const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void step_kernel(EnvView v, const void *__rest
             }
             er += r;  // Monitor: sum of float(reward) in order
             if (rew_out) rew_out[off] = (float)r;
+            if (rew64_out) rew64_out[off] = r;  // seam S1: the float64 the reference's env.step returns as float(reward) (envs.py:125-152)
             if (term_out) term_out[off] = (uint8_t)te;
             if (trunc_out) trunc_out[off] = (uint8_t)tr;
             if (te || tr) {
@@ -511,9 +513,11 @@ template <class T, int MODE>
 static void launch_step(tma_env *h, const void *actions, uint32_t tape_seed, uint32_t t0, int n_steps, float *obs, float *rew, uint8_t *te,
                         uint8_t *tr, float *tobs, double *epr, int32_t *epl, hipStream_t s) {
     using OS = ObsStaging<T>;
-    const unsigned blocks = (unsigned)ceil_div(h->v.N, OS::THREADS);
+    static const int small_threads = getenv("TMA_STEP_THREADS") ? atoi(getenv("TMA_STEP_THREADS")) : 0;  // measurement switch (tools/step_ab.py)
+    const int threads = (small_threads == 64 || small_threads == 128) && !OS::USE_LDS && h->v.N <= 65536 ? small_threads : OS::THREADS;
+    const unsigned blocks = (unsigned)ceil_div(h->v.N, threads);
     const size_t smem = OS::USE_LDS ? sizeof(float) * OS::THREADS * OS::OBSP : 0;
-    step_kernel<T, MODE><<<dim3(blocks), dim3(OS::THREADS), smem, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl);
+    step_kernel<T, MODE><<<dim3(blocks), dim3(threads), smem, s>>>(h->v, actions, tape_seed, t0, n_steps, obs, rew, te, tr, tobs, epr, epl, h->rew64_out);
 }
 
 // internal (not exported): bookkeeping after a kernel outside this file advanced the envs by n_steps
@@ -572,6 +576,7 @@ int tma_env_create(int task, int64_t num_envs, int device, uint32_t seed_base, u
         tma_env_destroy(h);
         return rc;
     }
+    TMA_HIP(hipDeviceSynchronize());  // the clears above ran on the null stream, which is not ordered against the caller's non-blocking streams
     *out = h;
     return TMA_OK;
 }
@@ -594,6 +599,10 @@ static int env_alloc(tma_env *h, int task, int64_t num_envs, int ring_depth) {
     TMA_HIP(hipMemset(v.filled_hi, 0, sizeof(uint32_t) * n));
     TMA_HIP(hipMemset(v.ep_ret, 0, sizeof(double) * n));
     TMA_HIP(hipMemset(v.stats, 0, sizeof(double) * n_stat));
+    // the spare Monitor-aggregate set of tma_env_detach_episode_log, allocated and cleared HERE (tma_env_create drains the device after this):
+    // a detach in the middle of a no-drain training loop then only swaps pointers -- no null-stream memset next to non-blocking streams
+    TMA_HIP(env_malloc(&h->d_stats, sizeof(double) * n_stat));
+    TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * n_stat));
     if (m.uses_mt) {
         RefillView &rv = h->rv;
         rv.nb = (int)ceil_div(num_envs, 256);
@@ -652,6 +661,12 @@ int tma_env_set_option(tma_env *h, const char *key, int64_t value) {
         return TMA_OK;
     }
     return fail(TMA_ERR_INVALID, "unknown option '%s'", key);
+}
+
+int tma_env_set_reward64(tma_env *h, double *plane) {
+    if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    h->rew64_out = plane;
+    return TMA_OK;
 }
 
 int tma_env_seed(tma_env *h, uint32_t seed_base) {
@@ -791,6 +806,13 @@ int tma_env_episode_log(tma_env *h, int64_t capacity) {
     TMA_HIP(env_malloc(&v.log_n, sizeof(unsigned long long)));
     TMA_HIP(hipMemset(v.log_n, 0, sizeof(unsigned long long)));
     v.log_cap = capacity;
+    // ... and the spare record buffers of the two-phase pop, for the same reason (this call already drains the device on entry and on exit)
+    TMA_HIP(env_malloc(&h->d_log_ret, sizeof(double) * (size_t)capacity));
+    TMA_HIP(env_malloc(&h->d_log_len, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(env_malloc(&h->d_log_env, sizeof(int32_t) * (size_t)capacity));
+    TMA_HIP(env_malloc(&h->d_log_n, sizeof(unsigned long long)));
+    TMA_HIP(hipMemset(h->d_log_n, 0, sizeof(unsigned long long)));
+    TMA_HIP(hipDeviceSynchronize());
     return TMA_OK;
 }
 
@@ -885,9 +907,13 @@ int tma_env_detach_episode_log(tma_env *h) {
     TMA_HIP(hipSetDevice(h->device));
     EnvView &v = h->v;
     const size_t n_stat = (size_t)ceil_div(v.N, 256) * 3;
+    // (both spare sets exist since tma_env_create / tma_env_episode_log; should one be missing, it is made here and the device drained before
+    //  it goes live -- a null-stream memset is not ordered against non-blocking streams)
+    bool made = false;
     if (!h->d_stats) {
         TMA_HIP(env_malloc(&h->d_stats, sizeof(double) * n_stat));
         TMA_HIP(hipMemset(h->d_stats, 0, sizeof(double) * n_stat));
+        made = true;
     }
     if (v.log_n && !h->d_log_n) {
         TMA_HIP(env_malloc(&h->d_log_ret, sizeof(double) * (size_t)v.log_cap));
@@ -895,7 +921,9 @@ int tma_env_detach_episode_log(tma_env *h) {
         TMA_HIP(env_malloc(&h->d_log_env, sizeof(int32_t) * (size_t)v.log_cap));
         TMA_HIP(env_malloc(&h->d_log_n, sizeof(unsigned long long)));
         TMA_HIP(hipMemset(h->d_log_n, 0, sizeof(unsigned long long)));
+        made = true;
     }
+    if (made) TMA_HIP(hipDeviceSynchronize());
     std::swap(v.stats, h->d_stats);
     if (v.log_n) {
         std::swap(v.log_ret, h->d_log_ret), std::swap(v.log_len, h->d_log_len), std::swap(v.log_env, h->d_log_env), std::swap(v.log_n, h->d_log_n);
@@ -931,6 +959,16 @@ int tma_env_pop_detached_episode_log(tma_env *h, double *ret_host, int32_t *len_
     for (size_t b = 0; b < nb; b++) stats3_host[0] += tmp[3 * b], stats3_host[1] += tmp[3 * b + 1], stats3_host[2] += tmp[3 * b + 2];
     *n_stored = n, *n_seen = (int64_t)seen;
     h->detached = false;
+    return TMA_OK;
+}
+
+// Stream-ordered clear of the LIVE set (records + Monitor aggregates): no host round trip, no synchronisation.
+int tma_env_clear_episode_log(tma_env *h, void *stream) {
+    if (!h) return fail(TMA_ERR_INVALID, "tma_env_clear_episode_log: null handle");
+    TMA_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->v.log_n) TMA_HIP(hipMemsetAsync(h->v.log_n, 0, sizeof(unsigned long long), s));
+    TMA_HIP(hipMemsetAsync(h->v.stats, 0, sizeof(double) * 3 * (size_t)ceil_div(h->v.N, 256), s));
     return TMA_OK;
 }
 

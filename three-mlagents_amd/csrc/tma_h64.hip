@@ -424,7 +424,7 @@ __device__ __forceinline__ void fold_adam_into_image(const AdamFold &f, const PL
         for (int jj = 0; jj < 4; jj++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float gv = (g2[jj][j] * 1.0f) * coef;
+                const float gv = (g2[jj][j] * f.scale) * coef;
                 p2[jj][j] = adam_update_h64(p2[jj][j], gv, m2[jj][j], v2[jj][j], f.beta1, f.beta2, inv_bc2, f.eps, f.lr_step);
                 if (keep) {
                     const int e = base + w2_off + (kr + 16 * jj) * 64 + nr + 16 * j;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void fold_adam_into_image(const AdamFold &f, const PL
         for (int i = 0; i < NO; i++) {
             const int y = o_tid + i * o_thr, x = y < w2_off ? y : y + 4096;
             if (y < n_other) {
-                const float gv = (go[i] * 1.0f) * coef;
+                const float gv = (go[i] * f.scale) * coef;
                 const float pnew = adam_update_h64(po[i], gv, mo[i], vo[i], f.beta1, f.beta2, inv_bc2, f.eps, f.lr_step);
                 image_store_h64(wimg, L.D, n_out, x, pnew);
                 if (keep) f.p_nxt[base + x] = pnew, f.m_nxt[base + x] = mo[i], f.v_nxt[base + x] = vo[i];

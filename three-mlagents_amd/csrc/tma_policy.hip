@@ -2405,7 +2405,7 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
                 const double bc1 = 1.0 - pow(beta1, (double)(step - 1)), bc2 = 1.0 - pow(beta2, (double)(step - 1));
                 f = AdamFold{grad, sqp, (int)ceil_div(L.P, 64), bufs[cur][0], bufs[cur][1], bufs[cur][2], bufs[cur ^ 1][0], bufs[cur ^ 1][1],
                              bufs[cur ^ 1][2], (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)sqrt(bc2), (float)eps,
-                             reinterpret_cast<double *>(ws + WS_NORM_OUT)};
+                             reinterpret_cast<double *>(ws + WS_NORM_OUT), 1.0f};
             }
             rc = minibatch_grad_impl(params, d, rb, &mb, hp, grad, workspace, stream, start > 0 ? &f : nullptr, start > 0 ? 1 : 0);
             if (rc) return rc;
@@ -2445,6 +2445,49 @@ int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_ro
     // all-reduced gradient, and taking it in every workgroup's prologue -- 147 64-lane f64 shuffle trees through the LDS crossbar of each CU --
     // measured 3.4 us per minibatch SLOWER than the sum-of-squares + optimizer launches it would replace: DESIGN.md section 10.)
     int64_t step = first_step;
+    // Round 5, H = 64 fast path: the dependent chain of a data-parallel minibatch was gradient -> slab_reduce -> all-reduce -> grad_sumsq64 -> Adam.
+    // What the collective forces is only that the NORM PARTIALS come from the all-reduced gradient; the step itself can still run where the
+    // single-GPU epoch runs it -- in the prologue of the next gradient launch (AdamFold, with the 1/world scale of the summed gradient in the
+    // same place adam_scatter_h64_kernel applies it).  Chain: gradient(+ step k - 1) -> slab_reduce (overwrite) -> all-reduce -> grad_sumsq64:
+    // one dependent launch fewer per minibatch, the epoch's last step by the ordinary optimizer launch.  Same routine on the same inputs
+    // as the unfolded sequence: bit-identical (tests/test_dist_gpu.py, test_native_data_parallel_epoch_equals_the_single_gpu_epoch).
+    // (Taking the partials inside the optimizer kernel instead -- every block re-summing the 37 KB gradient in shuffle-tree order, no
+    // grad_sumsq64 launch -- was built first and measured 1.2 us per minibatch SLOWER than the launch it removed: DESIGN.md section 10.)
+    const int64_t tail = total % batch_size;
+    static const bool no_dp_fold = getenv("TMA_DP_NO_FOLD") != nullptr || getenv("TMA_NO_ADAM_FOLD") != nullptr;  // A/B switch: the round-4 chain
+    if (L.img_pi >= 0 && L.P <= 64 * 256 && prepared_batch == batch_size && batch_size >= 256 && (tail == 0 || tail >= 256) && total > batch_size && !no_dp_fold) {
+        char *ws = static_cast<char *>(workspace);
+        hipStream_t s = (hipStream_t)stream;
+        const int64_t Pp = ((int64_t)L.P + 3) & ~(int64_t)3;
+        float *alt = reinterpret_cast<float *>(ws + fold_state_offset(L));
+        float *bufs[2][3] = {{params, exp_avg, exp_avg_sq}, {alt, alt + Pp, alt + 2 * Pp}};
+        int cur = 0;
+        double *sqp = sq_partials(ws, L);
+        const int n_part = (int)ceil_div(L.P, 64);
+        for (int64_t start = 0; start < total; start += batch_size, step++) {
+            const int64_t count = start + batch_size <= total ? batch_size : total - start;
+            const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared_batch, stats_world > 0 ? count * stats_world : 0};
+            AdamFold f{};
+            if (start > 0) {  // the step of the previous minibatch (index step - 1)
+                const double bc1 = 1.0 - pow(beta1, (double)(step - 1)), bc2 = 1.0 - pow(beta2, (double)(step - 1));
+                f = AdamFold{grad, sqp, n_part, bufs[cur][0], bufs[cur][1], bufs[cur][2], bufs[cur ^ 1][0], bufs[cur ^ 1][1],
+                             bufs[cur ^ 1][2], (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)sqrt(bc2), (float)eps,
+                             reinterpret_cast<double *>(ws + WS_NORM_OUT), (float)grad_scale};
+            }
+            rc = minibatch_grad_impl(params, d, rb, &mb, hp, grad, workspace, stream, start > 0 ? &f : nullptr, 1);
+            if (rc) return rc;
+            if (start > 0) cur ^= 1;
+            if (allreduce(ctx, grad, L.P) != 0) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_dp: the all-reduce callback failed");
+            grad_sumsq64_kernel<<<dim3((unsigned)n_part), dim3(64), 0, s>>>(grad, L.P, (float)grad_scale, sqp);
+            TMA_LAUNCH_CHECK();
+        }
+        const double bc1 = 1.0 - pow(beta1, (double)(step - 1)), bc2 = 1.0 - pow(beta2, (double)(step - 1));
+        adam_scatter_h64_kernel<<<dim3((unsigned)ceil_div(L.P, 256)), dim3(256), 0, s>>>(
+            params, grad, exp_avg, exp_avg_sq, L, sqp, n_part, (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2,
+            (float)sqrt(bc2), (float)eps, reinterpret_cast<double *>(ws + WS_NORM_OUT), (float)grad_scale, bufs[cur][0], bufs[cur][1], bufs[cur][2]);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     for (int64_t start = 0; start < total; start += batch_size, step++) {
         const int64_t count = start + batch_size <= total ? batch_size : total - start;
         const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared_batch, stats_world > 0 ? count * stats_world : 0};

@@ -74,6 +74,7 @@ struct AdamFold {
     float *p_nxt, *m_nxt, *v_nxt;        // ... and after it
     float max_norm, lr_step, beta1, beta2, bc2_sqrt, eps;  // (bc2_sqrt = sqrt(1 - beta2^t), lr_step = lr / (1 - beta1^t))
     double *norm_out;        // [2] total gradient norm, clip coefficient (statistics)
+    float scale;             // factor on the gradient before the clip (1 on one GPU; 1 / world on the all-reduced SUM, tma_ppo_train_epoch_dp)
 };
 
 struct Net {

@@ -103,7 +103,7 @@ class NativeComm:
         if self.rank == 0:
             _lib.check(L.tma_comm_unique_id(_lib.ptr(ident.numpy())))
         if self.world > 1:
-            on_gpu = td.get_backend() == "nccl"
+            on_gpu = "nccl" in str(td.get_backend())  # (also the composite "cpu:gloo,cuda:nccl")
             t = ident.to(self.device) if on_gpu else ident
             td.broadcast(t, src=0)
             ident = t.cpu()

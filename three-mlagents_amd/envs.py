@@ -13,6 +13,8 @@ from typing import Any
 import numpy as np
 import torch
 
+from . import _lib
+
 
 _REWARD_TABLES: dict[str, dict[float, float]] = {}
 
@@ -69,6 +71,10 @@ class HipSingleEnv:
         self.steps = 0
         self._started = False
         self._pending_obs = None  # observation of the auto-started next episode, handed out by the next reset()
+        # float64 reward of the last step, written by the step kernel beside its float32 rounding (include/tma.h tma_env_set_reward64): what
+        # the reference's env.step hands back for the float64-physics tasks (Bicycle / BrickBreak / Glider), whose rewards are no finite set
+        self._rew64 = torch.zeros((1, 1), dtype=torch.float64, device=self.engine.device)
+        _lib.check(_lib.lib().tma_env_set_reward64(self.engine._h, _lib.ptr(self._rew64)))
 
     def _info(self, steps: int) -> dict[str, Any]:
         info = {"steps": int(steps)}
@@ -129,8 +135,7 @@ class HipSingleEnv:
         exact = table.get(r32)
         if exact is not None:
             return exact
-        r6 = round(r32, 6)  # tasks without a finite reward set (float64 physics): the shortest decimal that rounds to the same float32
-        return r6 if np.float32(r6) == np.float32(r32) else r32
+        return float(self._rew64[0, 0].item())  # tasks without a finite reward set (float64 physics): the kernel's own float64
 
     def close(self) -> None:
         self.engine.close()

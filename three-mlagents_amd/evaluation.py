@@ -46,9 +46,10 @@ class _EvalBuffers:
 
 def evaluate_policy_begin(model, env, n_eval_episodes: int = 10, deterministic: bool = True, max_steps: int = 10_000_000,
                           chunk_steps: int | None = None, params: torch.Tensor | None = None, assume_clean_log: bool = False) -> dict:
-    """First half of evaluate_policy: reset + the FIRST native rollout chunk, enqueued on the current stream; nothing here waits for the GPU
-    when the env's episode log is known to be empty (`assume_clean_log` and the env was last used by a finished evaluation), so a caller
-    may queue it on a side stream and collect the result later (callbacks.EvalCallback).  `params`: the flat parameter buffer to evaluate
+    """First half of evaluate_policy: reset + a stream-ordered clear of the env's episode log (tma_env_clear_episode_log) + the FIRST native
+    rollout chunk, enqueued on the current stream; nothing here waits for the GPU, so a caller may queue it on a side stream and collect the
+    result later (callbacks.EvalCallback).  (`assume_clean_log` is accepted for callers of the round-4 signature and ignored: the clear costs
+    no synchronisation, so there is no flag to trust.)  `params`: the flat parameter buffer to evaluate
     (default: the model's live one) -- a snapshot lets the optimizer move on while the chunk runs."""
     eng = env.engine
     if getattr(model, "env", None) is env:  # the training env: its episode log feeds the Monitor file -- leave it alone
@@ -68,12 +69,10 @@ def evaluate_policy_begin(model, env, n_eval_episodes: int = 10, deterministic: 
     cap = max(4096, K * n)  # at most one episode per env and step can finish inside a chunk
     if getattr(eng, "_log_cap", 0) < cap:
         eng.episode_log(cap)
-        eng._eval_log_clean = False
     eng.reset(bufs.obs[0])
-    if not (assume_clean_log and getattr(eng, "_eval_log_clean", False)):  # (HipEnvEngine.step clears the mark)
-        eng.pop_episode_log()       # (drop what an earlier user of the env left; synchronises the stream)
-        eng.pop_episode_stats()
-    eng._eval_log_clean = False
+    # drop whatever an earlier user of the env left (a step() from a callback, a direct tma_rollout_collect, the previous evaluation's unused
+    # episodes and its Monitor aggregate): stream-ordered clear, no host round trip -- the chunk queued next starts from an empty log
+    eng.clear_episode_log()
     st = {"model": model, "env": env, "bufs": bufs, "K": K, "n": n, "targets": _targets(n_eval_episodes, n), "counts": np.zeros(n, dtype=np.int64),
           "t_end": np.zeros(n, dtype=np.int64), "found": [], "seed": (model.seed ^ 0xE7A1) & 0xFFFFFFFF, "steps": 0, "max_steps": max_steps,
           "deterministic": deterministic, "params": pol.params if params is None else params, "gamma": float(getattr(model, "gamma", 0.99)), "queued": False}
@@ -111,7 +110,6 @@ def evaluate_policy_finish(st: dict, return_episode_rewards: bool = False):
                     t_end[i] += int(length)  # the evaluation started from reset(): episode k of env i ends at the sum of its first k lengths
                     found.append((int(t_end[i]), int(i), float(ret), int(length)))
                     counts[i] += 1
-        eng._eval_log_clean = True  # every record of every chunk has been popped
         found.sort()  # by finishing step, then env: the order a per-step loop sees them (evaluate_policy_stepwise)
         rewards, lengths = [f[2] for f in found], [f[3] for f in found]
     if return_episode_rewards:

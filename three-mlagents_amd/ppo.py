@@ -267,9 +267,16 @@ class PPO:
         # and no stream hand-off per minibatch.  Any other backend (gloo: the CPU / one-GPU tests), TMA_NO_NATIVE_RCCL=1 or a failed self-check keep
         # the callback into torch.distributed.  TMA_NATIVE_RCCL=1 builds the communicator at world size 1 too (exercises real RCCL on one GPU).
         self._native_comm = None
-        want_native = os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and _dist_backend() == "nccl")
+        # ("nccl" IN the backend string: a group initialised without a backend name reports "cpu:gloo,cuda:nccl" and serves CUDA tensors over RCCL)
+        want_native = os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and "nccl" in (_dist_backend() or ""))
         if want_native and not os.environ.get("TMA_NO_NATIVE_RCCL"):
             self._native_comm = self._make_native_comm()
+        if self.world_size > 1 and self._native_comm is None and self.rank == 0:
+            import sys
+
+            print(f"three-mlagents_amd: data-parallel collectives go through the torch.distributed callback (backend {_dist_backend()!r}"
+                  f"{', TMA_NO_NATIVE_RCCL set' if os.environ.get('TMA_NO_NATIVE_RCCL') else ''}), not the library's own RCCL communicator",
+                  file=sys.stderr, flush=True)
 
     def _make_native_comm(self):
         """dist.NativeComm, checked against torch.distributed on a known vector before it is trusted with gradients; None (and one stderr
@@ -287,7 +294,7 @@ class PPO:
                 return mine
             import torch.distributed as tdist
 
-            flag = torch.tensor([1.0 if mine else 0.0], device=self.device if tdist.get_backend() == "nccl" else "cpu")
+            flag = torch.tensor([1.0 if mine else 0.0], device=self.device if "nccl" in str(tdist.get_backend()) else "cpu")
             tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
             return flag.item() == 1.0
 
@@ -537,6 +544,7 @@ class PPO:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(self.device))
         pending = None
+        n_logged = 0
 
         def finish(p):
             p["ev_train"].synchronize()
@@ -572,7 +580,8 @@ class PPO:
                     side = self.side_stream()
                     side.wait_event(ev_roll)
                     ep, lr_, ll_, le_, seen = eng.pop_detached_episode_log(C.c_void_p(side.cuda_stream))  # waits for the ROLLOUT only
-                    staging = self._stats_staging(iteration & 1)
+                    staging = self._stats_staging(n_logged & 1)  # (alternates per LOGGED iteration: row k's buffer is folded before row k + 2 is copied into it)
+                    n_logged += 1
                     _lib.check(_lib.lib().tma_ppo_stats_enqueue(_lib.ptr(self.workspace), _lib.ptr(staging), self._stream()))
                     ev_train = torch.cuda.Event(enable_timing=True)
                     ev_train.record(torch.cuda.current_stream(self.device))

@@ -125,7 +125,6 @@ class HipEnvEngine:
     def step(self, actions: torch.Tensor | None, *, n_steps: int = 1, tape_seed: int = 0, tape_t0: int = 0, outputs: dict | None = None,
              want_terminal_obs: bool = True, want_episode: bool = True) -> dict[str, torch.Tensor]:
         """One launch of `n_steps` vector steps.  `actions` None -> device-generated tape."""
-        self._eval_log_clean = False  # (evaluation.evaluate_policy_begin: episodes finished here land in the log a deferred evaluation would count)
         b = outputs if outputs is not None else self._out(n_steps)
         dtype = 0
         aptr = None
@@ -215,6 +214,10 @@ class HipEnvEngine:
                                                                stream_ptr if stream_ptr is not None else self._stream()))
         k = n.value
         return (float(st[0]), float(st[1]), int(st[2])), r[:k].copy(), l[:k].copy(), e[:k].copy(), int(seen.value)
+
+    def clear_episode_log(self) -> None:
+        """Empty the episode log and the Monitor aggregate, ordered on the current stream; no read-back, no synchronisation."""
+        _lib.check(_lib.lib().tma_env_clear_episode_log(self._h, self._stream()))
 
     def pop_episode_stats(self) -> tuple[float, float, int]:
         out = (C.c_double * 3)()
