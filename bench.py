@@ -482,6 +482,25 @@ def harness_train_task(args, dev):
     return res
 
 
+def threshold_leg():
+    """The reference's declared reward thresholds (registry.py:64,80,96,112,128) through harness.train_task, on the reference's own schedule
+    (`literal`: its n_envs, total_timesteps, batch 256) and at 4096 envs (`scaled`): final deterministic evaluation, timesteps and seconds to the
+    first evaluation at the threshold, wall time of the whole train_task call (tools/threshold_runs.py; tests/test_thresholds_gpu.py asserts them)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import threshold_runs
+
+    res = {}
+    for task in ("basic", "gridworld", "ball3d", "push", "walljump"):
+        for sched in ("literal", "scaled"):
+            r = threshold_runs.run(task, sched, seed=1)
+            r.pop("eval_curve", None)
+            res.setdefault(task, {})[sched] = r
+            f = r.get("first_eval_at_threshold") or {}
+            log(f"threshold {task} {sched}: final {r['final_eval_mean']:.3f} (threshold {r['threshold']}), first at {f.get('timesteps')} steps / "
+                f"{f.get('device_seconds')} s, train_task {r['train_task_wall_seconds']:.2f} s")
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # CPU leg (the oracle as the stated baseline; never the thing shipped)
 # ------------------------------------------------------------------------------------------------------------------------
@@ -726,7 +745,7 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
         r = out.get(key)
         if isinstance(r, dict):
             roofs[short] = ({"error": str(r["error"])[:80]} if "error" in r else
-                            _pick(r, ("bound", "launch_us", "us_per_vector_step", "achieved", "unit", "frac", "traffic")))
+                            {k: v for k, v in _pick(r, ("bound", "launch_us", "us_per_vector_step", "achieved", "unit", "frac", "traffic")).items() if v is not None})
     if roofs:
         optional.append(("other_rooflines", roofs))
     if isinstance(out.get("extra_configs"), list):
@@ -745,13 +764,18 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
     if isinstance(h, dict):
         optional.append(("harness_train_task", {"error": str(h["error"])[:80]} if "error" in h else
                          _pick(h, ("train_task_seconds", "direct_ppo_seconds", "overhead_frac", "steady_state_overhead_frac"))))
-    if isinstance(out.get("thresholds"), dict):
-        optional.append(("thresholds", out["thresholds"]))
+    th = out.get("thresholds")
+    if isinstance(th, dict):  # per task: [threshold, final eval literal, final eval scaled, seconds to threshold literal, ... scaled]
+        optional.append(("thresholds", {"error": str(th["error"])[:80]} if "error" in th else {
+            "_": "task: [threshold, final_literal, final_scaled, s_to_threshold_literal, s_to_threshold_scaled]",
+            **{t: [(v.get("literal") or {}).get("threshold"), (v.get("literal") or {}).get("final_eval_mean"), (v.get("scaled") or {}).get("final_eval_mean"),
+                   ((v.get("literal") or {}).get("first_eval_at_threshold") or {}).get("device_seconds"),
+                   ((v.get("scaled") or {}).get("first_eval_at_threshold") or {}).get("device_seconds")] for t, v in th.items() if isinstance(v, dict)}}))
     if isinstance(out.get("train_stats"), dict):
         optional.append(("train_stats", _pick(out["train_stats"], ("train/approx_kl", "train/clip_fraction", "train/explained_variance"))))
     line["extras_path"] = extras_path
     for k, v in optional:
-        line[k] = v
+        line[k] = _r(v, 4)  # (summaries: four digits; the side file has the full values)
     exact = {k: line[k] for k in ("value", "ms_per_step") if k in line}  # (a reader checks value against ms_per_step: these two are not rounded)
 
     def dump():
@@ -871,6 +895,10 @@ def main():
                 log(f"harness train_task: {out['harness_train_task']['train_task_seconds']:.3f} s vs direct {out['harness_train_task']['direct_ppo_seconds']:.3f} s")
             except Exception as exc:  # noqa: BLE001
                 out["harness_train_task"] = {"error": repr(exc)}
+            try:
+                out["thresholds"] = threshold_leg()
+            except Exception as exc:  # noqa: BLE001
+                out["thresholds"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, batch)
