@@ -2200,6 +2200,8 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
     }
     if (fold || overwrite) return fail(TMA_ERR_INVALID, "internal: folded optimizer step outside the H = 64 fast path");
     if (L.bf16) {  // column-parallel bf16-MFMA kernel (tma_bf16.hip) + deterministic slab reduction
+        if ((int64_t)rb->T * rb->N * L.D >= (int64_t)1 << 31)  // (its observation gather indexes the buffer with 32-bit arithmetic)
+            return fail(TMA_ERR_INVALID, "bf16 update: T * N * obs_dim = %lld exceeds 2^31", (long long)((int64_t)rb->T * rb->N * L.D));
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         int n_pi = 0, n_vf = 0, lrc;
         {

@@ -377,8 +377,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
             for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W1l + (j * 64 + lane) * 8), acc[j]);
 #pragma unroll
             for (int j = 0; j < NTW; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
+                bfq_store_rows(A1 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j]));
         }
         __syncthreads();
 #pragma unroll
@@ -394,8 +393,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
             }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
+                bfq_store_rows(A2 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j]));
         }
         __syncthreads();
     };
@@ -703,8 +701,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int m2 = 0; m2 < 2; m2++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+                    bfq_store_rows(A1 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j][m2]));
         }
         __syncthreads();
 #pragma unroll
@@ -720,8 +717,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_kernel(EnvView
             }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][r]);
+                bfq_store_rows(A2 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j]));
         }
         __syncthreads();
     };
@@ -1000,8 +996,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int m2 = 0; m2 < MT2; m2++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) A1[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+                    bfq_store_rows(A1 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j][m2]));
         }
         __syncthreads();
         {
@@ -1022,8 +1017,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int m2 = 0; m2 < MT2; m2++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) A2[(16 * m2 + 4 * g + r) * lda + n_base + 16 * j + r16] = (bf16_t)tma_tanh(acc[j][m2][r]);
+                    bfq_store_rows(A2 + (16 * m2 + 4 * g) * lda + n_base + 16 * j + r16, lda, tanh_quad_s(acc[j][m2]));
         }
         __syncthreads();
         if (wave < MT2) {

@@ -63,17 +63,68 @@ __device__ __forceinline__ f32x2 delta2(f32x2 dh, f32x2 h) {
         f32x2 o;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            float hh = h[i] * h[i];
-            asm volatile("" : "+v"(hh));
-            float om = 1.0f - hh;
+            // h is a bf16 value (8 significant bits), so h * h is exact in f32 and ONE v_fma_f32 rounds 1 - h^2 exactly as the
+            // multiply + subtract pair did: same bits, one instruction less per element (round 5)
+            float om = __builtin_fmaf(-h[i], h[i], 1.0f);
             asm volatile("" : "+v"(om));
             o[i] = dh[i] * om;
         }
         return o;
     }
-    const f32x2 hh = h * h;
-    const f32x2 om = 1.0f - hh;
+    const f32x2 om = __builtin_elementwise_fma(-h, h, f32x2{1.0f, 1.0f});
     return dh * om;
+}
+
+// ---- tile epilogues on PACKED pairs (round 5) ----
+// A C-layout quad (four consecutive samples of one column) leaves an epilogue as two registers of packed bf16: ONE v_cvt_pk_bf16_f32 per
+// element pair.  Everything downstream takes its halves from those registers -- the 8-byte store into the T image, the four 2-byte stores
+// into the row-major image (ds_write_b16 / ds_write_b16_d16_hi), the bias-gradient sums (v_dot2c_f32_bf16 against packed ones).  Written
+// element-wise (`A[..] = (bf16_t)x` beside a bf16x4 built from the same values) the compiler converted every element twice: 6 conversions
+// per quad instead of 2, 32 extra VALU instructions in each of the three epilogues that keep a row-major image, and the per-lane bias sums
+// cost 4 unpacks + 3 adds per quad where two dot instructions do.  Same RNE conversion of the same f32 values: the images hold the same bits.
+struct bfq {
+    uint32_t lo, hi;  // elements 0, 1 | 2, 3
+};
+__device__ __forceinline__ uint32_t bf_pack2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (bf16_t)a, v[1] = (bf16_t)b;
+    uint32_t p = __builtin_bit_cast(uint32_t, v);
+    asm volatile("" : "+v"(p));  // opaque: consumers split THIS register, nothing re-converts the f32 values
+    return p;
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+template <bool PK>
+__device__ __forceinline__ bfq tanh_quad(const f32x4 &acc) {
+    const f32x2 a = tma_tanh2<PK>(f32x2{acc[0], acc[1]}), b = tma_tanh2<PK>(f32x2{acc[2], acc[3]});
+    return bfq{bf_pack2(a[0], a[1]), bf_pack2(b[0], b[1])};
+}
+// (the rollout kernels' form: tma_tanh per element -- component for component tma_tanh2's operations)
+__device__ __forceinline__ bfq tanh_quad_s(const f32x4 &acc) {
+    return bfq{bf_pack2(tma_tanh(acc[0]), tma_tanh(acc[1])), bf_pack2(tma_tanh(acc[2]), tma_tanh(acc[3]))};
+}
+// dz = dh * (1 - h^2) with h the packed bf16 quad read back from the T image
+template <bool PK>
+__device__ __forceinline__ bfq delta_quad(const f32x4 &dh, const uint2 h) {
+    const f32x2 a = delta2<PK>(f32x2{dh[0], dh[1]}, f32x2{bf_lo(h.x), bf_hi(h.x)}), b = delta2<PK>(f32x2{dh[2], dh[3]}, f32x2{bf_lo(h.y), bf_hi(h.y)});
+    return bfq{bf_pack2(a[0], a[1]), bf_pack2(b[0], b[1])};
+}
+// rows r .. r + 3 of one column of a row-major image (dst = &A[r][n], ld elements per row)
+__device__ __forceinline__ void bfq_store_rows(bf16_t *dst, int ld, const bfq q) {
+    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)q.lo;
+    *reinterpret_cast<uint16_t *>(dst + ld) = (uint16_t)(q.lo >> 16);
+    *reinterpret_cast<uint16_t *>(dst + 2 * ld) = (uint16_t)q.hi;
+    *reinterpret_cast<uint16_t *>(dst + 3 * ld) = (uint16_t)(q.hi >> 16);
+}
+__device__ __forceinline__ void bfq_store_quad(bf16x4 *dst, const bfq q) { *reinterpret_cast<uint2 *>(dst) = uint2{q.lo, q.hi}; }
+// s + the four elements of the quad (f32 accumulate; v_dot2c_f32_bf16 with both weights 1.0)
+__device__ __forceinline__ float bfq_sum(float s, const bfq q) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t ones;
+    ones[0] = (bf16_t)1.0f, ones[1] = (bf16_t)1.0f;
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, q.lo), ones, s, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, q.hi), ones, s, false);
 }
 
 // B fragment `idx` of a fragment-major image.  The load is made through an explicit global (address space 1) pointer: a
@@ -230,17 +281,9 @@ __device__ __forceinline__ void bf_hidden_layer(const bf16_t *Ain, int ldin, int
         const int n = n_base + 16 * j + r16;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            bf16x4 q;
-#pragma unroll
-            for (int r0 = 0; r0 < 4; r0 += 2) {
-                const f32x2 th = tma_tanh2(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
-                q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
-#pragma unroll
-                for (int r = r0; r < r0 + 2; r++) {
-                    Aout[(16 * mt + 4 * g + r) * ldo + n] = q[r];
-                }
-            }
-            if constexpr (STORE_T) *t_quad<MT>(Tout, n, mt, g) = q;
+            const bfq q = tanh_quad<true>(acc[j][mt]);
+            bfq_store_rows(Aout + (16 * mt + 4 * g) * ldo + n, ldo, q);
+            if constexpr (STORE_T) bfq_store_quad(t_quad<MT>(Tout, n, mt, g), q);
         }
     }
 }
@@ -356,7 +399,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // twice the MFMA work, and the accumulators of four row tiles need the registers)
     constexpr int R = bf_ring_slots(SL, (MT == 4 ? 2 : 4) * NTW);
     constexpr bool PF = KS1C > 0 && KS1C <= 2;  // observation prefetch into registers: compile-time width, at most 8 registers per thread
-    constexpr int NX = PF ? 2 * MT * KS1C * 4 / NW : 1;
+    // Round 5: a thread owns column (tid & 7) of 8-column group cg of row (tid >> 3) + 8 NW rp -- the row (its buffer offset, its validity, both
+    // image addresses) is worked out once per row pass and the column groups differ by compile-time offsets; and only the CG groups that CAN
+    // hold observations are gathered and committed (KT1C == 1: D <= 16, two groups -- Ball3D's 6 and GridWorld's 4 floats used to be
+    // gathered and committed as 32 columns a row, 26 of them zeros, 96 + 65 VALU instructions per group); the padding columns of both
+    // images are cleared once per launch.
+    constexpr int CG = PF ? (KT1C == 1 ? 2 : 4 * KS1C) : 1, RP = PF ? 2 * MT / NW : 1;
+    static_assert(!PF || (2 * MT) % NW == 0, "observation prefetch: 64 NW threads cover 8 NW rows of 8 columns per pass");
+    constexpr int NX = PF ? RP * CG : 1;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR: fragment bases stay scalar
     // Every lane-derived LDS / global address in the group loop is loop-invariant; hoisted, there are far more of them than
     // registers and they come back as scratch reloads -- each one an s_waitcnt vmcnt(0) that drains the weight prefetch.
@@ -414,6 +464,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
     // one-block launch in front of every minibatch
     (void)ws_adv;
+    if constexpr (PF) {  // columns [8 CG, Kp1) of both observation images stay zero for the whole launch (P0 commits the first CG groups only)
+        for (int e = threadIdx.x; e < (M * ldx + Kp1 * M) / 8; e += blockDim.x) reinterpret_cast<uint4 *>(Xa)[e] = uint4{0u, 0u, 0u, 0u};
+    }
     __shared__ float adv_ms[2];
     if (IS_PI && hp.normalize_advantage && threadIdx.x < 64) {
         double a = 0.0, bsum = 0.0;
@@ -516,11 +569,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         if constexpr (PF) {
             const int tid = wave * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int e = tid + 64 * NW * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
-                const int64_t off = row_off_next[row];
-                const bool ok = off >= 0 && c < D;
-                px[i] = rb.obs[ok ? off * D + c : 0];
+            for (int rp = 0; rp < RP; rp++) {
+                const int64_t off = row_off_next[rp * 8 * NW + (tid >> 3)];
+                const int base = (int)off * D;  // (sample offsets are below 2^22, tma_ppo_epoch_prepare's OFFS_CAP: 32-bit index arithmetic)
+#pragma unroll
+                for (int cg = 0; cg < CG; cg++) {
+                    const int c = 8 * cg + (tid & 7);
+                    px[rp * CG + cg] = rb.obs[(off >= 0 && c < D) ? base + c : 0];
+                }
             }
         }
     };
@@ -559,12 +615,16 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         if constexpr (PF) {
             const int tid = wave * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int e = tid + 64 * NW * i, row = e / (32 * KS1C), c = e % (32 * KS1C);
-                const bool ok = row_off_next[row] >= 0 && c < D;  // row_off_next still names THIS group's rows (next fetch_meta: end of P2)
-                const bf16_t v = (bf16_t)(ok ? px[i] : 0.0f);
-                Xa[row * ldx + c] = v;
-                Xt[t_off<MT>(c, row)] = v;
+            for (int rp = 0; rp < RP; rp++) {
+                const int row = rp * 8 * NW + (tid >> 3);
+                const bool okr = row_off_next[row] >= 0;  // row_off_next still names THIS group's rows (next fetch_meta: end of P2)
+#pragma unroll
+                for (int cg = 0; cg < CG; cg++) {
+                    const int c = 8 * cg + (tid & 7);
+                    const bf16_t v = (bf16_t)((okr && c < D) ? px[rp * CG + cg] : 0.0f);
+                    Xa[row * ldx + c] = v;
+                    Xt[t_off<MT>(c, row)] = v;
+                }
             }
         } else {
             __syncthreads();
@@ -690,17 +750,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const int n = n_base + 16 * j + r16;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    bf16x4 q;
-#pragma unroll
-                    for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 th = tma_tanh2<!W8>(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
-                        q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
-#pragma unroll
-                        for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!bf_tr_reads<MT>()) A1[(16 * mt + 4 * g + r) * lda + n] = q[r];
-                        }
-                    }
-                    *t_quad<MT>(T1, n, mt, g) = q;
+                    const bfq q = tanh_quad<!W8>(acc[j][mt]);
+                    if constexpr (!bf_tr_reads<MT>()) bfq_store_rows(A1 + (16 * mt + 4 * g) * lda + n, lda, q);
+                    bfq_store_quad(t_quad<MT>(T1, n, mt, g), q);
                 }
             }
         }
@@ -788,17 +840,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         const int n = n_base + 16 * (jh * NH + jj) + r16;
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {
-                            bf16x4 q;
-#pragma unroll
-                            for (int r0 = 0; r0 < 4; r0 += 2) {
-                                const f32x2 th = tma_tanh2<!W8>(f32x2{acc[jj][mt][r0], acc[jj][mt][r0 + 1]});
-                                q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
-#pragma unroll
-                                for (int r = r0; r < r0 + 2; r++) {
-                                    if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
-                                }
-                            }
-                            *t_quad<MT>(T2, n, mt, g) = q;
+                            const bfq q = tanh_quad<!W8>(acc[jj][mt]);
+                            if constexpr (!bf_tr_reads<MT>()) bfq_store_rows(A2 + (16 * mt + 4 * g) * lda + n, lda, q);
+                            bfq_store_quad(t_quad<MT>(T2, n, mt, g), q);
                         }
                     }
                 }
@@ -844,17 +888,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const int n = n_base + 16 * j + r16;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    bf16x4 q;
-#pragma unroll
-                    for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 th = tma_tanh2<!W8>(f32x2{acc[j][mt][r0], acc[j][mt][r0 + 1]});
-                        q[r0] = (bf16_t)th[0], q[r0 + 1] = (bf16_t)th[1];
-#pragma unroll
-                        for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
-                        }
-                    }
-                    *t_quad<MT>(T2, n, mt, g) = q;
+                    const bfq q = tanh_quad<!W8>(acc[j][mt]);
+                    if constexpr (!bf_tr_reads<MT>()) bfq_store_rows(A2 + (16 * mt + 4 * g) * lda + n, lda, q);
+                    bfq_store_quad(t_quad<MT>(T2, n, mt, g), q);
                 }
             }
             }
@@ -1048,19 +1084,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int mt = 0; mt < MT; mt++) {
                     const f32x4 dh = mfma_bf(za[mt], w3b[j], z4);
                     bf16x4 *tq = t_quad<MT>(T2, n, mt, g);
-                    const bf16x4 h4 = *tq;
-                    bf16x4 q;
-#pragma unroll
-                    for (int r0 = 0; r0 < 4; r0 += 2) {
-                        const f32x2 dz = delta2<!W8>(f32x2{dh[r0], dh[r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
-                        q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
-#pragma unroll
-                        for (int r = r0; r < r0 + 2; r++) {
-                            if constexpr (!bf_tr_reads<MT>()) A2[(16 * mt + 4 * g + r) * lda + n] = q[r];
-                        }
-                    }
-                    if constexpr (BV && MAIN) sB2[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);  // (the bf16 deltas the weight gradient uses)
-                    *tq = q;
+                    const bfq q = delta_quad<!W8>(dh, *reinterpret_cast<const uint2 *>(tq));
+                    if constexpr (!bf_tr_reads<MT>()) bfq_store_rows(A2 + (16 * mt + 4 * g) * lda + n, lda, q);
+                    if constexpr (BV && MAIN) sB2[j] = bfq_sum(sB2[j], q);  // (the bf16 deltas the weight gradient uses)
+                    bfq_store_quad(tq, q);
                 }
             }
         }
@@ -1155,15 +1182,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {
                             bf16x4 *tq = t_quad<MT>(T1, n, mt, g);
-                            const bf16x4 h4 = *tq;
-                            bf16x4 q;
-#pragma unroll
-                            for (int r0 = 0; r0 < 4; r0 += 2) {
-                                const f32x2 dz = delta2<!W8>(f32x2{dh[jj][mt][r0], dh[jj][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
-                                q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
-                            }
-                            if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
-                            *tq = q;
+                            const bfq q = delta_quad<!W8>(dh[jj][mt], *reinterpret_cast<const uint2 *>(tq));
+                            if constexpr (BV && MAIN) sB1[j] = bfq_sum(sB1[j], q);
+                            bfq_store_quad(tq, q);
                         }
                     }
                 }
@@ -1210,15 +1231,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 bf16x4 *tq = t_quad<MT>(T1, n, mt, g);
-                const bf16x4 h4 = *tq;
-                bf16x4 q;
-#pragma unroll
-                for (int r0 = 0; r0 < 4; r0 += 2) {
-                    const f32x2 dz = delta2<!W8>(f32x2{dh1[j][mt][r0], dh1[j][mt][r0 + 1]}, f32x2{(float)h4[r0], (float)h4[r0 + 1]});
-                    q[r0] = (bf16_t)dz[0], q[r0 + 1] = (bf16_t)dz[1];
-                }
-                if constexpr (BV && MAIN) sB1[j] += ((float)q[0] + (float)q[1]) + ((float)q[2] + (float)q[3]);
-                *tq = q;
+                const bfq q = delta_quad<!W8>(dh1[j][mt], *reinterpret_cast<const uint2 *>(tq));
+                if constexpr (BV && MAIN) sB1[j] = bfq_sum(sB1[j], q);
+                bfq_store_quad(tq, q);
             }
         }
         }
