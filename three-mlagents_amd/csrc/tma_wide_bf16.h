@@ -209,6 +209,38 @@ __device__ __forceinline__ bf16x8 a_frag_t(const bf16_t *T, int mt, int ks, int 
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
+// The same reads with the address arithmetic hoisted out of the k loop (round 5).  For both swizzles t_swz<MT>(k + 32 ks) == t_swz<MT>(k)
+// (MT = 2: (-(k >> 2)) & 3 with 8 ks a multiple of 4; MT = 4: k & 7), so the two row addresses of a lane for k-step ks are those of k-step 0
+// plus ks * 32 image rows: two base pointers per row tile, computed once per phase, and a compile-time offset per k-step (the ds_read
+// offset field).  Recomputed per fragment, a_frag_t's addresses were ~250 of the ~880 VALU instructions of a 32-row group (P2: 128 for
+// 32 MFMAs, P5: 119 for 64).
+template <int MT>
+struct TrBase {
+    const bf16_t *lo[MT], *hi[MT];
+};
+template <int MT>
+__device__ __forceinline__ TrBase<MT> tr_base(const bf16_t *T, int lane) {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3, g = lane >> 4;
+    const int k0 = 8 * g + q, k1 = k0 + 4, sub = 4 * (p & 1);
+    TrBase<MT> b;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int ch = 2 * mt + (p >> 1);
+        b.lo[mt] = T + k0 * (16 * MT) + 8 * (ch ^ t_swz<MT>(k0)) + sub;
+        b.hi[mt] = T + k1 * (16 * MT) + 8 * (ch ^ t_swz<MT>(k1)) + sub;
+    }
+    return b;
+}
+template <int MT>
+__device__ __forceinline__ bf16x8 a_frag_tb(const TrBase<MT> &b, int mt, int ks) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) *lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b.lo[mt] + ks * 32 * 16 * MT));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b.hi[mt] + ks * 32 * 16 * MT));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 // A fragment of activations / deltas held in both images (A image + T image): the transposed read, or the row-major one
 template <int MT>
 __device__ __forceinline__ bf16x8 act_frag(const bf16_t *A, int ld, const bf16_t *T, int mt, int ks, int lane) {
@@ -661,16 +693,17 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int k = 0; k < KCC; k++) {
                     const int c = c0 + 64 * k + lane;
                     if (c < Kp1) {
-                        bf16_t col[RW];
+                        uint32_t pk[RW / 2];  // (one conversion per row pair; the 2-byte stores take the halves: see bfq)
 #pragma unroll
-                        for (int i = 0; i < RW; i++) {
-                            col[i] = (bf16_t)((rok[i] && c < D) ? t[k][i] : 0.0f);
-                            Xa[(wave * RW + i) * ldx + c] = col[i];
+                        for (int i = 0; i < RW; i += 2) {
+                            pk[i / 2] = bf_pack2((rok[i] && c < D) ? t[k][i] : 0.0f, (rok[i + 1] && c < D) ? t[k][i + 1] : 0.0f);
+                            *reinterpret_cast<uint16_t *>(Xa + (wave * RW + i) * ldx + c) = (uint16_t)pk[i / 2];
+                            *reinterpret_cast<uint16_t *>(Xa + (wave * RW + i + 1) * ldx + c) = (uint16_t)(pk[i / 2] >> 16);
                         }
                         if constexpr (RW == 8) {
-                            *reinterpret_cast<bf16x8 *>(Xt + t_off<MT>(c, wave * RW)) = bf16x8{col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7]};
+                            *reinterpret_cast<uint4 *>(Xt + t_off<MT>(c, wave * RW)) = uint4{pk[0], pk[1], pk[2], pk[3]};
                         } else {
-                            *reinterpret_cast<bf16x4 *>(Xt + t_off<MT>(c, wave * RW)) = bf16x4{col[0], col[1], col[2], col[3]};
+                            *reinterpret_cast<uint2 *>(Xt + t_off<MT>(c, wave * RW)) = uint2{pk[0], pk[1]};
                         }
                     }
                 }
@@ -858,8 +891,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             // k-step ahead -- tiles 2, 3 of the step are read while tiles 0, 1 multiply (16 registers instead of 32)
             constexpr int AH = MT == 4 ? 2 : MT;  // row tiles per A-fragment batch
             bf16x8 a[2][AH];
+            [[maybe_unused]] TrBase<MT> tb1;
+            if constexpr (bf_tr_reads<MT>()) tb1 = tr_base<MT>(T1, lane);
+            auto afrag1 = [&](int mt, int ks) -> bf16x8 {
+                if constexpr (bf_tr_reads<MT>()) return a_frag_tb<MT>(tb1, mt, ks);
+                else return a_frag(A1, lda, 16 * mt + r16, ks, g);
+            };
 #pragma unroll
-            for (int mt = 0; mt < AH; mt++) a[0][mt] = act_frag<MT>(A1, lda, T1, mt, 0, lane);
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = afrag1(mt, 0);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
 #pragma unroll
@@ -867,7 +906,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const int cur = (ks * (MT / AH) + hb) & 1, nb_ks = hb + 1 < MT / AH ? ks : ks + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
                     if (nb_ks < KS2) {
 #pragma unroll
-                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = act_frag<MT>(A1, lda, T1, (nb_h * AH + mt), nb_ks, lane);
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = afrag1(nb_h * AH + mt, nb_ks);
                     }
 #pragma unroll
                     for (int j = 0; j < NTW; j++) {
@@ -1194,8 +1233,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             TMA_RELANE();
             constexpr int AH = MT == 4 ? 2 : MT;
             bf16x8 a[2][AH];
+            [[maybe_unused]] TrBase<MT> tb2;
+            if constexpr (bf_tr_reads<MT>()) tb2 = tr_base<MT>(T2, lane);
+            auto afrag2 = [&](int mt, int ks) -> bf16x8 {
+                if constexpr (bf_tr_reads<MT>()) return a_frag_tb<MT>(tb2, mt, ks);
+                else return a_frag(A2, lda, 16 * mt + r16, ks, g);
+            };
 #pragma unroll
-            for (int mt = 0; mt < AH; mt++) a[0][mt] = act_frag<MT>(A2, lda, T2, mt, 0, lane);
+            for (int mt = 0; mt < AH; mt++) a[0][mt] = afrag2(mt, 0);
 #pragma unroll
             for (int ns = 0; ns < KS2; ns++) {
 #pragma unroll
@@ -1203,7 +1248,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const int cur = (ns * (MT / AH) + hb) & 1, nb_ns = hb + 1 < MT / AH ? ns : ns + 1, nb_h = hb + 1 < MT / AH ? hb + 1 : 0;
                     if (nb_ns < KS2) {
 #pragma unroll
-                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = act_frag<MT>(A2, lda, T2, (nb_h * AH + mt), nb_ns, lane);
+                        for (int mt = 0; mt < AH; mt++) a[cur ^ 1][mt] = afrag2(nb_h * AH + mt, nb_ns);
                     }
 #pragma unroll
                     for (int j = 0; j < NTW; j++) {
