@@ -344,15 +344,20 @@ def step_kernel_rooflines(out, args, env, model, world):
 # = 2048 per GPU; T = 2048 for the benchmark tier, training.py:362), same PPO schedule as the headline (32 minibatches x 10 epochs)
 EXTRA_CONFIGS = [
     dict(name="configs[2] Ball3D 4096 envs, MLP(256,256) bf16", task="ball3d", n_envs=4096, n_steps=1024, hidden=256, mfma="bf16"),
-    dict(name="configs[3] Push 2048 envs/GPU (the per-GPU shard of 8192 over 4), MLP(256,256) bf16", task="push", n_envs=2048, n_steps=2048, hidden=256,
+    dict(name="configs[3] Push 2048 envs/GPU (the per-GPU shard of 8192 over 4), MLP(256,256) bf16 (engine option: BASELINE.json does not name bf16 here)", task="push", n_envs=2048, n_steps=2048, hidden=256,
          mfma="bf16"),
-    dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU (the per-GPU shard of 16384 over 8), MLP(256,256) bf16", task="crawler", n_envs=2048,
+    dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU (the per-GPU shard of 16384 over 8), MLP(256,256) bf16 (engine option: BASELINE.json does not name bf16 here)", task="crawler", n_envs=2048,
          n_steps=2048, hidden=256, mfma="bf16"),
     dict(name="configs[0] Basic 8 envs, MLP(256,256) f32, the reference's literal batch 256", task="basic", n_envs=8, n_steps=1024, hidden=256, mfma="f32",
          batch=256),
     # SURVEY.md 8d config (2), second half: the headline env with the reference's DEFAULT net and dtype (training.py:363-365)
     dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 (reference default net)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="f32",
          steps=4, warmup=1),
+    # BASELINE.json names bf16 for configs[2] only: the like-for-like f32 figures of the configs[3] / [4] shards (exact-f32 MFMA wide kernel)
+    dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="f32",
+         steps=3, warmup=1),
+    dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="crawler", n_envs=2048, n_steps=2048, hidden=256,
+         mfma="f32", steps=3, warmup=1),
 ]
 
 
@@ -749,10 +754,13 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
     if roofs:
         optional.append(("other_rooflines", roofs))
     if isinstance(out.get("extra_configs"), list):
-        optional.append(("extra_configs", [
-            ({"config": str(e.get("config", ""))[:48], "error": str(e["error"])[:80]} if "error" in e else
-             {"config": str(e.get("config", "")).split(",")[0][:48], **_pick(e, ("task", "envs_per_gpu", "hidden", "dtype", "env_steps_per_sec", "ms_per_step")),
-              "grad_us": (e.get("roofline") or {}).get("launch_us"), "frac": (e.get("roofline") or {}).get("frac")}) for e in out["extra_configs"]]))
+        rows = {"_": "[task, envs/GPU, hidden, dtype, env_steps_per_sec, ms_per_step, grad_kernel_us, grad_roofline_frac]"}
+        for e in out["extra_configs"]:
+            key = f"{str(e.get('config', '?'))[:10]} {e.get('task', '')} {e.get('hidden', '')} {e.get('dtype', '')}".strip()
+            rows[key] = ("error: " + str(e["error"])[:60]) if "error" in e else [
+                e.get("task"), e.get("envs_per_gpu"), e.get("hidden"), e.get("dtype"), e.get("env_steps_per_sec"), e.get("ms_per_step"),
+                (e.get("roofline") or {}).get("launch_us"), (e.get("roofline") or {}).get("frac")]
+        optional.append(("extra_configs", rows))
     lit = {}
     for key, short in (("literal_batch_256", "h64"), ("literal_batch_256_h256", "h256")):
         r = out.get(key)

@@ -33,12 +33,12 @@ def test_line_is_bounded_and_round_trips():
         assert k in cpu, k
     assert len(cpu["sample"]) <= 200 and cpu["kind"] == "port"
     assert line["extras_path"] == "bench_extras.json" and "dropped_to_fit" not in line
-    assert len(line["extra_configs"]) == len(out["extra_configs"])
+    assert len(line["extra_configs"]) == len(out["extra_configs"]) + 1  # (+ the legend entry)
 
 
 def test_oversized_blocks_are_dropped_not_truncated():
     out = _canned()
-    out["extra_configs"] = out["extra_configs"] * 12  # a run that grew: optional blocks go, the contract keys stay
+    out["extra_configs"] = [dict(e, task=f"{e['task']}{i}") for i in range(12) for e in out["extra_configs"]]  # a run that grew: optional blocks go, the contract keys stay
     out["config"]["workload"] = "x" * 5000
     text = bench.compact_line(out, "bench_extras.json")
     assert len(text) < 4096
