@@ -93,14 +93,21 @@ struct LossStats {
 };
 
 // clipped-surrogate + entropy gradient wrt the head outputs of one 16-row tile (C layout), written to dz3[16][ld3]
-template <bool CONT>
+// RLO / RHI >= 0: the row range is a compile-time constant -- the rows of the range then form ONE basic block, and the scheduler interleaves
+// their dependent chains (max / exp / sum / log / exp over DPP reductions: ~140 instructions a row, each waiting for the one before).  With
+// the range in registers every row is a block of its own behind a wave-uniform branch and the chains run one after the other.
+template <bool CONT, int RLO = -1, int RHI = -1>
 __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
                                                  const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
                                                  int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4) {
     const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (r < r_lo || r >= r_hi) continue;  // (wave-uniform) a caller may split the four rows of a lane group over two waves
+        if constexpr (RLO >= 0) {
+            if (r < RLO || r >= RHI) continue;
+        } else {
+            if (r < r_lo || r >= r_hi) continue;  // (wave-uniform) a caller may split the four rows of a lane group over two waves
+        }
         const int row = g * 4 + r;
         const int64_t off = row_off[row];
         const bool valid = off >= 0;
@@ -156,13 +163,13 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
                 if (col < A) dlsd[j] += g_lp * ((d[j] * d[j]) / var - 1.0f) - (valid ? hp.ent_coef * invB : 0.0f);
             }
         }
-        if (valid && r16 == 0) {
-            st.a += (double)(-fminf(pl1, pl2));
-            st.ent += (double)ent;
-            st.kl += (double)((ratio - 1.0f) - (lpa - old));
-            st.clip += (fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
-            st.n += 1.0;
-        }
+        // (selects instead of a divergent branch: adding +0.0 leaves a sum as it is, and the row stays one basic block)
+        const bool on = valid && r16 == 0;
+        st.a += on ? (double)(-fminf(pl1, pl2)) : 0.0;
+        st.ent += on ? (double)ent : 0.0;
+        st.kl += on ? (double)((ratio - 1.0f) - (lpa - old)) : 0.0;
+        st.clip += (on && fabsf(ratio - 1.0f) > hp.clip_range) ? 1.0 : 0.0;
+        st.n += on ? 1.0 : 0.0;
     }
 }
 

@@ -847,8 +847,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         for (int mt = 0; mt < MT; mt++) acc[jj][mt] = f32x4{b, b, b, b};
                     }
                     bf16x8 a[2][2];  // A fragments of two row tiles, half a k-step ahead
+                    [[maybe_unused]] TrBase<MT> tb1;
+                    if constexpr (bf_tr_reads<MT>()) tb1 = tr_base<MT>(T1, lane);
+                    auto afrag1 = [&](int mt, int ks) -> bf16x8 {
+                        if constexpr (bf_tr_reads<MT>()) return a_frag_tb<MT>(tb1, mt, ks);
+                        else return a_frag(A1, lda, 16 * mt + r16, ks, g);
+                    };
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) a[0][mt] = act_frag<MT>(A1, lda, T1, mt, 0, lane);
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = afrag1(mt, 0);
 #pragma unroll
                     for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
@@ -856,7 +862,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             const int cur = hb, nb_ks = hb ? ks + 1 : ks, nb_h = hb ? 0 : 1;
                             if (nb_ks < KS2) {
 #pragma unroll
-                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = act_frag<MT>(A1, lda, T1, (nb_h * 2 + mt), nb_ks, lane);
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = afrag1(nb_h * 2 + mt, nb_ks);
                             }
 #pragma unroll
                             for (int jj = 0; jj < NH; jj++) {
@@ -984,8 +990,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 LossStats st;
                 float *dzt = dz3 + mt * 16 * ld3;
                 if constexpr (IS_PI) {
-                    policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                           lane, r_lo, r_hi);
+#define TMA_LOSS_ARGS out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane
+                    if constexpr (W8) {  // rows 0, 1 (waves 0-3) or 2, 3 (waves 4-7) of every lane group: a compile-time range per branch
+                        if (wave < 4) policy_loss_tile<CONT, 0, 2>(TMA_LOSS_ARGS);
+                        else policy_loss_tile<CONT, 2, 4>(TMA_LOSS_ARGS);
+                    } else {
+                        policy_loss_tile<CONT, 0, 4>(TMA_LOSS_ARGS);
+                    }
+#undef TMA_LOSS_ARGS
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -1195,8 +1207,14 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) dh[jj][mt] = z4;
                     bf16x8 a[2][2];
+                    [[maybe_unused]] TrBase<MT> tb2;
+                    if constexpr (bf_tr_reads<MT>()) tb2 = tr_base<MT>(T2, lane);
+                    auto afrag2 = [&](int mt, int ks) -> bf16x8 {
+                        if constexpr (bf_tr_reads<MT>()) return a_frag_tb<MT>(tb2, mt, ks);
+                        else return a_frag(A2, lda, 16 * mt + r16, ks, g);
+                    };
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) a[0][mt] = act_frag<MT>(A2, lda, T2, mt, 0, lane);
+                    for (int mt = 0; mt < 2; mt++) a[0][mt] = afrag2(mt, 0);
 #pragma unroll
                     for (int ns = 0; ns < KS2; ns++)
 #pragma unroll
@@ -1204,7 +1222,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             const int cur = hb, nb_ns = hb ? ns + 1 : ns, nb_h = hb ? 0 : 1;
                             if (nb_ns < KS2) {
 #pragma unroll
-                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = act_frag<MT>(A2, lda, T2, (nb_h * 2 + mt), nb_ns, lane);
+                                for (int mt = 0; mt < 2; mt++) a[cur ^ 1][mt] = afrag2(nb_h * 2 + mt, nb_ns);
                             }
 #pragma unroll
                             for (int jj = 0; jj < NH; jj++) {
