@@ -13,3 +13,8 @@ run "TMA_WIDE_ROWS=32" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
 run "TMA_CONT_ROWS=32" "tests/test_bf16_gpu.py tests/test_rollout_oracle_gpu.py"
 run "TMA_NO_DZ1_CACHE=1" "tests/test_bf16_gpu.py"
 run "TMA_NO_NATIVE_RCCL=1" "tests/test_dist_gpu.py"
+# round 5
+run "TMA_DP_NO_FOLD=1" "tests/test_dist_gpu.py tests/test_ppo_gpu.py"
+run "TMA_STEP_THREADS=64" "tests/test_env_gpu.py"
+run "TMA_BF_NPI=128" "tests/test_bf16_gpu.py"
+# (single-launch timing of the plain VecEnv.step path, round-3 library against this build on this box: python tools/step_ab.py --lib A.so --lib B.so)
