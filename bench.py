@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--n-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=0, help="0 -> 32 minibatches per epoch (the reference's default schedule: 8 envs x 1024 / 256)")
-    ap.add_argument("--mfma-dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--mfma-dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
                     help="MFMA operand type of the hidden-layer GEMMs (bf16: hidden 128/192/256 only; BASELINE.json configs[2])")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,13 +186,17 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
     fast = hidden == 64 and D <= 16 and not model.policy.continuous and mb.count >= 256
     wide = hidden in (128, 192, 256)
     peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
-    kname = ("tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
+    split = mfma == "bf16x3" and wide and mb.count >= 4096
+    kname = ("tma::ppo_grad_split3_kernel" if split else "tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else
+             "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
     return {
         "kernel": kname, "launch_group_us": g_grp, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
         "launch_us": g_med, "launch_us_source": "HIP events recorded by the library around the kernel launch on its stream (median)" if ks else
                      "HIP events around the whole tma_ppo_minibatch_grad call",
         "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
-        "note": ("bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
+        "note": ("three-term bf16 split of the f32 update (six bf16 MFMAs per f32-class product; csrc/tma_split3.h): f32-EQUIVALENT flops against the f32 MFMA peak "
+                 "-- the work runs on the bf16 pipe, so frac may approach or pass 1" if split else
+                 "bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
                  "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
     }
 
@@ -354,6 +358,9 @@ EXTRA_CONFIGS = [
     dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 (reference default net)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="f32",
          steps=4, warmup=1),
     # BASELINE.json names bf16 for configs[2] only: the like-for-like f32 figures of the configs[3] / [4] shards (exact-f32 MFMA wide kernel)
+    # ... and the same fp32 policy with the UPDATE on the bf16 MFMA as a three-term split (mfma_dtype "bf16x3", opt-in, f32-class accuracy: round 5)
+    dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 weights, bf16x3 update (opt-in)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="bf16x3",
+         steps=4, warmup=1),
     dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="f32",
          steps=3, warmup=1),
     dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="crawler", n_envs=2048, n_steps=2048, hidden=256,

@@ -144,7 +144,11 @@ typedef struct {
     int continuous; /* 0: Categorical head; 1: DiagGaussian head with a state-independent log_std */
     int mfma_dtype; /* 0: f32 MFMA everywhere (parity mode, every hidden width); 1: bf16 MFMA operands with f32 master
                        weights and f32 accumulation for the hidden-layer and head GEMMs (hidden = 128 / 192 / 256 only:
-                       BASELINE.json configs[2] "PPO MLP(256,256) bf16").  Rollout and update use the same forward code. */
+                       BASELINE.json configs[2] "PPO MLP(256,256) bf16").  Rollout and update use the same forward code.
+                       2 (round 5, opt-in): the f32 UPDATE of a Discrete 256 x 256 policy (the reference's default net,
+                       backend/mlagents/training.py:363-365; up to 32 observations) on the bf16 MFMA with every operand as three bf16
+                       terms and the six products of order <= 2 -- f32-class accuracy (2^-21 against float64, the exact-f32 MFMA's own
+                       figure) at ~1.8x the f32 matrix pipe; rollouts, evaluation and small minibatches run the exact-f32 kernels. */
     int device;     /* HIP device the parameter / rollout / workspace buffers live on: every tma_policy_* / tma_ppo_* call makes it
                        the calling thread's current device first (callers may be worker threads: backend/main.py:152
                        asyncio.to_thread).  -1: keep whatever device is current on the calling thread. */

@@ -139,3 +139,4 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         *n_pi_out = n_pi, *n_vf_out = n_vf;
         return TMA_OK;
 }
+

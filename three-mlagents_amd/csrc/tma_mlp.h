@@ -44,6 +44,9 @@ struct PLayout {
                          // W2[k = 16q + 4i + (l>>4)][n = 16t + (l&15)], input-gradient W2[k' = 16t + (l&15)][n = 16q + 4i + (l>>4)] -- so a
                          // lane's operands for four consecutive k-steps are one coalesced 16-byte load; -1 otherwise
     int fr1_pi, fr1_vf;  // same fragment layout for W1 (k padded with zero rows to 16 * ceil(D / 16)), present when fr_pi >= 0 and D > 32
+    int split;           // 1: mfma_dtype = 2 -- the UPDATE runs on the bf16 MFMA with every operand as three bf16 terms (tma_split3.h); rollouts,
+                         // evaluation and every derived f32 image are those of the exact-f32 mode
+    int sp_pi, sp_vf;    // float offsets of the three-plane fragment-major weight images of the two nets (3 x BfNet.size bf16 each); -1 otherwise
     int total;
 };
 
@@ -111,7 +114,8 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, in
     const bool fast = (H == 64) && (D <= 16) && !cont && (A <= 16);
     L.img_pi = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
     L.img_vf = fast ? o : -1, o += fast ? IMG_FLOATS : 0;
-    L.bf16 = bf16 ? 1 : 0;
+    L.bf16 = bf16 == 1 ? 1 : 0;
+    L.split = bf16 == 2 ? 1 : 0;
     L.bf_pi = L.bf_vf = -1;
     if (L.bf16) {
         L.bf_pi = o, o += bf_net_layout(D, H, A).size / 2;
@@ -126,6 +130,11 @@ __host__ __device__ inline PLayout make_layout(int D, int H, int A, int cont, in
     if (L.fr_pi >= 0 && D > 32) {
         L.fr1_pi = o, o += H * 16 * ((D + 15) / 16);
         L.fr1_vf = o, o += H * 16 * ((D + 15) / 16);
+    }
+    L.sp_pi = L.sp_vf = -1;
+    if (L.split) {
+        L.sp_pi = o, o += 3 * bf_net_layout(D, H, A).size / 2;
+        L.sp_vf = o, o += 3 * bf_net_layout(D, H, 1).size / 2;
     }
     L.total = o;
     return L;

@@ -1312,6 +1312,25 @@ __device__ __forceinline__ void scatter_derived_wide(float *params, const PLayou
     const BfNet B = bf_net_layout(D, H, n_out);
     const int KS2 = H >> 5, KS1 = ((D + 31) & ~31) >> 5;
     const bf16_t bv = (bf16_t)val;
+    if (L.split) {  // mfma_dtype = 2: the same slots in the three planes of the split images (hi, mid, lo: val == hi + mid + lo)
+        bf16_t *sp = reinterpret_cast<bf16_t *>(params + (vf ? L.sp_vf : L.sp_pi));
+        const float r1 = val - (float)bv;
+        const bf16_t bm = (bf16_t)r1, bl = (bf16_t)(r1 - (float)bm);
+        auto put = [&](int slot) { sp[slot] = bv, sp[B.size + slot] = bm, sp[2 * B.size + slot] = bl; };
+        int y = e - base;
+        if (y < D * H) {
+            const int k = y / H, n = y - k * H;
+            put(B.fW1 + (((n >> 4) * KS1 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7));
+        } else if ((y -= D * H + H) >= 0 && y < H * H) {
+            const int k = y / H, n = y - k * H;
+            put(B.fW2 + (((n >> 4) * KS2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7));
+            put(B.bW2 + (((k >> 4) * KS2 + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (k & 15)) * 8 + (n & 7));
+        } else if ((y -= H * H + H) >= 0 && y < H * n_out) {
+            const int k = y / n_out, a = y - k * n_out;
+            put(B.fW3 + (((a >> 4) * KS2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (a & 15)) * 8 + (k & 7));
+            put(B.bW3 + ((k >> 4) * 64 + ((a >> 3) & 3) * 16 + (k & 15)) * 8 + (a & 7));
+        }
+    }
     int x = e - base;
     if (x < D * H) {  // W1t[k][n]
         const int k = x / H, n = x - k * H;
@@ -1492,6 +1511,7 @@ static int launch_sync(float *params, const PLayout &L, hipStream_t s) {
         build_f32_frag_images_kernel<<<dim3((unsigned)ceil_div(4 * L.H * L.H, 256)), dim3(256), 0, s>>>(params, L);
         TMA_LAUNCH_CHECK();
     }
+    if (L.split) return tma_launch_build_split3(params, L, s);
     return TMA_OK;
 }
 
@@ -1538,7 +1558,10 @@ static int check_dims(const tma_policy_dims *d) {
     } else if (d->act_dim < 2 || d->act_dim > 16)
         return fail(TMA_ERR_INVALID, "Discrete action count must be in [2, 16] (got %d)", d->act_dim);
     if (d->device < -1) return fail(TMA_ERR_INVALID, "device must be >= 0, or -1 for the calling thread's current device (got %d)", d->device);
-    if (d->mfma_dtype != 0 && d->mfma_dtype != 1) return fail(TMA_ERR_INVALID, "mfma_dtype must be 0 (f32) or 1 (bf16), got %d", d->mfma_dtype);
+    if (d->mfma_dtype < 0 || d->mfma_dtype > 2) return fail(TMA_ERR_INVALID, "mfma_dtype must be 0 (f32), 1 (bf16) or 2 (bf16 x 3), got %d", d->mfma_dtype);
+    if (d->mfma_dtype == 2 && (d->hidden != 256 || d->continuous || d->obs_dim > 32))
+        return fail(TMA_ERR_INVALID, "mfma_dtype 2 (three-term bf16 split of the f32 update) covers Discrete heads, hidden 256 and up to 32 observations (got hidden %d, obs %d%s)",
+                    d->hidden, d->obs_dim, d->continuous ? ", Box actions" : "");
     if (d->mfma_dtype == 1) {
         if (d->hidden != 128 && d->hidden != 192 && d->hidden != 256)
             return fail(TMA_ERR_INVALID, "the bf16 MFMA path covers hidden widths 128 / 192 / 256 (got %d)", d->hidden);
@@ -2207,6 +2230,18 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         {
             GradTimer timer(s);
             lrc = tma_launch_grad_wide_bf(params, L, R, M, hpar, ws_adv, slabs, slots, ws, &n_pi, &n_vf, s);
+        }
+        if (lrc) return lrc;
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
+    if (wide_f32 && tma_split3_eligible(L, mbi->count)) {  // mfma_dtype = 2: the same update on the bf16 MFMA, every operand as three bf16 terms
+        float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
+        int n_pi = 0, n_vf = 0, lrc;
+        {
+            GradTimer timer(s);
+            lrc = tma_launch_grad_split3(params, L, R, M, hpar, slabs, slots, &n_pi, &n_vf, s);
         }
         if (lrc) return lrc;
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));

@@ -193,5 +193,10 @@ int tma_launch_epoch_h64p(float *params, const tma::PLayout &L, const tma::Rollo
 // tma_bf16.hip: the column-parallel bf16-MFMA gradient kernel (hidden 128 / 192 / 256); `ws` is the update workspace (dz1 cache)
 int tma_launch_grad_wide_bf(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
                             const float *ws_adv, float *slabs, double *slots, char *ws, int *n_pi_out, int *n_vf_out, hipStream_t s);
+// tma_bf16.hip: the three-term bf16 split of the 256-wide f32 update (mfma_dtype = 2; tma_split3.h) and the rebuild of its weight planes
+int tma_launch_grad_split3(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar, float *slabs,
+                           double *slots, int *n_pi_out, int *n_vf_out, hipStream_t s);
+int tma_launch_build_split3(float *params, const tma::PLayout &L, hipStream_t s);
+bool tma_split3_eligible(const tma::PLayout &L, int64_t count);
 // tma_policy.hip: zero the layer-1 weight columns of every slab (layouts that accumulate dW1 in place)
 int tma_launch_slab_zero_w1(float *slabs, int n_slabs, const tma::PLayout &L, hipStream_t s);

@@ -64,13 +64,13 @@ class HipActorCriticPolicy:
     """Parameters of SB3's ActorCriticPolicy(MlpPolicy) in one flat HBM buffer + the forward kernels."""
 
     def __init__(self, obs_dim: int, act_dim: int, continuous: bool, hidden: int, device, seed: int = 0, mfma_dtype: str = "f32"):
-        if mfma_dtype not in ("f32", "bf16"):
-            raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', got {mfma_dtype!r}")
+        if mfma_dtype not in ("f32", "bf16", "bf16x3"):  # bf16x3 (round 5): the f32 update on the bf16 MFMA, every operand as three bf16 terms (csrc/tma_split3.h)
+            raise ValueError(f"mfma_dtype must be 'f32', 'bf16' or 'bf16x3', got {mfma_dtype!r}")
         self.mfma_dtype = mfma_dtype
         self.obs_dim, self.act_dim, self.continuous, self.hidden = int(obs_dim), int(act_dim), bool(continuous), int(hidden)
         self.device = torch.device(device)
         # dims.device: every tma_policy_* / tma_ppo_* call makes it the calling thread's HIP device (learn() may run in a worker thread)
-        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0, 1 if mfma_dtype == "bf16" else 0,
+        self.dims = _lib.PolicyDims(int(obs_dim), int(hidden), int(act_dim), 1 if continuous else 0, {"f32": 0, "bf16": 1, "bf16x3": 2}[mfma_dtype],
                                     self.device.index if self.device.index is not None else -1)
         nt, ntot = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().tma_policy_param_count(C.byref(self.dims), C.byref(nt), C.byref(ntot)))

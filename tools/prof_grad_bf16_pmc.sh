@@ -11,7 +11,7 @@ if not f:
     print("no counters for", tag, open(f"gpurun_out/pmc_bf_{tag}.log").read()[-600:]); sys.exit(0)
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f[0])):
-    if "ppo_grad_wide" in r["Kernel_Name"]:
+    if "ppo_grad_wide" in r["Kernel_Name"] or "ppo_grad_split3" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(f"  {k:32s} mean={sum(v)/len(v):16.1f}  (n={len(v)})")
