@@ -341,6 +341,9 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
         S3_RELANE();
         // ---- P2: layer 2 forward through the weight ring: 48 (term, k-step) steps ----
         bf16x8 w3f[3][HK];  // this wave's head fragments (split-K: the k-steps of its own h2 columns), in flight behind the layer-2 epilogue
+        constexpr bool KEEP_H2 = false && !W8;  // (measured: +137 spilled registers, 708 against 692 us -- off) one wave per SIMD: this lane's h2 quads stay in registers until P4 forms dz2 from them (the same lane owns the
+                                       // same quads there) instead of being re-read from three planes and summed: -24 LDS reads, -160 VALU per group
+        float h2k[KEEP_H2 ? NTW : 1][MT][4];
         {
             f32x4 acc[NTW][MT];
 #pragma unroll
@@ -362,7 +365,9 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                 const int n = n_base + 16 * j + r16;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    const bfq3 q = split_quad(tma_tanh(acc[j][mt][0]), tma_tanh(acc[j][mt][1]), tma_tanh(acc[j][mt][2]), tma_tanh(acc[j][mt][3]));
+                    const float t0 = tma_tanh(acc[j][mt][0]), t1 = tma_tanh(acc[j][mt][1]), t2 = tma_tanh(acc[j][mt][2]), t3 = tma_tanh(acc[j][mt][3]);
+                    if constexpr (KEEP_H2) h2k[j][mt][0] = t0, h2k[j][mt][1] = t1, h2k[j][mt][2] = t2, h2k[j][mt][3] = t3;
+                    const bfq3 q = split_quad(t0, t1, t2, t3);
 #pragma unroll
                     for (int p = 0; p < 3; p++) bfq_store_quad(t_quad<MT>(T2 + p * T_PS, n, mt, g), q.p[p]);
                 }
@@ -403,8 +408,14 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             LossStats st;
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
-                policy_loss_tile<false>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane, r_lo,
-                                        r_lo + r_n);
+#define S3_LOSS_ARGS out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane
+                if constexpr (W8) {
+                    policy_loss_tile<false>(S3_LOSS_ARGS, r_lo, r_lo + r_n);
+                } else {  // rows 0, 1 (waves 0, 1) or 2, 3 (waves 2, 3): a compile-time range per branch, so that the two rows' chains interleave
+                    if (wave < 2) policy_loss_tile<false, 0, 2>(S3_LOSS_ARGS);
+                    else policy_loss_tile<false, 2, 4>(S3_LOSS_ARGS);
+                }
+#undef S3_LOSS_ARGS
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -490,7 +501,12 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                     const f32x4 dh = dhz[j][mt];
                     bf16x4 *tq = t_quad<MT>(T2, n, mt, g);
                     float h[4], dz[4];
-                    unsplit_quad(*reinterpret_cast<const uint2 *>(tq), *reinterpret_cast<const uint2 *>(tq + T_PS / 4), *reinterpret_cast<const uint2 *>(tq + 2 * (T_PS / 4)), h);
+                    if constexpr (KEEP_H2) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) h[r] = h2k[j][mt][r];
+                    } else {
+                        unsplit_quad(*reinterpret_cast<const uint2 *>(tq), *reinterpret_cast<const uint2 *>(tq + T_PS / 4), *reinterpret_cast<const uint2 *>(tq + 2 * (T_PS / 4)), h);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; r++) dz[r] = dh[r] * (1.0f - h[r] * h[r]);
                     sB2[j] += (dz[0] + dz[1]) + (dz[2] + dz[3]);

@@ -30,7 +30,7 @@ int tma_launch_grad_split3(const float *params, const PLayout &L, const Rollout 
                            int *n_pi_out, int *n_vf_out, hipStream_t s) {
     const int64_t groups = ceil_div(M.count, 32);
     static const int npi_env = getenv("TMA_S3_NPI") ? atoi(getenv("TMA_S3_NPI")) : 0;  // development switch: policy-net block count
-    const int cap_pi = npi_env > 0 ? npi_env : 132, cap_vf = 256 - cap_pi;
+    const int cap_pi = npi_env > 0 ? npi_env : 128, cap_vf = 256 - cap_pi;  // (swept 124 .. 140 at 131 072 samples: 686 us at 128, 688 at 132, 701 at 136, 720 at 124 / 140)
     const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
     const int smem = grad_split3_smem_bytes();
     // one wave per SIMD (64 columns, 512 registers: activation fragments a k-step ahead, 10 spilled registers) measured 692 us per 131 072 samples

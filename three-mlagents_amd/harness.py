@@ -60,7 +60,8 @@ def ppo_defaults(task: tasks.EngineTask, n_envs: int | None = None) -> dict[str,
     EVERY task; TMA_LITERAL_BATCH=1 (or an explicit model_kwargs["batch_size"]) selects 256 at any size.  `train_task` records the value that
     was used and the switch in metadata.json (`schedule`)."""
     width = [256, 256]
-    extra = {"mfma_dtype": "bf16"} if os.environ.get("TMA_MFMA_DTYPE", "").lower() == "bf16" else {}  # engine knob, BASELINE configs[2]
+    knob = os.environ.get("TMA_MFMA_DTYPE", "").lower()  # engine knob: bf16 (BASELINE configs[2]) or bf16x3 (the f32 update as a three-term bf16 split)
+    extra = {"mfma_dtype": knob} if knob in ("bf16", "bf16x3") else {}
     batch = 256
     if n_envs is not None and not os.environ.get("TMA_LITERAL_BATCH"):
         batch = 256 * max(1, int(n_envs) // 8)
