@@ -111,3 +111,30 @@ def test_comm_entry_points_validate_their_arguments():
     with pytest.raises(ValueError):
         _lib.check(L.tma_comm_bind_stream(None, None))
     assert L.tma_comm_allreduce_cb(None, None, 4) == 1 and L.tma_comm_destroy(None) == 0
+
+
+def test_policy_dims_validation_and_the_split_layout():
+    """tma_policy_param_count validates the shape without a GPU.  mfma_dtype 2 (three-term bf16 split of the f32 update, round 5): the f32 mode's
+    buffer + three planes of the fragment-major images per net; refused outside Discrete / hidden 256 / <= 32 observations."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+
+    def count(D, H, A, cont, dtype):
+        d = _lib.PolicyDims(D, H, A, cont, dtype, -1)
+        nt, n = C.c_int64(0), C.c_int64(0)
+        rc = L.tma_policy_param_count(C.byref(d), C.byref(nt), C.byref(n))
+        return rc, nt.value, n.value
+
+    rc0, nt0, n0 = count(6, 256, 5, 0, 0)
+    rc2, nt2, n2 = count(6, 256, 5, 0, 2)
+    assert rc0 == 0 and rc2 == 0 and nt0 == nt2 == (6 * 256 + 256 + 256 * 256 + 256) * 2 + 256 * 5 + 5 + 256 + 1
+    plane = lambda n_out: 256 * 32 + 2 * 256 * 256 + 16 * 256 + 256 * 32  # noqa: E731  (bf16 elements per plane: W1 | W2 fwd | W2 bwd | W3 fwd | W3 bwd)
+    assert n2 - n0 == 3 * (plane(5) + plane(1)) // 2
+    for bad in ((6, 128, 5, 0), (6, 256, 5, 1), (40, 256, 5, 0)):  # hidden 128, Box actions, 40 observations
+        rc, _, _ = count(*bad, 2)
+        assert rc == _lib.TMA_ERR_INVALID and b"mfma_dtype 2" in L.tma_last_error()
+    rc, _, _ = count(6, 256, 5, 0, 3)
+    assert rc == _lib.TMA_ERR_INVALID

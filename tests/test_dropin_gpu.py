@@ -414,3 +414,24 @@ def test_pipelined_logging_leaves_the_files_of_the_synchronous_order(tmp_path, m
     assert best_p[2] == best_s[2] and best_p[0].keys() == best_s[0].keys() and all(torch.equal(best_p[0][k], best_s[0][k]) for k in best_s[0])
     st_p, st_s = best_p[1].get("state", {}), best_s[1].get("state", {})
     assert st_p.keys() == st_s.keys() and all(torch.equal(torch.as_tensor(st_p[i][k]), torch.as_tensor(st_s[i][k])) for i in st_s for k in st_s[i])
+
+
+def test_stats_window_size_selects_sb3s_last_100_episode_window(tmp_path):
+    """SB3 logs rollout/ep_rew_mean over its ep_info_buffer (deque of the last `stats_window_size` = 100 finished episodes, carried across
+    iterations).  Opt-in here (default: the interval mean, reproducible): the window mean must be the mean of the last 100 Monitor records."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    env = make_vector_env("gridworld", n_envs=16, seed=3, monitor_dir=str(tmp_path / "monitor"))
+    model = PPO("MlpPolicy", env, n_steps=256, batch_size=512, n_epochs=1, seed=3, policy_kwargs={"net_arch": [64, 64]}, stats_window_size=100)
+    model.learn(16 * 256 * 3)
+    rows = []
+    for rank in range(16):
+        for ln in (tmp_path / "monitor" / f"{rank}.monitor.csv").read_text().splitlines()[2:]:
+            if not ln.startswith("#"):
+                rows.append(float(ln.split(",")[0]))
+    assert len(rows) > 300 and len(model._ep_info_r) == 100
+    win = float(np.mean(model._ep_info_r))
+    assert abs(model.logger_values["rollout/ep_rew_mean"] - win) < 1e-12
+    assert min(rows) - 1e-9 <= win <= max(rows) + 1e-9 and all(any(abs(x - r) < 1e-6 for r in set(round(v, 6) for v in rows)) for x in set(model._ep_info_r))
+    env.close()

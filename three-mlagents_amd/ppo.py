@@ -174,7 +174,7 @@ class PPO:
                  batch_size: int = 64, n_epochs: int = 10, gamma: float = 0.99, gae_lambda: float = 0.95, clip_range: float = 0.2,
                  clip_range_vf=None, normalize_advantage: bool = True, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, policy_kwargs: dict | None = None, tensorboard_log: str | None = None, verbose: int = 0,
-                 seed: int | None = None, device="auto", _init_setup_model: bool = True, **unused):
+                 seed: int | None = None, device="auto", _init_setup_model: bool = True, stats_window_size: int | None = None, **unused):
         if policy not in ("MlpPolicy", "MultiInputPolicy"):
             raise ValueError(f"three-mlagents_amd PPO supports MlpPolicy (vector observations), got '{policy}'")
         if clip_range_vf is not None:
@@ -183,6 +183,16 @@ class PPO:
             raise ValueError("schedules are not supported: pass constant learning_rate / clip_range (the reference does)")
         self.policy_class = policy
         self.env = env
+        # SB3's ep_info_buffer (OnPolicyAlgorithm: deque(maxlen=stats_window_size), default 100): rollout/ep_rew_mean / ep_len_mean over the LAST
+        # stats_window_size finished episodes, carried across iterations.  Here that is OPT-IN (stats_window_size=100): the window is filled from the
+        # device episode log (on with a monitor_dir), whose order WITHIN a vector step is the order the kernels' atomics landed -- with thousands of
+        # episodes per interval the last hundred are then a different sample from run to run, while the default, the mean over ALL episodes of the
+        # interval (DESIGN.md deviation 6), is reproducible to the last bit of a sum of doubles
+        import collections
+
+        self.stats_window_size = int(stats_window_size) if stats_window_size else 0
+        self._ep_info_r: collections.deque = collections.deque(maxlen=max(self.stats_window_size, 1))
+        self._ep_info_l: collections.deque = collections.deque(maxlen=max(self.stats_window_size, 1))
         self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = float(learning_rate), int(n_steps), int(batch_size), int(n_epochs)
         self.gamma, self.gae_lambda, self.clip_range = float(gamma), float(gae_lambda), float(clip_range)
         self.normalize_advantage, self.ent_coef, self.vf_coef = bool(normalize_advantage), float(ent_coef), float(vf_coef)
@@ -552,7 +562,7 @@ class PPO:
             s_ret, s_len, cnt = p["ep"]
             elapsed = max(ev0.elapsed_time(p["ev_train"]) * 1e-3, 1e-9)  # device timeline: learn() start -> the end of this iteration's update
             stats.update({"time/fps": p["num_timesteps"] / elapsed, "time/iterations": p["iteration"], "time/total_timesteps": p["num_timesteps"],
-                          "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
+                          "rollout/ep_rew_mean": p["window"][0], "rollout/ep_len_mean": p["window"][1],
                           "rollout/episodes": cnt, "train/n_updates": p["n_updates"]})
             self.logger_values = stats
             self._write_progress(stats, p["num_timesteps"])
@@ -590,17 +600,20 @@ class PPO:
                     t_prev = now
                     if pending is not None:
                         finish(pending)
-                    pending = dict(ev_train=ev_train, staging=staging, ep=ep, iteration=iteration, num_timesteps=self.num_timesteps, n_updates=self._n_updates)
+                    pending = dict(ev_train=ev_train, staging=staging, ep=ep, iteration=iteration, num_timesteps=self.num_timesteps, n_updates=self._n_updates,
+                                   window=self._episode_window(lr_, ll_, ep[0], ep[1], ep[2]))
                 elif logging:
                     s_ret, s_len, cnt = eng.pop_episode_stats()
+                    log = eng.pop_episode_log() if getattr(eng, "_log_cap", 0) > 0 else None
+                    win = self._episode_window(log[0] if log else None, log[1] if log else None, s_ret, s_len, cnt)
                     stats = self.pop_train_stats()
                     fps = self.num_timesteps / max(time.time() - t0, 1e-9)
                     stats.update({"time/fps": fps, "time/iterations": iteration, "time/total_timesteps": self.num_timesteps,
-                                  "rollout/ep_rew_mean": s_ret / cnt if cnt else float("nan"), "rollout/ep_len_mean": s_len / cnt if cnt else float("nan"),
+                                  "rollout/ep_rew_mean": win[0], "rollout/ep_len_mean": win[1],
                                   "rollout/episodes": cnt, "train/n_updates": self._n_updates})
                     self.logger_values = stats
                     self._write_progress(stats, self.num_timesteps)
-                    self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0)
+                    self._write_monitor(s_ret, s_len, cnt, t_prev, time.time() - t0, t0, log=log)
                     t_prev = time.time() - t0
                     if self.verbose >= 1 and self.rank == 0:
                         print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}), flush=True)
@@ -621,6 +634,19 @@ class PPO:
         self._join_monitor_writer()
         cb.on_training_end()
         return self
+
+    def _episode_window(self, returns, lengths, s_ret: float, s_len: float, cnt: float) -> tuple[float, float]:
+        """(ep_rew_mean, ep_len_mean) as SB3 logs them: the mean of the last `stats_window_size` finished episodes (this interval's records in the
+        order the kernels logged them, appended to what earlier intervals left); the interval mean when there is no per-episode log."""
+        if not self.stats_window_size:
+            return (s_ret / cnt, s_len / cnt) if cnt else (float("nan"), float("nan"))
+        if returns is not None and len(returns):
+            w = self.stats_window_size
+            self._ep_info_r.extend(np.asarray(returns[-w:], np.float64).tolist())
+            self._ep_info_l.extend(np.asarray(lengths[-w:], np.float64).tolist())
+        if len(self._ep_info_r):
+            return float(np.mean(self._ep_info_r)), float(np.mean(self._ep_info_l))
+        return (s_ret / cnt, s_len / cnt) if cnt else (float("nan"), float("nan"))
 
     def _stats_staging(self, which: int) -> torch.Tensor:
         bufs = getattr(self, "_staging_bufs", None)
