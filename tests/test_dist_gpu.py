@@ -175,7 +175,8 @@ def _run_two_ranks(task, hidden, mfma, N, T):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("task,hidden,mfma,N,T", [("gridworld", 64, "f32", 256, 64), ("push", 256, "f32", 256, 64), ("crawler", 256, "bf16", 128, 32)])
+@pytest.mark.parametrize("task,hidden,mfma,N,T", [("gridworld", 64, "f32", 256, 64), ("push", 256, "f32", 256, 64), ("crawler", 256, "bf16", 128, 32),
+                                                   ("gridworld", 256, "bf16x3", 256, 64)])  # (bf16x3: minibatches of 8 192 samples take the three-term split kernel)
 def test_two_ranks_one_gpu_replicas_stay_identical(task, hidden, mfma, N, T):
     (r0, p0, o0, t0, s0, a0, q0), (r1, p1, o1, t1, s1, a1, q1) = _run_two_ranks(task, hidden, mfma, N, T)
     assert np.array_equal(p0, p1)  # same all-reduced gradient, same global advantage statistics, same Adam state -> bit-identical replicas
