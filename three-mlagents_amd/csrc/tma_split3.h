@@ -131,6 +131,20 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
         asm volatile("" : "+v"(lane));     \
         r16 = lane & 15, g = lane >> 4;    \
     } while (0)
+#ifdef TMA_S3_TICKS  // diagnostic build (tools/s3_ticks.py): cycles per phase, wave 0 of block 0 of each net
+    __shared__ unsigned long long tick_lds[16];
+    if (threadIdx.x < 16) tick_lds[threadIdx.x] = 0;
+    long long tlast = clock64();
+    const bool tick_on = threadIdx.x == 0 && block_net == 0;
+#define S3_TICK(i)                                                     \
+    do {                                                               \
+        const long long tn = clock64();                                \
+        if (tick_on) tick_lds[i] += (unsigned long long)(tn - tlast);  \
+        tlast = clock64();                                             \
+    } while (0)
+#else
+#define S3_TICK(i)
+#endif
     const int D = L.D, A = L.A, NOUT = IS_PI ? A : 1;
     bf16_t *Xa = reinterpret_cast<bf16_t *>(smem), *Xt = Xa + 3 * XA_PS, *T1 = Xt + 3 * XT_PS, *T2 = T1 + 3 * T_PS, *Z3a = T2 + 3 * T_PS, *Z3t = Z3a + 3 * ZA_PS;
     float *dz3 = reinterpret_cast<float *>(Z3t + 3 * ZT_PS), *meta = dz3 + M * ld3, *scratch = meta + M * 4, *hpart = scratch + 128, *bias = hpart + 4 * MT * 2 * 256;
@@ -180,63 +194,99 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
         bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
     if (threadIdx.x < NW * 4 * 5) stat_lds[threadIdx.x] = 0.0;
     int nt0l = nt0;
-    bf16x8 ring[R];  // weight stream of a group: [fW2: w_lo, w_mid, w_hi][bW2: likewise], k-step outer, tile inner within a plane; R fragments ahead
+    // One H x H GEMM of the chain (layer-2 forward: activations T1, images fW2; input gradient: deltas T2, images bW2).  The six products are
+    // grouped by WEIGHT plane -- w_lo with a_hi; w_mid with a_mid, a_hi; w_hi with a_lo, a_mid, a_hi -- so a weight fragment is streamed ONCE and
+    // meets up to three activation planes while it is in registers.  (Product-major, every product pulling its own copy of the fragment, the
+    // launch was bound by the weight stream: 6 x 128 KB per GEMM and group from L2, 13 TB/s chip-wide at 950 us.)
+    // Two passes of 8 k-steps, balanced so that the R fragments the ring holds ahead are the same amount of MFMA work in both (the L2 round
+    // trip hides behind it): pass A takes w_hi AND w_lo of a k-step (4 products per tile = 32 MFMAs at NTW = 4; 2 NTW fragments per k-step: the
+    // ring is 2 k-steps deep), pass B takes w_mid (2 products = 16 MFMAs; NTW fragments per k-step: 4 k-steps deep).  With one weight plane
+    // per pass the w_lo pass had 8 MFMAs per k-step -- 512 cycles of cover for its loads, less than the round trip.
+    // Every slot, fragment index and LDS offset is a compile-time constant; a consumed slot is refilled at once with the fragment R positions on.
+    bf16x8 ring[R];
 #pragma unroll
-    for (int s = 0; s < R; s++) ring[s] = bf_frag(W.fW2 + 2 * (int64_t)wps, (nt0l + s % NTW) * KS2 + s / NTW, lane);
-    // One H x H GEMM of the chain (layer-2 forward: activations T1, images fW2; input gradient: deltas T2, images bW2): the six products
-    // grouped by WEIGHT plane, smallest weight plane first -- w_lo with a_hi; w_mid with a_mid, a_hi; w_hi with a_lo, a_mid, a_hi -- so a weight
-    // fragment is streamed ONCE and multiplied with up to three activation planes while it is in registers.  (Term-major, every product pulling
-    // its own copy of the fragment, the launch was bound by the weight stream: 6 x 128 KB per GEMM and group from L2, 13 TB/s chip-wide at 950 us.)
-    // A weight plane is 8 k-steps = twice the ring: every slot, fragment index and LDS offset of the body is a compile-time constant.  The slot
-    // consumed at k-step ks is refilled with the fragment four k-steps on: this plane's for ks < 4, else the next plane's (after w_hi: the first
-    // four k-steps of the OTHER stream's w_lo, for the phase that follows).
-    auto hh_plane = [&](auto qc, const TrBase<MT> &tb0, const bf16_t *wcur, const bf16_t *wnext, f32x4 (&acc)[NTW][MT]) {
-        constexpr int Q = decltype(qc)::value, NP = 3 - Q;  // activation planes 0 .. NP - 1 meet weight plane Q
-        // one wave per SIMD: the activation fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (nothing else hides the LDS round
-        // trip); two per SIMD: the partner wave does, and the registers are not there
-        constexpr int AB = W8 ? 1 : 2;
-        bf16x8 abuf[AB][NP][MT];
-        auto aload = [&](int slot, int ks) {
+    for (int s = 0; s < R; s++) {  // pass A of the forward stream, k-steps 0 and 1: slot = (ks % 2) * 2 NTW + plane * NTW + j (plane 0: w_hi, 1: w_lo)
+        const int ks = s / (2 * NTW), pl = (s / NTW) & 1, jj = s % NTW;
+        ring[s] = bf_frag(W.fW2 + (pl ? 2 : 0) * (int64_t)wps, (nt0l + jj) * KS2 + ks, lane);
+    }
+    auto hh_gemm = [&](const bf16_t *Timg, const bf16_t *wthis, const bf16_t *wother, f32x4 (&acc)[NTW][MT]) {
+        const TrBase<MT> tb0 = tr_base<MT>(Timg, lane);
+        const bf16_t *whi = wthis, *wmid = wthis + (int64_t)wps, *wlo = wthis + 2 * (int64_t)wps;
+        constexpr int AB = W8 ? 1 : 2;  // one wave per SIMD: activation fragments a k-step ahead (nothing else hides the LDS round trip)
+        {  // ---- pass A: w_hi x (a_lo, a_mid, a_hi) and w_lo x a_hi ----
+            bf16x8 abuf[AB][3][MT];
+            auto aload = [&](int slot, int ks) {
 #pragma unroll
-            for (int p = 0; p < NP; p++)
+                for (int p = 0; p < 3; p++)
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) abuf[slot][p][mt] = a_frag_tb_off<MT>(tb0, mt, p * T_PS + ks * KSTRIDE);
-        };
-        if constexpr (!W8) aload(0, 0);
+                    for (int mt = 0; mt < MT; mt++) abuf[slot][p][mt] = a_frag_tb_off<MT>(tb0, mt, p * T_PS + ks * KSTRIDE);
+            };
+            if constexpr (!W8) aload(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KS2; ks++) {
-            const int cur = W8 ? 0 : (ks & 1);
-            if constexpr (W8) aload(0, ks);
-            else if (ks + 1 < KS2) aload(cur ^ 1, ks + 1);
-            auto &a = abuf[cur];
-            // (plane outermost: an accumulator is written once per pass over the NTW x MT tiles -- back-to-back MFMAs into ONE accumulator wait
-            //  for each other's result, and with the tile loop outermost every second MFMA of a k-step did)
-#pragma unroll
-            for (int p = NP - 1; p >= 0; p--)
+            for (int ks = 0; ks < KS2; ks++) {
+                const int cur = W8 ? 0 : (ks & 1), sb = (ks & 1) * 2 * NTW;
+                if constexpr (W8) aload(0, ks);
+                else if (ks + 1 < KS2) aload(cur ^ 1, ks + 1);
+                auto &a = abuf[cur];
+                // (smallest products first; an accumulator is written once per sweep over the NTW x MT tiles)
 #pragma unroll
                 for (int j = 0; j < NTW; j++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[p][mt], ring[(ks * NTW + j) % R], acc[j][mt]);
+                    for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[0][mt], ring[sb + NTW + j], acc[j][mt]);  // a_hi . w_lo
 #pragma unroll
-            for (int j = 0; j < NTW; j++) {
-                const int slot = (ks * NTW + j) % R;
-#ifdef TMA_S3_PROBE  // timing-only builds: bit 0 of TMA_BF_DEBUG redirects every ring load to one hot fragment (what does the weight stream cost?)
-                if (hp.debug & 1) ring[slot] = bf_frag(wcur, j, lane);
-                else
-#endif
-                ring[slot] = ks < KS2 / 2 ? bf_frag(wcur, (nt0l + j) * KS2 + ks + KS2 / 2, lane) : bf_frag(wnext, (nt0l + j) * KS2 + ks - KS2 / 2, lane);
+                for (int p = 2; p >= 0; p--)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[p][mt], ring[sb + j], acc[j][mt]);  // a_lo, a_mid, a_hi . w_hi
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    if (ks + 2 < KS2) {  // two k-steps on in this pass
+                        ring[sb + j] = bf_frag(whi, (nt0l + j) * KS2 + ks + 2, lane);
+                        ring[sb + NTW + j] = bf_frag(wlo, (nt0l + j) * KS2 + ks + 2, lane);
+                    } else {  // the first four k-steps of pass B: its slot = (ks % 4) * NTW + j, i.e. k-steps 0, 1 here at ks = 6 and 2, 3 at ks = 7
+                        ring[sb + j] = bf_frag(wmid, (nt0l + j) * KS2 + 2 * (ks - 6), lane);
+                        ring[sb + NTW + j] = bf_frag(wmid, (nt0l + j) * KS2 + 2 * (ks - 6) + 1, lane);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        }
+        {  // ---- pass B: w_mid x (a_mid, a_hi) ----
+            bf16x8 abuf[AB][2][MT];
+            auto aload = [&](int slot, int ks) {
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) abuf[slot][p][mt] = a_frag_tb_off<MT>(tb0, mt, p * T_PS + ks * KSTRIDE);
+            };
+            if constexpr (!W8) aload(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                const int cur = W8 ? 0 : (ks & 1), sb = (ks & 3) * NTW;
+                if constexpr (W8) aload(0, ks);
+                else if (ks + 1 < KS2) aload(cur ^ 1, ks + 1);
+                auto &a = abuf[cur];
+#pragma unroll
+                for (int p = 1; p >= 0; p--)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[j][mt] = mfma_bf(a[p][mt], ring[sb + j], acc[j][mt]);
+#pragma unroll
+                for (int j = 0; j < NTW; j++) {
+                    if (ks + 4 < KS2) {
+                        ring[sb + j] = bf_frag(wmid, (nt0l + j) * KS2 + ks + 4, lane);
+                    } else {  // pass A of the OTHER stream (the phase that follows): k-step (ks - 4) / 2, plane (ks - 4) % 2 -> slot (ks' % 2) * 2 NTW + plane * NTW + j == sb + j
+                        const int ks2 = (ks - 4) >> 1, pl = (ks - 4) & 1;
+                        ring[sb + j] = bf_frag(wother + (pl ? 2 : 0) * (int64_t)wps, (nt0l + j) * KS2 + ks2, lane);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
-    auto hh_gemm = [&](const bf16_t *Timg, const bf16_t *wthis, const bf16_t *wother, f32x4 (&acc)[NTW][MT]) {
-        const TrBase<MT> tb0 = tr_base<MT>(Timg, lane);
-        const bf16_t *w2 = wthis + 2 * (int64_t)wps, *w1p = wthis + (int64_t)wps;
-        hh_plane(std::integral_constant<int, 2>{}, tb0, w2, w1p, acc);
-        hh_plane(std::integral_constant<int, 1>{}, tb0, w1p, wthis, acc);
-        hh_plane(std::integral_constant<int, 0>{}, tb0, wthis, wother + 2 * (int64_t)wps, acc);
-    };
-    static_assert(R == KS2 / 2 * NTW, "the ring is half a term deep");
+    static_assert(R == 4 * NTW && KS2 == 8, "the ring: two k-steps of pass A, four of pass B");
     // ---- prefetch registers for the next group's samples (the scheme of grad_wide_bf_body) ----
     float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
@@ -280,6 +330,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
         W.fW1 = launder_uniform(W.fW1), W.fW2 = launder_uniform(W.fW2), W.bW2 = launder_uniform(W.bW2), W.fW3 = launder_uniform(W.fW3);
         W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l), wps = launder_uniform(wps);
+        S3_TICK(0);
         S3_RELANE();
         // layer-1 fragments of the three planes: in flight under the commit
         bf16x8 w1[3][NTW];
@@ -306,6 +357,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             }
         }
         __syncthreads();
+        S3_TICK(1);
         const bool has_next = grp + n_blocks_net < n_groups;  // block-uniform
         fetch_off(grp + n_blocks_net);
         S3_RELANE();
@@ -338,6 +390,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             }
         }
         __syncthreads();
+        S3_TICK(2);
         S3_RELANE();
         // ---- P2: layer 2 forward through the weight ring: 48 (term, k-step) steps ----
         bf16x8 w3f[3][HK];  // this wave's head fragments (split-K: the k-steps of its own h2 columns), in flight behind the layer-2 epilogue
@@ -353,6 +406,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                 for (int mt = 0; mt < MT; mt++) acc[j][mt] = f32x4{b, b, b, b};
             }
             hh_gemm(T1, W.fW2, W.bW2, acc);
+            S3_TICK(3);
             if (!W8 || wave < 4) {
 #pragma unroll
                 for (int p = 0; p < 3; p++)
@@ -373,6 +427,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                 }
             }
         }
+        S3_TICK(4);
         if constexpr (W8) __syncthreads();  // (eight waves: the k-steps of head wave w are the h2 columns of waves 2 w and 2 w + 1)
         if (!W8 || wave < 4) {  // split-K head partial over k-steps wave * HK + i (four waves: this wave's own h2 columns -- its own stores, no barrier in front)
             const TrBase<MT> tb = tr_base<MT>(T2 + wave * HK * KSTRIDE, lane);
@@ -393,6 +448,15 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
         }
         __syncthreads();
         S3_RELANE();
+        S3_TICK(5);
+        bf16x8 w3b[3][NTW];  // head input-gradient fragments for P4.  One wave per SIMD: requested here, in flight behind the loss (measured: P4 opened with
+                             // an exposed L2 round trip); two per SIMD: requested in P4 (48 registers would sit through the loss)
+        if constexpr (!W8) {
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int j = 0; j < NTW; j++) w3b[p][j] = bf_frag(W.bW3 + (int64_t)p * wps, nt0l + j, lane);
+        }
         fetch_obs();
         __builtin_amdgcn_sched_barrier(0);
         // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2 (wave >> 1) .. + 1 of each lane group) ----
@@ -433,6 +497,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             }
         }
         __syncthreads();
+        S3_TICK(6);
         // ---- P3c: dz3 in three planes, both layouts: waves 0 / 1 write Z3a of tile 0 / 1, waves 2 / 3 Z3t (+ head bias sums) ----
         S3_RELANE();
         {
@@ -466,14 +531,16 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             }
         }
         __syncthreads();
+        S3_TICK(7);
         S3_RELANE();
         // ---- P4: head weight gradient (this wave's k rows); dz2 = (dz3 . W3^T) * (1 - h2^2), in place in the T2 planes ----
         {
-            bf16x8 w3b[3][NTW];  // head input-gradient fragments (requested here: 48 registers would otherwise sit through the loss), consumed after dW3
+            if constexpr (W8) {
 #pragma unroll
-            for (int p = 0; p < 3; p++)
+                for (int p = 0; p < 3; p++)
 #pragma unroll
-                for (int j = 0; j < NTW; j++) w3b[p][j] = bf_frag(W.bW3 + (int64_t)p * wps, nt0l + j, lane);
+                    for (int j = 0; j < NTW; j++) w3b[p][j] = bf_frag(W.bW3 + (int64_t)p * wps, nt0l + j, lane);
+            }
 #pragma unroll
             for (int t = S3_WG0; t < NT; t++) {
                 const bf16x8 zb = t_frag<MT>(Z3t + s3_tb(t) * ZT_PS, r16, 0, g);
@@ -517,6 +584,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
             }
         }
         __syncthreads();
+        S3_TICK(8);
         S3_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice] (term-outermost: four dz2 fragments live at a time);  dh1 = dz2 . W2^T (weight ring) ----
         f32x4 dh1[NTW][MT];
@@ -534,7 +602,7 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                 bf16x8 zb[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; j++) zb[j] = *reinterpret_cast<const bf16x8 *>(zp + j * 16 * (16 * MT));
-                constexpr int TA = 4, TAH = TA - 1;
+                constexpr int TA = W8 ? 4 : 8, TAH = TA - 1;  // h1 fragments TAH row tiles ahead (one wave per SIMD: seven -- at three the phase ran at half the pipe rate)
                 bf16x8 ta[TA];
 #pragma unroll
                 for (int kt = 0; kt < TAH; kt++) ta[kt] = *reinterpret_cast<const bf16x8 *>(ap + kt * 16 * (16 * MT));
@@ -543,13 +611,16 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                     if (kt + TAH < KT2) ta[(kt + TAH) % TA] = *reinterpret_cast<const bf16x8 *>(ap + (kt + TAH) * 16 * (16 * MT));
 #pragma unroll
                     for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma_bf(ta[kt % TA], zb[j], aW2[kt][j]);
+                    __builtin_amdgcn_sched_barrier(0);  // (per row tile: without the fence the scheduler sinks every read to its use -- one register set, lgkmcnt(0) in front of every four MFMAs)
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        S3_TICK(9);
         S3_RELANE();
         hh_gemm(T2, W.bW2, W.fW2, dh1);
+        S3_TICK(10);
         __syncthreads();  // every wave is done with T1 (all rows) and the dz2 planes
+        S3_TICK(11);
         S3_RELANE();
         // ---- P6: dz1 = dh1 * (1 - h1^2) in place in the T1 planes (own rows);  dW1 slice += X^T . dz1[:, slice] ----
 #pragma unroll
@@ -580,8 +651,15 @@ __device__ __forceinline__ void grad_split3_body(const float *__restrict__ param
                 for (int j = 0; j < NTW; j++) aW1[kt][j] = mfma_bf(a, zb[j], aW1[kt][j]);
             }
         }
+        S3_TICK(12);
         __syncthreads();
+        S3_TICK(13);
     }
+#ifdef TMA_S3_TICKS
+    if (tick_on)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_s3_ticks[IS_PI ? 0 : 1][i], tick_lds[i]);
+#endif
+#undef S3_TICK
 #undef S3_RELANE
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
     float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);

@@ -6,9 +6,22 @@
 #include <type_traits>
 
 namespace tma {
+#ifdef TMA_S3_TICKS
+__device__ unsigned long long g_s3_ticks[2][16];
+#endif
 #include "tma_wide_bf16.h"
 #include "tma_split3.h"
 }  // namespace tma
+
+#ifdef TMA_S3_TICKS
+extern "C" int tma_debug_s3_ticks(unsigned long long *out32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(tma::g_s3_ticks), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(tma::g_s3_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 using namespace tma;
 
