@@ -746,7 +746,7 @@ def compact_line(out, extras_path=None, limit=LINE_LIMIT):
         def med(x):
             return _pick(x, ("calls_timed", "median_us", "max_us", "bytes")) if isinstance(x, dict) else x
 
-        optional.append(("dp_timing", {"backend": dp.get("backend"), "allreduce_path": str(dp.get("allreduce_path", "")).split(" (")[0],
+        optional.append(("dp_timing", {"backend": dp.get("backend"), "allreduce_path": str(dp.get("allreduce_path", "")).split(" (")[0], "peer_exchange": (str(dp["peer_exchange"])[:160] if dp.get("peer_exchange") else None),
                                        "grad_allreduce": med(dp.get("grad_allreduce")), "adv_sums_allreduce": med(dp.get("adv_sums_allreduce")),
                                        "grad_allreduces_per_iteration": dp.get("grad_allreduces_per_iteration"),
                                        "adv_sums_allreduces_per_iteration": dp.get("adv_sums_allreduces_per_iteration"),
@@ -847,8 +847,9 @@ def main():
                         f"n_epochs={args.n_epochs}, batch_size={batch}/GPU ({(total + batch - 1) // batch} minibatches/epoch), lr=3e-4, gamma=0.99, "
                         f"gae_lambda=0.95, clip=0.2, ent=0.01, vf=0.5, max_grad_norm=0.5",
             "envs_per_gpu": N, "n_steps": T, "batch_size": batch, "n_epochs": args.n_epochs, "hidden": args.hidden,
-            "parallelism": (f"dp{world}: envs sharded by contiguous blocks, per minibatch one RCCL all-reduce of the flat f32 gradient, per epoch one "
-                            f"all-reduce of the minibatches' advantage (sum, sumsq) pairs") if world > 1 else "single GPU",
+            "parallelism": (f"dp{world}: envs sharded by contiguous blocks, per minibatch one all-reduce of the flat f32 gradient (RCCL, or the peer "
+                            f"exchange over xGMI when it is the faster one: dp_timing.allreduce_path), per epoch one all-reduce of the minibatches' "
+                            f"advantage (sum, sumsq) pairs") if world > 1 else "single GPU",
         },
         "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9), "ppo_updates_per_iteration": updates // args.steps,
         "rollout_env_steps_per_sec": env_steps / max(t_roll, 1e-9), "rollout_ms": t_roll / args.steps * 1e3,
@@ -866,8 +867,13 @@ def main():
         timing = model.dp_timing_collect()
         model.dp_timing = None
         out["dp_timing"] = {
-            "backend": td.get_backend(), "allreduce_path": "native (libtma_hip.so: ncclAllReduce on the compute stream from inside tma_ppo_train_epoch_dp)"
-            if model._native_comm is not None else "callback (ctypes -> Python -> torch.distributed.all_reduce)",
+            "backend": td.get_backend(),
+            "allreduce_path": ("native peer exchange (libtma_hip.so: slab_reduce_kernel stores the reduced gradient straight into every rank's inbox over xGMI, the "
+                               "sum-of-squares pass adds the ranks' words in rank order -- no collective launch in the minibatch chain)"
+                               if model._native_comm is not None and model._native_comm.p2p_enabled else
+                               "native (libtma_hip.so: ncclAllReduce on the compute stream from inside tma_ppo_train_epoch_dp)"
+                               if model._native_comm is not None else "callback (ctypes -> Python -> torch.distributed.all_reduce)"),
+            "peer_exchange": getattr(model._native_comm, "p2p_note", None) if model._native_comm is not None else None,
             "grad_allreduce": timing["grad_allreduce_us"], "adv_sums_allreduce": timing["adv_allreduce_us"],
             "grad_allreduces_per_iteration": updates // args.steps, "adv_sums_allreduces_per_iteration": args.n_epochs,
             "per_rank_rollout_ms": [float(t[0]) for t in per_rank], "per_rank_update_ms": [float(t[1]) for t in per_rank],
@@ -925,6 +931,18 @@ def main():
 
             out["env_sweep"] = [env_sweep.run(args.task, n, 32, 3, pl) for n in (4096, 65536, 1 << 20, 1 << 22) for pl in (1, 32)]
         extras_path = write_extras(out)
+    # The JSON line must be the LAST line of the job's stdout.  Native libraries write there too through C stdio (RCCL announces itself with a
+    # "Librccl path : ..." line at communicator creation), fully buffered when stdout is a pipe and flushed only at process exit -- i.e. BEHIND
+    # the line, from every rank.  So: every rank empties its C buffers, all ranks meet, and only then rank 0 prints.
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    dist.barrier()
+    if rank == 0:
         print(compact_line(out, extras_path), flush=True)
     dist.barrier()
 

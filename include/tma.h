@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 206
+#define TMA_VERSION 207
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -295,6 +295,29 @@ int tma_comm_allreduce(tma_comm *comm, void *buffer, int64_t count, int dtype, v
 int tma_comm_allreduce_cb(void *ctx, float *buffer, int64_t count);
 int tma_comm_timing(tma_comm *comm, int samples);
 int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out, int64_t *calls_out);
+/* ---- Peer exchange (round 5, ABI 207): the same SUM as direct xGMI stores between the GPUs of ONE node (up to 8 ranks), for messages where a
+ *      ring's 2 (world - 1) hops and the collective's own launch are the cost (the 64 x 64 policy's gradient is 37 KB, 320 times per headline
+ *      iteration).  Every rank owns an inbox in fine-grained device memory that its peers map through a HIP IPC handle; a sender stores each
+ *      32-bit payload word with the all-reduce's sequence number next to it as ONE 8-byte word into its slot of every inbox, a receiver reads
+ *      the `world` slots of its own inbox (system-scope 8-byte loads, until every word carries the expected sequence number) and adds them in
+ *      rank order -- the same order on every rank, so replicas stay bit-identical; no fence and no ordering between words is assumed
+ *      (csrc/tma_p2p.h has the protocol and why two slot parities suffice).
+ * Set-up: tma_comm_p2p_prepare(comm, max_words, handle_out[64]) allocates the inbox (slots of max_words 8-byte words; an f32 element is one
+ * word, an f64 element two) and exports its handle; the caller gathers the `world` handles over the channel it already has (rank order,
+ * 64 bytes each) and gives them to tma_comm_p2p_attach; tma_comm_p2p_enable(comm, 1) then routes every tma_comm_allreduce /
+ * tma_comm_allreduce_cb whose message fits a slot through the exchange (larger ones keep RCCL), and tma_ppo_train_epoch_dp -- given
+ * tma_comm_allreduce_cb and such a communicator -- FUSES it on its H = 64 path: the slab reduction stores the reduced gradient into the
+ * peers' inboxes, the sum-of-squares pass in front of the optimizer step reads the sum: no collective launch in the minibatch chain at all.
+ * tma_comm_create_p2p: a communicator WITHOUT an RCCL side (several ranks on one GPU, which RCCL does not allow: the one-GPU tests); its
+ * all-reduces must fit the exchange.  A receiver that waits longer than TMA_P2P_TIMEOUT_S (default 120) for a peer's words raises a flag:
+ * the all-reduce that was waiting returns garbage, every later one fails with TMA_ERR_HIP, tma_comm_p2p_status reports it -- nothing spins
+ * for ever.  tma_comm_timing brackets the RECEIVING kernel of an exchange (what the chain waits for once the sender kernel is done). */
+int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out);
+int tma_comm_p2p_prepare(tma_comm *comm, int64_t max_words, unsigned char *handle_out64);
+int tma_comm_p2p_attach(tma_comm *comm, const unsigned char *handles_world_x_64);
+int tma_comm_p2p_enable(tma_comm *comm, int on);
+int tma_comm_p2p_status(tma_comm *comm, int *enabled_out, int64_t *calls_out, int *timed_out_out, int64_t *slot_words_out);
+int tma_comm_p2p_set_timeout(tma_comm *comm, double seconds); /* receivers of later exchanges give up after this long (set-up: a short one for the self-check) */
 /* How many epochs of tma_ppo_train_epoch_local on this workspace fell back from the persistent launch to per-minibatch launches.  Synchronises `stream`. */
 int tma_ppo_persist_fallbacks(void *workspace, int64_t *count_out, void *stream);
 /* The minibatch order of the on-device permutation (the engine's stand-in for np.random.permutation in SB3's RolloutBuffer.get): writes, to

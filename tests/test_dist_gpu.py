@@ -132,11 +132,15 @@ def test_native_rccl_communicator_at_world_size_one():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert ok and used_n and not used_c and same and near_local
-    assert timed == 8 and issued == 1 + 24 and path.startswith("native")  # (1: the construction-time self-check)
+    assert timed == 8 and issued == 2 + 24 and path.startswith("native")  # (2: the construction-time self-check, one f32 and one f64 sum)
 
 
-def _worker(rank, world, port, q, task, hidden, mfma, N, T):
-    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+def _worker(rank, world, port, q, task, hidden, mfma, N, T, p2p=False):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    os.environ.pop("TMA_P2P", None)
+    if p2p:
+        os.environ["TMA_P2P"] = "1"
     from three_mlagents_amd import dist
 
     dist.init_from_env(backend="gloo")
@@ -151,6 +155,12 @@ def _worker(rank, world, port, q, task, hidden, mfma, N, T):
     model._last_obs_valid = False
     model.learn(2 * world * N * T)
     adv = model.buf["advantages"].double().cpu().numpy()
+    if p2p:  # every collective of the run went through the peer exchange: 2 probes + per iteration 2 epochs x (1 advantage-sum + 2 gradient) all-reduces
+        st = model._native_comm.p2p_status()
+        assert model._native_comm is not None and not model._native_comm.has_rccl and st["enabled"] and not st["timed_out"], st
+        assert st["calls"] == 2 + 2 * 2 * (1 + 2), st
+    else:
+        assert model._native_comm is None
     q.put((rank, model.policy.params[: model.policy.n_trainable].cpu().numpy(), first_obs.numpy(), model.num_timesteps,
            model._adv_sums.cpu().numpy(), float(adv.sum()), float((adv * adv).sum())))  # numpy: pickled by value
     env.close()
@@ -160,11 +170,11 @@ def _worker(rank, world, port, q, task, hidden, mfma, N, T):
     td.destroy_process_group()
 
 
-def _run_two_ranks(task, hidden, mfma, N, T):
+def _run_two_ranks(task, hidden, mfma, N, T, p2p=False):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, task, hidden, mfma, N, T)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, task, hidden, mfma, N, T, p2p)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=400) for _ in range(world)), key=lambda x: x[0])
@@ -203,6 +213,164 @@ def test_two_ranks_one_gpu_replicas_stay_identical(task, hidden, mfma, N, T):
     assert not np.array_equal(solo.policy.params[: solo.policy.n_trainable].cpu().numpy(), p0)
 
 
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_peer_exchange_equals_the_gloo_collectives():
+    """The peer exchange (include/tma.h tma_comm_p2p_*) carrying EVERY collective of a two-rank run -- both ranks on this one GPU, their inboxes
+    mapped into each other through HIP IPC handles, the gradient sum fused into slab_reduce_kernel (stores into both inboxes) and the
+    sum-of-squares pass (reads its own inbox), the f64 advantage sums through the stand-alone push / pull kernels -- against the same run over
+    gloo: at two ranks a + b is the same float whichever side adds, so parameters and advantage sums must agree bit for bit."""
+    a = _run_two_ranks("gridworld", 64, "f32", 256, 64, p2p=True)
+    b = _run_two_ranks("gridworld", 64, "f32", 256, 64, p2p=False)
+    assert np.array_equal(a[0][1], a[1][1])  # replicas identical
+    assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[0][4], b[0][4])  # and identical to the run over gloo
+
+
+def _p2p_raw_worker(rank, world, port, q, mode):
+    """tma_comm_* with the peer exchange only (no RCCL side), driven directly."""
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    if mode == "timeout":
+        os.environ["TMA_P2P_TIMEOUT_S"] = "0.5"
+    import time
+
+    from three_mlagents_amd import _lib, dist
+
+    dist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    comm = dist.NativeComm(dev, rccl=False)
+    comm.p2p_setup(16384)
+    comm.p2p_enable(True)
+    sp = _lib.stream_ptr(dev)
+    out = {}
+    if mode == "sums":
+        gen = torch.Generator(device="cpu").manual_seed(7)  # same stream of test vectors on every rank
+        ok, n_calls = True, 0
+        for it in range(300):
+            n = int(torch.randint(1, 16385, (1,), generator=gen).item())
+            base = torch.randn(world, n, generator=gen, dtype=torch.float32)
+            if it % 3 == 2:  # f64 messages (two words per element)
+                n = min(n, 8192)
+                x = base[rank, :n].double().to(dev) * 1.0000001
+                want = base[0, :n].double() * 1.0000001
+                for r in range(1, world):
+                    want = want + base[r, :n].double() * 1.0000001
+            else:
+                x = base[rank].to(dev)
+                want = base[0].clone()
+                for r in range(1, world):
+                    want = want + base[r]  # rank order
+            if (it + rank) % 7 == 0:
+                time.sleep(0.003)  # skew: one rank arrives late, the other's receiver waits
+            comm.all_reduce_(x, sp)
+            n_calls += 1
+            if it % 10 == 0:  # (mostly back to back without a host sync: the two-parity argument is what keeps consecutive exchanges apart)
+                ok = ok and bool(torch.equal(x.cpu(), want))
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(x.cpu(), want))
+        st = comm.p2p_status()
+        out = {"ok": ok, "calls": st["calls"], "n": n_calls, "timed_out": st["timed_out"]}
+        dist.barrier()
+    else:  # rank 1 never sends its words for the second exchange: rank 0's receiver gives up after TMA_P2P_TIMEOUT_S and says so
+        x = torch.ones(1000, dtype=torch.float32, device=dev)
+        comm.all_reduce_(x, sp)
+        torch.cuda.synchronize()
+        first = bool((x == float(world)).all())
+        err = ""
+        if rank == 0:
+            t0 = time.perf_counter()
+            comm.all_reduce_(x, sp)
+            torch.cuda.synchronize()
+            waited = time.perf_counter() - t0
+            try:
+                comm.all_reduce_(x, sp)
+            except RuntimeError as exc:
+                err = str(exc)
+            out = {"first": first, "waited": waited, "timed_out": comm.p2p_status()["timed_out"], "err": err}
+        else:
+            out = {"first": first}
+        dist.barrier()
+    q.put((rank, out))
+    dist.barrier()
+    comm.close()
+    import torch.distributed as td
+
+    td.destroy_process_group()
+
+
+def _run_p2p_raw(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_raw_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(400)
+def test_peer_exchange_sums_in_rank_order_under_skew():
+    """300 consecutive all-reduces of random lengths (f32 and f64) between two processes on this GPU, most of them without a host
+    synchronisation in between and with one rank arriving late every few calls: every checked result equals the rank-ordered sum bit for bit."""
+    res = _run_p2p_raw("sums")
+    for r in (0, 1):
+        assert res[r]["ok"] and res[r]["calls"] == res[r]["n"] == 300 and not res[r]["timed_out"], res
+
+
+@pytest.mark.timeout(400)
+def test_peer_exchange_receiver_gives_up_instead_of_spinning_for_ever():
+    res = _run_p2p_raw("timeout")
+    assert res[0]["first"] and res[1]["first"]
+    assert res[0]["timed_out"] and 0.4 < res[0]["waited"] < 30.0 and "timed out" in res[0]["err"], res[0]
+
+
+def _p2p_world1(q):
+    """World size 1: the fused exchange (slab_reduce_kernel -> own inbox -> grad_pull_sumsq64_kernel) against the plain data-parallel chain."""
+    os.environ.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(p2p, fuse=True):
+        for k in ("TMA_P2P", "TMA_P2P_NO_FUSE", "TMA_NATIVE_RCCL"):
+            os.environ.pop(k, None)
+        os.environ["TMA_DP_PATH"] = "1"
+        os.environ["TMA_NATIVE_RCCL"] = "1"
+        if p2p:
+            os.environ["TMA_P2P"] = "1"
+        env = make_vector_env("gridworld", n_envs=256, seed=5)
+        m = PPO("MlpPolicy", env, n_steps=64, batch_size=2048, n_epochs=3, seed=5, policy_kwargs={"net_arch": [64, 64]})
+        assert m._native_comm is not None and m._native_comm.p2p_enabled == p2p
+        m._native_comm.timing(8)
+        m.collect_rollouts()
+        m.train()
+        tim = m.dp_timing_collect()
+        st = m._native_comm.p2p_status()
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, tim["grad_allreduce_us"])
+        env.close()
+        return out
+
+    a, b = run(True), run(False)
+    same = all(bool(torch.equal(x, y)) for x, y in zip(a[:3], b[:3]))
+    q.put((same, a[3], a[4]["path"], a[4]["calls_timed"], b[3]))
+
+
+@pytest.mark.timeout(300)
+def test_fused_peer_exchange_at_world_size_one_changes_no_bit():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_p2p_world1, args=(q,))
+    p.start()
+    same, st, path, timed, st_off = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and st["enabled"] and not st["timed_out"] and st["calls"] == 2 + 24 and "peer exchange" in path and timed == 8
+    assert not st_off["enabled"] and st_off["calls"] == 0
+
+
 def test_bench_gpus_2_fails_cleanly_on_a_one_gpu_box():
     if torch.cuda.device_count() >= 2:
         pytest.skip("multi-GPU box: `bench.py --gpus 2` would really run")
@@ -211,13 +379,17 @@ def test_bench_gpus_2_fails_cleanly_on_a_one_gpu_box():
 
 
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_end_to_end_on_one_gpu():
+@pytest.mark.parametrize("p2p", [False, True])
+def test_bench_two_ranks_end_to_end_on_one_gpu(p2p):
     """The whole `bench.py --gpus 2` rank program (barriers, max-over-ranks timing, sharded envs, advantage-sum and gradient all-reduces,
     rank-0-only roofline legs and JSON line) under torch.distributed.run with two ranks -- on this one-GPU box over gloo with both ranks on
     device 0 (test hooks TMA_DIST_BACKEND / TMA_BENCH_ONE_DEVICE); on a multi-GPU node the same program runs one rank per GPU over RCCL."""
     import json
 
     env = dict(os.environ, TMA_DIST_BACKEND="gloo", TMA_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TMA_P2P", None)
+    if p2p:  # the collectives through the peer exchange (the communicator's only path under gloo) instead of the torch.distributed callback
+        env["TMA_P2P"] = "1"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -235,5 +407,8 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert t["backend"] == "gloo" and len(t["per_rank_rollout_ms"]) == len(t["per_rank_update_ms"]) == 2
     assert t["grad_allreduces_per_iteration"] == 10 * 32 and t["adv_sums_allreduces_per_iteration"] == 10
     assert t["grad_allreduce"]["calls_timed"] == 64 and t["grad_allreduce"]["median_us"] > 0 and t["grad_allreduce"]["bytes"] == 9350 * 4
-    assert t["adv_sums_allreduce"]["calls_timed"] == 20 and t["adv_sums_allreduce"]["median_us"] > 0 and t["adv_sums_allreduce"]["bytes"] == 32 * 16
+    if p2p:
+        assert t["allreduce_path"] == "native peer exchange" and t["peer_exchange"].startswith("on"), t
+    else:
+        assert t["adv_sums_allreduce"]["calls_timed"] == 20 and t["adv_sums_allreduce"]["median_us"] > 0 and t["adv_sums_allreduce"]["bytes"] == 32 * 16
     assert all(x > 0 for x in t["per_rank_rollout_ms"] + t["per_rank_update_ms"])

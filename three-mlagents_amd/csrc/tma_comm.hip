@@ -12,11 +12,13 @@
 // tests), and inside a PyTorch process the already-loaded librccl of that process is reused (same SONAME) instead of a second copy.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 #include "tma_common.h"
+#include "tma_p2p.h"
 
 namespace {
 
@@ -73,14 +75,121 @@ const char *rccl_why() {
 }  // namespace
 
 struct tma_comm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;  // null: a communicator without RCCL (tma_comm_create_p2p): every all-reduce goes through the peer exchange
     int world = 1, rank = 0, device = -1;
     hipStream_t stream = nullptr;  // tma_comm_bind_stream: the stream tma_comm_allreduce_cb enqueues on
     // timing (bench.py dp_timing): HIP events around the next `want` all-reduces issued through this communicator
     int want = 0;
     std::vector<hipEvent_t> ev;
     int64_t calls = 0;
+    // peer exchange (tma_p2p.h): own inbox [2 parities][world][cap] 8-byte words in fine-grained device memory, the peers' inboxes as opened
+    // from their IPC handles, the sequence number of the last all-reduce that went through it, the host-mapped timeout flag
+    unsigned long long *inbox = nullptr;
+    unsigned long long *peer[tma::P2P_MAX_WORLD] = {};
+    int64_t cap = 0;
+    bool attached = false, p2p_on = false;
+    uint32_t seq = 0;
+    int *err_host = nullptr, *err_dev = nullptr;
+    long long timeout_ticks = 0;
+    int64_t p2p_calls = 0;
 };
+
+
+// ---- peer exchange: stand-alone kernels (an all-reduce that is not fused into its producer / consumer: tma_comm_allreduce) ----
+namespace tma {
+
+__global__ __launch_bounds__(256) void p2p_push_kernel(const uint32_t *__restrict__ src, int64_t n_words, PeerPush p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) p2p_push(p, i, src[i]);
+}
+
+__global__ __launch_bounds__(256) void p2p_pull_f32_kernel(float *__restrict__ dst, int64_t n, PeerPull q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = p2p_pull_f32(q, i);
+}
+
+// f64 payloads travel as two words (low half at 2 i, high half at 2 i + 1)
+__global__ __launch_bounds__(256) void p2p_pull_f64_kernel(double *__restrict__ dst, int64_t n, PeerPull q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long lo[P2P_MAX_WORLD], hi[P2P_MAX_WORLD];
+    p2p_wait(q, 2 * i, lo);
+    p2p_wait(q, 2 * i + 1, hi);
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_WORLD; r++) {
+        if (r < q.world) {
+            const double v = __longlong_as_double((long long)(((hi[r] & 0xFFFFFFFFull) << 32) | (lo[r] & 0xFFFFFFFFull)));
+            s = r == 0 ? v : s + v;
+        }
+    }
+    dst[i] = s;
+}
+
+bool tma_comm_p2p_ready(const tma_comm *c, int64_t count_words) { return c && c->p2p_on && c->attached && count_words >= 1 && count_words <= c->cap; }
+
+int tma_comm_p2p_next(tma_comm *c, int64_t count_words, PeerPush *push, PeerPull *pull) {
+    if (!tma_comm_p2p_ready(c, count_words)) return fail(TMA_ERR_INVALID, "peer exchange: not attached / enabled, or %lld words exceed the slot", (long long)count_words);
+    if (*c->err_host) return fail(TMA_ERR_HIP, "peer exchange: an earlier all-reduce timed out waiting for a peer's words (rank %d of %d)", c->rank, c->world);
+    if (++c->seq == 0) c->seq = 1;  // (0 is the sequence number of a word nobody wrote yet)
+    const int64_t parity = c->seq & 1;
+    *push = PeerPush{};
+    for (int d = 0; d < c->world; d++) push->dst[d] = c->peer[d] + (parity * c->world + c->rank) * c->cap;
+    push->world = c->world, push->seq = c->seq;
+    *pull = PeerPull{c->inbox + parity * c->world * c->cap, c->cap, c->world, c->seq, c->err_dev, c->timeout_ticks};
+    c->p2p_calls++;
+    c->calls++;
+    return TMA_OK;
+}
+
+hipStream_t tma_comm_bound_stream(const tma_comm *c) { return c->stream; }
+
+int tma_comm_time_begin(tma_comm *c, hipStream_t s) {
+    if (!c || (int)(c->ev.size() / 2) >= c->want) return 0;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return 0;
+    if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return 0;
+    }
+    c->ev.push_back(a), c->ev.push_back(b);
+    (void)hipEventRecord(a, s);
+    return 1;
+}
+
+void tma_comm_time_end(tma_comm *c, hipStream_t s) { (void)hipEventRecord(c->ev.back(), s); }
+
+}  // namespace tma
+
+namespace {
+
+void p2p_release(tma_comm *c) {
+    for (int r = 0; r < tma::P2P_MAX_WORLD; r++) {
+        if (c->peer[r] && c->peer[r] != c->inbox) (void)hipIpcCloseMemHandle(c->peer[r]);
+        c->peer[r] = nullptr;
+    }
+    if (c->inbox) (void)hipFree(c->inbox);
+    if (c->err_host) (void)hipHostFree(c->err_host);
+    c->inbox = nullptr, c->err_host = nullptr, c->err_dev = nullptr, c->attached = false, c->p2p_on = false, c->cap = 0;
+}
+
+int p2p_allreduce(tma_comm *c, void *buffer, int64_t count, int dtype, hipStream_t s) {
+    const int64_t words = dtype == 0 ? count : 2 * count;
+    tma::PeerPush push;
+    tma::PeerPull pull;
+    int rc = tma::tma_comm_p2p_next(c, words, &push, &pull);
+    if (rc) return rc;
+    tma::p2p_push_kernel<<<dim3((unsigned)tma::ceil_div(words, 256)), dim3(256), 0, s>>>(static_cast<const uint32_t *>(buffer), words, push);
+    TMA_LAUNCH_CHECK();
+    const int timed = tma::tma_comm_time_begin(c, s);
+    if (dtype == 0) tma::p2p_pull_f32_kernel<<<dim3((unsigned)tma::ceil_div(count, 256)), dim3(256), 0, s>>>(static_cast<float *>(buffer), count, pull);
+    else tma::p2p_pull_f64_kernel<<<dim3((unsigned)tma::ceil_div(count, 256)), dim3(256), 0, s>>>(static_cast<double *>(buffer), count, pull);
+    TMA_LAUNCH_CHECK();
+    if (timed) tma::tma_comm_time_end(c, s);
+    return TMA_OK;
+}
+
+}  // namespace
 
 #define TMA_NCCL(expr)                                                                                                       \
     do {                                                                                                                     \
@@ -126,6 +235,7 @@ int tma_comm_destroy(tma_comm *c) {
     Rccl *R = rccl();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (R && c->comm) (void)R->CommDestroy(c->comm);
+    p2p_release(c);
     delete c;
     return TMA_OK;
 }
@@ -139,9 +249,11 @@ int tma_comm_bind_stream(tma_comm *c, void *stream) {
 int tma_comm_allreduce(tma_comm *c, void *buffer, int64_t count, int dtype, void *stream) {
     if (!c || !buffer || count < 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_allreduce: null argument or empty buffer");
     if (dtype != 0 && dtype != 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_allreduce: dtype must be 0 (f32) or 1 (f64)");
+    hipStream_t s = (hipStream_t)stream;
+    if (tma::tma_comm_p2p_ready(c, dtype == 0 ? count : 2 * count)) return p2p_allreduce(c, buffer, count, dtype, s);
+    if (!c->comm) return tma::fail(TMA_ERR_INVALID, "tma_comm_allreduce: this communicator has no RCCL side and %lld elements do not fit its peer exchange", (long long)count);
     Rccl *R = rccl();
     if (!R) return tma::fail(TMA_ERR_HIP, "tma_comm_allreduce: %s", rccl_why());
-    hipStream_t s = (hipStream_t)stream;
     const bool timed = (int)(c->ev.size() / 2) < c->want;
     if (timed) {
         hipEvent_t a, b;
@@ -184,6 +296,105 @@ int tma_comm_pop_timing(tma_comm *c, float *us_out, int capacity, int *n_out, in
     c->want = 0;
     *n_out = n;
     if (calls_out) *calls_out = c->calls;
+    return TMA_OK;
+}
+
+// ---- peer exchange: set-up (include/tma.h) ----
+int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out) {
+    if (!out) return tma::fail(TMA_ERR_INVALID, "tma_comm_create_p2p: null argument");
+    if (world < 1 || world > tma::P2P_MAX_WORLD || rank < 0 || rank >= world) return tma::fail(TMA_ERR_INVALID, "tma_comm_create_p2p: rank %d of world %d (at most %d ranks)", rank, world, tma::P2P_MAX_WORLD);
+    if (device >= 0) TMA_HIP(hipSetDevice(device));
+    tma_comm *c = new tma_comm();
+    c->world = world, c->rank = rank, c->device = device;
+    *out = c;
+    return TMA_OK;
+}
+
+int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *handle_out64) {
+    if (!c || !handle_out64 || max_words < 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: bad argument");
+    if (c->world > tma::P2P_MAX_WORLD) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: the peer exchange serves at most %d ranks (world %d)", tma::P2P_MAX_WORLD, c->world);
+    if (c->inbox) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: already prepared");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (c->device >= 0) TMA_HIP(hipSetDevice(c->device));
+    const int64_t cap = (max_words + 63) & ~(int64_t)63;
+    const size_t bytes = (size_t)2 * c->world * cap * sizeof(unsigned long long);
+    void *p = nullptr;
+    // fine-grained: stores arriving over xGMI are visible to this GPU's system-scope loads without a cache flush in between
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_prepare: no fine-grained / uncached device memory for a %zu-byte inbox", bytes);
+        }
+    }
+    c->inbox = static_cast<unsigned long long *>(p), c->cap = cap;
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->err_host = 0;
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->err_dev), c->err_host, 0);
+    }
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess && c->world > 1) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        p2p_release(c);
+        return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_prepare: %s", hipGetErrorString(e));
+    }
+    memset(handle_out64, 0, 64);
+    if (c->world > 1) memcpy(handle_out64, &h, 64);
+    const char *ts = getenv("TMA_P2P_TIMEOUT_S");
+    const double secs = ts ? atof(ts) : 120.0;
+    c->timeout_ticks = (long long)((secs > 0.001 ? secs : 0.001) * 1e8);
+    return TMA_OK;
+}
+
+int tma_comm_p2p_attach(tma_comm *c, const unsigned char *handles) {
+    if (!c || !c->inbox || (!handles && c->world > 1)) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach: prepare first / null handles");
+    if (c->attached) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach: already attached");
+    if (c->device >= 0) TMA_HIP(hipSetDevice(c->device));
+    for (int r = 0; r < c->world; r++) {
+        if (r == c->rank) {
+            c->peer[r] = c->inbox;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + 64 * (size_t)r, 64);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (int q = 0; q < r; q++)
+                if (q != c->rank && c->peer[q]) (void)hipIpcCloseMemHandle(c->peer[q]), c->peer[q] = nullptr;
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_attach: hipIpcOpenMemHandle of rank %d's inbox failed: %s", r, hipGetErrorString(e));
+        }
+        c->peer[r] = static_cast<unsigned long long *>(p);
+    }
+    c->attached = true;
+    return TMA_OK;
+}
+
+int tma_comm_p2p_enable(tma_comm *c, int on) {
+    if (!c) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_enable: null communicator");
+    if (on && !c->attached) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_enable: attach first");
+    if (!on && !c->comm && c->world > 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_enable: a communicator without RCCL cannot switch its peer exchange off");
+    c->p2p_on = on != 0;
+    return TMA_OK;
+}
+
+int tma_comm_p2p_set_timeout(tma_comm *c, double seconds) {
+    if (!c || !(seconds > 0.0)) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_set_timeout: bad argument");
+    c->timeout_ticks = (long long)((seconds > 0.001 ? seconds : 0.001) * 1e8);  // wall_clock64(): 100 MHz
+    return TMA_OK;
+}
+
+int tma_comm_p2p_status(tma_comm *c, int *enabled, int64_t *calls, int *timed_out, int64_t *slot_words) {
+    if (!c) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_status: null communicator");
+    if (enabled) *enabled = c->p2p_on ? 1 : 0;
+    if (calls) *calls = c->p2p_calls;
+    if (timed_out) *timed_out = c->err_host ? *c->err_host : 0;
+    if (slot_words) *slot_words = c->cap;
     return TMA_OK;
 }
 

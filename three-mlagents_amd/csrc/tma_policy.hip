@@ -12,6 +12,7 @@
 // Formulas: SURVEY.md Appendix C.3 / C.5.  "Parity unpinned" at this boundary (SB3 is not importable here); checked
 // against a torch-CPU autograd restatement in tests/.
 #include "tma_h64_tile.h"
+#include "tma_p2p.h"
 
 #include <cstring>
 #include <cmath>
@@ -1169,7 +1170,7 @@ static int grad_wide_smem_bytes(const PLayout &L, int nw = 4) {
 // tma_ppo_adam_step_local skip its own pass over the gradient for the norm.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs_pi, int P, float *__restrict__ grad,
                                                           int n_slabs_vf = -1, int vf_begin = 0, int vf_end = 0, double *__restrict__ sq_part = nullptr,
-                                                          int overwrite = 0) {
+                                                          int overwrite = 0, PeerPush push = PeerPush{}) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -1203,6 +1204,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
             // (overwrite: the previous minibatch's gradient is still there -- its optimizer step ran inside the gradient launch, AdamFold)
             gnew = (overwrite ? 0.0f : grad[e]) + (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
             grad[e] = gnew;
+            // data-parallel peer exchange (tma_p2p.h): this rank's reduced gradient straight into every rank's inbox -- the all-reduce's send half
+            if (push.world > 0) p2p_push(push, e, __float_as_uint(gnew));
         }
         if (sq_part) {
             double sq = (double)gnew * (double)gnew;
@@ -1261,6 +1264,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params, f
 __global__ __launch_bounds__(64) void grad_sumsq64_kernel(const float *__restrict__ grad, int P, float scale, double *__restrict__ sq_part) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     const float gv = e < P ? grad[e] * scale : 0.0f;
+    double sq = (double)gv * (double)gv;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
+}
+
+// The receive half of the peer exchange fused into the same pass: grad[e] = sum over the ranks (rank order) of the words their slab
+// reductions stored into this rank's inbox, then the partials of the scaled sum exactly as above.
+__global__ __launch_bounds__(64) void grad_pull_sumsq64_kernel(float *__restrict__ grad, int P, float scale, double *__restrict__ sq_part, PeerPull pull) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    float gsum = 0.0f;
+    if (e < P) {
+        gsum = p2p_pull_f32(pull, e);
+        grad[e] = gsum;
+    }
+    const float gv = gsum * scale;
     double sq = (double)gv * (double)gv;
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
     if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
@@ -2150,7 +2168,7 @@ int tma_policy_bootstrap(const float *params, const tma_policy_dims *d, const fl
 
 // fold (H = 64 fast path only): the previous minibatch's optimizer step, done in the prologue of this gradient launch (AdamFold)
 static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, const tma_rollout *rb, const tma_minibatch *mbi, const tma_ppo_hparams *hp,
-                               float *grad, void *workspace, void *stream, const AdamFold *fold, int overwrite) {
+                               float *grad, void *workspace, void *stream, const AdamFold *fold, int overwrite, const PeerPush *push = nullptr) {
     int rc = enter(d);
     if (rc) return rc;
     if (!params || !rb || !mbi || !hp || !grad || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_minibatch_grad: null argument");
@@ -2217,11 +2235,12 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             lrc = tma_launch_grad_h64(params, L, R, M, hpar, adv_part, nbk, slabs, slots, &blocks4, s, fold);
         }
         if (lrc) return lrc;
-        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L), overwrite);
+        slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, (int)blocks4, L.P, grad, -1, 0, 0, sq_partials(ws, L), overwrite,
+                                                                                   push ? *push : PeerPush{});
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     }
-    if (fold || overwrite) return fail(TMA_ERR_INVALID, "internal: folded optimizer step outside the H = 64 fast path");
+    if (fold || overwrite || push) return fail(TMA_ERR_INVALID, "internal: folded optimizer step outside the H = 64 fast path");
     if (L.bf16) {  // column-parallel bf16-MFMA kernel (tma_bf16.hip) + deterministic slab reduction
         if ((int64_t)rb->T * rb->N * L.D >= (int64_t)1 << 31)  // (its observation gather indexes the buffer with 32-bit arithmetic)
             return fail(TMA_ERR_INVALID, "bf16 update: T * N * obs_dim = %lld exceeds 2^31", (long long)((int64_t)rb->T * rb->N * L.D));
@@ -2501,6 +2520,10 @@ int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_ro
         int cur = 0;
         double *sqp = sq_partials(ws, L);
         const int n_part = (int)ceil_div(L.P, 64);
+        // the library's own communicator with its peer exchange on (tma_comm_p2p_enable) and bound to this stream: fuse the exchange
+        static const bool no_p2p_fuse = getenv("TMA_P2P_NO_FUSE") != nullptr;  // A/B switch: push / pull as launches of their own (tma_comm_allreduce)
+        tma_comm *comm = allreduce == &tma_comm_allreduce_cb ? static_cast<tma_comm *>(ctx) : nullptr;
+        const bool fused = comm && !no_p2p_fuse && tma_comm_p2p_ready(comm, L.P) && tma_comm_bound_stream(comm) == s;
         for (int64_t start = 0; start < total; start += batch_size, step++) {
             const int64_t count = start + batch_size <= total ? batch_size : total - start;
             const tma_minibatch mb{nullptr, perm_seed, perm_epoch, start, count, prepared_batch, stats_world > 0 ? count * stats_world : 0};
@@ -2510,6 +2533,22 @@ int tma_ppo_train_epoch_dp(float *params, const tma_policy_dims *d, const tma_ro
                 f = AdamFold{grad, sqp, n_part, bufs[cur][0], bufs[cur][1], bufs[cur][2], bufs[cur ^ 1][0], bufs[cur ^ 1][1],
                              bufs[cur ^ 1][2], (float)max_grad_norm, (float)(lr / bc1), (float)beta1, (float)beta2, (float)sqrt(bc2), (float)eps,
                              reinterpret_cast<double *>(ws + WS_NORM_OUT), (float)grad_scale};
+            }
+            if (fused) {
+                // peer exchange, fused: slab_reduce_kernel stores this rank's reduced gradient into every rank's inbox, the sum-of-squares pass
+                // reads the rank-ordered sum out of this rank's own -- no collective launch between the two
+                PeerPush push;
+                PeerPull pull;
+                rc = tma_comm_p2p_next(comm, L.P, &push, &pull);
+                if (rc) return rc;
+                rc = minibatch_grad_impl(params, d, rb, &mb, hp, grad, workspace, stream, start > 0 ? &f : nullptr, 1, &push);
+                if (rc) return rc;
+                if (start > 0) cur ^= 1;
+                const int timed = tma_comm_time_begin(comm, s);
+                grad_pull_sumsq64_kernel<<<dim3((unsigned)n_part), dim3(64), 0, s>>>(grad, L.P, (float)grad_scale, sqp, pull);
+                TMA_LAUNCH_CHECK();
+                if (timed) tma_comm_time_end(comm, s);
+                continue;
             }
             rc = minibatch_grad_impl(params, d, rb, &mb, hp, grad, workspace, stream, start > 0 ? &f : nullptr, 1);
             if (rc) return rc;

@@ -88,7 +88,7 @@ class NativeComm:
     the native epoch loop itself, on the compute stream, with no Python / torch.distributed call per minibatch.  The 128-byte unique id is
     drawn on rank 0 and broadcast over the torch.distributed group that already exists (any backend); a world of one needs no group."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, rccl: bool = True):
         import ctypes as C
 
         import torch.distributed as td
@@ -96,9 +96,16 @@ class NativeComm:
         from . import _lib
 
         L = _lib.lib()
+        self.world, self.rank, self.device = world_size(), rank(), torch.device(device)
+        self.has_rccl, self.p2p_enabled, self.p2p_note = bool(rccl), False, ""
+        if not rccl:  # a communicator with the peer exchange only (several ranks on ONE GPU: the one-GPU tests; RCCL wants a device per rank)
+            handle = C.c_void_p()
+            _lib.check(L.tma_comm_create_p2p(self.world, self.rank, self.device.index if self.device.index is not None else -1, C.byref(handle)))
+            self._h, self._L = handle, L
+            self.callback = C.cast(L.tma_comm_allreduce_cb, _lib.AllReduceFn)
+            return
         if not L.tma_comm_available():
             raise RuntimeError("librccl.so.1 could not be bound by libtma_hip.so")
-        self.world, self.rank, self.device = world_size(), rank(), torch.device(device)
         ident = torch.zeros(128, dtype=torch.uint8)
         if self.rank == 0:
             _lib.check(L.tma_comm_unique_id(_lib.ptr(ident.numpy())))
@@ -129,6 +136,63 @@ class NativeComm:
         code = {torch.float32: 0, torch.float64: 1}[t.dtype]
         _lib.check(self._L.tma_comm_allreduce(self._h, _lib.ptr(t), t.numel(), code, stream_ptr))
         return t
+
+    # ---- peer exchange (include/tma.h tma_comm_p2p_*): all-reduces of up to `max_words` 32-bit words as direct stores into the peers' inboxes ----
+    def p2p_prepare(self, max_words: int) -> bytes:
+        """Allocate this rank's inbox and return its 64-byte IPC handle."""
+        import ctypes as C
+
+        from . import _lib
+
+        buf = (C.c_ubyte * 64)()
+        _lib.check(self._L.tma_comm_p2p_prepare(self._h, int(max_words), buf))
+        return bytes(buf)
+
+    def p2p_attach(self, handles: list[bytes]) -> None:
+        """Map the peers' inboxes (`handles`: every rank's p2p_prepare() result, in rank order)."""
+        import ctypes as C
+
+        from . import _lib
+
+        blob = b"".join(handles)
+        assert len(blob) == 64 * self.world
+        _lib.check(self._L.tma_comm_p2p_attach(self._h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)))
+
+    def p2p_enable(self, on: bool = True) -> None:
+        from . import _lib
+
+        _lib.check(self._L.tma_comm_p2p_enable(self._h, 1 if on else 0))
+        self.p2p_enabled = bool(on)
+
+    def p2p_set_timeout(self, seconds: float) -> None:
+        from . import _lib
+
+        _lib.check(self._L.tma_comm_p2p_set_timeout(self._h, float(seconds)))
+
+    def p2p_status(self) -> dict:
+        import ctypes as C
+
+        from . import _lib
+
+        en, calls, bad, words = C.c_int(0), C.c_int64(0), C.c_int(0), C.c_int64(0)
+        _lib.check(self._L.tma_comm_p2p_status(self._h, C.byref(en), C.byref(calls), C.byref(bad), C.byref(words)))
+        return {"enabled": bool(en.value), "calls": int(calls.value), "timed_out": bool(bad.value), "slot_words": int(words.value)}
+
+    def p2p_setup(self, max_words: int) -> None:
+        """prepare + gather the handles over torch.distributed (the group that already exists, any backend) + attach.  Collective over the ranks;
+        raises on the rank where a step fails (the caller agrees on the outcome across ranks before it enables the exchange)."""
+        import torch.distributed as td
+
+        mine = self.p2p_prepare(max_words)
+        if self.world == 1:
+            self.p2p_attach([mine])
+            return
+        on_gpu = "nccl" in str(td.get_backend())
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        t = t.to(self.device) if on_gpu else t
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        td.all_gather(out, t)
+        self.p2p_attach([bytes(o.cpu().numpy().tobytes()) for o in out])
 
     def timing(self, samples: int) -> None:
         from . import _lib

@@ -278,7 +278,12 @@ class PPO:
         # the callback into torch.distributed.  TMA_NATIVE_RCCL=1 builds the communicator at world size 1 too (exercises real RCCL on one GPU).
         self._native_comm = None
         # ("nccl" IN the backend string: a group initialised without a backend name reports "cpu:gloo,cuda:nccl" and serves CUDA tensors over RCCL)
-        want_native = os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and "nccl" in (_dist_backend() or ""))
+        # On top of it, the PEER EXCHANGE (tma_comm_p2p_*: the gradient sum as direct xGMI stores into the peers' inboxes, fused into the slab
+        # reduction and the sum-of-squares pass on the H = 64 path -- no collective launch in the minibatch chain): set up, checked and TIMED against
+        # RCCL at construction, kept when it is the faster one.  TMA_P2P=0: never; TMA_P2P=1: always, and with a non-RCCL backend (gloo: several
+        # ranks on one GPU, the tests) a communicator that has ONLY the exchange.
+        want_native = (os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and "nccl" in (_dist_backend() or ""))
+                       or (os.environ.get("TMA_P2P") == "1" and torch.cuda.is_available()))
         if want_native and not os.environ.get("TMA_NO_NATIVE_RCCL"):
             self._native_comm = self._make_native_comm()
         if self.world_size > 1 and self._native_comm is None and self.rank == 0:
@@ -308,30 +313,124 @@ class PPO:
             tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
             return flag.item() == 1.0
 
-        # first agreement BEFORE any native collective step: a rank that cannot bind RCCL must not leave the others inside the unique-id
-        # broadcast or ncclCommInitRank
-        if not agree(bool(_lib.lib().tma_comm_available())):
-            print("three-mlagents_amd: native RCCL communicator not used (librccl.so.1 could not be bound on every rank); collectives go through "
-                  "torch.distributed", file=sys.stderr, flush=True)
-            return None
-        try:
-            comm = _dist.NativeComm(self.device)
-            probe = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.rank + 1)
-            comm.all_reduce_(probe, self._stream())
+        def probe_ok(c) -> bool:  # exact-integer sums: f32 over 1024 elements, f64 over 8 (the advantage-sum message)
+            tri = float(self.world_size * (self.world_size + 1) // 2)
+            p32 = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.rank + 1)
+            p64 = (torch.arange(1, 9, dtype=torch.float64, device=self.device) + 2.0 ** 40) * float(self.rank + 1)
+            c.all_reduce_(p32, self._stream())
+            c.all_reduce_(p64, self._stream())
             torch.cuda.current_stream(self.device).synchronize()
-            want = torch.arange(1, 1025, dtype=torch.float32, device=self.device) * float(self.world_size * (self.world_size + 1) // 2)
-            ok = bool(torch.equal(probe, want))
+            return bool(torch.equal(p32, torch.arange(1, 1025, dtype=torch.float32, device=self.device) * tri)
+                        and torch.equal(p64, (torch.arange(1, 9, dtype=torch.float64, device=self.device) + 2.0 ** 40) * tri))
+
+        use_rccl = self.world_size == 1 or "nccl" in (_dist_backend() or "")  # (gloo group + TMA_P2P=1: the exchange alone)
+        if use_rccl:
+            # first agreement BEFORE any native collective step: a rank that cannot bind RCCL must not leave the others inside the unique-id
+            # broadcast or ncclCommInitRank
+            if not agree(bool(_lib.lib().tma_comm_available())):
+                print("three-mlagents_amd: native RCCL communicator not used (librccl.so.1 could not be bound on every rank); collectives go through "
+                      "torch.distributed", file=sys.stderr, flush=True)
+                return None
+        try:
+            comm = _dist.NativeComm(self.device, rccl=use_rccl)
+            ok = probe_ok(comm) if use_rccl else True
             why = "" if ok else "self-check of the native all-reduce against the expected sum failed"
         except Exception as exc:  # noqa: BLE001
             why = str(exc)
         if not agree(ok) and ok:
             ok, why = False, "another rank could not use its native communicator"
-        if ok:
+        if ok and os.environ.get("TMA_P2P") != "0" and (self.world_size > 1 or os.environ.get("TMA_P2P") == "1"):
+            self._setup_peer_exchange(comm, agree, probe_ok, use_rccl)
+        if ok and (use_rccl or comm.p2p_enabled):
             return comm
+        if ok:
+            why = f"no RCCL side for this backend and no peer exchange either ({comm.p2p_note})"
         if comm is not None:
             comm.close()
-        print(f"three-mlagents_amd: native RCCL communicator not used ({why}); collectives go through torch.distributed", file=sys.stderr, flush=True)
+        print(f"three-mlagents_amd: native communicator not used ({why}); collectives go through torch.distributed", file=sys.stderr, flush=True)
         return None
+
+    def _setup_peer_exchange(self, comm, agree, probe_ok, has_rccl: bool) -> None:
+        """Peer exchange on top of `comm` (dist.NativeComm.p2p_*): inbox + handle gather + attach, an exact-sum self-check, and -- when RCCL is
+        there to compare with -- a timing contest on a gradient-sized message (stand-alone launches both ways, max over ranks); the exchange
+        stays on when it wins or TMA_P2P=1 forces it.  Every step is followed by an agreement over torch.distributed, so the ranks leave with the
+        same answer; the outcome is one stderr line on rank 0 and comm.p2p_note."""
+        import sys
+        import time
+
+        from . import dist as _dist
+
+        P = int(self.grad.numel())
+        words = max(65536, (P + 4095) // 4096 * 4096)  # slot size: the flat gradient (an inbox is 2 x world x 8 bytes per word)
+        note, on = "", False
+
+        def step(fn) -> tuple[bool, object]:
+            try:
+                return True, fn()
+            except Exception as exc:  # noqa: BLE001
+                return False, exc
+
+        if self.world_size > 8 or P > (1 << 20):
+            note = f"not applicable (world {self.world_size}, {P} gradient words; it serves <= 8 ranks and <= {1 << 20} words)"
+        else:
+            good, mine = step(lambda: comm.p2p_prepare(words))
+            if not agree(good):
+                note = f"inbox allocation / IPC export failed{'' if good else f': {mine}'}"
+            else:
+                if self.world_size > 1:
+                    import torch.distributed as tdist
+
+                    t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+                    t = t.to(self.device) if "nccl" in str(tdist.get_backend()) else t
+                    gathered = [torch.zeros_like(t) for _ in range(self.world_size)]
+                    tdist.all_gather(gathered, t)
+                    handles = [g.cpu().numpy().tobytes() for g in gathered]
+                else:
+                    handles = [mine]
+                good, exc = step(lambda: comm.p2p_attach(handles))
+                if not agree(good):
+                    note = f"mapping a peer's inbox failed{'' if good else f': {exc}'}"
+                else:
+                    comm.p2p_enable(True)
+                    comm.p2p_set_timeout(10.0)  # the ranks are in step here (the agreement above): a peer's words are microseconds away or never come
+                    good, res = step(lambda: probe_ok(comm))
+                    good = good and bool(res) and not comm.p2p_status()["timed_out"]
+                    if good and not os.environ.get("TMA_P2P_TIMEOUT_S"):
+                        comm.p2p_set_timeout(120.0)
+                    if not agree(good):
+                        note = "self-check of the exchange against the expected sums failed"
+                    elif not has_rccl or os.environ.get("TMA_P2P") == "1":
+                        on, note = True, "on (TMA_P2P=1)" if has_rccl else "on (the communicator's only path)"
+                    else:
+                        def per_call_us(n: int = 40) -> float:
+                            g = torch.zeros(P, dtype=torch.float32, device=self.device)
+                            for _ in range(5):
+                                comm.all_reduce_(g, self._stream())
+                            torch.cuda.current_stream(self.device).synchronize()
+                            _dist.barrier()
+                            t0 = time.perf_counter()
+                            for _ in range(n):
+                                comm.all_reduce_(g, self._stream())
+                            torch.cuda.current_stream(self.device).synchronize()
+                            return _dist.allreduce_max_float((time.perf_counter() - t0) / n * 1e6, device=self.device)
+
+                        t_p2p = per_call_us()
+                        comm.p2p_enable(False)
+                        t_rccl = per_call_us()
+                        # (the contest runs the exchange as two launches of its own; fused into the H = 64 chain it has none -- 4.7 us per minibatch less,
+                        # measured at world size 1, tools/r05_run4.sh -- so a near tie goes to the exchange there)
+                        margin = 3.0 if self.policy.dims.hidden == 64 else 0.0
+                        on = agree(t_p2p < t_rccl + margin)
+                        note = (f"{'on' if on else 'off'}: {t_p2p:.1f} us per {4 * P}-byte all-reduce against RCCL's {t_rccl:.1f} us (dependent chain of 40, "
+                                "stand-alone launches both ways, max over ranks)")
+        if comm.p2p_status()["slot_words"] and comm.p2p_enabled != on:
+            try:
+                comm.p2p_enable(on)
+            except Exception:  # noqa: BLE001  (a communicator without RCCL cannot switch it off: the caller drops the communicator)
+                comm.p2p_enabled = False
+        comm.p2p_note = note
+        if self.rank == 0 and (self.world_size > 1 or os.environ.get("TMA_P2P") == "1"):
+            print(f"three-mlagents_amd: peer exchange for the gradient all-reduce {note}", file=sys.stderr, flush=True)
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
@@ -497,8 +596,11 @@ class PPO:
             us, calls = self._native_comm.pop_timing()
             us.sort()
             out["grad_allreduce_us"] = {"calls_timed": len(us), "median_us": us[len(us) // 2] if us else None, "max_us": us[-1] if us else None,
-                                        "bytes": int(self.grad.numel() * 4), "path": "native: ncclAllReduce issued by libtma_hip.so on the compute stream",
-                                        "allreduces_issued": calls}
+                                        "bytes": int(self.grad.numel() * 4),
+                                        "path": ("native: peer exchange (direct stores into the peers' inboxes, fused into the slab reduction / sum-of-squares kernels; "
+                                                 "timed: the receiving kernel)" if self._native_comm.p2p_enabled
+                                                 else "native: ncclAllReduce issued by libtma_hip.so on the compute stream"),
+                                        "peer_exchange": self._native_comm.p2p_note, "allreduces_issued": calls}
             out["adv_allreduce_us"] = {"calls_timed": 0, "median_us": None, "max_us": None, "bytes": int(getattr(self, "_adv_sums", torch.empty(0)).numel() * 8),
                                        "path": "native (f64, same communicator; not timed separately: one per epoch)"}
             return out
