@@ -302,9 +302,11 @@ int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out,
  *      the `world` slots of its own inbox (system-scope 8-byte loads, until every word carries the expected sequence number) and adds them in
  *      rank order -- the same order on every rank, so replicas stay bit-identical; no fence and no ordering between words is assumed
  *      (csrc/tma_p2p.h has the protocol and why two slot parities suffice).
- * Set-up: tma_comm_p2p_prepare(comm, max_words, handle_out[64]) allocates the inbox (slots of max_words 8-byte words; an f32 element is one
- * word, an f64 element two) and exports its handle; the caller gathers the `world` handles over the channel it already has (rank order,
- * 64 bytes each) and gives them to tma_comm_p2p_attach; tma_comm_p2p_enable(comm, 1) then routes every tma_comm_allreduce /
+ * Set-up: tma_comm_p2p_prepare(comm, max_words, ticket_out[128]) allocates the inbox (slots of max_words 8-byte words; an f32 element is one
+ * word, an f64 element two) and writes a 128-byte ticket (the inbox's IPC handle + the PCI bus id of its device); the caller gathers the
+ * `world` tickets over the channel it already has (rank order) and gives them to tma_comm_p2p_attach, which refuses (TMA_ERR_HIP, nothing
+ * mapped) unless every peer's device is this rank's own or a visible one with peer access (switched on there);
+ * tma_comm_p2p_enable(comm, 1) then routes every tma_comm_allreduce /
  * tma_comm_allreduce_cb whose message fits a slot through the exchange (larger ones keep RCCL), and tma_ppo_train_epoch_dp -- given
  * tma_comm_allreduce_cb and such a communicator -- FUSES it on its H = 64 path: the slab reduction stores the reduced gradient into the
  * peers' inboxes, the sum-of-squares pass in front of the optimizer step reads the sum: no collective launch in the minibatch chain at all.
@@ -313,8 +315,8 @@ int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out,
  * the all-reduce that was waiting returns garbage, every later one fails with TMA_ERR_HIP, tma_comm_p2p_status reports it -- nothing spins
  * for ever.  tma_comm_timing brackets the RECEIVING kernel of an exchange (what the chain waits for once the sender kernel is done). */
 int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out);
-int tma_comm_p2p_prepare(tma_comm *comm, int64_t max_words, unsigned char *handle_out64);
-int tma_comm_p2p_attach(tma_comm *comm, const unsigned char *handles_world_x_64);
+int tma_comm_p2p_prepare(tma_comm *comm, int64_t max_words, unsigned char *ticket_out128);
+int tma_comm_p2p_attach(tma_comm *comm, const unsigned char *tickets_world_x_128);
 int tma_comm_p2p_enable(tma_comm *comm, int on);
 int tma_comm_p2p_status(tma_comm *comm, int *enabled_out, int64_t *calls_out, int *timed_out_out, int64_t *slot_words_out);
 int tma_comm_p2p_set_timeout(tma_comm *comm, double seconds); /* receivers of later exchanges give up after this long (set-up: a short one for the self-check) */

@@ -310,8 +310,8 @@ int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out) {
     return TMA_OK;
 }
 
-int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *handle_out64) {
-    if (!c || !handle_out64 || max_words < 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: bad argument");
+int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *ticket_out128) {
+    if (!c || !ticket_out128 || max_words < 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: bad argument");
     if (c->world > tma::P2P_MAX_WORLD) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: the peer exchange serves at most %d ranks (world %d)", tma::P2P_MAX_WORLD, c->world);
     if (c->inbox) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: already prepared");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
@@ -342,25 +342,60 @@ int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *handle_o
         p2p_release(c);
         return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_prepare: %s", hipGetErrorString(e));
     }
-    memset(handle_out64, 0, 64);
-    if (c->world > 1) memcpy(handle_out64, &h, 64);
+    // the ticket: the IPC handle and the PCI bus id of the device the inbox lives on (a peer needs it to find that device among the ones IT sees)
+    memset(ticket_out128, 0, 128);
+    if (c->world > 1) memcpy(ticket_out128, &h, 64);
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetPCIBusId(reinterpret_cast<char *>(ticket_out128) + 64, 63, dev);
+    if (e != hipSuccess) {
+        p2p_release(c);
+        return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_prepare: %s", hipGetErrorString(e));
+    }
     const char *ts = getenv("TMA_P2P_TIMEOUT_S");
     const double secs = ts ? atof(ts) : 120.0;
     c->timeout_ticks = (long long)((secs > 0.001 ? secs : 0.001) * 1e8);
     return TMA_OK;
 }
 
-int tma_comm_p2p_attach(tma_comm *c, const unsigned char *handles) {
-    if (!c || !c->inbox || (!handles && c->world > 1)) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach: prepare first / null handles");
+int tma_comm_p2p_attach(tma_comm *c, const unsigned char *tickets) {
+    if (!c || !c->inbox || (!tickets && c->world > 1)) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach: prepare first / null tickets");
     if (c->attached) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach: already attached");
     if (c->device >= 0) TMA_HIP(hipSetDevice(c->device));
+    int mydev = 0;
+    TMA_HIP(hipGetDevice(&mydev));
+    char mybus[64] = {0};
+    TMA_HIP(hipDeviceGetPCIBusId(mybus, 63, mydev));
+    // every peer's device must be one THIS process can store to: the same device (several ranks on one GPU), or a visible one with peer access
+    // (checked and switched on here -- a store through a mapping without it would be a memory fault, not an error code)
+    for (int r = 0; r < c->world; r++) {
+        if (r == c->rank) continue;
+        char bus[64] = {0};
+        memcpy(bus, tickets + 128 * (size_t)r + 64, 63);
+        if (strcmp(bus, mybus) == 0) continue;
+        int pdev = -1, can = 0;
+        if (hipDeviceGetByPCIBusId(&pdev, bus) != hipSuccess || pdev < 0) {
+            (void)hipGetLastError();
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_attach: rank %d's device %s is not visible to this process", r, bus);
+        }
+        if (hipDeviceCanAccessPeer(&can, mydev, pdev) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_attach: no peer access from device %s to rank %d's device %s", mybus, r, bus);
+        }
+        const hipError_t pe = hipDeviceEnablePeerAccess(pdev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_attach: hipDeviceEnablePeerAccess(%s) failed: %s", bus, hipGetErrorString(pe));
+        }
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < c->world; r++) {
         if (r == c->rank) {
             c->peer[r] = c->inbox;
             continue;
         }
         hipIpcMemHandle_t h;
-        memcpy(&h, handles + 64 * (size_t)r, 64);
+        memcpy(&h, tickets + 128 * (size_t)r, 64);
         void *p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {

@@ -139,12 +139,12 @@ class NativeComm:
 
     # ---- peer exchange (include/tma.h tma_comm_p2p_*): all-reduces of up to `max_words` 32-bit words as direct stores into the peers' inboxes ----
     def p2p_prepare(self, max_words: int) -> bytes:
-        """Allocate this rank's inbox and return its 64-byte IPC handle."""
+        """Allocate this rank's inbox and return its 128-byte ticket (IPC handle + PCI bus id of the device)."""
         import ctypes as C
 
         from . import _lib
 
-        buf = (C.c_ubyte * 64)()
+        buf = (C.c_ubyte * 128)()
         _lib.check(self._L.tma_comm_p2p_prepare(self._h, int(max_words), buf))
         return bytes(buf)
 
@@ -155,7 +155,7 @@ class NativeComm:
         from . import _lib
 
         blob = b"".join(handles)
-        assert len(blob) == 64 * self.world
+        assert len(blob) == 128 * self.world
         _lib.check(self._L.tma_comm_p2p_attach(self._h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)))
 
     def p2p_enable(self, on: bool = True) -> None:
