@@ -445,6 +445,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // TMA_RELANE at the head of a phase re-derives lane / r16 / g from an opaque copy, so the addresses of that phase are
     // computed there (a few VALU instructions) and die with it.
     int lane = lane0, r16 = lane0 & 15, g = lane0 >> 4;
+    // (mrow / mlane -- the metadata row of this lane, below -- follow the same rule: their three LDS addresses, hoisted, were the spills of the
+    //  Ball3D / Push instantiation, and one of the reloads sat right behind the next group's gathers with an s_waitcnt vmcnt(0))
+    int mrow = 0;
+    bool mlane = false;
 #ifdef TMA_BF_PHASE_TICKS  // diagnostic build (make libtma_hip_bfticks.so, tools/bf_ticks.py): cycles per phase, wave 0 of block 0 of each net
     // (sums are kept in LDS and copied out once at the end: a global atomic per stamp stays in vmcnt for ~1 k cycles and every counted wait
     //  for a weight fragment behind it would wait for it too)
@@ -461,11 +465,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #else
 #define TMA_TICK(i)
 #endif
-#define TMA_RELANE()                       \
-    do {                                   \
-        lane = lane0;                      \
-        asm volatile("" : "+v"(lane));     \
-        r16 = lane & 15, g = lane >> 4;    \
+#define TMA_RELANE()                                              \
+    do {                                                          \
+        lane = lane0;                                             \
+        asm volatile("" : "+v"(lane));                            \
+        r16 = lane & 15, g = lane >> 4;                           \
+        mrow = wave * (M / NW) + lane, mlane = lane < M / NW;     \
     } while (0)
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
@@ -572,8 +577,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // ---- prefetch registers for the next group's samples ----
     float pm0 = 0.0f, pm1 = 0.0f, pm2 = 0.0f, pm3 = 0.0f, px[NX];
     int64_t poff = -1;
-    const int mrow = wave * (M / NW) + lane0;  // sample row whose metadata this lane gathers (lanes < M/NW of every wave: the Feistel
-    const bool mlane = lane0 < M / NW;         // permutation arithmetic is spread over the waves instead of skewing wave 0)
+    mrow = wave * (M / NW) + lane0;  // sample row whose metadata this lane gathers (lanes < M/NW of every wave: the Feistel
+    mlane = lane0 < M / NW;          // permutation arithmetic is spread over the waves instead of skewing wave 0)
     int32_t noff = -1;  // cached buffer offset of this lane's row in the NEXT group, loaded one phase before fetch_meta needs it
     auto fetch_off = [&](int64_t grp) {  // (cache present) issue only; j beyond the minibatch reads a clamped entry that fetch_meta ignores
         if (mb.offs && mlane) {
