@@ -365,6 +365,8 @@ EXTRA_CONFIGS = [
          steps=3, warmup=1),
     dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="crawler", n_envs=2048, n_steps=2048, hidden=256,
          mfma="f32", steps=3, warmup=1),
+    dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 weights, bf16x3 update (opt-in)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="bf16x3",
+         steps=3, warmup=1),
 ]
 
 

@@ -522,6 +522,20 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
 // element in the same order as the first row tile of a full group.
 // NW = 8 (round 4, single-pass shapes): two waves per SIMD, 32 columns each -- the dW2 slice of a wave is 128 accumulator registers instead of 256,
 // and one wave's LDS waits and epilogues run beside its SIMD partner's MFMAs (the f32 MFMA pipe was 60 % busy with one wave per SIMD).
+#ifndef TMA_HALF_RING
+#define TMA_HALF_RING 4
+#endif
+#ifdef TMA_WIDE_PHASE_TICKS  // diagnostic build (make libtma_hip_wticks.so, tools/wide_ticks.py): cycles per phase of the f32 wide gradient kernel, wave 0 of block 0 of each net
+__device__ unsigned long long g_wide_ticks[2][16];
+#define TMA_WTICK(i)                                                      \
+    do {                                                                  \
+        const long long tn_ = clock64();                                  \
+        if (wtick_on) wtick_lds[i] += (unsigned long long)(tn_ - wtlast); \
+        wtlast = clock64();                                               \
+    } while (0)
+#else
+#define TMA_WTICK(i)
+#endif
 template <bool CONT, bool IS_PI, int NTW, int KT1C, int PASS, int NQ1C, bool HALF = false, int NW = 4>
 __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params, const PLayout &L, const Rollout &rb, const Minibatch &mb,
                                                const HParams &hp, const float *__restrict__ ws_adv, float *__restrict__ slab,
@@ -544,6 +558,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         asm volatile("" : "+v"(lane));     \
         r16 = lane & 15, g = lane >> 4;    \
     } while (0)
+#ifdef TMA_WIDE_PHASE_TICKS
+    __shared__ unsigned long long wtick_lds[16];
+    if (threadIdx.x < 16) wtick_lds[threadIdx.x] = 0;
+    long long wtlast = clock64();
+    const bool wtick_on = threadIdx.x == 0 && block_net == 0;
+#endif
     const int D = L.D, A = L.A;
     const int NOUT = IS_PI ? A : 1;
     const int ldx = ((D + 3) & ~3) + 2, KS1 = (D + 3) >> 2, KT1 = (D + 15) >> 4;
@@ -556,6 +576,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     float *scratch = reinterpret_cast<float *>(row_off + M);  // 64 floats
     float *hpart = scratch + 64;  // [4 waves][2 tiles][2][64 lanes][4]: split-K partial head outputs
     float *bias = hpart + NW * 2 * 2 * 256;  // b1[H], b2[H], b3[32] (zero padded): LDS copies, so no global load sits in front of a phase
+    // buffer offsets of the NEXT group's rows (round 5): fetched during the current group, so that a group starts with ONE memory round trip --
+    // metadata and observation rows together -- instead of three dependent ones (offset -> metadata -> barrier -> observation rows)
+    int64_t *row_off_next = reinterpret_cast<int64_t *>(bias + 2 * H + 32);
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
@@ -599,13 +622,22 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     LossStats st;
     for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
         bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
+    auto next_off = [&](int64_t grp_n) -> int64_t {  // buffer offset of row threadIdx.x of group grp_n (-1: padding row / beyond the minibatch)
+        const int64_t j = grp_n * MG + threadIdx.x;
+        if ((int)threadIdx.x >= MG || j >= mb.count) return -1;
+        return mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
+    };
+    if (threadIdx.x < M) row_off_next[threadIdx.x] = next_off(block_net);
     __syncthreads();
     // The two H x H weight streams of a row group (layer-2 forward, then layer-2 input-gradient) come from the fragment-major f32
     // images (PLayout::fr_pi) through a register ring of R fragments: one 16-byte load per lane feeds four k-steps (8 MFMAs), and
     // the slot a fragment is consumed from is reloaded at once with the fragment R positions further down the cyclic stream --
     // 2 k cycles of MFMA work of lookahead that carries across phases, barriers and row groups.
     constexpr int NQ = H / 16, S1 = NTW * NQ1C, SL = S1 + 2 * NTW * NQ;
-    constexpr int R = SL % 4 == 0 ? 4 : (SL % 5 == 0 ? 5 : 3);  // ring slots are static registers: R must divide the cyclic stream
+    // (half groups halve the MFMA work behind every fragment, i.e. the lookahead a slot buys: the four-wave half-group kernel has the registers
+    //  of the compiled-out second row tile to spare; -DTMA_HALF_RING=16 gives it a ring four times as deep -- measured 40.3 us against 41.9 at 256 samples,
+    //  both behind the eight-wave kernel's 34.8, so the default stays 4)
+    constexpr int R = (HALF && NW == 4 && SL % TMA_HALF_RING == 0) ? TMA_HALF_RING : (SL % 4 == 0 ? 4 : (SL % 5 == 0 ? 5 : 3));  // ring slots are static registers: R must divide the cyclic stream
     static_assert(SL % R == 0, "ring must divide the per-group fragment stream");
     const float *fr = params + (IS_PI ? L.fr_pi : L.fr_vf), *fr1 = params + (IS_PI ? L.fr1_pi : L.fr1_vf);
     int nt0 = wave * NTW;
@@ -623,6 +655,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         for (int s = 0; s < R; s++) ring[s] = sload(s);
     }
     const int64_t n_groups = (mb.count + MG - 1) / MG;
+    TMA_WTICK(0);  // prologue
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
         f32x4 zc[NTW][2];  // PASS 2: cached dz1 operands of this wave, in flight under the gathers of P0
         if constexpr (PASS == 2) {
@@ -642,24 +675,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             nt0 = __builtin_amdgcn_readfirstlane(nt0);
         }
         TMA_RELANE();
-        // ---- P0: gather sample metadata and the observation rows ----
-        if (threadIdx.x < M) {
-            const int64_t j = grp * MG + threadIdx.x;
-            int64_t off = -1;
-            float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
-            if ((int)threadIdx.x < MG && j < mb.count) {
-                off = mb.offs ? (int64_t)mb.offs[j] : sample_offset(mb, mb.start + j, rb.T, rb.N);
-                if constexpr (PASS != 2) {
-                    m0 = rb.log_probs[off], m1 = rb.advantages[off], m2 = rb.returns[off];
-                    if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[off]);
-                }
-            }
-            meta[threadIdx.x * 4 + 0] = m0, meta[threadIdx.x * 4 + 1] = m1, meta[threadIdx.x * 4 + 2] = m2, meta[threadIdx.x * 4 + 3] = m3;
-            row_off[threadIdx.x] = off;
-        }
-        __syncthreads();
+        // ---- P0: gather sample metadata and the observation rows (row offsets: row_off_next, left there by the previous group) ----
         {
-            // Wave w gathers rows 8w .. 8w+7, lane l the columns l, l + 64, ...: the row's buffer offset is wave-uniform (scalar base +
+            // Wave w gathers rows RW w .. RW w + RW - 1, lane l the columns l, l + 64, ...: the row's buffer offset is wave-uniform (scalar base +
             // lane offset, no 64-bit per-lane address arithmetic) and a whole batch of loads is in flight before the first store.
             // (The element-indexed form of this loop -- e = tid + 256 i, row = e / D -- was instruction-bound at Crawler width.)
             typedef const float __attribute__((address_space(1))) *gf_ptr;
@@ -667,11 +685,23 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             bool rok[RW];
 #pragma unroll
             for (int i = 0; i < RW; i++) {
-                const int64_t off = row_off[wave * RW + i];
+                const int64_t off = row_off_next[wave * RW + i];
                 const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)off >> 32));
                 const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
                 rok[i] = offu >= 0;
                 rbase[i] = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (rok[i] ? offu * D : 0)));
+            }
+            // the metadata of row threadIdx.x: issued in front of the observation loads, consumed behind them (one round trip for both)
+            int64_t moff = -1;
+            float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+            if (threadIdx.x < M) {
+                moff = row_off_next[threadIdx.x];
+                if constexpr (PASS != 2) {
+                    if (moff >= 0) {
+                        m0 = rb.log_probs[moff], m1 = rb.advantages[moff], m2 = rb.returns[moff];
+                        if constexpr (!CONT) m3 = __int_as_float(static_cast<const int32_t *>(rb.actions)[moff]);
+                    }
+                }
             }
             const int Dp = (D + 3) & ~3;
             for (int c0 = 0; c0 < Dp; c0 += 192) {
@@ -694,8 +724,13 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     }
                 }
             }
+            if (threadIdx.x < M) {
+                meta[threadIdx.x * 4 + 0] = m0, meta[threadIdx.x * 4 + 1] = m1, meta[threadIdx.x * 4 + 2] = m2, meta[threadIdx.x * 4 + 3] = m3;
+                row_off[threadIdx.x] = moff;
+            }
         }
         __syncthreads();
+        TMA_WTICK(1);  // P0 gathers
         TMA_RELANE();
         if constexpr (PASS == 2) {
 #pragma unroll
@@ -709,6 +744,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #pragma unroll
                     for (int sidx = 0; sidx < 8; sidx++) aW1[kt][j] = mfma16(a[sidx], zc[j][sidx >> 2][sidx & 3], aW1[kt][j]);
             }
+            if (threadIdx.x < M) row_off_next[threadIdx.x] = grp + n_blocks_net < n_groups ? next_off(grp + n_blocks_net) : -1;  // (read in front of the barrier above)
             __syncthreads();
             continue;
         }
@@ -785,6 +821,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     for (int r = 0; r < 4; r++) h1[(mt * 16 + g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(acc[j][mt][r]);
         }
         __syncthreads();
+        TMA_WTICK(2);  // P1 layer 1
         TMA_RELANE();
         // ---- P2: layer 2 forward, one 16-column tile at a time (8 accumulator registers live), weights through the ring ----
 #pragma unroll
@@ -821,6 +858,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_WTICK(3);  // P2 layer 2
         TMA_RELANE();
         // ---- P3a: split-K head: wave w multiplies k-steps [w*H/16, (w+1)*H/16) of h2 for both row tiles; all of its weight loads
         // go out together (one L2 round trip per group instead of a dependent load per k-step on two waves) ----
@@ -851,9 +889,13 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         }
         __syncthreads();
         TMA_RELANE();
-        // ---- P3b: loss: wave mt (0, 1) takes row tile mt ----
-        if (wave < MTN) {
-            const int mt = wave;
+        // ---- P3b: loss: wave mt (0, 1) takes row tile mt.  Eight waves, Categorical head (round 5): the four rows of a lane group go to four
+        // waves per row tile -- the loss is a dependent chain of transcendentals per row (4.2 k cycles per group on two waves while the other six
+        // sat at the barrier); per row the same operations, so the same dz3 and the same per-row statistics ----
+        constexpr bool LOSS8 = NW == 8 && IS_PI && !CONT;
+        const int loss_mt = LOSS8 ? (MTN == 2 ? (wave & 1) : 0) : wave, loss_part = LOSS8 ? (MTN == 2 ? (wave >> 1) : wave) : 0;
+        if (LOSS8 ? loss_part < 4 : wave < MTN) {
+            const int mt = loss_mt;
             f32x4 out[NT3];
 #pragma unroll
             for (int q = 0; q < NT3; q++) {
@@ -864,7 +906,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 for (int w = 0; w < NW; w++) out[q] += *reinterpret_cast<const f32x4 *>(hpart + (((w * 2 + mt) * 2 + q) * 64 + lane) * 4);
             }
             float *dzt = dz3 + mt * 16 * ld3;
-            if constexpr (IS_PI) {
+            if constexpr (LOSS8) {
+#define TMA_WLOSS_ARGS out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane
+                if (loss_part == 0) policy_loss_tile<CONT, 0, 1>(TMA_WLOSS_ARGS);
+                else if (loss_part == 1) policy_loss_tile<CONT, 1, 2>(TMA_WLOSS_ARGS);
+                else if (loss_part == 2) policy_loss_tile<CONT, 2, 3>(TMA_WLOSS_ARGS);
+                else policy_loss_tile<CONT, 3, 4>(TMA_WLOSS_ARGS);
+#undef TMA_WLOSS_ARGS
+            } else if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
                                        lane);
             } else {
@@ -879,7 +928,11 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_WTICK(4);  // P3 head + loss
         TMA_RELANE();
+        // (the next group's row offsets: requested here, parked in LDS at the end of the group -- row_off_next was last read in front of P1's barrier)
+        int64_t noff = -1;
+        if (threadIdx.x < M && grp + n_blocks_net < n_groups) noff = next_off(grp + n_blocks_net);
         // ---- P4: head weight gradient (this wave's k rows), head bias, and dz2 = (dz3 . W3) * (1 - h2^2) in place ----
         {
 #pragma unroll
@@ -938,6 +991,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     }
         }
         __syncthreads();
+        TMA_WTICK(5);  // P4 dW3 + dz2
         TMA_RELANE();
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dz1 = (dz2 . W2) * (1 - h1^2) kept in registers until every wave is done with h1 ----
         f32x4 dz1[NTW][2];
@@ -965,6 +1019,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     for (int j = 0; j < NTW; j++) aW2[kt][j] = mfma16(av[sidx], bf[j][sidx], aW2[kt][j]);
                 __builtin_amdgcn_sched_barrier(0);  // do not let the scheduler hoist later tiles' reads over this one (register budget)
             }
+            TMA_WTICK(6);  // P5a dW2
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
                 f32x4 c0 = z4, c1 = z4;
@@ -994,6 +1049,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
         }
         __syncthreads();
+        TMA_WTICK(7);  // P5b dh1
 #pragma unroll
         for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1052,7 +1108,9 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 }
             }
         }
+        if (threadIdx.x < M) row_off_next[threadIdx.x] = noff;
         __syncthreads();
+        TMA_WTICK(8);  // P6 dz1 + dW1
     }
 #undef TMA_RELANE
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
@@ -1091,6 +1149,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 }
         }
     }
+    TMA_WTICK(9);  // slab store issue
+#ifdef TMA_WIDE_PHASE_TICKS
+    __syncthreads();
+    if (threadIdx.x == 0 && block_net == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_wide_ticks[IS_PI ? 0 : 1][i], wtick_lds[i]);
+#endif
     if constexpr (!MAIN) return;
     if (wave == 0) {
 #pragma unroll
@@ -1119,11 +1183,14 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         for (int o = 32; o > 0; o >>= 1) sv[q] += __shfl_down(sv[q], o, 64);
     __syncthreads();
     double *red = reinterpret_cast<double *>(smem);
-    if (lane == 0 && wave < 2)
+    constexpr int NWS = (NW == 8 && IS_PI && !CONT) ? NW : 2;  // waves that carry loss statistics (P3b)
+    if (lane == 0 && wave < NWS)
         for (int q = 0; q < 5; q++) red[wave * 5 + q] = sv[q];
     __syncthreads();
     if (threadIdx.x < 5) {
-        const double ssum = red[threadIdx.x] + red[5 + threadIdx.x];
+        double ssum = red[threadIdx.x] + red[5 + threadIdx.x];
+#pragma unroll
+        for (int w = 2; w < NWS; w++) ssum += red[w * 5 + threadIdx.x];
         const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
         if (q >= 0) stat_slot[q] += ssum;
     }
@@ -1159,7 +1226,7 @@ __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
 
 static int grad_wide_smem_bytes(const PLayout &L, int nw = 4) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + nw * 2 * 2 * 256 + 2 * L.H + 32) * 4;
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + nw * 2 * 2 * 256 + 2 * L.H + 32 + 2 * 32) * 4;  // (last term: row_off_next)
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
@@ -2589,6 +2656,18 @@ __global__ __launch_bounds__(256) void pack_samples_kernel(Rollout rb, int D, in
     if (xs == 8) dst[1] = float4{x[4], x[5], x[6], x[7]};
     dst[xs >> 2] = float4{rb.log_probs[row], rb.advantages[row], __int_as_float(static_cast<const int32_t *>(rb.actions)[row]), rb.returns[row]};
 }
+
+#ifdef TMA_WIDE_PHASE_TICKS
+extern "C" int tma_debug_wide_ticks(unsigned long long *out32, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(tma::g_wide_ticks), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tma::g_wide_ticks), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 int64_t tma_ppo_packed_floats(const tma_policy_dims *d, int T, int64_t N) {
     if (!d || check_dims(d) || T < 1 || N < 1) return 0;
