@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void ppo_grad_kernel(const float *__restrict__
 #ifndef TMA_HALF_RING
 #define TMA_HALF_RING 4
 #endif
+constexpr int W2_DEFER_ROWS = 1024;  // rows per image of the dW2 deferral buffer ([net][h1 | dz2][W2_DEFER_ROWS][H]: half-group minibatches of <= 1024 samples)
 #ifdef TMA_WIDE_PHASE_TICKS  // diagnostic build (make libtma_hip_wticks.so, tools/wide_ticks.py): cycles per phase of the f32 wide gradient kernel, wave 0 of block 0 of each net
 __device__ unsigned long long g_wide_ticks[2][16];
 #define TMA_WTICK(i)                                                      \
@@ -1008,8 +1009,24 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 }
                 ab2[j] += c;
             }
+            // Half groups with a deferral buffer (round 5, minibatches of <= 1024 samples): dW2 = h1^T . dz2 is NOT accumulated here -- a block's
+            // rank-16 contribution would leave as a 256 KB slab that sixteen to sixty-four blocks write and slab_reduce_kernel reads back.  The group's
+            // h1 and dz2 rows (16 KB each) go to the buffer instead and wide_small_reduce_kernel forms H1^T . DZ2 over the whole minibatch as ONE
+            // GEMM spread over 128 workgroups, straight into the gradient.
+            const bool defer_w2 = HALF && dz1c != nullptr;  // (block-uniform)
+            if (defer_w2) {
+                float *bh = dz1c, *bz = bh + (int64_t)W2_DEFER_ROWS * H;  // (dz1c: this net's [h1 | dz2] pair -- the launch passes the net stride)
+                for (int e = threadIdx.x; e < 16 * (H / 4); e += 64 * NW) {
+                    const int row = e / (H / 4), c4 = (e % (H / 4)) * 4;
+                    const float *ph = h1 + row * ld + c4, *pz = h2 + row * ld + c4;
+                    const int64_t o = (grp * 16 + row) * (int64_t)H + c4;
+                    *reinterpret_cast<f32x4 *>(bh + o) = f32x4{ph[0], ph[1], ph[2], ph[3]};
+                    *reinterpret_cast<f32x4 *>(bz + o) = f32x4{pz[0], pz[1], pz[2], pz[3]};
+                }
+            }
 #pragma unroll
             for (int kt = 0; kt < KT2; kt++) {  // one A fragment (8 LDS reads) feeds all NTW column tiles
+                if (defer_w2) break;
                 float av[8];
 #pragma unroll
                 for (int sidx = 0; sidx < SN; sidx++) av[sidx] = h1[(4 * sidx + g) * ld + kt * 16 + r16];
@@ -1121,10 +1138,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     for (int j = 0; j < NTW; j++) {
         const int col = n_base + 16 * j + r16;
         if constexpr (MAIN) {
+            if (!(HALF && dz1c != nullptr)) {  // (deferred: wide_small_reduce_kernel writes dW2 straight into the gradient)
 #pragma unroll
-            for (int kt = 0; kt < KT2; kt++)
+                for (int kt = 0; kt < KT2; kt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+                    for (int r = 0; r < 4; r++) gW2[(int64_t)(kt * 16 + g * 4 + r) * H + col] = aW2[kt][j][r];
+            }
         }
         if constexpr (acc_w1) {
 #pragma unroll
@@ -1279,6 +1298,92 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
             for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
             if (lane == 0) sq_part[blockIdx.x] = sq;
         }
+    }
+}
+
+// Small minibatches of the f32 256-wide path (half groups with the dW2 deferral buffer, <= 1024 samples): ONE launch finishes the gradient.
+//  * workgroups [0, 128): dW2 of one net as a GEMM over the whole minibatch -- block (net, ti, tj) forms rows [16 ti, 16 ti + 16) x columns
+//    [64 tj, 64 tj + 64) of H1^T . DZ2 on sixteen waves: wave (u, ks) the 16-column tile u over the ks-th quarter of the samples (operands
+//    straight from the L2-resident buffer the gradient kernel left, sixteen k-steps of four samples per batch of loads -- at 256 samples ONE
+//    memory round trip per wave), the four partial tiles of a column tile added in slice order through LDS, the result added to the gradient,
+//    one sum-of-squares partial per (row, 64 columns);
+//  * workgroups behind them: slab_reduce_kernel's work on the parameters that are NOT a W2 entry (W1, biases, head, log_std: 64 consecutive
+//    entries of that compacted index space per block, sixteen slab ranges folded through LDS in a fixed order).
+// The partials fill the same ceil(P / 64) slots slab_reduce_kernel fills -- [0, 2048) the W2 strips, then the compacted chunks -- and the
+// optimizer kernel only ever sums all of them, in a fixed order: deterministic; the norm's last bits differ from the slab path's (another
+// partition of the same squares).
+__global__ __launch_bounds__(1024) void wide_small_reduce_kernel(const float *__restrict__ slabs, int n_slabs_pi, int n_slabs_vf, PLayout L,
+                                                                 const float *__restrict__ w2buf, int rows, float *__restrict__ grad,
+                                                                 double *__restrict__ sq_part) {
+    constexpr int H = 256;
+    __shared__ float tile[4][16][68];  // [sample quarter][row][64 columns + pad]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x < 128) {
+        const int net = blockIdx.x >> 6, ti = (blockIdx.x >> 2) & 15, tj = blockIdx.x & 3;
+        const int r16 = lane & 15, g = lane >> 4, u = wave & 3, ks = wave >> 2;
+        const float *A0 = w2buf + (int64_t)(2 * net) * (W2_DEFER_ROWS * H) + 16 * ti + r16;
+        const float *B0 = w2buf + (int64_t)(2 * net + 1) * (W2_DEFER_ROWS * H) + 64 * tj + 16 * u + r16;
+        // wave w finishes row w at the end: lane l = column 64 tj + l (256 contiguous bytes of the gradient; its old value is requested now)
+        const int row = wave, k = 16 * ti + row;
+        const int64_t e = (int64_t)(net == 0 ? L.pW2t : L.vW2t) + (int64_t)k * H + 64 * tj + lane;
+        const float gold = grad[e];
+        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int nq = rows >> 2, per = (nq + 3) >> 2;  // k-steps of four samples; this wave's are [ks per, min(nq, (ks + 1) per))
+        const int q_end = (ks + 1) * per < nq ? (ks + 1) * per : nq;
+        for (int q0 = ks * per; q0 < q_end; q0 += 16) {
+            float a[16], b[16];
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const bool in = q0 + v < q_end;  // (rows behind the minibatch hold an earlier launch's data)
+                const int64_t o = (int64_t)(4 * (in ? q0 + v : 0) + g) * H;
+                a[v] = in ? A0[o] : 0.0f, b[v] = in ? B0[o] : 0.0f;
+            }
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc = mfma16(a[v], b[v], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) tile[ks][4 * g + r][16 * u + r16] = acc[r];
+        __syncthreads();
+        const float gnew = gold + (((tile[0][row][lane] + tile[1][row][lane]) + tile[2][row][lane]) + tile[3][row][lane]);
+        grad[e] = gnew;
+        double sq = (double)gnew * (double)gnew;
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) sq_part[net * 1024 + k * 4 + tj] = sq;
+        return;
+    }
+    float(*part)[64] = reinterpret_cast<float(*)[64]>(&tile[0][0][0]);  // [16 slab ranges][64 lanes]
+    const int chunk = blockIdx.x - 128, q = wave;
+    const int s = chunk * 64 + lane, P_small = L.P - 2 * H * H;
+    const int a0 = L.pW2t, a1 = L.vW2t - H * H;  // compacted index space: [0, a0) | the flat entries between the two W2 blocks | those behind the second
+    const int e = s < a0 ? s : (s < a1 ? s + H * H : s + 2 * H * H);
+    const bool live = s < P_small;
+    const int n_slabs = (live && e >= L.vW1t && e < L.log_std) ? n_slabs_vf : n_slabs_pi;
+    const int per = (n_slabs + 15) >> 4;
+    const int b0 = q * per < n_slabs ? q * per : n_slabs, b1 = (b0 + per < n_slabs) ? b0 + per : n_slabs;
+    float sum = 0.0f;
+    const float gold = (live && q == 0) ? grad[e] : 0.0f;
+    if (live) {
+        float t[4];  // (<= 64 slabs: a range holds at most four)
+#pragma unroll
+        for (int v = 0; v < 4; v++) t[v] = b0 + v < b1 ? slabs[(int64_t)(b0 + v) * L.P + e] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; v++) sum += t[v];
+        for (int b = b0 + 4; b < b1; b++) sum += slabs[(int64_t)b * L.P + e];
+    }
+    part[q][lane] = sum;
+    __syncthreads();
+    if (q == 0) {
+        float gnew = 0.0f;
+        if (live) {
+            float tot = part[0][lane];
+#pragma unroll
+            for (int v = 1; v < 16; v++) tot += part[v][lane];
+            gnew = gold + tot;
+            grad[e] = gnew;
+        }
+        double sq = (double)gnew * (double)gnew;
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) sq_part[2048 + chunk] = sq;
     }
 }
 
@@ -2359,9 +2464,14 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         };
         const bool eight = L.H == 256 && (kt1 == 1 || kt1 == 2) && getenv("TMA_WIDE_NW4") == nullptr;
         const int smem8 = grad_wide_smem_bytes(L, 8);
+        // half groups on the eight-wave kernel (<= 1024 samples: <= 64 slabs in use): dW2 deferred to wide_small_reduce_kernel through a buffer behind
+        // slab 64 of the workspace's slab area (TMA_NO_DEFER_W2=1: the slab path throughout)
+        static const bool no_defer = getenv("TMA_NO_DEFER_W2") != nullptr;
+        const bool defer_w2 = half && eight && !no_defer && n_pi <= 64 && groups * 16 <= W2_DEFER_ROWS && (int64_t)64 * L.P + 4 * (int64_t)W2_DEFER_ROWS * L.H <= (int64_t)slab_cap(L) * L.P;
+        float *const w2buf = defer_w2 ? slabs + (int64_t)64 * L.P : nullptr;
         auto launch8 = [&](auto k) -> int {
             TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
-            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, nullptr, DZ1_CAP * L.H);
+            k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, w2buf, (int64_t)2 * W2_DEFER_ROWS * L.H);
             return TMA_OK;
         };
         // (as on the bf16 path) minibatches that fit the dz1 cache: chain pass + dW1 from the cached operands; else chain + recompute
@@ -2393,6 +2503,12 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         }
         if (lrc) return lrc;
         TMA_LAUNCH_CHECK();
+        if (defer_w2) {
+            wide_small_reduce_kernel<<<dim3((unsigned)(128 + ceil_div(L.P - 2 * L.H * L.H, 64))), dim3(1024), 0, s>>>(slabs, n_pi, n_vf, L, w2buf, (int)(groups * 16), grad,
+                                                                                                                  sq_partials(ws, L));
+            TMA_LAUNCH_CHECK();
+            return TMA_OK;
+        }
         slab_reduce_kernel<<<dim3((unsigned)ceil_div(L.P, 64)), dim3(256), 0, s>>>(slabs, n_pi, L.P, grad, n_vf, L.vW1t, L.log_std, sq_partials(ws, L));
         TMA_LAUNCH_CHECK();
         return TMA_OK;

@@ -20,3 +20,4 @@ run "TMA_BF_NPI=128" "tests/test_bf16_gpu.py"
 # (single-launch timing of the plain VecEnv.step path, round-3 library against this build on this box: python tools/step_ab.py --lib A.so --lib B.so)
 run "TMA_P2P_NO_FUSE=1" "tests/test_dist_gpu.py"   # the peer exchange as push / pull launches of its own
 run "TMA_NO_SPLIT3=1" "tests/test_dist_gpu.py"      # mfma_dtype 2 on the exact-f32 kernels
+run "TMA_NO_DEFER_W2=1" "tests/test_ppo_gpu.py"            # small f32 256-wide minibatches on the slab path
