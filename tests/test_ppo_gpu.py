@@ -915,3 +915,51 @@ def test_packed_records_are_refused_for_shapes_without_them():
         rv = _lib.Rollout(None, None, None, None, None, 8, 64, None)
         buf = torch.zeros(16, device="cuda")
         assert L.tma_ppo_pack_samples(C.byref(rv), C.byref(pol.dims), _lib.ptr(buf), _lib.stream_ptr()) == _lib.TMA_ERR_INVALID
+
+
+_DEFER_SCRIPT = r"""
+import ctypes as C, sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import test_ppo_gpu as t
+out = {{}}
+for (D, A, cont, B) in [(6, 5, False, 256), (21, 3, False, 1000), (8, 2, True, 512), (4, 5, False, 200)]:  # (>= 128 samples: below that the generic kernel with float atomics runs)
+    pol, sd = t._policy(D, 256, A, cont)
+    T, N = 16, 80
+    obs, actions, old_lp, adv, ret = t._rollout(pol, sd, D, A, cont, T, N)
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(2))
+    bufs = dict(obs=obs, actions=actions, old_lp=old_lp, adv=adv, ret=ret)
+    g1, st, _ = t._hip_grad(pol, bufs, T, N, perm, 11, B, t.HP)
+    g2, _, _ = t._hip_grad(pol, bufs, T, N, perm, 11, B, t.HP)
+    assert torch.equal(g1, g2)
+    out[(D, A, cont, B)] = (g1.cpu(), st)
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_small_wide_minibatch_deferred_dw2_equals_the_slab_path(tmp_path):
+    """f32 256-wide policies, minibatches <= 1024 samples: dW2 from the follow-up GEMM launch (wide_small_reduce_kernel, default) against
+    per-block slabs + slab_reduce_kernel (TMA_NO_DEFER_W2=1) -- the same gradient up to the summation order of the sample dimension, the
+    same loss statistics bit for bit, each path deterministic; Discrete and Box heads, ragged sizes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "defer.py"
+    script.write_text(_DEFER_SCRIPT.format(root=root, tests=os.path.join(root, "tests")))
+    res = []
+    for env_extra in ({}, {"TMA_NO_DEFER_W2": "1"}):
+        env = dict(os.environ, **env_extra)
+        env.pop("TMA_NO_DEFER_W2", None) if not env_extra else None
+        out = tmp_path / f"g{len(res)}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(torch.load(out))
+    for key in res[0]:
+        (ga, sa), (gb, sb) = res[0][key], res[1][key]
+        scale = float(gb.abs().max())
+        assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1.0), key
+        assert sa == sb, key
+        D, A, cont, B = key
+        w2 = slice(D * 256 + 256, D * 256 + 256 + 65536)
+        assert float(ga[w2].abs().max()) > 0 and not torch.equal(ga[w2], gb[w2]) or B <= 16, key  # (the W2 block really took another route)

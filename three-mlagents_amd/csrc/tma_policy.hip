@@ -1330,17 +1330,22 @@ __global__ __launch_bounds__(1024) void wide_small_reduce_kernel(const float *__
         f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const int nq = rows >> 2, per = (nq + 3) >> 2;  // k-steps of four samples; this wave's are [ks per, min(nq, (ks + 1) per))
         const int q_end = (ks + 1) * per < nq ? (ks + 1) * per : nq;
-        for (int q0 = ks * per; q0 < q_end; q0 += 16) {
-            float a[16], b[16];
+        auto run = [&](auto kb) {  // batches of KB k-steps: all 2 KB loads of a batch in flight together, then its MFMAs (same order for every KB)
+            constexpr int KB = decltype(kb)::value;
+            for (int q0 = ks * per; q0 < q_end; q0 += KB) {
+                float a[KB], b[KB];
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                const bool in = q0 + v < q_end;  // (rows behind the minibatch hold an earlier launch's data)
-                const int64_t o = (int64_t)(4 * (in ? q0 + v : 0) + g) * H;
-                a[v] = in ? A0[o] : 0.0f, b[v] = in ? B0[o] : 0.0f;
+                for (int v = 0; v < KB; v++) {
+                    const bool in = q0 + v < q_end;  // (rows behind the minibatch hold an earlier launch's data)
+                    const int64_t o = (int64_t)(4 * (in ? q0 + v : 0) + g) * H;
+                    a[v] = in ? A0[o] : 0.0f, b[v] = in ? B0[o] : 0.0f;
+                }
+#pragma unroll
+                for (int v = 0; v < KB; v++) acc = mfma16(a[v], b[v], acc);
             }
-#pragma unroll
-            for (int v = 0; v < 16; v++) acc = mfma16(a[v], b[v], acc);
-        }
+        };
+        if (per <= 16) run(std::integral_constant<int, 16>{});  // <= 256 samples: one batch
+        else run(std::integral_constant<int, 32>{});
 #pragma unroll
         for (int r = 0; r < 4; r++) tile[ks][4 * g + r][16 * u + r16] = acc[r];
         __syncthreads();
