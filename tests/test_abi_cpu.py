@@ -138,3 +138,37 @@ def test_policy_dims_validation_and_the_split_layout():
         assert rc == _lib.TMA_ERR_INVALID and b"mfma_dtype 2" in L.tma_last_error()
     rc, _, _ = count(6, 256, 5, 0, 3)
     assert rc == _lib.TMA_ERR_INVALID
+
+
+def test_peer_exchange_entry_points_refuse_bad_use_without_touching_a_gpu():
+    """include/tma.h tma_comm_p2p_* (ABI 207): argument and ordering errors come back as status codes before any HIP call -- a communicator
+    without an RCCL side, never attached to peers, must refuse to enable its exchange and must refuse an all-reduce (nothing to carry it)."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    h = C.c_void_p()
+    for world, rank in ((0, 0), (9, 0), (2, 2), (2, -1)):  # the exchange serves 1..8 ranks of one node
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_create_p2p(world, rank, -1, C.byref(h)))
+    _lib.check(L.tma_comm_create_p2p(2, 1, -1, C.byref(h)))  # (device -1: the calling thread's current device -- no HIP call yet)
+    try:
+        en, calls, bad, words = C.c_int(7), C.c_int64(7), C.c_int(7), C.c_int64(7)
+        _lib.check(L.tma_comm_p2p_status(h, C.byref(en), C.byref(calls), C.byref(bad), C.byref(words)))
+        assert (en.value, calls.value, bad.value, words.value) == (0, 0, 0, 0)
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_enable(h, 1))  # attach first
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_attach(h, None))  # prepare first
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_prepare(h, 0, (C.c_ubyte * 128)()))  # empty slots
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_set_timeout(h, 0.0))
+        buf = (C.c_float * 16)()
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_allreduce(h, buf, 16, 0, None))  # no RCCL side and no exchange: nothing can carry it
+        assert "peer exchange" in _lib.last_error()
+        assert L.tma_comm_allreduce_cb(h, buf, 16) != 0  # the callback form reports failure instead of raising through C frames
+    finally:
+        _lib.check(L.tma_comm_destroy(h))
