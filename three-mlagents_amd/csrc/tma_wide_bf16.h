@@ -189,6 +189,9 @@ __device__ __forceinline__ bf16x8 a_frag(const bf16_t *A, int ld, int row, int k
 #define TMA_BF_TR_READS 1  // 0: row-major A images + ds_read_b128 everywhere (A/B builds).  Used for 32-row groups only: at 64-row groups the
                            // eight per-row-tile address registers of the transposed reads push the 510-register variant into spills (+3 %)
 #endif
+#ifndef TMA_BF_PFD
+#define TMA_BF_PFD 0
+#endif
 #ifndef TMA_BF_TR_MT4
 #define TMA_BF_TR_MT4 0  // 1: transposed reads (no row-major activation images) at 64-row groups too (A/B builds)
 #endif
@@ -580,6 +583,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     mrow = wave * (M / NW) + lane0;  // sample row whose metadata this lane gathers (lanes < M/NW of every wave: the Feistel
     mlane = lane0 < M / NW;          // permutation arithmetic is spread over the waves instead of skewing wave 0)
     int32_t noff = -1;  // cached buffer offset of this lane's row in the NEXT group, loaded one phase before fetch_meta needs it
+    int32_t noff_n = -1;  // PASS 2: ... and of the group after the next (a whole iteration ahead)
     auto fetch_off = [&](int64_t grp) {  // (cache present) issue only; j beyond the minibatch reads a clamped entry that fetch_meta ignores
         if (mb.offs && mlane) {
             const int64_t j = grp * M + mrow;
@@ -618,10 +622,83 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
     };
     const int64_t n_groups = (mb.count + M - 1) / M;
+    // PASS 2 (round 5): the observation rows of the NEXT group are requested in front of this group's MFMAs and converted at the top of the next
+    // iteration.  No LDS hop for the offsets: lane i < M / NW of a wave holds the buffer offset of row wave * (M / NW) + i (fetch_meta's `poff`) --
+    // exactly the rows this wave gathers -- so the wave-uniform row bases are v_readlane's of its own register.
+    // PASS 0 at the two-pass widths (round 5, TMA_BF_PFD, off): nobody reads the observation images after layer 1, so the NEXT group's rows can be
+    // requested at the start of P6 and converted into the (single) images at its end -- the group loop's top then has no gather and one barrier
+    // less.  Built and measured at the Crawler width: the twelve staging registers, live through P6 only, still cost the eight-wave kernel 20
+    // spilled registers (it sits at 248 of 256) and the gradient call went from 429 to 464 us on one box.  The PASS 2 form above stays.
+    constexpr bool PFD = TMA_BF_PFD && !PF && two_pass && PASS == 0 && MT == 2;
+    constexpr int RWD = M / NW, KCD = (PASS == 2 || PFD) ? (32 * KS1C + 63) / 64 : 1;
+    float tpf[KCD][RWD];
+    typedef const float __attribute__((address_space(1))) *gfd_ptr;
+    auto pf2_issue = [&]() {
+        if constexpr (PASS == 2 || PFD) {
+#pragma unroll
+            for (int i = 0; i < RWD; i++) {
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)poff, i), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)poff >> 32), i);
+                const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
+                gfd_ptr base = reinterpret_cast<gfd_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (offu >= 0 ? offu * D : 0)));
+#pragma unroll
+                for (int k = 0; k < KCD; k++) {
+                    const int c = 64 * k + lane0;
+                    tpf[k][i] = base[c < D ? c : 0];
+                }
+            }
+        }
+    };
+    auto pfd_commit = [&]() {  // tpf -> both observation images (the rows named by `poff`); same conversions and stores as the direct gather
+        if constexpr (PFD) {
+            bool rok[RWD];
+#pragma unroll
+            for (int i = 0; i < RWD; i++) rok[i] = (int32_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)poff >> 32), i) >= 0;
+#pragma unroll
+            for (int k = 0; k < KCD; k++) {
+                const int c = 64 * k + lane0;
+                if (c < Kp1) {
+                    uint32_t pk[RWD / 2];
+#pragma unroll
+                    for (int i = 0; i < RWD; i += 2) {
+                        pk[i / 2] = bf_pack2((rok[i] && c < D) ? tpf[k][i] : 0.0f, (rok[i + 1] && c < D) ? tpf[k][i + 1] : 0.0f);
+                        *reinterpret_cast<uint16_t *>(Xa + (wave * RWD + i) * ldx + c) = (uint16_t)pk[i / 2];
+                        *reinterpret_cast<uint16_t *>(Xa + (wave * RWD + i + 1) * ldx + c) = (uint16_t)(pk[i / 2] >> 16);
+                    }
+                    if constexpr (RWD == 8) {
+                        *reinterpret_cast<uint4 *>(Xt + t_off<MT>(c, wave * RWD)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                    } else {
+                        *reinterpret_cast<uint2 *>(Xt + t_off<MT>(c, wave * RWD)) = uint2{pk[0], pk[1]};
+                    }
+                }
+            }
+        }
+    };
+    bf16x8 zpf[PASS == 2 ? NTW : 1][PASS == 2 ? MK : 1];
+    auto zc_issue = [&](int64_t grp_n) {
+        if constexpr (PASS == 2) {
+            const bf16_t *gi = dz1c + grp_n * (int64_t)(H * M);
+#pragma unroll
+            for (int j = 0; j < NTW; j++)
+#pragma unroll
+                for (int kk = 0; kk < MK; kk++) {
+                    const int row = n_base + 16 * j + (lane0 & 15);
+                    zpf[j][kk] = *reinterpret_cast<const bf16x8 *>(gi + row * (16 * MT) + 8 * ((4 * kk + (lane0 >> 4)) ^ t_swz<MT>(row)));
+                }
+        }
+    };
     if (block_net < n_groups) {
         fetch_meta(block_net, false);
         __syncthreads();
         fetch_obs();
+        pf2_issue();
+        pfd_commit();  // (PFD: the first group's rows, converted here; the loop's first barrier publishes them)
+        zc_issue(block_net);
+        if constexpr (PASS == 2) {
+            if (mb.offs && mlane) {
+                const int64_t j = (block_net + (int64_t)n_blocks_net) * M + mrow;
+                noff_n = mb.offs[j < mb.count ? j : 0];
+            }
+        }
     }
     for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
         // The weight images do not change during the launch, so every fragment load below is loop-invariant and LICM would
@@ -632,17 +709,19 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         W.bW3 = launder_uniform(W.bW3), nt0l = launder_uniform(nt0l);
         TMA_TICK(0);
         TMA_RELANE();
-        bf16x8 zc[NTW][MK];  // PASS 2: this wave's dz1 fragments of the group, in flight under the observation gather
+        bf16x8 zc[NTW][MK];  // PASS 2: this wave's dz1 fragments of the group (requested a group ago, like the observation rows)
         if constexpr (PASS == 2) {
-            const bf16_t *gi = dz1c + grp * (int64_t)(H * M);
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
-                for (int kk = 0; kk < MK; kk++) {
-                    const int row = n_base + 16 * j + r16;
-                    zc[j][kk] = *reinterpret_cast<const bf16x8 *>(gi + row * (16 * MT) + 8 * ((4 * kk + g) ^ t_swz<MT>(row)));
-                }
-            fetch_off(grp + n_blocks_net);
+                for (int kk = 0; kk < MK; kk++) zc[j][kk] = zpf[j][kk];
+            // the next group's offsets were requested an iteration ago (fetch_meta below uses them at once: no wait in front of the row requests);
+            // the group after that is requested now
+            noff = noff_n;
+            if (mb.offs && mlane) {
+                const int64_t j = (grp + 2 * (int64_t)n_blocks_net) * M + mrow;
+                noff_n = mb.offs[j < mb.count ? j : 0];
+            }
         }
         // ---- P0: commit the prefetched metadata / observation rows (bf16, both images) ----
         if (mlane) {
@@ -661,6 +740,28 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     const bf16_t v = (bf16_t)((okr && c < D) ? px[rp * CG + cg] : 0.0f);
                     Xa[row * ldx + c] = v;
                     Xt[t_off<MT>(c, row)] = v;
+                }
+            }
+        } else if constexpr (PFD) {
+            // (the images were filled at the end of the previous group's P6 / in the prologue)
+        } else if constexpr (PASS == 2) {
+            // commit of the rows pf2_issue requested a group ago (only the T image: this pass reads nothing else)
+            static_assert(MT == 2, "PASS 2 commit: RWD rows of one column are one (half) chunk of the T image");
+            bool rok[RWD];
+#pragma unroll
+            for (int i = 0; i < RWD; i++) rok[i] = (int32_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)poff >> 32), i) >= 0;
+#pragma unroll
+            for (int k = 0; k < KCD; k++) {
+                const int c = 64 * k + lane;
+                if (c < Kp1) {
+                    uint32_t pk[RWD / 2];
+#pragma unroll
+                    for (int i = 0; i < RWD; i += 2) pk[i / 2] = bf_pack2((rok[i] && c < D) ? tpf[k][i] : 0.0f, (rok[i + 1] && c < D) ? tpf[k][i + 1] : 0.0f);
+                    if constexpr (RWD == 8) {
+                        *reinterpret_cast<uint4 *>(Xt + t_off<MT>(c, wave * RWD)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                    } else {
+                        *reinterpret_cast<uint2 *>(Xt + t_off<MT>(c, wave * RWD)) = uint2{pk[0], pk[1]};
+                    }
                 }
             }
         } else {
@@ -716,7 +817,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
         __syncthreads();
         if constexpr (PASS == 2) {
-            if (grp + n_blocks_net < n_groups) fetch_meta(grp + n_blocks_net, true);
+            if (grp + n_blocks_net < n_groups) {
+                fetch_meta(grp + n_blocks_net, true);
+                pf2_issue();  // the next group's observation rows: in flight under the MFMAs below
+                zc_issue(grp + n_blocks_net);
+            }
 #pragma unroll
             for (int kt = 0; kt < KT1A; kt++)
 #pragma unroll
@@ -1291,6 +1396,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         __syncthreads();  // every wave is done with T1 (all rows) and A2
         TMA_TICK(7);
         TMA_RELANE();
+        if constexpr (PFD) {
+            if (has_next) pf2_issue();  // `poff` names the next group's rows since the end of P2
+        }
         // ---- P6: dz1 = dh1 * (1 - h1^2) in place in T1 (own rows);  dW1 slice += X^T . dz1[:, slice] ----
         if (!(dbg & 8))
 #pragma unroll
@@ -1359,6 +1467,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         }
                 }
             }
+        }
+        if constexpr (PFD) {
+            if (has_next) pfd_commit();
         }
         __syncthreads();
         TMA_TICK(9);
