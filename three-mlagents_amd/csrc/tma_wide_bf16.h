@@ -625,10 +625,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     // PASS 2 (round 5): the observation rows of the NEXT group are requested in front of this group's MFMAs and converted at the top of the next
     // iteration.  No LDS hop for the offsets: lane i < M / NW of a wave holds the buffer offset of row wave * (M / NW) + i (fetch_meta's `poff`) --
     // exactly the rows this wave gathers -- so the wave-uniform row bases are v_readlane's of its own register.
-    // PASS 0 at the two-pass widths (round 5, TMA_BF_PFD, off): nobody reads the observation images after layer 1, so the NEXT group's rows can be
-    // requested at the start of P6 and converted into the (single) images at its end -- the group loop's top then has no gather and one barrier
-    // less.  Built and measured at the Crawler width: the twelve staging registers, live through P6 only, still cost the eight-wave kernel 20
-    // spilled registers (it sits at 248 of 256) and the gradient call went from 429 to 464 us on one box.  The PASS 2 form above stays.
+    // PASS 0 at the two-pass widths (round 5, -DTMA_BF_PFD=1, OFF): nobody reads the observation images after layer 1, so the NEXT group's rows
+    // can be requested during the group and converted into the (single) images before its end -- the group loop's top then has no gather and one
+    // barrier less.  Measured at the Crawler width (gradient call, one box, against 430 us with the PASS 2 form alone): whole rows requested at
+    // the start of P6 or of the loss phase: twelve staging registers -> 20 spilled registers in the eight-wave kernel (248 of 256 before), 464 us;
+    // one 64-column chunk per phase (loss / P4 / P4 -> P5: four staging registers, 2 spilled): 428 us -- no gain: the 3 k cycles a group spends
+    // in P0 are the conversions and the 2-byte image stores as much as the round trip.  Left off; the PASS 2 form above stays.
     constexpr bool PFD = TMA_BF_PFD && !PF && two_pass && PASS == 0 && MT == 2;
     constexpr int RWD = M / NW, KCD = (PASS == 2 || PFD) ? (32 * KS1C + 63) / 64 : 1;
     float tpf[KCD][RWD];
@@ -644,6 +646,41 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 for (int k = 0; k < KCD; k++) {
                     const int c = 64 * k + lane0;
                     tpf[k][i] = base[c < D ? c : 0];
+                }
+            }
+        }
+    };
+    float tch[RWD];  // PFD: one 64-column chunk of the next group's rows at a time (the eight-wave kernel has no twelve registers to spare)
+    auto pfd_issue_k = [&](int k) {
+        if constexpr (PFD) {
+#pragma unroll
+            for (int i = 0; i < RWD; i++) {
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)poff, i), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)poff >> 32), i);
+                const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
+                gfd_ptr base = reinterpret_cast<gfd_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (offu >= 0 ? offu * D : 0)));
+                const int c = 64 * k + lane0;
+                tch[i] = base[c < D ? c : 0];
+            }
+        }
+    };
+    auto pfd_commit_k = [&](int k) {
+        if constexpr (PFD) {
+            bool rok[RWD];
+#pragma unroll
+            for (int i = 0; i < RWD; i++) rok[i] = (int32_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)poff >> 32), i) >= 0;
+            const int c = 64 * k + lane0;
+            if (c < Kp1) {
+                uint32_t pk[RWD / 2];
+#pragma unroll
+                for (int i = 0; i < RWD; i += 2) {
+                    pk[i / 2] = bf_pack2((rok[i] && c < D) ? tch[i] : 0.0f, (rok[i + 1] && c < D) ? tch[i + 1] : 0.0f);
+                    *reinterpret_cast<uint16_t *>(Xa + (wave * RWD + i) * ldx + c) = (uint16_t)pk[i / 2];
+                    *reinterpret_cast<uint16_t *>(Xa + (wave * RWD + i + 1) * ldx + c) = (uint16_t)(pk[i / 2] >> 16);
+                }
+                if constexpr (RWD == 8) {
+                    *reinterpret_cast<uint4 *>(Xt + t_off<MT>(c, wave * RWD)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+                } else {
+                    *reinterpret_cast<uint2 *>(Xt + t_off<MT>(c, wave * RWD)) = uint2{pk[0], pk[1]};
                 }
             }
         }
@@ -1156,6 +1193,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
         TMA_TICK(4);
         TMA_RELANE();
+        if constexpr (PFD) {
+            if (has_next) pfd_issue_k(0);  // `poff` names the next group's rows since the end of P2
+        }
         // ---- P3b: loss -- every wave takes half the rows of one tile (tile wave & 1, rows 2*(wave >> 1) .. +1 of each lane group) ----
         static_assert(MT == 2 || MT == 4, "the loss / dz3 split below assumes two row tiles and four waves");
         if (!(dbg & 4)) {
@@ -1221,6 +1261,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         __syncthreads();
         TMA_TICK(5);
         TMA_RELANE();
+        if constexpr (PFD) {
+            if (has_next) {  // (nobody reads the observation images after layer 1 in this pass)
+                pfd_commit_k(0);
+                if constexpr (KCD > 1) pfd_issue_k(1);
+            }
+        }
         // ---- P4: head weight gradient (this wave's k rows); dz2 = (dz3 . W3^T) * (1 - h2^2) in place in A2 / T2 ----
         if (!(dbg & 16)) {
 #pragma unroll
@@ -1252,9 +1298,18 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 }
             }
         }
+        if constexpr (PFD && KCD > 1) {
+            if (has_next) {
+                pfd_commit_k(1);
+                if constexpr (KCD > 2) pfd_issue_k(2);
+            }
+        }
         __syncthreads();
         TMA_TICK(6);
         TMA_RELANE();
+        if constexpr (PFD && KCD > 2) {
+            if (has_next) pfd_commit_k(2);
+        }
         // ---- P5: dW2 slice += h1^T . dz2[:, slice];  dh1 = dz2 . W2^T for this wave's columns (weight ring) ----
         f32x4 dh1[MT == 4 ? 1 : NTW][MT];  // (64-row groups form dh1 half by half further down)
         if constexpr (MT != 4) {
@@ -1396,9 +1451,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         __syncthreads();  // every wave is done with T1 (all rows) and A2
         TMA_TICK(7);
         TMA_RELANE();
-        if constexpr (PFD) {
-            if (has_next) pf2_issue();  // `poff` names the next group's rows since the end of P2
-        }
         // ---- P6: dz1 = dh1 * (1 - h1^2) in place in T1 (own rows);  dW1 slice += X^T . dz1[:, slice] ----
         if (!(dbg & 8))
 #pragma unroll
@@ -1467,9 +1519,6 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         }
                 }
             }
-        }
-        if constexpr (PFD) {
-            if (has_next) pfd_commit();
         }
         __syncthreads();
         TMA_TICK(9);
