@@ -360,6 +360,42 @@ def _p2p_world1(q):
     q.put((same, a[3], a[4]["path"], a[4]["calls_timed"], b[3]))
 
 
+def _p2p_contest_world1(q):
+    """TMA_P2P=auto at world size 1 with the RCCL side present: the start-up procedure a node runs (inbox, ticket, attach, exact-sum check,
+    timing contest against ncclAllReduce, agreement) end to end, then a training step on whichever path won."""
+    os.environ.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "TMA_DP_PATH": "1", "TMA_NATIVE_RCCL": "1", "TMA_P2P": "auto"})
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    env = make_vector_env("gridworld", n_envs=256, seed=5)
+    m = PPO("MlpPolicy", env, n_steps=64, batch_size=2048, n_epochs=2, seed=5, policy_kwargs={"net_arch": [64, 64]})
+    c = m._native_comm
+    note, on, rccl = (c.p2p_note, c.p2p_enabled, c.has_rccl) if c is not None else ("", None, None)
+    m.collect_rollouts()
+    m.train()
+    st = c.p2p_status() if c is not None else {}
+    finite = bool(torch.isfinite(m.policy.params).all())
+    env.close()
+    q.put((c is not None, rccl, on, note, st, finite))
+
+
+@pytest.mark.timeout(300)
+def test_peer_exchange_start_up_contest_runs_end_to_end():
+    if os.environ.get("TMA_NO_NATIVE_RCCL"):
+        pytest.skip("TMA_NO_NATIVE_RCCL keeps every collective on the torch.distributed callback: no native communicator to carry the exchange")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_p2p_contest_world1, args=(q,))
+    p.start()
+    have, rccl, on, note, st, finite = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert have and rccl and finite and not st["timed_out"]
+    # the contest ran and left its two figures; which side won at ONE rank (where RCCL has nothing to do) is not asserted
+    assert note.startswith(("on:", "off:")) and "us per" in note and "RCCL's" in note, note
+    assert st["enabled"] == on and (st["calls"] >= 2 + 45 if not on else st["calls"] >= 2 + 45 + 16)
+
+
 @pytest.mark.timeout(300)
 def test_fused_peer_exchange_at_world_size_one_changes_no_bit():
     if os.environ.get("TMA_NO_NATIVE_RCCL"):

@@ -283,7 +283,7 @@ class PPO:
         # RCCL at construction, kept when it is the faster one.  TMA_P2P=0: never; TMA_P2P=1: always, and with a non-RCCL backend (gloo: several
         # ranks on one GPU, the tests) a communicator that has ONLY the exchange.
         want_native = (os.environ.get("TMA_NATIVE_RCCL") == "1" or (self.world_size > 1 and "nccl" in (_dist_backend() or ""))
-                       or (os.environ.get("TMA_P2P") == "1" and torch.cuda.is_available()))
+                       or (os.environ.get("TMA_P2P") in ("1", "auto") and torch.cuda.is_available()))
         if want_native and not os.environ.get("TMA_NO_NATIVE_RCCL"):
             self._native_comm = self._make_native_comm()
         if self.world_size > 1 and self._native_comm is None and self.rank == 0:
@@ -339,7 +339,8 @@ class PPO:
             why = str(exc)
         if not agree(ok) and ok:
             ok, why = False, "another rank could not use its native communicator"
-        if ok and os.environ.get("TMA_P2P") != "0" and (self.world_size > 1 or os.environ.get("TMA_P2P") == "1"):
+        # (TMA_P2P=auto: the whole start-up procedure -- contest included -- at any world size: how the one-GPU tests run the code a node runs)
+        if ok and os.environ.get("TMA_P2P") != "0" and (self.world_size > 1 or os.environ.get("TMA_P2P") in ("1", "auto")):
             self._setup_peer_exchange(comm, agree, probe_ok, use_rccl)
         if ok and (use_rccl or comm.p2p_enabled):
             return comm
@@ -429,7 +430,7 @@ class PPO:
             except Exception:  # noqa: BLE001  (a communicator without RCCL cannot switch it off: the caller drops the communicator)
                 comm.p2p_enabled = False
         comm.p2p_note = note
-        if self.rank == 0 and (self.world_size > 1 or os.environ.get("TMA_P2P") == "1"):
+        if self.rank == 0 and (self.world_size > 1 or os.environ.get("TMA_P2P") in ("1", "auto")):
             print(f"three-mlagents_amd: peer exchange for the gradient all-reduce {note}", file=sys.stderr, flush=True)
 
     def _stream(self):
