@@ -1,0 +1,851 @@
+// tma_h256p.hip -- one PPO epoch at the reference's literal batch_size = 256 on its DEFAULT policy (two 256 x 256 tanh nets, exact f32) as ONE
+// persistent launch.
+//
+// Replaces, for one pass of `for rollout_data in self.rollout_buffer.get(self.batch_size)` in stable-baselines3 2.9.0's PPO.train (third
+// party; the loop model.learn() drives at /root/reference/backend/mlagents/training.py:166-170 with batch_size = 256 from training.py:379
+// and net_arch = dict(pi=[256, 256], vf=[256, 256]) from training.py:363-365), every minibatch's forward / loss / backward /
+// clip_grad_norm_ / Adam step.  As launches that is three dependent kernels per optimizer step (ppo_grad_wide_kernel on 32 workgroups,
+// wide_small_reduce_kernel, adam_scatter_wide_kernel: 34 us, the gradient launch at 0.06 of the f32 MFMA peak): a 256-sample minibatch is
+// 207 MFLOP -- 1.3 us of the chip -- behind 547 KB of weights that every workgroup has to stream and a gradient that leaves as slabs.
+//
+// Here the step is COLUMN-parallel and resident.  Each net runs on the 32 CUs of one XCD (two XCDs in all: the nets only meet in the clip
+// norm), as 4 row groups (64 samples) x 8 column slices (32 hidden units): workgroup (r, c) keeps W1[:, slice c], W2[:, slice c],
+// W3[slice c, :] and the biases in LDS for the whole epoch, the Adam moments of the parameters it owns in registers, and per step exchanges
+// only activations and partial gradients through its XCD's L2:
+//
+//   X1  h1 slices (64 x 32 each) + last step's updated W2 quarters -> every workgroup gathers h1[64 rows][256] and W2[:, slice c]
+//       layer 2 on the slice, split-K head partial of the slice
+//   X2  head partials of the row group's 8 slices -> outputs, loss, dz3 (redundantly in the 8 workgroups of a row group), dz2 slice,
+//       dW3 / db2 / dW2 partials over the 64 rows; dh1 is NOT gathered: dz1 = (dz2[:, slice c] . W2[:, slice c]^T) * (1 - h1^2) is this
+//       slice's additive share of dz1, and dW1 = X^T dz1, db1 = sum dz1 are linear in it, so each workgroup leaves its share of the WHOLE
+//       layer-1 gradient (no second activation exchange, no [out][in] weight copy)
+//   X3  partial gradients -> workgroup (r, c) sums quarter r of dW2[:, slice c] over the four row groups, every workgroup of a slice sums
+//       the slice's small tensors (W1, b1, b2, W3; b3), sum of squares of what it owns -> one 16-byte granule
+//   X4  64 granules (both XCDs) -> clip coefficient -> Adam on the owned quarter (moments in registers) and, redundantly in the slice's four
+//       workgroups, on the small tensors -> LDS weights rewritten, quarter published, layer 1 of the NEXT minibatch -> X1.
+//
+// Every sum runs in a fixed order (no floating-point atomics): run-to-run bit-identical.  The order differs from the launch path's (which
+// accumulates dh1 over all 256 columns before the tanh derivative and reduces 16-row slabs), so the two paths agree to rounding, not to the
+// bit: tests/test_h256p_gpu.py holds them to 2e-6 after an epoch and both to the torch restatement of SB3's loop.
+//
+// Placement and failure are tma_h64p.hip's: hand-offs are plain stores + L1-bypassing (sc1) loads, valid between CUs that share an L2, so
+// workgroups read HW_REG_XCC_ID, the first claimer fixes a net's XCD and the first 32 workgroups on it take the roles; the granules of X4
+// cross XCDs and are stored / polled with sc0 sc1.  Every spin is bounded; a role that cannot be filled or a peer that never arrives sets the
+// abort word, nothing is committed, and tma_ppo_train_epoch_local re-runs the epoch through the per-minibatch launches from its snapshot.
+#include "tma_ppo_types.h"
+
+#include <cstring>
+#include <cstdlib>
+
+namespace tma {
+
+constexpr int QR = 4, QC = 8, QCU = QR * QC;  // row groups x column slices = workgroups per net
+constexpr int QROWS = 64, QCOLS = 32, QH = 256, QB = 256;
+constexpr int QGRID = 512;   // workgroups launched: two rounds of the chip, so a claimed XCD that was dealt fewer than 32 in the first still fills
+constexpr int QT = 512;      // threads per workgroup (eight waves, two per SIMD)
+// LDS (floats)
+constexpr int W2S_LD = 80, H1_LD = 260, H2_LD = 36, DZ2_LD = 48, X_LD = 33, DZ3_LD = 17, W1_LD = 48;
+constexpr int L_W2S = 0;                        // [16 q][2 j][4 g][W2S_LD]: W2t[k = 16q + 4g + i][n = 32c + 16j + r16] at row (q, j, g), word 4 r16 + i
+constexpr int L_H1 = L_W2S + 128 * W2S_LD;      // [64][H1_LD] h1 of the row group, all 256 columns (later dz1 in place)
+constexpr int L_H2 = L_H1 + QROWS * H1_LD;      // [64][H2_LD] h2 of the slice
+constexpr int L_DZ2 = L_H2 + QROWS * H2_LD;     // [64][DZ2_LD] dz2 of the slice
+constexpr int L_X = L_DZ2 + QROWS * DZ2_LD;     // [64][X_LD] observation rows, zero beyond D
+constexpr int L_DZ3 = L_X + QROWS * X_LD;       // [64][DZ3_LD]
+constexpr int L_META = L_DZ3 + QROWS * DZ3_LD;  // [64][4] old log-prob, advantage, return, action bits
+constexpr int L_ROFF = L_META + QROWS * 4;      // int64[64] (all >= 0: full minibatches only)
+constexpr int L_W1S = L_ROFF + 2 * QROWS;       // [32 k][W1_LD] W1t[k][32c + n], rows >= D zero
+constexpr int L_B1 = L_W1S + 32 * W1_LD;        // [32]
+constexpr int L_B2 = L_B1 + 32;                 // [32]
+constexpr int L_B3 = L_B2 + 32;                 // [16] zero beyond NOUT
+constexpr int L_W3S = L_B3 + 16;                // [32 k][16] W3t[32c + k][a], zero beyond NOUT
+constexpr int L_RED = L_W3S + 32 * 16;          // double[8 waves][6]
+constexpr int L_FLOATS = L_RED + 2 * 8 * 6;
+// persistent region (bytes from ws + WS_SLABS)
+constexpr int R_SYNC = 0;           // u32 words, 32 apart (one 128-byte line each): see SW_*
+constexpr int SW_CLAIM = 0;         // +net: XCD + 1 of the net
+constexpr int SW_ROLES = 2;         // +net: roles taken
+constexpr int SW_ABORT = 4;
+constexpr int SW_X1 = 5;            // +net
+constexpr int SW_X3 = 7;            // +net
+constexpr int SW_X2 = 9;            // +4 net + r
+constexpr int R_GRAN = 4096;        // 16-byte granules {step tag, -, f64 sum of squares}: [2 parities][64] same-XCD copies, then (+2048) the cross-XCD copies
+constexpr int R_TICKS = 3072;       // u64[32] phase ticks of role (0, 0, 0) (inside the sync page, behind its words)
+constexpr int R_H1X = 8192;                            // [2][32][64][32] f32
+constexpr int R_W2Q = R_H1X + 2 * QCU * 8192;          // [2][32][512] f32x4: the owner's updated W2 quarter
+constexpr int R_HP = R_W2Q + 2 * QCU * 8192;           // [2][32][4 tiles][64] f32x4 head partials
+constexpr int R_GW2 = R_HP + 2 * QCU * 4096;           // [2][32][16 kt][2 j][64] f32x4 dW2 partials
+constexpr int R_GW1 = R_GW2 + 2 * QCU * 32768;         // [2][32][2 kt1][16 nt][64] f32x4 dW1 partials (whole layer)
+constexpr int R_GB1 = R_GW1 + 2 * QCU * 32768;         // [2][32][256] f32
+constexpr int GSM_F = 576;                             // floats per workgroup: db2[32] | db3[16] | dW3[2 i][64][4]
+constexpr int R_GSM = R_GB1 + 2 * QCU * 1024;          // [2][32][GSM_F]
+constexpr int R_TABLE = R_GSM + 2 * QCU * GSM_F * 4;   // float2[n_mb]: (lr / (1 - beta1^t), sqrt(1 - beta2^t)) per optimizer step
+
+struct Epoch256Args {
+    float *params, *exp_avg, *exp_avg_sq;
+    PLayout L;
+    Rollout rb;
+    HParams hp;
+    const int32_t *offs;     // buffer offset of every row of the permuted epoch (tma_ppo_epoch_prepare)
+    const double *adv_part;  // (sum, sum of squares) of every minibatch's advantages, adv_stride pairs per minibatch
+    int adv_stride;
+    int n_mb;
+    float beta1, beta2, eps, max_norm;
+    char *region;
+    double *stat_slots, *norm_out;
+    int *err_out;
+    int ticks;
+};
+
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned q_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int Q_SC0 = 1, Q_SC1 = 16;  // cache-policy bits of the raw buffer intrinsics on gfx940+
+constexpr int Q_OOB = 0x7FFFFFF0;     // a byte offset beyond every buffer's range: the load returns zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x40000000, 0x00020000);
+}
+__device__ __forceinline__ f32x4 q_ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, Q_SC1));
+}
+__device__ __forceinline__ float q_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, Q_SC1));
+}
+__device__ __forceinline__ void q_st4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void q_st1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
+
+// one lane waits until *ctr >= want; false on abort (set by a peer) or after ~2^22 polls
+__device__ __forceinline__ bool q_wait_ge(unsigned *ctr, unsigned want, unsigned *abortw) {
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        spins++;
+        if ((spins & 1023) == 0 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (spins > (1 << 22)) {
+            __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+#define QP_TICK(i)                                                                      \
+    do {                                                                                \
+        if (tick_on) {                                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
+            tick_out[i] += t_ - tick_prev;                                              \
+            tick_prev = __builtin_amdgcn_s_memtime();                                   \
+        }                                                                               \
+    } while (0)
+
+// torch.optim.Adam on one parameter with the clip-scaled gradient: adam_update_h64 (tma_mlp.h), the routine adam_scatter_wide_kernel runs too
+__device__ __forceinline__ float q_adam(float p, float g, float coef, float &mm, float &vv, float beta1, float beta2, float inv_bc2_sqrt, float eps,
+                                        float lr_step) {
+    const float gv = (g * 1.0f) * coef;
+    return adam_update_h64(p, gv, mm, vv, beta1, beta2, inv_bc2_sqrt, eps, lr_step);
+}
+
+// The small tensors of column slice c as one index space: [W1t[k][n] : 32 D | b1 : 32 | b2 : 32 | W3t[k][a] : 32 NOUT | b3 : NOUT]
+struct SmallMap {
+    int lds;      // LDS word of the parameter
+    int nat;      // offset from the net's first parameter in PLayout's flat order
+    int src;      // byte offset of producer 0's partial inside the region
+    int stride;   // bytes between producers
+    int np;       // producers (32: the layer-1 gradient is a sum over every workgroup of the net; 4: the slice's row groups)
+    int kind;     // 0 W1, 1 b1, 2 b2, 3 W3, 4 b3, -1 none
+};
+__device__ __forceinline__ SmallMap small_map(int e, int D, int NOUT, int c, int net) {
+    SmallMap m;
+    m.kind = -1, m.lds = L_RED, m.nat = 0, m.src = Q_OOB, m.stride = 0, m.np = 0;
+    const int oB1 = D * QH, oW2 = oB1 + QH, oB2 = oW2 + QH * QH, oW3 = oB2 + QH, oB3 = oW3 + QH * NOUT;
+    int x = e;
+    if (x < 32 * D) {
+        const int k = x >> 5, nl = x & 31, n = 32 * c + nl;
+        m.kind = 0, m.lds = L_W1S + k * W1_LD + nl, m.nat = k * QH + n;
+        m.src = R_GW1 + net * QCU * 32768 + ((((k >> 4) * 16 + (n >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3)) * 4;
+        m.stride = 32768, m.np = 32;
+        return m;
+    }
+    x -= 32 * D;
+    if (x < 32) {
+        m.kind = 1, m.lds = L_B1 + x, m.nat = oB1 + 32 * c + x;
+        m.src = R_GB1 + net * QCU * 1024 + (32 * c + x) * 4, m.stride = 1024, m.np = 32;
+        return m;
+    }
+    x -= 32;
+    if (x < 32) {
+        m.kind = 2, m.lds = L_B2 + x, m.nat = oB2 + 32 * c + x;
+        m.src = R_GSM + (net * QCU + c) * GSM_F * 4 + x * 4, m.stride = QC * GSM_F * 4, m.np = 4;
+        return m;
+    }
+    x -= 32;
+    if (x < 32 * NOUT) {
+        const int k = x / NOUT, a = x - k * NOUT;
+        m.kind = 3, m.lds = L_W3S + k * 16 + a, m.nat = oW3 + (32 * c + k) * NOUT + a;
+        m.src = R_GSM + (net * QCU + c) * GSM_F * 4 + (48 + (((k >> 4) * 64 + ((k & 15) >> 2) * 16 + a) * 4 + (k & 3))) * 4;
+        m.stride = QC * GSM_F * 4, m.np = 4;
+        return m;
+    }
+    x -= 32 * NOUT;
+    if (x < NOUT) {
+        m.kind = 4, m.lds = L_B3 + x, m.nat = oB3 + x;
+        m.src = R_GSM + (net * QCU + 0) * GSM_F * 4 + (32 + x) * 4, m.stride = QC * GSM_F * 4, m.np = 4;
+        return m;
+    }
+    return m;
+}
+
+template <bool IS_PI, int KT1, int NSM>
+__device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, float *smem) {
+    __shared__ int ok_s;
+    __shared__ double tot_s;
+    const PLayout &L = a.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+    const int D = L.D, A = L.A, NOUT = IS_PI ? A : 1, KS1 = (D + 3) >> 2, NS = (NOUT + 3) >> 2;
+    const int net = IS_PI ? 0 : 1, r = cu >> 3, c = cu & 7;
+    const int t = wave >> 1, j = wave & 1;  // this wave's 16-row tile and 16-column tile of the slice
+    const int base = IS_PI ? L.pW1t : L.vW1t;
+    const int oW2 = D * QH + QH;
+    const int n_small = 32 * D + 64 + 32 * NOUT + NOUT;
+    float *W2s = smem + L_W2S, *H1 = smem + L_H1, *H2 = smem + L_H2, *DZ2 = smem + L_DZ2, *Xs = smem + L_X, *DZ3 = smem + L_DZ3;
+    float *meta = smem + L_META, *W1s = smem + L_W1S, *b1s = smem + L_B1, *b2s = smem + L_B2, *b3s = smem + L_B3, *W3s = smem + L_W3S;
+    int64_t *row_off = reinterpret_cast<int64_t *>(smem + L_ROFF);
+    double *red = reinterpret_cast<double *>(smem + L_RED);
+    unsigned *sync = reinterpret_cast<unsigned *>(a.region + R_SYNC);
+    unsigned *abortw = sync + 32 * SW_ABORT, *cntX1 = sync + 32 * (SW_X1 + net), *cntX3 = sync + 32 * (SW_X3 + net);
+    unsigned *cntX2 = sync + 32 * (SW_X2 + 4 * net + r);
+    const __amdgpu_buffer_rsrc_t reg = q_rsrc(a.region);
+    const bool tick_on = a.ticks != 0 && net == 0 && cu == 0 && tid == 0;
+    unsigned long long tick_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long *tick_out = reinterpret_cast<unsigned long long *>(a.region + R_TICKS);
+    const int n_mb = a.n_mb;
+    const float invB = 1.0f / (float)QB;
+
+    // ---- resident state ----
+    for (int e = tid; e < L_FLOATS - L_W1S; e += QT) smem[L_W1S + e] = 0.0f;  // small-tensor arrays: zero padding rows / columns
+    for (int e = tid; e < QROWS * X_LD; e += QT) Xs[e] = 0.0f;
+    __syncthreads();
+    // W2t[:, slice c]: thread (kt_l, jq, lane) owns the four parameters k = 16 kt + 4 g + rr, n = 32 c + 16 jq + r16 of every quarter's kt = 4 r' + kt_l
+    const int kt_l = tid >> 7, jq = (tid >> 6) & 1;
+    const int w2_row = ((0 * 2 + jq) * 4 + g) * W2S_LD + r16 * 4;  // + kt * 8 * W2S_LD
+    f32x4 m_w2, v_w2;
+    {
+        const float *gW2 = a.params + base + oW2;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kt = kt_l + 4 * u;
+            f32x4 w;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) w[rr] = gW2[(16 * kt + 4 * g + rr) * QH + 32 * c + 16 * jq + r16];
+            *reinterpret_cast<f32x4 *>(W2s + kt * 8 * W2S_LD + w2_row) = w;
+        }
+        const int kt = 4 * r + kt_l;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int e = base + oW2 + (16 * kt + 4 * g + rr) * QH + 32 * c + 16 * jq + r16;
+            m_w2[rr] = a.exp_avg[e], v_w2[rr] = a.exp_avg_sq[e];
+        }
+    }
+    float p_sm[NSM], m_sm[NSM], v_sm[NSM];
+    int lds_sm[NSM], src_sm[NSM], cfg_sm[NSM];  // cfg: producer stride | (32 producers ? 1 : 0) << 24 | counted in the norm << 25 | live << 26
+#pragma unroll
+    for (int u = 0; u < NSM; u++) {
+        const int e = tid + QT * u;
+        const SmallMap sm = small_map(e < n_small ? e : n_small, D, NOUT, c, net);
+        const bool live = sm.kind >= 0;
+        lds_sm[u] = live ? sm.lds : L_RED + 8 * 6 * 2 - 1;  // (a scratch word nobody reads)
+        src_sm[u] = sm.src;
+        const bool counted = live && r == 0 && (sm.kind != 4 || c == 0);
+        cfg_sm[u] = sm.stride | ((sm.np == 32 ? 1 : 0) << 24) | ((counted ? 1 : 0) << 25) | ((live ? 1 : 0) << 26);
+        p_sm[u] = live ? a.params[base + sm.nat] : 0.0f;
+        m_sm[u] = live ? a.exp_avg[base + sm.nat] : 0.0f;
+        v_sm[u] = live ? a.exp_avg_sq[base + sm.nat] : 0.0f;
+        if (live) smem[sm.lds] = p_sm[u];
+    }
+    // ---- sample prefetch: thread (row = tid >> 3, sub = tid & 7) ----
+    const int prow = tid >> 3, psub = tid & 7;
+    auto off_of = [&](int s) -> int32_t {
+        const int sc = s < n_mb ? s : n_mb - 1;
+        return a.offs[(int64_t)sc * QB + QROWS * r + prow];
+    };
+    int32_t nx_off = off_of(0);
+    float pf_x[4], pf_m = 0.0f;
+    int32_t pf_off = 0;
+    double pf_adv_a = 0.0, pf_adv_b = 0.0;
+    float2 pf_tb = make_float2(0.0f, 1.0f);
+    auto fetch = [&](int s_next) {  // rows of the minibatch whose offset is in nx_off; then the offset one minibatch further
+        const int64_t row = nx_off;
+        pf_off = nx_off;
+        nx_off = off_of(s_next + 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int col = psub + 8 * u;
+            pf_x[u] = col < D ? a.rb.obs[row * D + col] : 0.0f;
+        }
+        if (psub == 0) pf_m = a.rb.log_probs[row];
+        else if (psub == 1) pf_m = a.rb.advantages[row];
+        else if (psub == 2) pf_m = a.rb.returns[row];
+        else if (psub == 3) pf_m = __int_as_float(static_cast<const int32_t *>(a.rb.actions)[row]);
+        const int sc = s_next < n_mb ? s_next : n_mb - 1;
+        pf_adv_a = a.adv_part[2 * (int64_t)sc * a.adv_stride];
+        pf_adv_b = a.adv_part[2 * (int64_t)sc * a.adv_stride + 1];
+        pf_tb = reinterpret_cast<const float2 *>(a.region + R_TABLE)[sc];
+    };
+    float amean = 0.0f, astd = 1.0f;
+    float2 tb = make_float2(0.0f, 1.0f);
+    auto commit = [&]() {  // the prefetched minibatch into LDS (nobody reads Xs / meta between P6 and the next layer 1)
+#pragma unroll
+        for (int u = 0; u < 4; u++) Xs[prow * X_LD + psub + 8 * u] = pf_x[u];
+        if (psub < 4) meta[prow * 4 + psub] = pf_m;
+        if (psub == 4) row_off[prow] = (int64_t)pf_off;
+        tb = pf_tb;
+        amean = 0.0f, astd = 1.0f;
+        if (IS_PI && a.hp.normalize_advantage) {  // (adv_final_kernel's fold; one partial pair per 256-sample minibatch)
+            const double n = (double)QB, mean = pf_adv_a / n;
+            double var = (pf_adv_b - n * mean * mean) / (n - 1.0);
+            if (var < 0.0) var = 0.0;
+            amean = (float)mean;
+            astd = (float)sqrt(var);
+        }
+    };
+    fetch(0);
+    commit();
+    fetch(1);
+    LossStats st;
+    float dlsd[2] = {0.0f, 0.0f};
+    float last_norm = 0.0f, last_coef = 1.0f;
+    __syncthreads();
+
+    // layer 1 of the slice for the minibatch in Xs -> h1 columns [32 c, 32 c + 32) of H1, then the slice (and, behind a step, the owner's
+    // updated W2 quarter, already stored) published: arrival on X1
+    auto layer1_publish = [&]() {
+        {
+            const float bv = b1s[16 * j + r16];
+            f32x4 acc = f32x4{bv, bv, bv, bv};
+            for (int ks = 0; ks < KS1; ks++) {
+                const float av = Xs[(16 * t + r16) * X_LD + 4 * ks + g];
+                const float bw = W1s[(4 * ks + g) * W1_LD + 16 * j + r16];
+                acc = mfma16(av, bw, acc);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) H1[(16 * t + 4 * g + rr) * H1_LD + 32 * c + 16 * j + r16] = tma_tanh(acc[rr]);
+        }
+        __syncthreads();
+        {
+            const int row = tid >> 3, c4 = (tid & 7) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(H1 + row * H1_LD + 32 * c + c4);
+            q_st4(reg, R_H1X + ((net * QCU + cu) * QROWS + row) * 128 + c4 * 4, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everything this workgroup publishes is in the L2 before anyone is told
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cntX1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    layer1_publish();
+    QP_TICK(0);
+
+    for (int s = 0; s < n_mb; s++) {
+        const float2 tbs = tb;
+        const float amean_s = amean, astd_s = astd;
+        // ---- X1: the net's 32 workgroups have published h1 slices (and W2 quarters) ----
+        if (tid == 0) ok_s = q_wait_ge(cntX1, (unsigned)QCU * (unsigned)(s + 1), abortw) ? 1 : 0;
+        __syncthreads();
+        if (!ok_s) return;
+        QP_TICK(1);
+        {
+            const int row = tid >> 3, c4 = (tid & 7) * 4;
+            f32x4 hv[QC - 1], wq[QR - 1];
+#pragma unroll
+            for (int u = 0; u < QC - 1; u++) {
+                const int p = u + (u >= c ? 1 : 0);
+                hv[u] = q_ld4(reg, R_H1X + ((net * QCU + r * QC + p) * QROWS + row) * 128 + c4 * 4);
+            }
+            if (s > 0) {
+#pragma unroll
+                for (int u = 0; u < QR - 1; u++) {
+                    const int rq = u + (u >= r ? 1 : 0);
+                    wq[u] = q_ld4(reg, R_W2Q + ((net * QCU + rq * QC + c) * QT + tid) * 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QC - 1; u++) {
+                const int p = u + (u >= c ? 1 : 0);
+                *reinterpret_cast<f32x4 *>(H1 + row * H1_LD + 32 * p + c4) = hv[u];
+            }
+            if (s > 0) {
+#pragma unroll
+                for (int u = 0; u < QR - 1; u++) {
+                    const int rq = u + (u >= r ? 1 : 0);
+                    *reinterpret_cast<f32x4 *>(W2s + (4 * rq + kt_l) * 8 * W2S_LD + w2_row) = wq[u];
+                }
+            }
+        }
+        __syncthreads();
+        QP_TICK(2);
+        // ---- P2: layer 2 forward on the slice: tile (t, j) ----
+        f32x4 h2;
+        {
+            const float bv = b2s[16 * j + r16];
+            f32x4 acc = f32x4{bv, bv, bv, bv};
+            const float *pa = H1 + (16 * t + r16) * H1_LD + 4 * g, *pb = W2s + (j * 4 + g) * W2S_LD + r16 * 4;
+            // four k-groups (16 k each) per batch: their eight 16-byte LDS reads in flight together, fenced so that the scheduler does not hoist all 32
+            f32x4 a4[2][4], b4[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a4[0][u] = *reinterpret_cast<const f32x4 *>(pa + 16 * u), b4[0][u] = *reinterpret_cast<const f32x4 *>(pb + u * 8 * W2S_LD);
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                if (qq + 1 < 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a4[(qq + 1) & 1][u] = *reinterpret_cast<const f32x4 *>(pa + 16 * (4 * (qq + 1) + u));
+                        b4[(qq + 1) & 1][u] = *reinterpret_cast<const f32x4 *>(pb + (4 * (qq + 1) + u) * 8 * W2S_LD);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc = mfma16(a4[qq & 1][u][i], b4[qq & 1][u][i], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                h2[rr] = tma_tanh(acc[rr]);
+                H2[(16 * t + 4 * g + rr) * H2_LD + 16 * j + r16] = h2[rr];
+            }
+        }
+        __syncthreads();
+        QP_TICK(3);
+        // ---- P3a: split-K head partial of the slice (32 of the 256 k), tile t on wave (t, 0) ----
+        if (j == 0) {
+            f32x4 part = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) part = mfma16(H2[(16 * t + r16) * H2_LD + 4 * ks + g], W3s[(4 * ks + g) * 16 + r16], part);
+            q_st4(reg, R_HP + (((net * QCU + cu) * 4 + t) * 64 + lane) * 16, part);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cntX2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_s = q_wait_ge(cntX2, (unsigned)QC * (unsigned)(s + 1), abortw) ? 1 : 0;
+        }
+        // (the next minibatch's rows: requested here, parked in LDS behind P6)
+        __syncthreads();
+        if (!ok_s) return;
+        QP_TICK(4);
+        // ---- P3b: head outputs of tile t = b3 + the eight slices' partials in slice order; loss; dz3 ----
+        if (IS_PI || j == 0) {
+            f32x4 hp8[QC];
+#pragma unroll
+            for (int p = 0; p < QC; p++) hp8[p] = q_ld4(reg, R_HP + (((net * QCU + r * QC + p) * 4 + t) * 64 + lane) * 16);
+            const float bv = b3s[r16];
+            f32x4 out[1];
+            out[0] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+            for (int p = 0; p < QC; p++) out[0] += hp8[p];
+            float *dzt = DZ3 + 16 * t * DZ3_LD;
+            if constexpr (IS_PI) {
+                if (j == 0) policy_loss_tile<false, 0, 2>(out, meta + t * 64, row_off + t * 16, nullptr, nullptr, A, amean_s, astd_s, a.hp, invB, dzt, DZ3_LD, dlsd, st, lane);
+                else policy_loss_tile<false, 2, 4>(out, meta + t * 64, row_off + t * 16, nullptr, nullptr, A, amean_s, astd_s, a.hp, invB, dzt, DZ3_LD, dlsd, st, lane);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int row = 4 * g + rr;
+                    const float diff = out[0][rr] - meta[(16 * t + row) * 4 + 2];
+                    dzt[row * DZ3_LD + r16] = (r16 == 0) ? (a.hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                    if (r16 == 0) st.a += (double)(diff * diff);
+                }
+            }
+        }
+        __syncthreads();
+        QP_TICK(5);
+        // ---- P4: dW3 of the slice over the 64 rows (waves 0, 1), db3 (wave 2 of slice 0), dz2 = (dz3 . W3^T) * (1 - h2^2) ----
+        if (wave < 2) {
+            f32x4 acc3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int sx = 0; sx < 16; sx++) acc3 = mfma16(H2[(4 * sx + g) * H2_LD + 16 * wave + r16], DZ3[(4 * sx + g) * DZ3_LD + r16], acc3);
+            q_st4(reg, R_GSM + (net * QCU + cu) * GSM_F * 4 + (48 + (wave * 64 + lane) * 4) * 4, acc3);
+        } else if (wave == 2 && c == 0) {
+            float cb = 0.0f;
+#pragma unroll
+            for (int sx = 0; sx < 16; sx++) cb += DZ3[(4 * sx + g) * DZ3_LD + r16];
+            cb += __shfl_xor(cb, 16, 64), cb += __shfl_xor(cb, 32, 64);
+            if (g == 0) q_st1(reg, R_GSM + (net * QCU + cu) * GSM_F * 4 + (32 + r16) * 4, cb);
+        }
+        {
+            f32x4 accd = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ns = 0; ns < NS; ns++) accd = mfma16(DZ3[(16 * t + r16) * DZ3_LD + 4 * ns + g], W3s[(16 * j + r16) * 16 + 4 * ns + g], accd);
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) DZ2[(16 * t + 4 * g + rr) * DZ2_LD + 16 * j + r16] = accd[rr] * (1.0f - h2[rr] * h2[rr]);
+        }
+        __syncthreads();
+        QP_TICK(6);
+        // ---- P5a: dW2[:, slice] over the 64 rows: wave w the k-tiles 2w, 2w + 1, both column tiles; db2 ----
+        {
+            f32x4 acc2[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) acc2[kk][0] = acc2[kk][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float cb0 = 0.0f, cb1 = 0.0f;
+            const float *pa = H1 + g * H1_LD + 32 * wave + r16, *pb = DZ2 + g * DZ2_LD + r16;
+#pragma unroll
+            for (int sx = 0; sx < 16; sx++) {
+                const float a0 = pa[4 * sx * H1_LD], a1 = pa[4 * sx * H1_LD + 16];
+                const float b0 = pb[4 * sx * DZ2_LD], b1 = pb[4 * sx * DZ2_LD + 16];
+                acc2[0][0] = mfma16(a0, b0, acc2[0][0]);
+                acc2[0][1] = mfma16(a0, b1, acc2[0][1]);
+                acc2[1][0] = mfma16(a1, b0, acc2[1][0]);
+                acc2[1][1] = mfma16(a1, b1, acc2[1][1]);
+                cb0 += b0, cb1 += b1;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    q_st4(reg, R_GW2 + ((((net * QCU + cu) * 16 + 2 * wave + kk) * 2 + jj) * 64 + lane) * 16, acc2[kk][jj]);
+            if (wave == 0) {
+                cb0 += __shfl_xor(cb0, 16, 64), cb0 += __shfl_xor(cb0, 32, 64);
+                cb1 += __shfl_xor(cb1, 16, 64), cb1 += __shfl_xor(cb1, 32, 64);
+                if (g == 0) {
+                    q_st1(reg, R_GSM + (net * QCU + cu) * GSM_F * 4 + r16 * 4, cb0);
+                    q_st1(reg, R_GSM + (net * QCU + cu) * GSM_F * 4 + (16 + r16) * 4, cb1);
+                }
+            }
+        }
+        QP_TICK(7);
+        // ---- P5b: this slice's share of dh1 for tile t, columns [128 j, 128 j + 128): K = the slice's 32 columns ----
+        f32x4 dh1[8];
+        {
+            float av[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) av[ks] = DZ2[(16 * t + r16) * DZ2_LD + 4 * ks + g];
+            const float *pb = W2s + (r16 >> 2) * W2S_LD + g * 4 + (r16 & 3);
+#pragma unroll
+            for (int nt = 0; nt < 8; nt++) {
+                f32x4 accn = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) accn = mfma16(av[ks], pb[(((8 * j + nt) * 2 + (ks >> 2)) * 4) * W2S_LD + (ks & 3) * 16], accn);
+                dh1[nt] = accn;
+            }
+        }
+        __syncthreads();  // (every wave is done reading h1)
+        QP_TICK(8);
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                float *pp = H1 + (16 * t + 4 * g + rr) * H1_LD + 16 * (8 * j + nt) + r16;
+                const float h = *pp;
+                *pp = dh1[nt][rr] * (1.0f - h * h);
+            }
+        __syncthreads();
+        // ---- P6: this workgroup's share of the WHOLE layer-1 gradient: wave w the columns [32 w, 32 w + 32) ----
+        {
+            f32x4 accw[KT1][2];
+#pragma unroll
+            for (int k1 = 0; k1 < KT1; k1++) accw[k1][0] = accw[k1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float cb0 = 0.0f, cb1 = 0.0f;
+            const float *pb = H1 + g * H1_LD + 32 * wave + r16, *px = Xs + g * X_LD + r16;
+#pragma unroll
+            for (int sx = 0; sx < 16; sx++) {
+                const float b0 = pb[4 * sx * H1_LD], b1 = pb[4 * sx * H1_LD + 16];
+#pragma unroll
+                for (int k1 = 0; k1 < KT1; k1++) {
+                    const float av = px[4 * sx * X_LD + 16 * k1];
+                    accw[k1][0] = mfma16(av, b0, accw[k1][0]);
+                    accw[k1][1] = mfma16(av, b1, accw[k1][1]);
+                }
+                cb0 += b0, cb1 += b1;
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < KT1; k1++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    if (16 * k1 + 4 * g < D)  // (rows k = 16 k1 + 4 g + rr beyond D are never read)
+                        q_st4(reg, R_GW1 + ((((net * QCU + cu) * 2 + k1) * 16 + 2 * wave + jj) * 64 + lane) * 16, accw[k1][jj]);
+            cb0 += __shfl_xor(cb0, 16, 64), cb0 += __shfl_xor(cb0, 32, 64);
+            cb1 += __shfl_xor(cb1, 16, 64), cb1 += __shfl_xor(cb1, 32, 64);
+            if (g == 0) {
+                q_st1(reg, R_GB1 + (net * QCU + cu) * 1024 + (32 * wave + r16) * 4, cb0);
+                q_st1(reg, R_GB1 + (net * QCU + cu) * 1024 + (32 * wave + 16 + r16) * 4, cb1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        QP_TICK(9);
+        // ---- X3: the net's partial gradients ----
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cntX3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_s = q_wait_ge(cntX3, (unsigned)QCU * (unsigned)(s + 1), abortw) ? 1 : 0;
+        }
+        commit();      // the next minibatch's rows and constants (Xs, meta: dead since P6's barrier)
+        fetch(s + 2);  // ... and the one after it into the registers
+        __syncthreads();
+        if (!ok_s) return;
+        QP_TICK(10);
+        // ---- reduce what this workgroup owns: quarter r of dW2[:, slice c] over the row groups in order; the slice's small tensors ----
+        f32x4 g_w2;
+        float g_sm[NSM];
+        {
+            f32x4 pq[QR];
+#pragma unroll
+            for (int rq = 0; rq < QR; rq++)
+                pq[rq] = q_ld4(reg, R_GW2 + ((((net * QCU + rq * QC + c) * 16 + 4 * r + kt_l) * 2 + jq) * 64 + lane) * 16);
+            double sq = 0.0;
+            {  // PB partials of every slot per batch of loads (the 32-producer sums take 32 / PB L2 round trips, the others one); producer order
+                float sum[NSM];
+#pragma unroll
+                for (int u = 0; u < NSM; u++) sum[u] = 0.0f;
+                bool any_wide = false;
+#pragma unroll
+                for (int u = 0; u < NSM; u++) any_wide = any_wide || ((cfg_sm[u] >> 24) & 1);
+                constexpr int PB = NSM <= 2 ? 16 : 8;  // (register budget)
+                const int n_batch = __builtin_amdgcn_ballot_w64(any_wide) != 0 ? 32 / PB : 1;  // (wave-uniform)
+#pragma unroll 1
+                for (int b = 0; b < n_batch; b++) {
+                    float tv[NSM][PB];
+#pragma unroll
+                    for (int u = 0; u < NSM; u++) {
+                        const int cfg = cfg_sm[u], stride = cfg & 0xFFFFFF;
+                        const bool wide = (cfg >> 24) & 1;
+#pragma unroll
+                        for (int p = 0; p < PB; p++) tv[u][p] = q_ld1(reg, ((b == 0 && p < 4) || wide) ? src_sm[u] + (PB * b + p) * stride : Q_OOB);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NSM; u++)
+#pragma unroll
+                        for (int p = 0; p < PB; p++) sum[u] += tv[u][p];
+                }
+#pragma unroll
+                for (int u = 0; u < NSM; u++) {
+                    g_sm[u] = sum[u];
+                    if ((cfg_sm[u] >> 25) & 1) sq += (double)sum[u] * (double)sum[u];
+                }
+            }
+            g_w2 = ((pq[0] + pq[1]) + pq[2]) + pq[3];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) sq += (double)g_w2[rr] * (double)g_w2[rr];
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+            if (lane == 0) red[wave] = sq;
+        }
+        __syncthreads();
+        QP_TICK(11);
+        // ---- X4: one 16-byte granule {step tag, -, sum of squares} per workgroup, both nets; wave 0 polls the 64 granules, one per lane ----
+        if (wave == 0) {
+            const unsigned tag = (unsigned)(s + 1);
+            const __amdgpu_buffer_rsrc_t r_gr = q_rsrc(a.region + R_GRAN);
+            // two copies of every granule, double-buffered by step parity (a workgroup that has seen all 64 may publish the next step's before a
+            // slow poller is done): LOC for the pollers of the same XCD (plain store: the line stays in this L2; sc1 polls), REM for the other
+            // net's (sc0 sc1 on both sides: written through, polled past the L2)
+            const int loc = 16 * (net * QCU + 64 * (s & 1)), rem = 2048 + 16 * ((1 - net) * QCU + 64 * (s & 1));
+            if (lane == 0) {
+                double sqb = red[0];
+#pragma unroll
+                for (int w = 1; w < 8; w++) sqb += red[w];
+                const q_u32x2 h = __builtin_bit_cast(q_u32x2, sqb);
+                const q_u32x4 gv = q_u32x4{tag, 0u, h[0], h[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(gv, r_gr, loc + 16 * cu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(gv, r_gr, 2048 + 16 * (net * QCU + cu + 64 * (s & 1)), 0, Q_SC0 | Q_SC1);
+            }
+            // lane l polls granule l of the policy net (l < 32) or granule l - 32 of the value net: the same order in every workgroup
+            const bool mine = (lane >> 5) == net;
+            q_u32x4 gr;
+            int spins = 0;
+            bool fine = true;
+            for (;;) {
+                const q_u32x4 gl = __builtin_amdgcn_raw_buffer_load_b128(r_gr, mine ? loc + 16 * (lane & 31) : Q_OOB, 0, Q_SC1);
+                const q_u32x4 gm = __builtin_amdgcn_raw_buffer_load_b128(r_gr, mine ? Q_OOB : rem + 16 * (lane & 31), 0, Q_SC0 | Q_SC1);
+                gr = mine ? gl : gm;
+                if (__builtin_amdgcn_ballot_w64(gr[0] != tag) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                spins++;
+                if ((spins & 1023) == 0 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) fine = false;
+                if (spins > (1 << 22)) {
+                    __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fine = false;
+                }
+                if (!fine) break;
+            }
+            // the 64 sums in a fixed tree (the same in every workgroup: one clip coefficient, bit for bit)
+            double tot = __builtin_bit_cast(double, q_u32x2{gr[2], gr[3]});
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+            if (lane == 0) tot_s = tot, ok_s = fine ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ok_s) return;
+        QP_TICK(12);
+        // ---- clip coefficient, Adam on the owned W2 quarter and (redundantly in the slice's four workgroups) on the small tensors ----
+        {
+            const float total_norm = (float)sqrt(tot_s);
+            float coef = a.max_norm / (total_norm + 1e-6f);
+            coef = coef > 1.0f ? 1.0f : coef;
+            if (a.max_norm <= 0.0f) coef = 1.0f;
+            last_norm = total_norm, last_coef = coef;
+            const float lr_step = tbs.x, bc2_sqrt = 1.0f / tbs.y;  // (adam_scatter_wide_kernel: inv_bc2 = 1.0f / bc2_sqrt)
+            float *pw = W2s + (4 * r + kt_l) * 8 * W2S_LD + w2_row;
+            f32x4 w = *reinterpret_cast<const f32x4 *>(pw);
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                float mm = m_w2[rr], vv = v_w2[rr];
+                w[rr] = q_adam(w[rr], g_w2[rr], coef, mm, vv, a.beta1, a.beta2, bc2_sqrt, a.eps, lr_step);
+                m_w2[rr] = mm, v_w2[rr] = vv;
+            }
+            *reinterpret_cast<f32x4 *>(pw) = w;
+            q_st4(reg, R_W2Q + ((net * QCU + cu) * QT + tid) * 16, w);
+#pragma unroll
+            for (int u = 0; u < NSM; u++) {
+                float mm = m_sm[u], vv = v_sm[u];
+                const float pn = q_adam(p_sm[u], g_sm[u], coef, mm, vv, a.beta1, a.beta2, bc2_sqrt, a.eps, lr_step);
+                if ((cfg_sm[u] >> 26) & 1) {
+                    p_sm[u] = pn, m_sm[u] = mm, v_sm[u] = vv;
+                    smem[lds_sm[u]] = pn;
+                }
+            }
+        }
+        __syncthreads();
+        QP_TICK(13);
+        if (s + 1 < n_mb) layer1_publish();
+        QP_TICK(14);
+    }
+
+    // ---- epilogue: nothing is committed once any workgroup gave up on a wait (the host re-runs the epoch from its snapshot) ----
+    if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    double stv[5] = {st.a, st.ent, st.kl, (double)st.clip, (double)st.n};
+#pragma unroll
+    for (int qi = 0; qi < 5; qi++)
+        for (int o = 32; o > 0; o >>= 1) stv[qi] += __shfl_down(stv[qi], o, 64);
+    __syncthreads();
+    if (lane == 0)
+        for (int qi = 0; qi < 5; qi++) red[wave * 6 + qi] = stv[qi];
+    __syncthreads();
+    if (c == 0 && tid < 5) {  // (the eight workgroups of a row group computed the same loss rows: slice 0 reports them)
+        double sum = 0.0;
+        for (int w = 0; w < 8; w++) sum += red[w * 6 + tid];
+        // slot layout {policy_loss, value_sq_err, entropy, approx_kl, clipped, n}
+        const int qi = IS_PI ? (tid == 0 ? 0 : tid + 1) : (tid == 0 ? 1 : -1);
+        if (qi >= 0) a.stat_slots[r * 8 + qi] += sum;
+    }
+    {
+        const int kt = 4 * r + kt_l;
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(W2s + kt * 8 * W2S_LD + w2_row);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int e = base + oW2 + (16 * kt + 4 * g + rr) * QH + 32 * c + 16 * jq + r16;
+            a.params[e] = w[rr], a.exp_avg[e] = m_w2[rr], a.exp_avg_sq[e] = v_w2[rr];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NSM; u++) {
+        const int e = tid + QT * u;
+        if (e >= n_small) continue;
+        const SmallMap sm = small_map(e, D, NOUT, c, net);
+        if (r == 0 && (sm.kind != 4 || c == 0)) {
+            a.params[base + sm.nat] = p_sm[u], a.exp_avg[base + sm.nat] = m_sm[u], a.exp_avg_sq[base + sm.nat] = v_sm[u];
+        }
+    }
+    if (IS_PI && cu == 0 && tid == 0) a.norm_out[0] = (double)last_norm, a.norm_out[1] = (double)last_coef;
+}
+
+template <int KT1, int NSM>
+__global__ __launch_bounds__(QT, 2) void ppo_epoch_h256p_kernel(Epoch256Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int role_s;
+    unsigned *sync = reinterpret_cast<unsigned *>(a.region + R_SYNC);
+    if (threadIdx.x == 0) {
+        // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on.  The first claimer of a net fixes the net's XCD.
+        const unsigned myx = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) + 1u;
+        int net = -1;
+        const unsigned old0 = atomicCAS(sync + 32 * SW_CLAIM, 0u, myx);
+        if (old0 == 0u || old0 == myx) net = 0;
+        else {
+            const unsigned old1 = atomicCAS(sync + 32 * (SW_CLAIM + 1), 0u, myx);
+            if (old1 == 0u || old1 == myx) net = 1;
+        }
+        int role = -1;
+        if (net >= 0) {
+            const unsigned slot = atomicAdd(sync + 32 * (SW_ROLES + net), 1u);
+            if (slot < (unsigned)QCU) role = net * QCU + (int)slot;
+        }
+        role_s = role;
+    }
+    __syncthreads();
+    const int role = role_s;
+    if (role < 0) return;
+    if (__hip_atomic_load(sync + 32 * SW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {  // abort word set before the launch (TMA_PERSIST_FORCE_FAIL)
+        if (threadIdx.x == 0) *a.err_out = 1;
+        return;
+    }
+    if (role < QCU) epoch256_body<true, KT1, NSM>(a, role, smem);
+    else epoch256_body<false, KT1, NSM>(a, role - QCU, smem);
+    // a failed wait anywhere: record it (parameters were left untouched by every workgroup that saw the abort)
+    if (threadIdx.x == 0 && __hip_atomic_load(sync + 32 * SW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) *a.err_out = 1;
+}
+
+// (lr / (1 - beta1^t), sqrt(1 - beta2^t)) for t = first_step .. first_step + n - 1 (tma_h64p.hip's table)
+__global__ void adam_table256_kernel(float2 *table, int n, int64_t first_step, double lr, double beta1, double beta2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = (double)(first_step + i);
+    const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+    table[i] = make_float2((float)(lr / bc1), (float)sqrt(bc2));
+}
+
+}  // namespace tma
+
+using namespace tma;
+
+bool tma_epoch_h256p_eligible(const PLayout &L, int64_t batch_size, int64_t total) {
+    const bool off = getenv("TMA_NO_PERSIST") != nullptr || getenv("TMA_NO_PERSIST256") != nullptr;  // (read per call: tests switch paths inside one process)
+    if (off || L.bf16 || L.split || L.fr_pi < 0 || L.H != QH || L.cont || L.A > 16 || L.D > 32 || batch_size != QB) return false;
+    if (total < 2 * batch_size || total % batch_size != 0) return false;
+    const int64_t n_mb = total / batch_size;
+    return n_mb <= 65535 && R_TABLE + n_mb * 8 <= (int64_t)slab_cap(L) * L.P * 4;
+}
+
+int tma_launch_epoch_h256p(float *params, const PLayout &L, const Rollout &R, const HParams &hp, const int32_t *offs, const double *adv_part,
+                           int adv_stride, int64_t total, int64_t batch_size, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr,
+                           double beta1, double beta2, double eps, double max_grad_norm, char *ws, hipStream_t s) {
+    static const int ticks = getenv("TMA_H256P_TICKS") ? 1 : 0;
+    Epoch256Args a;
+    a.params = params, a.exp_avg = exp_avg, a.exp_avg_sq = exp_avg_sq;
+    a.L = L, a.rb = R, a.hp = hp;
+    a.offs = offs, a.adv_part = adv_part, a.adv_stride = adv_stride;
+    a.n_mb = (int)(total / batch_size);
+    a.beta1 = (float)beta1, a.beta2 = (float)beta2, a.eps = (float)eps, a.max_norm = (float)max_grad_norm;
+    a.region = ws + WS_SLABS;
+    a.stat_slots = reinterpret_cast<double *>(ws + WS_STATS);
+    a.norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
+    a.err_out = reinterpret_cast<int *>(ws + WS_PERSIST_ERR);
+    a.ticks = ticks;
+    const int n_small = 32 * L.D + 64 + 32 * (L.A > 1 ? L.A : 1) + (L.A > 1 ? L.A : 1);
+    const int nsm = (n_small + QT - 1) / QT;
+    if (nsm > 4) return TMA_ERR_INVALID;
+    const int smem = L_FLOATS * 4;
+    TMA_HIP(hipMemsetAsync(a.region, 0, R_H1X, s));
+    const char *force_fail = getenv("TMA_PERSIST_FORCE_FAIL");
+    if (force_fail != nullptr && strcmp(force_fail, "late") != 0)  // test hook: the launch finds its abort word set, commits nothing and reports the failure
+        TMA_HIP(hipMemsetAsync(a.region + R_SYNC + 32 * SW_ABORT * 4, 1, 1, s));
+    adam_table256_kernel<<<dim3((unsigned)((a.n_mb + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<float2 *>(a.region + R_TABLE), a.n_mb, first_step, lr,
+                                                                                      beta1, beta2);
+    TMA_LAUNCH_CHECK();
+    auto launch = [&](auto k) -> int {
+        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3(QGRID), dim3(QT), smem, s>>>(a);
+        return TMA_OK;
+    };
+    int rc;
+    const bool kt2 = L.D > 16;
+    if (nsm == 1) rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 1>) : launch(ppo_epoch_h256p_kernel<1, 1>);
+    else if (nsm == 2) rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 2>) : launch(ppo_epoch_h256p_kernel<1, 2>);
+    else rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 4>) : launch(ppo_epoch_h256p_kernel<1, 4>);
+    if (rc) return rc;
+    TMA_LAUNCH_CHECK();
+    return TMA_OK;
+}
+
+// diagnostic: the phase-tick sums role (0, 0, 0) left behind (TMA_H256P_TICKS=1)
+extern "C" int tma_debug_h256p_ticks(void *workspace, unsigned long long *out16) {
+    if (!workspace || !out16) return TMA_ERR_INVALID;
+    TMA_HIP(hipDeviceSynchronize());
+    TMA_HIP(hipMemcpy(out16, static_cast<char *>(workspace) + WS_SLABS + R_TICKS, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    return TMA_OK;
+}

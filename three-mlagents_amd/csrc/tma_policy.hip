@@ -1603,12 +1603,11 @@ __global__ __launch_bounds__(256) void adam_scatter_wide_kernel(float *__restric
     const float gv = (g_e * scale) * coef_s;
     grad[e] = 0.0f;
     float mm = m_e, vv = v_e;
-    mm = mm + (gv - mm) * (1.0f - beta1);
-    vv = vv * beta2 + (gv * gv) * (1.0f - beta2);
+    // (round 6: adam_update_h64 -- hardware sqrt / rcp + explicit FMAs, the H = 64 kernels' routine -- here as well: the 256-wide persistent epoch
+    //  kernel, tma_h256p.hip, runs it on every workgroup each step, and the two paths share one arithmetic)
+    const float pn = adam_update_h64(p_e, gv, mm, vv, beta1, beta2, 1.0f / bc2_sqrt, eps, lr_step);
     m[e] = mm;
     v[e] = vv;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    const float pn = p_e - lr_step * (mm / denom);
     params[e] = pn;
     if (e < L.log_std) scatter_derived_wide(params, L, e, pn);
 }
@@ -1734,7 +1733,9 @@ struct GradTimer {
 static inline int64_t fold_state_offset(const PLayout &L) {
     return (WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8 + dz1_cache_bytes(L) + 15) & ~(int64_t)15;
 }
-static inline int64_t fold_state_bytes(const PLayout &L) { return L.img_pi >= 0 ? 3 * (((int64_t)L.P + 3) & ~(int64_t)3) * 4 : 0; }
+// (also the snapshot the persistent epoch kernels' fallback restores: H = 64 fast-path layouts and the 256-wide layouts tma_h256p.hip takes)
+static inline bool h256p_layout(const PLayout &L) { return !L.bf16 && L.fr_pi >= 0 && L.H == 256 && !L.cont && L.A <= 16 && L.D <= 32; }
+static inline int64_t fold_state_bytes(const PLayout &L) { return (L.img_pi >= 0 || h256p_layout(L)) ? 3 * (((int64_t)L.P + 3) & ~(int64_t)3) * 4 : 0; }
 
 static double *sq_partials(char *ws, const PLayout &L) {
     const int n = (int)ceil_div(L.P, 64);
@@ -2582,8 +2583,11 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         if (rc) return rc;
     }
     const PLayout L = layout_of(d);
-    if (prepared && total % batch_size == 0 && tma_epoch_h64p_eligible(L, batch_size, total)) {
-        // the reference's literal batch_size = 256 on an H = 64 policy: the whole epoch as one persistent launch (tma_h64p.hip)
+    const bool p64 = prepared && total % batch_size == 0 && tma_epoch_h64p_eligible(L, batch_size, total);
+    const bool p256 = !p64 && prepared && h256p_layout(L) && tma_epoch_h256p_eligible(L, batch_size, total);
+    if (p64 || p256) {
+        // the reference's literal batch_size = 256: the whole epoch as one persistent launch (H = 64: tma_h64p.hip; the reference's default
+        // 256 x 256 policy: tma_h256p.hip)
         if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
         char *ws = static_cast<char *>(workspace);
         const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
@@ -2602,20 +2606,20 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
         TMA_HIP(hipMemcpyAsync(snap + Pp, exp_avg, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
         TMA_HIP(hipMemcpyAsync(snap + 2 * Pp, exp_avg_sq, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
         TMA_HIP(hipMemcpyAsync(ws + WS_PERSIST_SNAP, ws + WS_STATS, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
-        rc = tma_launch_epoch_h64p(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
-                                   reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size, exp_avg, exp_avg_sq,
-                                   first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
+        rc = (p64 ? tma_launch_epoch_h64p : tma_launch_epoch_h256p)(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
+                                                                    reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size,
+                                                                    exp_avg, exp_avg_sq, first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
         if (rc) return rc;
-        // The persistent kernel needs eight workgroups resident on one XCD at the same time; a concurrent kernel, a CU mask or a
-        // preempted wave can deny that, in which case it gives up on a bounded wait and commits NOTHING.  Check per epoch (one 4-byte
-        // read-back: the epoch is ~10^5 times longer) and, on failure, run this epoch through the per-minibatch launches below --
-        // training goes on, the event is counted (tma_ppo_persist_fallbacks) and reported once on stderr.
+        // The persistent kernels need their workgroups resident together on one XCD per group (H = 64: eight on one; 256-wide: 32 on each of
+        // two); a concurrent kernel, a CU mask or a preempted wave can deny that, in which case they give up on a bounded wait and commit
+        // NOTHING.  Check per epoch (one 4-byte read-back: the epoch is ~10^5 times longer) and, on failure, run this epoch through the
+        // per-minibatch launches below -- training goes on, the event is counted (tma_ppo_persist_fallbacks) and reported once on stderr.
         int persist_err = 0;
         TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
         TMA_HIP(hipStreamSynchronize((hipStream_t)stream));
         if (const char *ff = getenv("TMA_PERSIST_FORCE_FAIL"))  // test hook "late": the launch ran and committed EVERYTHING, then is declared failed
             if (!strcmp(ff, "late")) persist_err = 1;
-        if (!persist_err) return TMA_OK;
+        if (!persist_err) return p256 ? launch_sync(params, L, ps) : TMA_OK;  // (the 256-wide kernel writes the trainable region; its derived images follow here)
         TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), ps));
         TMA_HIP(hipMemcpyAsync(params, snap, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
         TMA_HIP(hipMemcpyAsync(exp_avg, snap + Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));

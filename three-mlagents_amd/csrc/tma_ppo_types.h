@@ -190,6 +190,12 @@ int tma_launch_epoch_h64p(float *params, const tma::PLayout &L, const tma::Rollo
                           const double *adv_part, int adv_stride, int64_t total, int64_t batch_size, float *exp_avg, float *exp_avg_sq,
                           int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm, char *ws, hipStream_t s);
 
+// tma_h256p.hip: the same for the reference's default 256 x 256 policy (exact f32, Discrete heads, observations <= 32): 2 x 32 workgroups on two XCDs
+bool tma_epoch_h256p_eligible(const tma::PLayout &L, int64_t batch_size, int64_t total);
+int tma_launch_epoch_h256p(float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::HParams &hp, const int32_t *offs,
+                           const double *adv_part, int adv_stride, int64_t total, int64_t batch_size, float *exp_avg, float *exp_avg_sq,
+                           int64_t first_step, double lr, double beta1, double beta2, double eps, double max_grad_norm, char *ws, hipStream_t s);
+
 // tma_bf16.hip: the column-parallel bf16-MFMA gradient kernel (hidden 128 / 192 / 256); `ws` is the update workspace (dz1 cache)
 int tma_launch_grad_wide_bf(const float *params, const tma::PLayout &L, const tma::Rollout &R, const tma::Minibatch &M, const tma::HParams &hpar,
                             const float *ws_adv, float *slabs, double *slots, char *ws, int *n_pi_out, int *n_vf_out, hipStream_t s);
