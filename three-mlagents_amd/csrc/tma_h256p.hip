@@ -65,9 +65,11 @@ constexpr int R_SYNC = 0;           // u32 words, 32 apart (one 128-byte line ea
 constexpr int SW_CLAIM = 0;         // +net: XCD + 1 of the net
 constexpr int SW_ROLES = 2;         // +net: roles taken
 constexpr int SW_ABORT = 4;
-constexpr int SW_X1 = 5;            // +net
-constexpr int SW_X3 = 7;            // +net
-constexpr int SW_X2 = 9;            // +4 net + r
+// arrival FLAGS, not counters: workgroup cu stores its step tag into word cu of its group's line (32 concurrent arrivals on one counter
+// serialise in the L2's atomic unit, ~11 ns each; plain stores to one line do not) and a poll is ONE wave load of the line
+constexpr int SW_X1 = 5;            // +net: 32 words, word cu
+constexpr int SW_X3 = 7;            // +net: 32 words
+constexpr int SW_X2 = 9;            // +4 net + r: 8 words, word c
 constexpr int R_GRAN = 4096;        // 16-byte granules {step tag, -, f64 sum of squares}: [2 parities][64] same-XCD copies, then (+2048) the cross-XCD copies
 constexpr int R_TICKS = 3072;       // u64[32] phase ticks of role (0, 0, 0) (inside the sync page, behind its words)
 constexpr int R_H1X = 8192;                            // [2][32][64][32] f32
@@ -116,19 +118,28 @@ __device__ __forceinline__ void q_st1(__amdgpu_buffer_rsrc_t r, int byte_off, fl
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
 }
 
-// one lane waits until *ctr >= want; false on abort (set by a peer) or after ~2^22 polls
-__device__ __forceinline__ bool q_wait_ge(unsigned *ctr, unsigned want, unsigned *abortw) {
+// Waves 0..NPOLL-1 wait until the n (<= 32) flag words at byte offset `off` of the region all carry `want`: each polls the whole line with one
+// L1-bypassing load, the waves out of step with each other (a poll is an L2 round trip: four pollers quarter the granularity a single one
+// has), and the first to see it complete tells the others through LDS.  false on abort (set by a peer) or after ~2^20 polls of this wave.
+constexpr int NPOLL = 4;
+__device__ __forceinline__ bool q_wait_flags(__amdgpu_buffer_rsrc_t reg, int off, int n, unsigned want, volatile unsigned *lds_seen, unsigned *abortw,
+                                             int lane, int wave) {
     int spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(1);
+    for (int k = 0; k < wave; k++) __builtin_amdgcn_s_sleep(2);
+    for (;;) {
+        if (*lds_seen >= want) return true;
+        const unsigned v = __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(reg, lane < n ? off + 4 * lane : Q_OOB, 0, Q_SC1));
+        if (__builtin_amdgcn_ballot_w64(lane < n && v < want) == 0) {
+            if (lane == 0) *lds_seen = want;
+            return true;
+        }
         spins++;
-        if ((spins & 1023) == 0 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (spins > (1 << 22)) {
+        if ((spins & 255) == 0 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (spins > (1 << 20)) {
             __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
     }
-    return true;
 }
 
 #define QP_TICK(i)                                                                      \
@@ -147,28 +158,22 @@ __device__ __forceinline__ float q_adam(float p, float g, float coef, float &mm,
     return adam_update_h64(p, gv, mm, vv, beta1, beta2, inv_bc2_sqrt, eps, lr_step);
 }
 
-// The small tensors of column slice c as one index space: [W1t[k][n] : 32 D | b1 : 32 | b2 : 32 | W3t[k][a] : 32 NOUT | b3 : NOUT]
+// The small tensors of column slice c.  W1t[:, slice] goes by QUADS: thread 511 - vi (vi < 32 ceil(D / 4)) owns W1t[4 gk .. 4 gk + 3][32 c + nl],
+// nl = vi & 31, gk = vi >> 5 -- the four rows one lane of a producer's dW1 accumulator holds, so a producer's share is ONE 16-byte load.  The
+// rest is one scalar index space: [b1 : 32 | b2 : 32 | W3t[k][a] : 32 NOUT | b3 : NOUT], b1 first (its 32-producer sums then sit in wave 0 only).
 struct SmallMap {
     int lds;      // LDS word of the parameter
     int nat;      // offset from the net's first parameter in PLayout's flat order
     int src;      // byte offset of producer 0's partial inside the region
     int stride;   // bytes between producers
     int np;       // producers (32: the layer-1 gradient is a sum over every workgroup of the net; 4: the slice's row groups)
-    int kind;     // 0 W1, 1 b1, 2 b2, 3 W3, 4 b3, -1 none
+    int kind;     // 1 b1, 2 b2, 3 W3, 4 b3, -1 none
 };
 __device__ __forceinline__ SmallMap small_map(int e, int D, int NOUT, int c, int net) {
     SmallMap m;
     m.kind = -1, m.lds = L_RED, m.nat = 0, m.src = Q_OOB, m.stride = 0, m.np = 0;
     const int oB1 = D * QH, oW2 = oB1 + QH, oB2 = oW2 + QH * QH, oW3 = oB2 + QH, oB3 = oW3 + QH * NOUT;
     int x = e;
-    if (x < 32 * D) {
-        const int k = x >> 5, nl = x & 31, n = 32 * c + nl;
-        m.kind = 0, m.lds = L_W1S + k * W1_LD + nl, m.nat = k * QH + n;
-        m.src = R_GW1 + net * QCU * 32768 + ((((k >> 4) * 16 + (n >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3)) * 4;
-        m.stride = 32768, m.np = 32;
-        return m;
-    }
-    x -= 32 * D;
     if (x < 32) {
         m.kind = 1, m.lds = L_B1 + x, m.nat = oB1 + 32 * c + x;
         m.src = R_GB1 + net * QCU * 1024 + (32 * c + x) * 4, m.stride = 1024, m.np = 32;
@@ -198,24 +203,47 @@ __device__ __forceinline__ SmallMap small_map(int e, int D, int NOUT, int c, int
 }
 
 template <bool IS_PI, int KT1, int NSM>
-__device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, float *smem) {
+__device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, float *smem) {
     __shared__ int ok_s;
     __shared__ double tot_s;
     const PLayout &L = a.L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    // lane-derived indices are RE-DERIVED at every phase (QP_RELANE): held across the step loop, the dozens of lane addresses the phases use would
+    // be hoisted in front of it and pin ~60 registers for the whole epoch (tma_policy.hip's TMA_RELANE)
+    int tid = tid0, lane = tid0 & 63, r16 = lane & 15, g = lane >> 4;
+#ifdef TMA_Q_NORELANE  // A/B switch
+#define QP_RELANE() do { } while (0)
+#else
+#define QP_RELANE()                        \
+    do {                                   \
+        tid = tid0;                        \
+        asm volatile("" : "+v"(tid));      \
+        lane = tid & 63;                   \
+        r16 = lane & 15, g = lane >> 4;    \
+        cu = cu0;                          \
+        asm volatile("" : "+s"(cu));       \
+        r = cu >> 3, c = cu & 7;           \
+    } while (0)
+#endif
     const int D = L.D, A = L.A, NOUT = IS_PI ? A : 1, KS1 = (D + 3) >> 2, NS = (NOUT + 3) >> 2;
-    const int net = IS_PI ? 0 : 1, r = cu >> 3, c = cu & 7;
+    constexpr int net = IS_PI ? 0 : 1;
+    int cu = cu0, r = cu0 >> 3, c = cu0 & 7;  // (wave-uniform; re-derived per phase as well: the region offsets built from them are then recomputed
+                                              //  by a few scalar instructions instead of being held -- and spilled -- across the whole step loop)
     const int t = wave >> 1, j = wave & 1;  // this wave's 16-row tile and 16-column tile of the slice
     const int base = IS_PI ? L.pW1t : L.vW1t;
     const int oW2 = D * QH + QH;
-    const int n_small = 32 * D + 64 + 32 * NOUT + NOUT;
+    const int n_small = 64 + 32 * NOUT + NOUT;  // the scalar index space
+    const int nV = 32 * KS1;                    // W1 quads
     float *W2s = smem + L_W2S, *H1 = smem + L_H1, *H2 = smem + L_H2, *DZ2 = smem + L_DZ2, *Xs = smem + L_X, *DZ3 = smem + L_DZ3;
     float *meta = smem + L_META, *W1s = smem + L_W1S, *b1s = smem + L_B1, *b2s = smem + L_B2, *b3s = smem + L_B3, *W3s = smem + L_W3S;
     int64_t *row_off = reinterpret_cast<int64_t *>(smem + L_ROFF);
     double *red = reinterpret_cast<double *>(smem + L_RED);
     unsigned *sync = reinterpret_cast<unsigned *>(a.region + R_SYNC);
-    unsigned *abortw = sync + 32 * SW_ABORT, *cntX1 = sync + 32 * (SW_X1 + net), *cntX3 = sync + 32 * (SW_X3 + net);
-    unsigned *cntX2 = sync + 32 * (SW_X2 + 4 * net + r);
+    unsigned *abortw = sync + 32 * SW_ABORT;
+    const int offX1 = R_SYNC + 128 * (SW_X1 + net), offX3 = R_SYNC + 128 * (SW_X3 + net), offX2 = R_SYNC + 128 * (SW_X2 + 4 * net + r);
+    __shared__ unsigned seen_s[3];  // last step tag a polling wave saw complete, per exchange
+    if (tid < 3) seen_s[tid] = 0u;
+    if (tid == 0) ok_s = 1;
     const __amdgpu_buffer_rsrc_t reg = q_rsrc(a.region);
     const bool tick_on = a.ticks != 0 && net == 0 && cu == 0 && tid == 0;
     unsigned long long tick_prev = __builtin_amdgcn_s_memtime();
@@ -228,8 +256,8 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
     for (int e = tid; e < QROWS * X_LD; e += QT) Xs[e] = 0.0f;
     __syncthreads();
     // W2t[:, slice c]: thread (kt_l, jq, lane) owns the four parameters k = 16 kt + 4 g + rr, n = 32 c + 16 jq + r16 of every quarter's kt = 4 r' + kt_l
-    const int kt_l = tid >> 7, jq = (tid >> 6) & 1;
-    const int w2_row = ((0 * 2 + jq) * 4 + g) * W2S_LD + r16 * 4;  // + kt * 8 * W2S_LD
+    const int kt_l = wave >> 1, jq = wave & 1;
+#define w2_row ((jq * 4 + g) * W2S_LD + r16 * 4)  /* + kt * 8 * W2S_LD */
     f32x4 m_w2, v_w2;
     {
         const float *gW2 = a.params + base + oW2;
@@ -264,8 +292,26 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         v_sm[u] = live ? a.exp_avg_sq[base + sm.nat] : 0.0f;
         if (live) smem[sm.lds] = p_sm[u];
     }
+    // the W1 quad of thread 511 - vi (rows beyond D: zero parameters, zero gradients -- they stay zero and are never written back)
+    f32x4 p_w1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, m_w1 = p_w1, v_w1 = p_w1;
+    const bool has_v = wave >= 8 - ((nV + 63) >> 6);  // (wave-uniform) this wave holds W1 quads
+    {
+        const int vi = QT - 1 - tid, nl = vi & 31, gk = vi >> 5;
+        if (vi < nV) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = 4 * gk + rr;
+                if (k < D) {
+                    const int e = base + k * QH + 32 * c + nl;
+                    p_w1[rr] = a.params[e], m_w1[rr] = a.exp_avg[e], v_w1[rr] = a.exp_avg_sq[e];
+                    W1s[k * W1_LD + nl] = p_w1[rr];
+                }
+            }
+        }
+    }
     // ---- sample prefetch: thread (row = tid >> 3, sub = tid & 7) ----
-    const int prow = tid >> 3, psub = tid & 7;
+#define prow (tid >> 3)
+#define psub (tid & 7)
     auto off_of = [&](int s) -> int32_t {
         const int sc = s < n_mb ? s : n_mb - 1;
         return a.offs[(int64_t)sc * QB + QROWS * r + prow];
@@ -320,7 +366,8 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
 
     // layer 1 of the slice for the minibatch in Xs -> h1 columns [32 c, 32 c + 32) of H1, then the slice (and, behind a step, the owner's
     // updated W2 quarter, already stored) published: arrival on X1
-    auto layer1_publish = [&]() {
+    auto layer1_publish = [&](unsigned x1_tag) {
+        QP_RELANE();
         {
             const float bv = b1s[16 * j + r16];
             f32x4 acc = f32x4{bv, bv, bv, bv};
@@ -340,19 +387,20 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everything this workgroup publishes is in the L2 before anyone is told
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cntX1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(x1_tag, reg, offX1 + 4 * cu, 0, 0);
     };
-    layer1_publish();
+    layer1_publish(1u);
     QP_TICK(0);
 
     for (int s = 0; s < n_mb; s++) {
         const float2 tbs = tb;
         const float amean_s = amean, astd_s = astd;
         // ---- X1: the net's 32 workgroups have published h1 slices (and W2 quarters) ----
-        if (tid == 0) ok_s = q_wait_ge(cntX1, (unsigned)QCU * (unsigned)(s + 1), abortw) ? 1 : 0;
+        if (wave < NPOLL && !q_wait_flags(reg, offX1, QCU, (unsigned)(s + 1), &seen_s[0], abortw, lane, wave)) ok_s = 0;
         __syncthreads();
         if (!ok_s) return;
         QP_TICK(1);
+        QP_RELANE();
         {
             const int row = tid >> 3, c4 = (tid & 7) * 4;
             f32x4 hv[QC - 1], wq[QR - 1];
@@ -383,6 +431,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(2);
+        QP_RELANE();
         // ---- P2: layer 2 forward on the slice: tile (t, j) ----
         f32x4 h2;
         {
@@ -416,6 +465,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(3);
+        QP_RELANE();
         // ---- P3a: split-K head partial of the slice (32 of the 256 k), tile t on wave (t, 0) ----
         if (j == 0) {
             f32x4 part = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -425,14 +475,13 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(cntX2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_s = q_wait_ge(cntX2, (unsigned)QC * (unsigned)(s + 1), abortw) ? 1 : 0;
-        }
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), reg, offX2 + 4 * c, 0, 0);
+        if (wave < NPOLL && !q_wait_flags(reg, offX2, QC, (unsigned)(s + 1), &seen_s[1], abortw, lane, wave)) ok_s = 0;
         // (the next minibatch's rows: requested here, parked in LDS behind P6)
         __syncthreads();
         if (!ok_s) return;
         QP_TICK(4);
+        QP_RELANE();
         // ---- P3b: head outputs of tile t = b3 + the eight slices' partials in slice order; loss; dz3 ----
         if (IS_PI || j == 0) {
             f32x4 hp8[QC];
@@ -459,6 +508,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(5);
+        QP_RELANE();
         // ---- P4: dW3 of the slice over the 64 rows (waves 0, 1), db3 (wave 2 of slice 0), dz2 = (dz3 . W3^T) * (1 - h2^2) ----
         if (wave < 2) {
             f32x4 acc3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -480,6 +530,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(6);
+        QP_RELANE();
         // ---- P5a: dW2[:, slice] over the 64 rows: wave w the k-tiles 2w, 2w + 1, both column tiles; db2 ----
         {
             f32x4 acc2[2][2];
@@ -512,6 +563,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
             }
         }
         QP_TICK(7);
+        QP_RELANE();
         // ---- P5b: this slice's share of dh1 for tile t, columns [128 j, 128 j + 128): K = the slice's 32 columns ----
         f32x4 dh1[8];
         {
@@ -529,6 +581,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();  // (every wave is done reading h1)
         QP_TICK(8);
+        QP_RELANE();
 #pragma unroll
         for (int nt = 0; nt < 8; nt++)
 #pragma unroll
@@ -538,6 +591,8 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
                 *pp = dh1[nt][rr] * (1.0f - h * h);
             }
         __syncthreads();
+        QP_TICK(15);
+        QP_RELANE();
         // ---- P6: this workgroup's share of the WHOLE layer-1 gradient: wave w the columns [32 w, 32 w + 32) ----
         {
             f32x4 accw[KT1][2];
@@ -569,21 +624,22 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
                 q_st1(reg, R_GB1 + (net * QCU + cu) * 1024 + (32 * wave + 16 + r16) * 4, cb1);
             }
         }
+        QP_TICK(16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         QP_TICK(9);
+        QP_RELANE();
         // ---- X3: the net's partial gradients ----
-        if (tid == 0) {
-            __hip_atomic_fetch_add(cntX3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_s = q_wait_ge(cntX3, (unsigned)QCU * (unsigned)(s + 1), abortw) ? 1 : 0;
-        }
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), reg, offX3 + 4 * cu, 0, 0);
         commit();      // the next minibatch's rows and constants (Xs, meta: dead since P6's barrier)
         fetch(s + 2);  // ... and the one after it into the registers
+        if (wave < NPOLL && !q_wait_flags(reg, offX3, QCU, (unsigned)(s + 1), &seen_s[2], abortw, lane, wave)) ok_s = 0;
         __syncthreads();
         if (!ok_s) return;
         QP_TICK(10);
+        QP_RELANE();
         // ---- reduce what this workgroup owns: quarter r of dW2[:, slice c] over the row groups in order; the slice's small tensors ----
-        f32x4 g_w2;
+        f32x4 g_w2, g_w1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         float g_sm[NSM];
         {
             f32x4 pq[QR];
@@ -591,34 +647,51 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
             for (int rq = 0; rq < QR; rq++)
                 pq[rq] = q_ld4(reg, R_GW2 + ((((net * QCU + rq * QC + c) * 16 + 4 * r + kt_l) * 2 + jq) * 64 + lane) * 16);
             double sq = 0.0;
-            {  // PB partials of every slot per batch of loads (the 32-producer sums take 32 / PB L2 round trips, the others one); producer order
+            // The gradient loads are bound by the NUMBER of wave-level load instructions (each scatters over many lines), not by their
+            // latency: every wave issues only what its lanes need -- 32 producers where it holds layer-1 entries, 4 elsewhere.
+            {
                 float sum[NSM];
 #pragma unroll
-                for (int u = 0; u < NSM; u++) sum[u] = 0.0f;
-                bool any_wide = false;
+                for (int u = 0; u < NSM; u++) {
+                    const int cfg = cfg_sm[u], stride = cfg & 0xFFFFFF;
+                    const bool wide = (cfg >> 24) & 1;
+                    float tv4[4];
 #pragma unroll
-                for (int u = 0; u < NSM; u++) any_wide = any_wide || ((cfg_sm[u] >> 24) & 1);
-                constexpr int PB = NSM <= 2 ? 16 : 8;  // (register budget)
-                const int n_batch = __builtin_amdgcn_ballot_w64(any_wide) != 0 ? 32 / PB : 1;  // (wave-uniform)
-#pragma unroll 1
-                for (int b = 0; b < n_batch; b++) {
-                    float tv[NSM][PB];
+                    for (int p = 0; p < 4; p++) tv4[p] = q_ld1(reg, src_sm[u] + p * stride);  // (dead slots: src beyond the buffer, zeros)
+                    sum[u] = 0.0f;
+                    if (u == 0 && wave == 0) {  // (wave-uniform) b1: the first 32 entries of the scalar space
+                        float tv[28];
 #pragma unroll
-                    for (int u = 0; u < NSM; u++) {
-                        const int cfg = cfg_sm[u], stride = cfg & 0xFFFFFF;
-                        const bool wide = (cfg >> 24) & 1;
+                        for (int p = 0; p < 28; p++) tv[p] = q_ld1(reg, wide ? src_sm[u] + (4 + p) * stride : Q_OOB);
 #pragma unroll
-                        for (int p = 0; p < PB; p++) tv[u][p] = q_ld1(reg, ((b == 0 && p < 4) || wide) ? src_sm[u] + (PB * b + p) * stride : Q_OOB);
+                        for (int p = 0; p < 4; p++) sum[u] += tv4[p];
+#pragma unroll
+                        for (int p = 0; p < 28; p++) sum[u] += tv[p];
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 4; p++) sum[u] += tv4[p];
                     }
-#pragma unroll
-                    for (int u = 0; u < NSM; u++)
-#pragma unroll
-                        for (int p = 0; p < PB; p++) sum[u] += tv[u][p];
                 }
 #pragma unroll
                 for (int u = 0; u < NSM; u++) {
                     g_sm[u] = sum[u];
                     if ((cfg_sm[u] >> 25) & 1) sq += (double)sum[u] * (double)sum[u];
+                }
+            }
+            if (has_v) {  // (wave-uniform) W1 quads: one 16-byte load per producer, two batches of sixteen, producer order
+                const int vi = QT - 1 - tid, nl = vi & 31, gk = vi >> 5, n = 32 * c + nl;
+                const int src = vi < nV ? R_GW1 + net * QCU * 32768 + ((((gk >> 2) * 16 + (n >> 4)) * 64 + (gk & 3) * 16 + (n & 15)) * 16) : Q_OOB;
+#pragma unroll 1
+                for (int b = 0; b < 2; b++) {
+                    f32x4 tq[16];
+#pragma unroll
+                    for (int p = 0; p < 16; p++) tq[p] = q_ld4(reg, vi < nV ? src + (16 * b + p) * 32768 : Q_OOB);
+#pragma unroll
+                    for (int p = 0; p < 16; p++) g_w1 += tq[p];
+                }
+                if (r == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) sq += (double)g_w1[rr] * (double)g_w1[rr];
                 }
             }
             g_w2 = ((pq[0] + pq[1]) + pq[2]) + pq[3];
@@ -629,6 +702,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(11);
+        QP_RELANE();
         // ---- X4: one 16-byte granule {step tag, -, sum of squares} per workgroup, both nets; wave 0 polls the 64 granules, one per lane ----
         if (wave == 0) {
             const unsigned tag = (unsigned)(s + 1);
@@ -673,6 +747,7 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         __syncthreads();
         if (!ok_s) return;
         QP_TICK(12);
+        QP_RELANE();
         // ---- clip coefficient, Adam on the owned W2 quarter and (redundantly in the slice's four workgroups) on the small tensors ----
         {
             const float total_norm = (float)sqrt(tot_s);
@@ -691,6 +766,16 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
             }
             *reinterpret_cast<f32x4 *>(pw) = w;
             q_st4(reg, R_W2Q + ((net * QCU + cu) * QT + tid) * 16, w);
+            if (has_v) {
+                const int vi = QT - 1 - tid, nl = vi & 31, gk = vi >> 5;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    float mm = m_w1[rr], vv = v_w1[rr];
+                    p_w1[rr] = q_adam(p_w1[rr], g_w1[rr], coef, mm, vv, a.beta1, a.beta2, bc2_sqrt, a.eps, lr_step);
+                    m_w1[rr] = mm, v_w1[rr] = vv;
+                    if (vi < nV) W1s[(4 * gk + rr) * W1_LD + nl] = p_w1[rr];  // (rows 4 gk + rr < 32: the array's zero rows beyond D get their zeros back)
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NSM; u++) {
                 float mm = m_sm[u], vv = v_sm[u];
@@ -703,7 +788,8 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         }
         __syncthreads();
         QP_TICK(13);
-        if (s + 1 < n_mb) layer1_publish();
+        QP_RELANE();
+        if (s + 1 < n_mb) layer1_publish((unsigned)(s + 2));
         QP_TICK(14);
     }
 
@@ -731,6 +817,19 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu, flo
         for (int rr = 0; rr < 4; rr++) {
             const int e = base + oW2 + (16 * kt + 4 * g + rr) * QH + 32 * c + 16 * jq + r16;
             a.params[e] = w[rr], a.exp_avg[e] = m_w2[rr], a.exp_avg_sq[e] = v_w2[rr];
+        }
+    }
+    if (r == 0) {
+        const int vi = QT - 1 - tid, nl = vi & 31, gk = vi >> 5;
+        if (vi < nV) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = 4 * gk + rr;
+                if (k < D) {
+                    const int e = base + k * QH + 32 * c + nl;
+                    a.params[e] = p_w1[rr], a.exp_avg[e] = m_w1[rr], a.exp_avg_sq[e] = v_w1[rr];
+                }
+            }
         }
     }
 #pragma unroll
@@ -789,6 +888,10 @@ __global__ void adam_table256_kernel(float2 *table, int n, int64_t first_step, d
     table[i] = make_float2((float)(lr / bc1), (float)sqrt(bc2));
 }
 
+#undef w2_row
+#undef prow
+#undef psub
+#undef QP_RELANE
 }  // namespace tma
 
 using namespace tma;
@@ -816,9 +919,9 @@ int tma_launch_epoch_h256p(float *params, const PLayout &L, const Rollout &R, co
     a.norm_out = reinterpret_cast<double *>(ws + WS_NORM_OUT);
     a.err_out = reinterpret_cast<int *>(ws + WS_PERSIST_ERR);
     a.ticks = ticks;
-    const int n_small = 32 * L.D + 64 + 32 * (L.A > 1 ? L.A : 1) + (L.A > 1 ? L.A : 1);
+    const int n_small = 64 + 33 * (L.A > 1 ? L.A : 1);  // scalar small-tensor entries of a slice (b1, b2, W3, b3): <= 592
     const int nsm = (n_small + QT - 1) / QT;
-    if (nsm > 4) return TMA_ERR_INVALID;
+    if (nsm > 2) return TMA_ERR_INVALID;
     const int smem = L_FLOATS * 4;
     TMA_HIP(hipMemsetAsync(a.region, 0, R_H1X, s));
     const char *force_fail = getenv("TMA_PERSIST_FORCE_FAIL");
@@ -835,17 +938,16 @@ int tma_launch_epoch_h256p(float *params, const PLayout &L, const Rollout &R, co
     int rc;
     const bool kt2 = L.D > 16;
     if (nsm == 1) rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 1>) : launch(ppo_epoch_h256p_kernel<1, 1>);
-    else if (nsm == 2) rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 2>) : launch(ppo_epoch_h256p_kernel<1, 2>);
-    else rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 4>) : launch(ppo_epoch_h256p_kernel<1, 4>);
+    else rc = kt2 ? launch(ppo_epoch_h256p_kernel<2, 2>) : launch(ppo_epoch_h256p_kernel<1, 2>);
     if (rc) return rc;
     TMA_LAUNCH_CHECK();
     return TMA_OK;
 }
 
 // diagnostic: the phase-tick sums role (0, 0, 0) left behind (TMA_H256P_TICKS=1)
-extern "C" int tma_debug_h256p_ticks(void *workspace, unsigned long long *out16) {
-    if (!workspace || !out16) return TMA_ERR_INVALID;
+extern "C" int tma_debug_h256p_ticks(void *workspace, unsigned long long *out24) {
+    if (!workspace || !out24) return TMA_ERR_INVALID;
     TMA_HIP(hipDeviceSynchronize());
-    TMA_HIP(hipMemcpy(out16, static_cast<char *>(workspace) + WS_SLABS + R_TICKS, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    TMA_HIP(hipMemcpy(out24, static_cast<char *>(workspace) + WS_SLABS + R_TICKS, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost));
     return TMA_OK;
 }
