@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define TMA_VERSION 207
+#define TMA_VERSION 208
 
 enum { TMA_OK = 0, TMA_ERR_INVALID = 1, TMA_ERR_UNKNOWN_TASK = 2, TMA_ERR_HIP = 3 };
 
@@ -80,10 +80,11 @@ int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tap
                  double *ep_ret_out, int32_t *ep_len_out, void *stream);
 /* Seam S1 (backend/mlagents/envs.py:125-152): the reference's single env returns `float(reward)` of the value the task computed in float64
  * (Basic 0.09000000000000001, Bicycle / BrickBreak / Glider rewards out of float64 physics); `rew_out` carries its float32 rounding, which is
- * what SB3's VecEnv keeps.  tma_env_set_reward64(env, plane): every tma_env_step launched afterwards ALSO stores the float64 reward at
- * plane[k * num_envs + i] (device memory owned by the caller, n_steps * num_envs doubles); NULL turns it off.  The fused rollout kernels
- * (tma_rollout_collect) do not write it: they replace SB3's float32 buffer, not the Gymnasium single-env surface. */
-int tma_env_set_reward64(tma_env *env, double *plane);
+ * what SB3's VecEnv keeps.  tma_env_set_reward64(env, plane, capacity): every tma_env_step launched afterwards ALSO stores the float64 reward
+ * at plane[k * num_envs + i] (device memory owned by the caller, `capacity` doubles >= num_envs; a step call with n_steps * num_envs beyond it
+ * is refused with TMA_ERR_INVALID); NULL turns it off -- the caller does that before it frees the plane.  The fused rollout kernels
+ * (tma_rollout_collect) do not write it: they replace SB3's float32 buffer, not the Gymnasium single-env surface.  (ABI 208: the capacity.) */
+int tma_env_set_reward64(tma_env *env, double *plane, int64_t capacity);
 /* `reps` consecutive single-step launches with the same action buffer and output planes, issued from native code with no
  * host-language round trip in between (launch-latency measurements; semantics = calling tma_env_step `reps` times) */
 int tma_env_step_repeat(tma_env *h, const void *actions, int action_dtype, int reps, float *obs_out, float *rew_out, uint8_t *term_out,
@@ -303,9 +304,11 @@ int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out,
  *      rank order -- the same order on every rank, so replicas stay bit-identical; no fence and no ordering between words is assumed
  *      (csrc/tma_p2p.h has the protocol and why two slot parities suffice).
  * Set-up: tma_comm_p2p_prepare(comm, max_words, ticket_out[128]) allocates the inbox (slots of max_words 8-byte words; an f32 element is one
- * word, an f64 element two) and writes a 128-byte ticket (the inbox's IPC handle + the PCI bus id of its device); the caller gathers the
+ * word, an f64 element two) and writes a 128-byte ticket (the inbox's IPC handle, the PCI bus id of its device, a 64-bit identity of the host); the caller gathers the
  * `world` tickets over the channel it already has (rank order) and gives them to tma_comm_p2p_attach, which refuses (TMA_ERR_HIP, nothing
- * mapped) unless every peer's device is this rank's own or a visible one with peer access (switched on there);
+ * mapped) unless every peer runs on THIS host and its device is this rank's own or a visible one with peer access (switched on there).  A
+ * receiver that does not get its words within the timeout raises the communicator's error flag and delivers NaN (never a sum of stale
+ * words); every later exchange then fails at once (tma_comm_p2p_status.timed_out, checked by the caller behind its stream synchronisation);
  * tma_comm_p2p_enable(comm, 1) then routes every tma_comm_allreduce /
  * tma_comm_allreduce_cb whose message fits a slot through the exchange (larger ones keep RCCL), and tma_ppo_train_epoch_dp -- given
  * tma_comm_allreduce_cb and such a communicator -- FUSES it on its H = 64 path: the slab reduction stores the reduced gradient into the

@@ -170,8 +170,8 @@ def _worker(rank, world, port, q, task, hidden, mfma, N, T, p2p=False):
     td.destroy_process_group()
 
 
-def _run_two_ranks(task, hidden, mfma, N, T, p2p=False):
-    world, port = 2, _free_port()
+def _run_two_ranks(task, hidden, mfma, N, T, p2p=False, world=2):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, task, hidden, mfma, N, T, p2p)) for r in range(world)]
@@ -213,18 +213,28 @@ def test_two_ranks_one_gpu_replicas_stay_identical(task, hidden, mfma, N, T):
     assert not np.array_equal(solo.policy.params[: solo.policy.n_trainable].cpu().numpy(), p0)
 
 
-@pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_peer_exchange_equals_the_gloo_collectives():
-    """The peer exchange (include/tma.h tma_comm_p2p_*) carrying EVERY collective of a two-rank run -- both ranks on this one GPU, their inboxes
-    mapped into each other through HIP IPC handles, the gradient sum fused into slab_reduce_kernel (stores into both inboxes) and the
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_two_ranks_one_gpu_peer_exchange_equals_the_gloo_collectives(world):
+    """The peer exchange (include/tma.h tma_comm_p2p_*) carrying EVERY collective of a `world`-rank run -- all ranks on this one GPU, their
+    inboxes mapped into each other through HIP IPC handles, the gradient sum fused into slab_reduce_kernel (stores into every inbox) and the
     sum-of-squares pass (reads its own inbox), the f64 advantage sums through the stand-alone push / pull kernels -- against the same run over
-    gloo: at two ranks a + b is the same float whichever side adds, so parameters and advantage sums must agree bit for bit."""
+    gloo.  At two ranks a + b is the same float whichever side adds, so parameters and advantage sums agree bit for bit; at 4 and 8 ranks
+    (P2P_MAX_WORLD: the world sizes a node runs at) the exchange adds in rank order and gloo in its own, so the replicas of each run are held
+    to be bit-identical among themselves and the two runs to agree to rounding (2e-6 after the run's 8 optimizer steps)."""
     if os.environ.get("TMA_NO_NATIVE_RCCL"):
         pytest.skip("TMA_NO_NATIVE_RCCL keeps every collective on the torch.distributed callback: no native communicator to carry the exchange")
-    a = _run_two_ranks("gridworld", 64, "f32", 256, 64, p2p=True)
-    b = _run_two_ranks("gridworld", 64, "f32", 256, 64, p2p=False)
-    assert np.array_equal(a[0][1], a[1][1])  # replicas identical
-    assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[0][4], b[0][4])  # and identical to the run over gloo
+    N, T = (256, 64) if world == 2 else (128, 64)
+    a = _run_two_ranks("gridworld", 64, "f32", N, T, p2p=True, world=world)
+    b = _run_two_ranks("gridworld", 64, "f32", N, T, p2p=False, world=world)
+    for r in range(1, world):
+        assert np.array_equal(a[0][1], a[r][1]) and np.array_equal(b[0][1], b[r][1])  # replicas identical, every rank
+        assert np.array_equal(a[0][4], a[r][4])
+    if world == 2:
+        assert np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[0][4], b[0][4])  # and identical to the run over gloo
+    else:
+        assert np.allclose(a[0][1], b[0][1], rtol=0, atol=2e-6), float(np.abs(a[0][1] - b[0][1]).max())
+        assert np.allclose(a[0][4], b[0][4], rtol=1e-12, atol=1e-9)
 
 
 def _p2p_raw_worker(rank, world, port, q, mode):
@@ -300,8 +310,8 @@ def _p2p_raw_worker(rank, world, port, q, mode):
     td.destroy_process_group()
 
 
-def _run_p2p_raw(mode):
-    world, port = 2, _free_port()
+def _run_p2p_raw(mode, world=2):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_p2p_raw_worker, args=(r, world, port, q, mode)) for r in range(world)]
@@ -314,12 +324,14 @@ def _run_p2p_raw(mode):
     return res
 
 
-@pytest.mark.timeout(400)
-def test_peer_exchange_sums_in_rank_order_under_skew():
-    """300 consecutive all-reduces of random lengths (f32 and f64) between two processes on this GPU, most of them without a host
-    synchronisation in between and with one rank arriving late every few calls: every checked result equals the rank-ordered sum bit for bit."""
-    res = _run_p2p_raw("sums")
-    for r in (0, 1):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_exchange_sums_in_rank_order_under_skew(world):
+    """300 consecutive all-reduces of random lengths (f32 and f64) between `world` processes on this GPU (2, 4 and P2P_MAX_WORLD = 8: the
+    two-parity argument and the rank-ordered sums at the world sizes a node runs at), most of them without a host synchronisation in between
+    and with one rank arriving late every few calls: every checked result equals the rank-ordered sum bit for bit."""
+    res = _run_p2p_raw("sums", world)
+    for r in range(world):
         assert res[r]["ok"] and res[r]["calls"] == res[r]["n"] == 300 and not res[r]["timed_out"], res
 
 
@@ -418,9 +430,9 @@ def test_bench_gpus_2_fails_cleanly_on_a_one_gpu_box():
     assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("p2p", [False, True])
-def test_bench_two_ranks_end_to_end_on_one_gpu(p2p):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("p2p,gpus", [(False, 2), (True, 2), (False, 8), (True, 8)])
+def test_bench_two_ranks_end_to_end_on_one_gpu(p2p, gpus):
     """The whole `bench.py --gpus 2` rank program (barriers, max-over-ranks timing, sharded envs, advantage-sum and gradient all-reduces,
     rank-0-only roofline legs and JSON line) under torch.distributed.run with two ranks -- on this one-GPU box over gloo with both ranks on
     device 0 (test hooks TMA_DIST_BACKEND / TMA_BENCH_ONE_DEVICE); on a multi-GPU node the same program runs one rank per GPU over RCCL."""
@@ -434,19 +446,21 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(p2p):
         env["TMA_P2P"] = "1"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-envs", "512", "--n-steps", "64", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
+    # (gpus = 8: the driver's `--gpus 8` rank program, one JSON line with n_gpus 8 and a dp_timing object -- the first real 8-GPU run must not
+    #  fail on plumbing)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--n-envs", "512", "--n-steps", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=860, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512 and d["value"] > 0
-    assert d["value"] == pytest.approx(2 * 512 * 64 / (d["ms_per_step"] * 1e-3), rel=1e-6)  # whole-job env-steps of both ranks / max-over-ranks time
+    assert d["n_gpus"] == gpus and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 512 and d["value"] > 0
+    assert d["value"] == pytest.approx(gpus * 512 * 64 / (d["ms_per_step"] * 1e-3), rel=1e-6)  # whole-job env-steps of all ranks / max-over-ranks time
     assert "roofline" in d and "cpu_baseline" not in d and "extra_configs" not in d  # CPU baseline and extras are N = 1 legs
     # what the first real multi-GPU run will be read by: per-collective timings and every rank's own rollout / update split
     t = d["dp_timing"]
-    assert t["backend"] == "gloo" and len(t["per_rank_rollout_ms"]) == len(t["per_rank_update_ms"]) == 2
+    assert t["backend"] == "gloo" and len(t["per_rank_rollout_ms"]) == len(t["per_rank_update_ms"]) == gpus
     assert t["grad_allreduces_per_iteration"] == 10 * 32 and t["adv_sums_allreduces_per_iteration"] == 10
     assert t["grad_allreduce"]["calls_timed"] == 64 and t["grad_allreduce"]["median_us"] > 0 and t["grad_allreduce"]["bytes"] == 9350 * 4
     if p2p:

@@ -153,7 +153,7 @@ def test_reward64_plane_matches_the_reference_float64_rewards(golden, task):
     n, T, base = [int(x) for x in g["meta"][:3]]
     eng = _engine(task, n, seed=base, ring_depth=8)
     plane = torch.full((1, n), float("nan"), dtype=torch.float64, device="cuda")
-    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, C.c_void_p(plane.data_ptr())))
+    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, C.c_void_p(plane.data_ptr()), plane.numel()))
     eng.reset()
     actions = torch.from_numpy(g["actions"]).cuda()
     inexact, worst = 0, 0.0
@@ -175,7 +175,7 @@ def test_reward64_plane_matches_the_reference_float64_rewards(golden, task):
     print(f"[{task}] float64 rewards not bit-identical to the reference: {inexact} of {n * T}, largest difference {worst:.3e}")
     # (no bound on the COUNT: once a trajectory has picked up one last-bit difference every later reward of that env carries it --
     #  glider: 17 595 of 41 600 -- the bound that matters is the size of the difference, asserted per step above)
-    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, None))
+    _lib.check(_lib.lib().tma_env_set_reward64(eng._h, None, 0))
     plane.fill_(7.0)
     eng.step(actions[0])
     assert bool((plane == 7.0).all())  # NULL turns it off

@@ -56,7 +56,7 @@ SIGNATURES = {
     "tma_env_create": (_i32, [_i32, _i64, _i32, _u32, _u32, _i32, C.POINTER(_vp)]),
     "tma_env_destroy": (_i32, [_vp]),
     "tma_env_seed": (_i32, [_vp, _u32]),
-    "tma_env_set_reward64": (_i32, [_vp, _vp]),
+    "tma_env_set_reward64": (_i32, [_vp, _vp, _i64]),
     "tma_env_reset": (_i32, [_vp, _vp, _vp]),
     "tma_env_step": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tma_env_step_repeat": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -20,6 +20,8 @@
 #include "tma_common.h"
 #include "tma_p2p.h"
 
+#include <unistd.h>
+
 namespace {
 
 typedef struct ncclComm *ncclComm_t;
@@ -113,8 +115,10 @@ __global__ __launch_bounds__(256) void p2p_pull_f64_kernel(double *__restrict__ 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     unsigned long long lo[P2P_MAX_WORLD], hi[P2P_MAX_WORLD];
-    p2p_wait(q, 2 * i, lo);
-    p2p_wait(q, 2 * i + 1, hi);
+    if (!p2p_wait(q, 2 * i, lo) || !p2p_wait(q, 2 * i + 1, hi)) {  // timed out: NaN, never a sum of stale words (p2p_pull_f32)
+        dst[i] = __longlong_as_double(0x7FF8000000000000LL);
+        return;
+    }
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < P2P_MAX_WORLD; r++) {
@@ -131,7 +135,7 @@ bool tma_comm_p2p_ready(const tma_comm *c, int64_t count_words) { return c && c-
 int tma_comm_p2p_next(tma_comm *c, int64_t count_words, PeerPush *push, PeerPull *pull) {
     if (!tma_comm_p2p_ready(c, count_words)) return fail(TMA_ERR_INVALID, "peer exchange: not attached / enabled, or %lld words exceed the slot", (long long)count_words);
     if (*c->err_host) return fail(TMA_ERR_HIP, "peer exchange: an earlier all-reduce timed out waiting for a peer's words (rank %d of %d)", c->rank, c->world);
-    if (++c->seq == 0) c->seq = 1;  // (0 is the sequence number of a word nobody wrote yet)
+    if (++c->seq == 0) c->seq = 2;  // (0 is the sequence number of a word nobody wrote yet; 0xFFFFFFFF was odd, so the wrap lands on an EVEN number: the two-parity argument holds across it)
     const int64_t parity = c->seq & 1;
     *push = PeerPush{};
     for (int d = 0; d < c->world; d++) push->dst[d] = c->peer[d] + (parity * c->world + c->rank) * c->cap;
@@ -310,6 +314,22 @@ int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out) {
     return TMA_OK;
 }
 
+// 64-bit identity of THIS host for the ticket: the kernel's boot id (unique per boot of a machine), else the host name.  Two ranks on different
+// machines can see equal PCI bus ids; an IPC handle of another host must be refused by name, not by what hipIpcOpenMemHandle makes of it.
+static unsigned long long p2p_host_id() {
+    char buf[256] = {0};
+    FILE *f = fopen("/proc/sys/kernel/random/boot_id", "r");
+    size_t n = 0;
+    if (f) {
+        n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+    }
+    if (n == 0 && gethostname(buf, sizeof(buf) - 1) != 0) snprintf(buf, sizeof(buf), "unknown-host");
+    unsigned long long h = 1469598103934665603ull;  // FNV-1a
+    for (const char *q = buf; *q; q++) h = (h ^ (unsigned char)*q) * 1099511628211ull;
+    return h ? h : 1ull;
+}
+
 int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *ticket_out128) {
     if (!c || !ticket_out128 || max_words < 1) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: bad argument");
     if (c->world > tma::P2P_MAX_WORLD) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_prepare: the peer exchange serves at most %d ranks (world %d)", tma::P2P_MAX_WORLD, c->world);
@@ -347,7 +367,11 @@ int tma_comm_p2p_prepare(tma_comm *c, int64_t max_words, unsigned char *ticket_o
     if (c->world > 1) memcpy(ticket_out128, &h, 64);
     int dev = 0;
     e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetPCIBusId(reinterpret_cast<char *>(ticket_out128) + 64, 63, dev);
+    if (e == hipSuccess) e = hipDeviceGetPCIBusId(reinterpret_cast<char *>(ticket_out128) + 64, 47, dev);
+    {  // bytes [112, 120): the host identity (bus ids are ~13 characters; the string stays NUL-terminated in front of it)
+        const unsigned long long hid = p2p_host_id();
+        memcpy(ticket_out128 + 112, &hid, 8);
+    }
     if (e != hipSuccess) {
         p2p_release(c);
         return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_prepare: %s", hipGetErrorString(e));
@@ -371,7 +395,11 @@ int tma_comm_p2p_attach(tma_comm *c, const unsigned char *tickets) {
     for (int r = 0; r < c->world; r++) {
         if (r == c->rank) continue;
         char bus[64] = {0};
-        memcpy(bus, tickets + 128 * (size_t)r + 64, 63);
+        memcpy(bus, tickets + 128 * (size_t)r + 64, 47);
+        unsigned long long hid = 0;
+        memcpy(&hid, tickets + 128 * (size_t)r + 112, 8);
+        if (hid != p2p_host_id())
+            return tma::fail(TMA_ERR_HIP, "tma_comm_p2p_attach: rank %d runs on another host (the peer exchange is one node's xGMI; its bus id %s means nothing here)", r, bus);
         if (strcmp(bus, mybus) == 0) continue;
         int pdev = -1, can = 0;
         if (hipDeviceGetByPCIBusId(&pdev, bus) != hipSuccess || pdev < 0) {

@@ -663,9 +663,11 @@ int tma_env_set_option(tma_env *h, const char *key, int64_t value) {
     return fail(TMA_ERR_INVALID, "unknown option '%s'", key);
 }
 
-int tma_env_set_reward64(tma_env *h, double *plane) {
+int tma_env_set_reward64(tma_env *h, double *plane, int64_t capacity) {
     if (!h) return fail(TMA_ERR_INVALID, "null env handle");
+    if (plane && capacity < h->v.N) return fail(TMA_ERR_INVALID, "tma_env_set_reward64: a plane of %lld doubles cannot hold one step of %lld envs", (long long)capacity, (long long)h->v.N);
     h->rew64_out = plane;
+    h->rew64_cap = plane ? capacity : 0;
     return TMA_OK;
 }
 
@@ -712,6 +714,8 @@ int tma_env_step(tma_env *h, const void *actions, int action_dtype, uint32_t tap
     if (!h->is_reset) return fail(TMA_ERR_INVALID, "tma_env_step before tma_env_reset");
     if (!obs_out) return fail(TMA_ERR_INVALID, "tma_env_step: obs_out is null");
     if (n_steps < 1) return fail(TMA_ERR_INVALID, "n_steps must be >= 1 (got %d)", n_steps);
+    if (h->rew64_out && (int64_t)n_steps * h->v.N > h->rew64_cap)  // (tma_env_set_reward64: the kernel writes plane[k * N + i] for every step k)
+        return fail(TMA_ERR_INVALID, "n_steps=%d x %lld envs exceed the registered float64 reward plane (%lld doubles)", n_steps, (long long)h->v.N, (long long)h->rew64_cap);
     const TaskMeta &m = kMeta[h->task];
     if (m.uses_mt && h->steps_since_refill + n_steps > h->v.D)
         return fail(TMA_ERR_INVALID, "n_steps=%d exceeds the %d steps left before a reset-ring refill is due", n_steps,

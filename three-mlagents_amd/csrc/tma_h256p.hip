@@ -469,8 +469,12 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
         // ---- P3a: split-K head partial of the slice (32 of the 256 k), tile t on wave (t, 0) ----
         if (j == 0) {
             f32x4 part = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float ha[8], wb[8];  // (all sixteen LDS reads in flight, then the MFMA chain)
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) part = mfma16(H2[(16 * t + r16) * H2_LD + 4 * ks + g], W3s[(4 * ks + g) * 16 + r16], part);
+            for (int ks = 0; ks < 8; ks++) ha[ks] = H2[(16 * t + r16) * H2_LD + 4 * ks + g], wb[ks] = W3s[(4 * ks + g) * 16 + r16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) part = mfma16(ha[ks], wb[ks], part);
             q_st4(reg, R_HP + (((net * QCU + cu) * 4 + t) * 64 + lane) * 16, part);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -512,8 +516,12 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
         // ---- P4: dW3 of the slice over the 64 rows (waves 0, 1), db3 (wave 2 of slice 0), dz2 = (dz3 . W3^T) * (1 - h2^2) ----
         if (wave < 2) {
             f32x4 acc3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float ha[16], zb[16];
 #pragma unroll
-            for (int sx = 0; sx < 16; sx++) acc3 = mfma16(H2[(4 * sx + g) * H2_LD + 16 * wave + r16], DZ3[(4 * sx + g) * DZ3_LD + r16], acc3);
+            for (int sx = 0; sx < 16; sx++) ha[sx] = H2[(4 * sx + g) * H2_LD + 16 * wave + r16], zb[sx] = DZ3[(4 * sx + g) * DZ3_LD + r16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 16; sx++) acc3 = mfma16(ha[sx], zb[sx], acc3);
             q_st4(reg, R_GSM + (net * QCU + cu) * GSM_F * 4 + (48 + (wave * 64 + lane) * 4) * 4, acc3);
         } else if (wave == 2 && c == 0) {
             float cb = 0.0f;
@@ -582,14 +590,19 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
         __syncthreads();  // (every wave is done reading h1)
         QP_TICK(8);
         QP_RELANE();
+        {  // dz1 = dh1 * (1 - h1^2) in place: all 32 reads of this lane in flight, then the 32 writes (element by element an LDS round trip each)
+            float *pp = H1 + (16 * t + 4 * g) * H1_LD + 128 * j + r16;
+            float hv1[8][4];
 #pragma unroll
-        for (int nt = 0; nt < 8; nt++)
+            for (int nt = 0; nt < 8; nt++)
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                float *pp = H1 + (16 * t + 4 * g + rr) * H1_LD + 16 * (8 * j + nt) + r16;
-                const float h = *pp;
-                *pp = dh1[nt][rr] * (1.0f - h * h);
-            }
+                for (int rr = 0; rr < 4; rr++) hv1[nt][rr] = pp[rr * H1_LD + 16 * nt];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) pp[rr * H1_LD + 16 * nt] = dh1[nt][rr] * (1.0f - hv1[nt][rr] * hv1[nt][rr]);
+        }
         __syncthreads();
         QP_TICK(15);
         QP_RELANE();
@@ -600,16 +613,26 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
             for (int k1 = 0; k1 < KT1; k1++) accw[k1][0] = accw[k1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             float cb0 = 0.0f, cb1 = 0.0f;
             const float *pb = H1 + g * H1_LD + 32 * wave + r16, *px = Xs + g * X_LD + r16;
+            // eight sample k-steps per batch: their LDS reads in flight together (two MFMAs per k-step do not cover an LDS round trip)
 #pragma unroll
-            for (int sx = 0; sx < 16; sx++) {
-                const float b0 = pb[4 * sx * H1_LD], b1 = pb[4 * sx * H1_LD + 16];
+            for (int s0 = 0; s0 < 16; s0 += 8) {
+                float b0[8], b1[8], av[KT1][8];
 #pragma unroll
-                for (int k1 = 0; k1 < KT1; k1++) {
-                    const float av = px[4 * sx * X_LD + 16 * k1];
-                    accw[k1][0] = mfma16(av, b0, accw[k1][0]);
-                    accw[k1][1] = mfma16(av, b1, accw[k1][1]);
+                for (int u = 0; u < 8; u++) {
+                    b0[u] = pb[4 * (s0 + u) * H1_LD], b1[u] = pb[4 * (s0 + u) * H1_LD + 16];
+#pragma unroll
+                    for (int k1 = 0; k1 < KT1; k1++) av[k1][u] = px[4 * (s0 + u) * X_LD + 16 * k1];
                 }
-                cb0 += b0, cb1 += b1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int k1 = 0; k1 < KT1; k1++) {
+                        accw[k1][0] = mfma16(av[k1][u], b0[u], accw[k1][0]);
+                        accw[k1][1] = mfma16(av[k1][u], b1[u], accw[k1][1]);
+                    }
+                    cb0 += b0[u], cb1 += b1[u];
+                }
             }
 #pragma unroll
             for (int k1 = 0; k1 < KT1; k1++)

@@ -82,6 +82,7 @@ struct tma_env {
     unsigned long long *d_log_n = nullptr;
     bool detached = false;  // the detached set holds data that has not been popped yet
     double *rew64_out = nullptr;  // tma_env_set_reward64: caller-owned [n_steps][N] plane tma_env_step also writes the f64 reward into
+    int64_t rew64_cap = 0;        // ... and the doubles it holds (a step call that would write beyond it is refused)
     // side stream + events of the policy-only fused rollout (tma_rollout_collect): the batched value / bootstrap launches of chunk c run beside
     // the chunk kernel of chunk c + 1
     hipStream_t side = nullptr;

@@ -46,7 +46,9 @@ __device__ __forceinline__ void p2p_push(const PeerPush &p, int64_t i, uint32_t 
     for (int d = 0; d < p.world; d++) __hip_atomic_store(p.dst[d] + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// the `world` words of element i, all loads of a round in flight together; false after a timeout (the words are then whatever was there)
+// the `world` words of element i, all loads of a round in flight together.  false after a timeout -- or AT ONCE when the communicator's error
+// flag is already up (an earlier pull of this or any queued exchange gave up: the ~320 exchanges a learn() iteration has queued then drain
+// in microseconds instead of spinning a timeout each); the words are then whatever was there and the caller must not use them.
 __device__ __forceinline__ bool p2p_wait(const PeerPull &q, int64_t i, unsigned long long (&w)[P2P_MAX_WORLD]) {
     long long t0 = 0;
     for (int round = 0;; round++) {
@@ -59,19 +61,25 @@ __device__ __forceinline__ bool p2p_wait(const PeerPull &q, int64_t i, unsigned 
             }
         }
         if (ok) return true;
-        if (round == 0) t0 = (long long)wall_clock64();
-        else if ((round & 63) == 0 && (long long)wall_clock64() - t0 > q.timeout) {
-            __hip_atomic_store(q.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
+        if (round == 0) {
+            if (__hip_atomic_load(q.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+            t0 = (long long)wall_clock64();
+        } else if ((round & 63) == 0) {
+            if (__hip_atomic_load(q.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+            if ((long long)wall_clock64() - t0 > q.timeout) {
+                __hip_atomic_store(q.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
         }
         __builtin_amdgcn_s_sleep(1);
     }
 }
 
-// sum over the ranks in rank order (world 1: the rank's own value, bit for bit)
+// sum over the ranks in rank order (world 1: the rank's own value, bit for bit).  After a timeout the result is NaN: the optimizer step
+// that consumes it turns every parameter into NaN, which no later check can miss -- a sum of stale words would train on silently.
 __device__ __forceinline__ float p2p_pull_f32(const PeerPull &q, int64_t i) {
     unsigned long long w[P2P_MAX_WORLD];
-    p2p_wait(q, i, w);
+    if (!p2p_wait(q, i, w)) return __uint_as_float(0x7FC00000u);
     float s = __uint_as_float((uint32_t)w[0]);
 #pragma unroll
     for (int r = 1; r < P2P_MAX_WORLD; r++)

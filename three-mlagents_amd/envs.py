@@ -74,7 +74,7 @@ class HipSingleEnv:
         # float64 reward of the last step, written by the step kernel beside its float32 rounding (include/tma.h tma_env_set_reward64): what
         # the reference's env.step hands back for the float64-physics tasks (Bicycle / BrickBreak / Glider), whose rewards are no finite set
         self._rew64 = torch.zeros((1, 1), dtype=torch.float64, device=self.engine.device)
-        _lib.check(_lib.lib().tma_env_set_reward64(self.engine._h, _lib.ptr(self._rew64)))
+        _lib.check(_lib.lib().tma_env_set_reward64(self.engine._h, _lib.ptr(self._rew64), 1))
 
     def _info(self, steps: int) -> dict[str, Any]:
         info = {"steps": int(steps)}
@@ -138,7 +138,19 @@ class HipSingleEnv:
         return float(self._rew64[0, 0].item())  # tasks without a finite reward set (float64 physics): the kernel's own float64
 
     def close(self) -> None:
+        if getattr(self, "_rew64", None) is not None:  # the engine must not keep a pointer into a tensor this wrapper is about to drop
+            try:
+                _lib.check(_lib.lib().tma_env_set_reward64(self.engine._h, None, 0))
+            except Exception:  # noqa: BLE001  (an engine that is already closed)
+                pass
+            self._rew64 = None
         self.engine.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def render(self):
         return None

@@ -137,6 +137,7 @@ def train_task(config, *, callback=None, model_kwargs=None):
         record = dict(task=task.card(), config=dataclasses.asdict(config), algorithm=algo, substituted_for=stands_in_for, schedule=schedule, run_id=run.id, model_filename=run.zip_name,
                       model_path=str(run.zip_path), mean_reward=mean, std_reward=std, episode_rewards=[float(r) for r in returns],
                       episode_lengths=[int(n) for n in lengths], train_log=model.logger_values,
+                      data_parallel=dict(world_size=getattr(model, "world_size", 1), allreduce_path=getattr(model, "allreduce_path", "none")),
                       software=dict(three_mlagents_amd=__version__, engine="libtma_hip.so (gfx950)"), created_at=time.strftime("%Y-%m-%dT%H:%M:%S%z"))
         with open(run.metadata, "w", encoding="utf-8") as fh:
             json.dump(record, fh, indent=2, default=str)

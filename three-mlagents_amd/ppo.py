@@ -340,7 +340,12 @@ class PPO:
         if not agree(ok) and ok:
             ok, why = False, "another rank could not use its native communicator"
         # (TMA_P2P=auto: the whole start-up procedure -- contest included -- at any world size: how the one-GPU tests run the code a node runs)
-        if ok and os.environ.get("TMA_P2P") != "0" and (self.world_size > 1 or os.environ.get("TMA_P2P") in ("1", "auto")):
+        # OPT-IN (round 6, ADVICE): the exchange has run between processes sharing one GPU only -- never across xGMI -- and a bad mapping there
+        # is a memory fault, not an error code; a timing contest also lets the SAME job land on RCCL (ring order) or the exchange (rank order)
+        # from one start to the next, i.e. different gradient bits.  Until a multi-GPU node has passed tests/test_dist_gpu.py the default is
+        # RCCL, every time; TMA_P2P=1 forces the exchange, TMA_P2P=auto runs the checked contest.  The path taken is recorded
+        # (self.allreduce_path -> the saved model's data["tma"], metadata.json).
+        if ok and os.environ.get("TMA_P2P") in ("1", "auto"):
             self._setup_peer_exchange(comm, agree, probe_ok, use_rccl)
         if ok and (use_rccl or comm.p2p_enabled):
             return comm
@@ -396,7 +401,9 @@ class PPO:
                     comm.p2p_set_timeout(10.0)  # the ranks are in step here (the agreement above): a peer's words are microseconds away or never come
                     good, res = step(lambda: probe_ok(comm))
                     good = good and bool(res) and not comm.p2p_status()["timed_out"]
-                    if good and not os.environ.get("TMA_P2P_TIMEOUT_S"):
+                    try:  # the running timeout: the user's TMA_P2P_TIMEOUT_S, else 120 s (the 10 s above served the self-check only)
+                        comm.p2p_set_timeout(float(os.environ.get("TMA_P2P_TIMEOUT_S") or 120.0))
+                    except ValueError:
                         comm.p2p_set_timeout(120.0)
                     if not agree(good):
                         note = "self-check of the exchange against the expected sums failed"
@@ -432,6 +439,26 @@ class PPO:
         comm.p2p_note = note
         if self.rank == 0 and (self.world_size > 1 or os.environ.get("TMA_P2P") in ("1", "auto")):
             print(f"three-mlagents_amd: peer exchange for the gradient all-reduce {note}", file=sys.stderr, flush=True)
+
+    @property
+    def allreduce_path(self) -> str:
+        """Which implementation sums the gradient across ranks: "none" (one rank), "torch.distributed" (callback per minibatch), "rccl" (the
+        library's own communicator) or "peer_exchange" (tma_comm_p2p_*).  Fixed at construction; part of a run's provenance (summation order)."""
+        if self.world_size == 1 and self._native_comm is None:
+            return "none"
+        if self._native_comm is None:
+            return "torch.distributed"
+        return "peer_exchange" if self._native_comm.p2p_enabled else "rccl"
+
+    def check_collectives(self) -> None:
+        """Raise (on every rank that sees it) when a peer-exchange pull gave up waiting for a peer: the gradient it delivered is NaN and so is
+        every parameter since.  Called behind the stream synchronisations of learn() and in front of save(): a checkpoint is never written from
+        such a state without an exception."""
+        comm = self._native_comm
+        if comm is not None and comm.p2p_enabled and comm.p2p_status()["timed_out"]:
+            raise RuntimeError("three-mlagents_amd: a peer-exchange all-reduce timed out waiting for a peer's words (rank skew beyond "
+                               "TMA_P2P_TIMEOUT_S, or a peer died); the gradient of that minibatch -- and every parameter since -- is NaN.  "
+                               "Restart from the last checkpoint; TMA_P2P=0 keeps the collectives on RCCL.")
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
@@ -615,6 +642,7 @@ class PPO:
     def pop_train_stats(self) -> dict[str, float]:
         out = (C.c_double * 8)()
         _lib.check(_lib.lib().tma_ppo_pop_stats(_lib.ptr(self.workspace), out, self._stream()))
+        self.check_collectives()  # (pop_stats synchronised the stream)
         n = max(out[5], 1.0)
         fb = C.c_int64(0)
         _lib.check(_lib.lib().tma_ppo_persist_fallbacks(_lib.ptr(self.workspace), C.byref(fb), self._stream()))
@@ -661,6 +689,7 @@ class PPO:
 
         def finish(p):
             p["ev_train"].synchronize()
+            self.check_collectives()
             stats = self._fold_train_stats(p["staging"])
             s_ret, s_len, cnt = p["ep"]
             elapsed = max(ev0.elapsed_time(p["ev_train"]) * 1e-3, 1e-9)  # device timeline: learn() start -> the end of this iteration's update
@@ -904,7 +933,8 @@ class PPO:
             "rollout_buffer_class": None, "rollout_buffer_kwargs": {}, "batch_size": self.batch_size, "n_epochs": self.n_epochs, "clip_range": self.clip_range,
             "clip_range_vf": None, "normalize_advantage": self.normalize_advantage, "target_kl": None, "verbose": self.verbose, "_custom_logger": False,
             "tma": {"engine": "three-mlagents_amd", "task_id": getattr(env, "task_id", None), "mfma_dtype": self.policy_kwargs.get("mfma_dtype", "f32"),
-                    "adam_step": self._adam_step, "obs_dim": pol.obs_dim, "act_dim": pol.act_dim, "continuous": pol.continuous, "hidden": pol.hidden},
+                    "adam_step": self._adam_step, "allreduce_path": self.allreduce_path if hasattr(self, "_native_comm") else "none",
+                    "world_size": getattr(self, "world_size", 1), "obs_dim": pol.obs_dim, "act_dim": pol.act_dim, "continuous": pol.continuous, "hidden": pol.hidden},
         }
         data.update(sb3_format.data_members(obs_space, act_space))
         return data
@@ -932,6 +962,9 @@ class PPO:
         from . import sb3_format
 
         fz = _frozen
+        if fz is None and getattr(self, "_native_comm", None) is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+            self.check_collectives()
         sd = self.policy.state_dict() if fz is None else self.policy.named_from_flat(fz["params"][: self.policy.n_trainable])
         order = sb3_format.parameter_order(self.policy.continuous)
         sd = {k: sd[k] for k in order}  # torch's registration order of an ActorCriticPolicy: also the optimizer's parameter indices

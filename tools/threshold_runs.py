@@ -81,17 +81,21 @@ if __name__ == "__main__":
     ap.add_argument("--schedules", default="literal,scaled")
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seeds", default=None, help="comma-separated seeds: every (task, schedule) once per seed (overrides --seed)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     rows = []
+    seeds = [int(x) for x in a.seeds.split(",")] if a.seeds else [a.seed]
     for t in a.tasks.split(","):
         for s in a.schedules.split(","):
-            try:
-                r = run(t, s, seed=a.seed, iterations=a.iterations)
-            except Exception as exc:  # noqa: BLE001
-                r = {"task": t, "schedule": s, "error": repr(exc)}
-            rows.append(r)
-            print(json.dumps(r), flush=True)
+            for seed in seeds:
+                try:
+                    r = run(t, s, seed=seed, iterations=a.iterations)
+                except Exception as exc:  # noqa: BLE001
+                    r = {"task": t, "schedule": s, "error": repr(exc)}
+                r["seed"] = seed
+                rows.append(r)
+                print(json.dumps(r), flush=True)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(rows, f, indent=1)
