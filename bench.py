@@ -194,11 +194,49 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
         "launch_us": g_med, "launch_us_source": "HIP events recorded by the library around the kernel launch on its stream (median)" if ks else
                      "HIP events around the whole tma_ppo_minibatch_grad call",
         "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
+        # what follows the gradient kernel inside one tma_ppo_minibatch_grad call: the slab reduction launch and the boundary in front of it
+        "slab_reduce_us": (g_grp - g_med) if ks else None,
         "note": ("three-term bf16 split of the f32 update (six bf16 MFMAs per f32-class product; csrc/tma_split3.h): f32-EQUIVALENT flops against the f32 MFMA peak "
                  "-- the work runs on the bf16 pipe, so frac may approach or pass 1" if split else
                  "bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
                  "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
     }
+
+
+def kernel_spills(family):
+    """Spilled VGPRs / scratch bytes of every instantiation of a kernel family, read from the AMDGPU metadata notes of the built objects
+    (tools/kernel_regs.py: csrc/*.o travel with the tree).  None when the objects or llvm-readelf are not there."""
+    try:
+        import subprocess
+        import sys as _sys
+
+        _sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_regs as kr
+
+        rows = []
+        for obj in sorted(__import__("glob").glob(os.path.join(ROOT, "three-mlagents_amd", "csrc", "*.o"))):
+            for elf in kr.device_elfs(obj):
+                rows += list(kr.kernels(elf))
+        names = subprocess.run([kr.CXXFILT], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.split("\n")
+        out = {}
+        for r, n in zip(rows, names):
+            short = __import__("re").sub(r"\(.*", "", n).replace("void ", "").replace("tma::", "")
+            if family.replace("tma::", "") in short and r["vgpr_spill"].isdigit():
+                out[short] = {"spilled_vgprs": int(r["vgpr_spill"]), "scratch_bytes": int(r["scratch"]) if r["scratch"].isdigit() else None, "vgprs": int(r["vgpr"]) if r["vgpr"].isdigit() else None}
+        return out or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def spill_summary(family, pick=None):
+    """{family, instantiation (when `pick` names one), spilled_vgprs, max over the family}"""
+    ks = kernel_spills(family)
+    if not ks:
+        return None
+    mx = max(v["spilled_vgprs"] for v in ks.values())
+    one = next((k for k in ks if pick and pick in k), None)
+    return {"family": family, "instantiation": one, "spilled_vgprs": ks[one]["spilled_vgprs"] if one else None, "scratch_bytes": ks[one]["scratch_bytes"] if one else None,
+            "family_max_spilled_vgprs": mx, "family_instantiations": len(ks)}
 
 
 def attach_pmc_traffic(roof, name):
@@ -356,17 +394,17 @@ EXTRA_CONFIGS = [
          batch=256),
     # SURVEY.md 8d config (2), second half: the headline env with the reference's DEFAULT net and dtype (training.py:363-365)
     dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 (reference default net)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="f32",
-         steps=4, warmup=1),
+         steps=6, warmup=1),
     # BASELINE.json names bf16 for configs[2] only: the like-for-like f32 figures of the configs[3] / [4] shards (exact-f32 MFMA wide kernel)
     # ... and the same fp32 policy with the UPDATE on the bf16 MFMA as a three-term split (mfma_dtype "bf16x3", opt-in, f32-class accuracy: round 5)
     dict(name="configs[1] GridWorld 4096 envs, MLP(256,256) f32 weights, bf16x3 update (opt-in)", task="gridworld", n_envs=4096, n_steps=1024, hidden=256, mfma="bf16x3",
-         steps=4, warmup=1),
+         steps=6, warmup=1),
     dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="f32",
-         steps=3, warmup=1),
+         steps=6, warmup=1),
     dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="crawler", n_envs=2048, n_steps=2048, hidden=256,
-         mfma="f32", steps=3, warmup=1),
+         mfma="f32", steps=6, warmup=1),
     dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 weights, bf16x3 update (opt-in)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="bf16x3",
-         steps=3, warmup=1),
+         steps=6, warmup=1),
 ]
 
 
@@ -391,7 +429,8 @@ def run_extra(cfg, args, dev):
                "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": warm,
                "env_steps_per_sec": steps * total / el, "ms_per_step": el / steps * 1e3, "rollout_ms": t_roll / steps * 1e3,
                "update_ms": (el - t_roll) / steps * 1e3, "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9),
-               "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic")}}
+               "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic")},
+               "slab_reduce_us": roof.get("slab_reduce_us"), "grad_kernel_spilled_vgprs": spill_summary(roof["kernel"])}
         log(f"extra {cfg['name']}: {res['env_steps_per_sec'] / 1e6:.2f} M env-steps/s, {res['ms_per_step']:.1f} ms/iter, grad {roof['launch_us']:.0f} us")
         return res
     finally:
@@ -427,7 +466,12 @@ def literal_batch_256(args, dev, hidden=None):
                 "approx_kl": round(st["train/approx_kl"], 6), "us_per_optimizer_step": t_epoch / n_mb * 1e6,
                 "update_path": ("per-minibatch launches (TMA_NO_PERSIST set)" if os.environ.get("TMA_NO_PERSIST") else
                                 "persistent epoch kernel ppo_epoch_h64p_kernel (csrc/tma_h64p.hip): one launch per epoch")
-                if args.hidden == 64 and args.mfma_dtype == "f32" else "per-minibatch launches",
+                if args.hidden == 64 and args.mfma_dtype == "f32" else
+                ("persistent epoch kernel ppo_epoch_h256p_kernel (csrc/tma_h256p.hip): one launch per epoch, 2 x 32 workgroups on two XCDs"
+                 if args.hidden == 256 and args.mfma_dtype == "f32" and not os.environ.get("TMA_NO_PERSIST") and not model.policy.continuous
+                 and model.policy.obs_dim <= 32 and model.policy.act_dim <= 16 else "per-minibatch launches"),
+                # the step as a fraction of the f32 MFMA peak (SURVEY.md 8d flops; the whole step, exchanges included, not one kernel's launch)
+                "mfma_f32_frac_of_step": 256 * mlp_flops_per_sample(model.policy.obs_dim, args.hidden, model.policy.act_dim)[1] / (t_epoch / n_mb) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "workload": f"{args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, batch_size 256 "
                             "(reference training.py:379), one epoch timed"}
     finally:
@@ -617,6 +661,7 @@ def _cpu_legs(cfg, threads, seconds, n_epochs, seed):
     return {"threads": threads, "env_only_steps_per_s": n_env * N / t_env, "env_gae_steps_per_s": n_env * N / (t_env + t_gae),
             "rollout_env_steps_per_s": 1.0 / roll_per_env_step, "ppo_updates_per_sec": 1.0 / t_upd, "update_ms_per_minibatch": t_upd * 1e3,
             "env_steps_per_s": total / iter_s, "batch_size": batch, "minibatches_per_epoch": n_mb,
+            "update_minibatch_samples_timed": bs, "update_scale_factor": batch / bs,  # (t_update is measured at bs samples and scaled linearly to `batch`)
             "sample": f"env-only {n_env} x {N} steps ({t_env:.2f} s) + GAE ({t_gae * 1e3:.1f} ms); rollout {n_roll} x {N} steps incl. policy + GAE ({t_roll:.2f} s); "
                       f"{n_upd} optimizer steps on {bs}-sample minibatches, scaled x{batch / bs:.0f} to batch {batch}"}
 
@@ -668,7 +713,9 @@ def cpu_baseline(args, seconds, batch):
                                         "62-64 k raw env.step()/s/core for GridWorld (no policy, no VecEnv); through SB3's DummyVecEnv + PPO the reference "
                                         "trains at about 1-2 k env-steps/s.  The C port timed here is the build's restatement, not the reference's Python: "
                                         "its single-thread env-only rate (configs[*].single_thread.env_only_steps_per_s) is what relates to the 62-64 k figure",
-        "sample": f"headline: {args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, {args.n_epochs} epochs x minibatches of {batch}; "
+        "extrapolated": True, "update_scale_factor": a.get("update_scale_factor"), "update_minibatch_samples_timed": a.get("update_minibatch_samples_timed"),
+        "sample": f"extrapolated: every leg is a time-boxed sample and the update leg is timed on {a.get('update_minibatch_samples_timed')}-sample minibatches and scaled x{a.get('update_scale_factor') or 1:.0f} "
+                  f"to the schedule's batch; headline: {args.task}, {args.n_envs} envs x {args.n_steps} steps, MLP {args.hidden}x{args.hidden}, {args.n_epochs} epochs x minibatches of {batch}; "
                   f"{a.get('threads')} of {cores_all} logical CPUs (the best of 1 / {mid} / {cores_all} threads); " + str(a.get("sample")) + "; value = n_envs*n_steps / (n_envs*n_steps*t_rollout_per_env_step + n_epochs*n_minibatches*t_update)",
         "rollout_env_steps_per_s": a.get("rollout_env_steps_per_s"), "env_only_steps_per_s": a.get("env_only_steps_per_s"),
         "env_gae_steps_per_s": a.get("env_gae_steps_per_s"), "update_ms_per_minibatch": a.get("update_ms_per_minibatch"),
@@ -889,6 +936,7 @@ def main():
             attach_pmc_traffic(roof, "gradbf_kernel")
         if roof["kernel"] == "tma::ppo_grad_h64_kernel" and args.task == "gridworld":
             attach_pmc_traffic(roof, "grad_kernel")
+        roof["spills"] = spill_summary(roof["kernel"], pick=f"ppo_grad_h64_kernel<{model.policy.obs_dim if model.policy.obs_dim in (4, 6) else 0}, 2>" if roof["kernel"].endswith("h64_kernel") else None)
         out["roofline"] = roof
         step_kernel_rooflines(out, args, env, model, world)
     env.close()

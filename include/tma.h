@@ -320,6 +320,11 @@ int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out,
 int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out);
 int tma_comm_p2p_prepare(tma_comm *comm, int64_t max_words, unsigned char *ticket_out128);
 int tma_comm_p2p_attach(tma_comm *comm, const unsigned char *tickets_world_x_128);
+/* The same wiring for `world` communicators that live in ONE process (each created with tma_comm_create_p2p(world, r, device) and prepared
+ * with the same max_words): peers[r] is rank r's communicator, its inbox is used directly.  For drivers that run several ranks as streams of
+ * one process -- the tests run the exchange at the world sizes of a node (4, 8) on one GPU this way; a receiver spins on words another
+ * rank's sender stores, so every rank needs a stream (hardware queue) of its own. */
+int tma_comm_p2p_attach_local(tma_comm *comm, tma_comm *const *peers_world);
 int tma_comm_p2p_enable(tma_comm *comm, int on);
 int tma_comm_p2p_status(tma_comm *comm, int *enabled_out, int64_t *calls_out, int *timed_out_out, int64_t *slot_words_out);
 int tma_comm_p2p_set_timeout(tma_comm *comm, double seconds); /* receivers of later exchanges give up after this long (set-up: a short one for the self-check) */

@@ -6,10 +6,13 @@ one of them is trained twice through harness.train_task with the reference's PPO
 10 epochs, n_steps 1024 / 2048) and checked on the deterministic evaluation the reference's EvalCallback / final evaluate_policy run:
   literal  the reference's own schedule: its n_envs (1 or 8), its total_timesteps, batch_size 256;
   scaled   4096 envs, batch_size 256 * 4096 / 8 (the same minibatches per epoch), a few PPO iterations.
-Measured on MI355X (tools/threshold_runs.py, profiles/r05_thresholds.json): every run takes 0.7 - 6 s of wall time.  The literal GridWorld
-run is the one whose evaluation hovers AROUND its threshold at the reference's 100 k timesteps (0.70 - 0.82 from 40 k steps on: PPO with
-one env, where the reference's own default for this task is DQN): it is held to the best evaluation (the policy the reference's
-EvalCallback keeps as best_model.zip), all others also to the final one."""
+Measured on MI355X (tools/threshold_runs.py, profiles/r06_thresholds.json): every run takes 0.7 - 6 s of wall time.  The literal GridWorld
+run is the one whose FINAL evaluation sits at its threshold rather than above it (PPO with one env and 100 k timesteps, where the reference's
+own default for this task is DQN; 100 evaluation episodes with a standard deviation of 0.6: +-0.06 on a mean): per seed 0.64 - 0.88, every
+seed passing 0.75 at some evaluation from 10 - 20 k steps on.  It is therefore asserted over FIVE seeds: every seed's best evaluation (the
+policy the reference's EvalCallback keeps as best_model.zip) at or above the threshold, and the MEDIAN of the five final evaluations at or
+above it -- one seed may end low, the schedule may not (a regression of the median to 0.66 fails).  All other cases: one seed, final >=
+threshold."""
 import os
 import sys
 
@@ -21,21 +24,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 CASES = [(t, s) for t in ("basic", "gridworld", "ball3d", "push", "walljump") for s in ("literal", "scaled")]
-FINAL_MAY_HOVER = {("gridworld", "literal")}
+MEDIAN_OF_SEEDS = {("gridworld", "literal"): (1, 2, 3, 4, 5)}
 
 
 @pytest.mark.parametrize("task,schedule", CASES)
 def test_reference_reward_threshold_is_reached(task, schedule):
+    import statistics
+
     import threshold_runs
 
-    r = threshold_runs.run(task, schedule, seed=1)
-    print({k: r[k] for k in ("task", "schedule", "threshold", "final_eval_mean", "first_eval_at_threshold", "train_task_wall_seconds", "total_timesteps")})
-    assert r["threshold"] is not None
-    assert r["first_eval_at_threshold"] is not None, (task, schedule, r["eval_curve"])  # some evaluation of the run is at or above the threshold
-    best = max(m for _, m in r["eval_curve"] + [[0, r["first_eval_at_threshold"]["eval_mean"]]])
-    assert best >= r["threshold"]
-    if (task, schedule) in FINAL_MAY_HOVER:
-        assert r["final_eval_mean"] >= r["threshold"] - 0.1, r
-    else:
+    seeds = MEDIAN_OF_SEEDS.get((task, schedule), (1,))
+    finals = []
+    for seed in seeds:
+        r = threshold_runs.run(task, schedule, seed=seed)
+        print({k: r[k] for k in ("task", "schedule", "threshold", "final_eval_mean", "first_eval_at_threshold", "train_task_wall_seconds", "total_timesteps")}, "seed", seed)
+        assert r["threshold"] is not None
+        assert r["first_eval_at_threshold"] is not None, (task, schedule, seed, r["eval_curve"])  # some evaluation of the run is at or above the threshold
+        best = max(m for _, m in r["eval_curve"] + [[0, r["first_eval_at_threshold"]["eval_mean"]]])
+        assert best >= r["threshold"]
+        assert r["train_task_wall_seconds"] < 60.0  # seconds, not the reference's minutes: a run that crawls is a regression too
+        finals.append(r["final_eval_mean"])
+    if len(seeds) == 1:
         assert r["reached"], (task, schedule, r["final_eval_mean"], r["threshold"])
-    assert r["train_task_wall_seconds"] < 60.0  # seconds, not the reference's minutes: a run that crawls is a regression too
+    else:
+        print(f"[{task} {schedule}] final evaluations over seeds {seeds}: {finals}, median {statistics.median(finals):.4f}")
+        assert statistics.median(finals) >= r["threshold"], (task, schedule, finals)

@@ -115,6 +115,7 @@ SIGNATURES = {
     "tma_comm_create_p2p": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "tma_comm_p2p_prepare": (_i32, [_vp, _i64, _vp]),
     "tma_comm_p2p_attach": (_i32, [_vp, _vp]),
+    "tma_comm_p2p_attach_local": (_i32, [_vp, _vp]),
     "tma_comm_p2p_enable": (_i32, [_vp, _i32]),
     "tma_comm_p2p_set_timeout": (_i32, [_vp, C.c_double]),
     "tma_comm_p2p_status": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)]),

@@ -93,6 +93,7 @@ struct tma_comm {
     uint32_t seq = 0;
     int *err_host = nullptr, *err_dev = nullptr;
     long long timeout_ticks = 0;
+    bool local_peers = false;  // tma_comm_p2p_attach_local: the peers' inboxes are pointers of this process, not IPC mappings
     int64_t p2p_calls = 0;
 };
 
@@ -169,7 +170,7 @@ namespace {
 
 void p2p_release(tma_comm *c) {
     for (int r = 0; r < tma::P2P_MAX_WORLD; r++) {
-        if (c->peer[r] && c->peer[r] != c->inbox) (void)hipIpcCloseMemHandle(c->peer[r]);
+        if (c->peer[r] && c->peer[r] != c->inbox && !c->local_peers) (void)hipIpcCloseMemHandle(c->peer[r]);
         c->peer[r] = nullptr;
     }
     if (c->inbox) (void)hipFree(c->inbox);
@@ -435,6 +436,19 @@ int tma_comm_p2p_attach(tma_comm *c, const unsigned char *tickets) {
         c->peer[r] = static_cast<unsigned long long *>(p);
     }
     c->attached = true;
+    return TMA_OK;
+}
+
+int tma_comm_p2p_attach_local(tma_comm *c, tma_comm *const *peers) {
+    if (!c || !c->inbox || !peers) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach_local: prepare first / null peers");
+    if (c->attached) return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach_local: already attached");
+    for (int r = 0; r < c->world; r++) {
+        const tma_comm *p = peers[r];
+        if (!p || !p->inbox || p->world != c->world || p->rank != r || p->cap != c->cap || (r == c->rank && p != c))
+            return tma::fail(TMA_ERR_INVALID, "tma_comm_p2p_attach_local: peer %d is not a prepared communicator of this world (same slot size, rank %d)", r, r);
+    }
+    for (int r = 0; r < c->world; r++) c->peer[r] = peers[r]->inbox;  // (same address space: the inbox itself, no IPC mapping; p2p_release skips them)
+    c->attached = true, c->local_peers = true;
     return TMA_OK;
 }
 
