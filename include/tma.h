@@ -259,6 +259,14 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
+/* `n_epochs` consecutive epochs (permutations perm_epoch0, perm_epoch0 + 1, ...; optimizer steps first_step ...) in one call.  Where a persistent
+ * epoch kernel takes the shape (batch_size 256: H = 64 fast-path layouts, and the reference's default 256 x 256 f32 policy with a Discrete head
+ * and <= 32 observations) and n_epochs * T * N sample offsets fit the workspace cache (2^22), ALL the epochs run as ONE launch -- the
+ * reference's own 1- and 8-env schedules are 4 and 32 optimizer steps per epoch, where a launch per epoch is mostly launch; otherwise (and
+ * when such a launch cannot place its workgroups) exactly tma_ppo_train_epoch_local per epoch.  Same results either way. */
+int tma_ppo_train_epochs_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch0, int n_epochs,
+                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
+                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
 /* One epoch of PPO.train on ONE RANK of a data-parallel job (env shards per GPU, one gradient all-reduce per
  * minibatch; the reference itself is one process, backend/mlagents/training.py:71-89,150): for every minibatch of batch_size local rows --
  * tma_ppo_minibatch_grad, then `allreduce(ctx, grad, n_trainable)` (the caller's collective: SUM over the ranks, in place, enqueued on

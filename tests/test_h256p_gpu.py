@@ -154,3 +154,53 @@ def test_h256p_long_epoch_through_ppo(monkeypatch):
     assert torch.allclose(p0, p1, rtol=0, atol=2e-5), float((p0 - p1).abs().max())
     for k in ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/approx_kl", "train/n_samples"):
         assert abs(s0[k] - s1[k]) <= 1e-4 * max(1.0, abs(s1[k])), (k, s0[k], s1[k])
+
+
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_all_epochs_in_one_persistent_launch_equal_a_launch_per_epoch(hidden, monkeypatch):
+    """tma_ppo_train_epochs_local: where a persistent epoch kernel takes the shape and the epochs' sample offsets fit the workspace, the
+    n_epochs of PPO.train run as ONE launch (the reference's own 8-env schedule: 32 optimizer steps an epoch) -- weights, moments and the
+    step count stay on the chip between epochs.  Same kernel, same permutations, same Adam table: bit-identical to one launch per epoch
+    (TMA_EPOCH_PER_CALL=1), for the 64 x 64 kernel (tma_h64p.hip) and the 256 x 256 one (tma_h256p.hip); and the forced failure of the
+    one launch hands every epoch back (to per-epoch launches that fail the same way, then to the per-minibatch launches)."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    task = "basic" if hidden == 256 else "gridworld"  # (Basic's 21 observations are beyond the 64-wide persistent kernel's 16)
+
+    def run(per_call, force_fail=False):
+        monkeypatch.delenv("TMA_NO_PERSIST", raising=False)
+        monkeypatch.delenv("TMA_PERSIST_FORCE_FAIL", raising=False)
+        if per_call:
+            monkeypatch.setenv("TMA_EPOCH_PER_CALL", "1")
+        else:
+            monkeypatch.delenv("TMA_EPOCH_PER_CALL", raising=False)
+        if force_fail:
+            monkeypatch.setenv("TMA_PERSIST_FORCE_FAIL", "1")
+        env = make_vector_env(task, n_envs=8, seed=3)
+        m = PPO("MlpPolicy", env, n_steps=128, batch_size=256, n_epochs=5, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
+        for _ in range(2):
+            m.collect_rollouts()
+            m.train()
+        st = m.pop_train_stats()
+        out = (m.policy.params.cpu(), m.exp_avg.cpu(), m.exp_avg_sq.cpu(), st, m._adam_step)
+        env.close()
+        return out
+
+    p0, m0, v0, s0, n0 = run(False)
+    p1, m1, v1, s1, n1 = run(True)
+    assert n0 == n1 == 2 * 5 * 4 and "train/persist_fallbacks" not in s0 and "train/persist_fallbacks" not in s1
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    for k in ("train/policy_gradient_loss", "train/value_loss", "train/entropy_loss", "train/approx_kl", "train/n_samples"):
+        assert abs(s0[k] - s1[k]) <= 1e-12 * max(1.0, abs(s1[k])), (k, s0[k], s1[k])  # (the same per-step sums, folded per launch instead of per epoch)
+    p2, m2, v2, s2, n2 = run(False, force_fail=True)
+    monkeypatch.setenv("TMA_NO_PERSIST", "1")
+    monkeypatch.delenv("TMA_PERSIST_FORCE_FAIL", raising=False)
+    env = make_vector_env(task, n_envs=8, seed=3)
+    ref = PPO("MlpPolicy", env, n_steps=128, batch_size=256, n_epochs=5, seed=3, policy_kwargs={"net_arch": [hidden, hidden]})
+    for _ in range(2):
+        ref.collect_rollouts()
+        ref.train()
+    assert n2 == 40 and s2["train/persist_fallbacks"] == 10.0  # (two train() calls x five epochs, each epoch counted once)
+    assert torch.equal(p2, ref.policy.params.cpu()) and torch.equal(m2, ref.exp_avg.cpu())
+    env.close()

@@ -97,6 +97,8 @@ SIGNATURES = {
     "tma_ppo_persist_fallbacks": (_i32, [_vp, C.POINTER(_i64), _vp]),
     "tma_ppo_train_epoch_local": (_i32, [_vp, _pd, C.POINTER(Rollout), _u32, _u32, _i64, C.POINTER(PPOHParams), _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                          _f64, _vp, _vp]),
+    "tma_ppo_train_epochs_local": (_i32, [_vp, _pd, C.POINTER(Rollout), _u32, _u32, _i32, _i64, C.POINTER(PPOHParams), _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
+                                          _f64, _vp, _vp]),
     "tma_ppo_train_epoch_dp": (_i32, [_vp, _pd, C.POINTER(Rollout), _u32, _u32, _i64, _i64, _i32, C.POINTER(PPOHParams), _vp, _vp, _vp, _i64, _f64, _f64, _f64,
                                       _f64, _f64, _f64, None, _vp, _vp, _vp]),  # (None: the AllReduceFn slot, filled in below)
     "tma_ppo_pop_stats": (_i32, [_vp, C.POINTER(_f64), _vp]),

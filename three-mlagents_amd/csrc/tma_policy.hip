@@ -2568,6 +2568,107 @@ int tma_ppo_minibatch_grad(const float *params, const tma_policy_dims *d, const 
     return minibatch_grad_impl(params, d, rb, mbi, hp, grad, workspace, stream, nullptr, 0);
 }
 
+// The persistent epoch kernels (tma_h64p.hip: H = 64; tma_h256p.hip: the reference's default 256 x 256 policy) over `n_epochs` consecutive
+// epochs of the reference's literal batch_size = 256 in ONE launch: the sample offsets and advantage partials of every epoch are laid out
+// behind each other (epoch e: permutation perm_epoch0 + e, offsets at [e * total, (e + 1) * total), partials of its minibatches behind
+// those of epoch e - 1) and the kernel walks n_epochs * n_mb optimizer steps -- weights, moments and step count never leave the chip
+// between epochs.  *ran = 1: everything is committed (parameters, moments, derived images, statistics).  *ran = 0: the shape is not
+// eligible, or the launch could not place / synchronise its workgroups: the state is what it was before the call (snapshot restored,
+// the event counted) and the caller runs the epochs through the per-minibatch launches.
+static int persistent_epochs(float *params, const tma_policy_dims *d, const tma_rollout *rb, const PLayout &L, uint32_t perm_seed, uint32_t perm_epoch0,
+                             int n_epochs, int64_t batch_size, const tma_ppo_hparams *hp, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr,
+                             double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream, int *ran) {
+    *ran = 0;
+    const int64_t total = (int64_t)rb->T * rb->N, all = total * n_epochs;
+    if (n_epochs < 1 || all > OFFS_CAP || batch_size < 256 || total % batch_size != 0) return TMA_OK;
+    const bool p64 = tma_epoch_h64p_eligible(L, batch_size, all);
+    const bool p256 = !p64 && h256p_layout(L) && tma_epoch_h256p_eligible(L, batch_size, all);
+    if (!p64 && !p256) return TMA_OK;
+    if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
+    char *ws = static_cast<char *>(workspace);
+    hipStream_t ps = (hipStream_t)stream;
+    const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
+    int stride = (int)ceil_div(batch_size, 1024);
+    if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
+    const int64_t n_mb = total / batch_size;
+    for (int e = 0; e < n_epochs; e++) {  // (tma_ppo_epoch_prepare's launch, epoch e at its place)
+        Minibatch M{nullptr, perm_seed, perm_epoch0 + (uint32_t)e, 0, total, total, nullptr, total, nullptr, 0};
+        adv_partial_kernel<<<dim3(stride, (unsigned)n_mb), dim3(256), 0, ps>>>(rb->advantages, M, rb->T, rb->N,
+                                                                               reinterpret_cast<double *>(ws + offs_base + OFFS_CAP * 4) + 2 * e * n_mb * stride,
+                                                                               reinterpret_cast<int32_t *>(ws + offs_base) + e * total, batch_size);
+        TMA_LAUNCH_CHECK();
+    }
+    const Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N, rb->packed};
+    const HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, hp->normalize_advantage ? 1 : 0, 0};
+    // Snapshot of what the launch may commit (trainable parameters, both moments, its 64 statistic slots) in the idle half of the AdamFold
+    // double buffer: "commit nothing after an abort" is a per-block decision inside the kernel, so a block that gives up on its LAST wait
+    // can raise the abort word after another block has already written its net -- the fallback restores the snapshot first and is
+    // therefore the same results whatever the kernel managed to write (4 small device copies per launch).
+    const int64_t Pp = ((int64_t)L.P + 3) & ~(int64_t)3;
+    float *snap = reinterpret_cast<float *>(ws + fold_state_offset(L));
+    TMA_HIP(hipMemcpyAsync(snap, params, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(snap + Pp, exp_avg, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(snap + 2 * Pp, exp_avg_sq, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(ws + WS_PERSIST_SNAP, ws + WS_STATS, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
+    int rc = (p64 ? tma_launch_epoch_h64p : tma_launch_epoch_h256p)(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
+                                                                    reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, all, batch_size,
+                                                                    exp_avg, exp_avg_sq, first_step, lr, beta1, beta2, eps, max_grad_norm, ws, ps);
+    if (rc) return rc;
+    // The persistent kernels need their workgroups resident together on one XCD per group (H = 64: eight on one; 256-wide: 32 on each of
+    // two); a concurrent kernel, a CU mask or a preempted wave can deny that, in which case they give up on a bounded wait and commit
+    // NOTHING.  Check per launch (one 4-byte read-back: the launch is ~10^5 times longer) and, on failure, hand the epochs back to the
+    // per-minibatch launches -- training goes on, the event is counted (tma_ppo_persist_fallbacks) and reported once on stderr.
+    int persist_err = 0;
+    TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, ps));
+    TMA_HIP(hipStreamSynchronize(ps));
+    if (const char *ff = getenv("TMA_PERSIST_FORCE_FAIL"))  // test hook "late": the launch ran and committed EVERYTHING, then is declared failed
+        if (!strcmp(ff, "late")) persist_err = 1;
+    if (!persist_err) {
+        *ran = 1;
+        return p256 ? launch_sync(params, L, ps) : TMA_OK;  // (the 256-wide kernel writes the trainable region; its derived images follow here)
+    }
+    TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), ps));
+    TMA_HIP(hipMemcpyAsync(params, snap, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(exp_avg, snap + Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(exp_avg_sq, snap + 2 * Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
+    TMA_HIP(hipMemcpyAsync(ws + WS_STATS, ws + WS_PERSIST_SNAP, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
+    rc = launch_sync(params, L, ps);  // derived copies and weight images of the restored parameters
+    if (rc) return rc;
+    if (n_epochs == 1) persist_fallback_note(ws, ps);  // (a multi-epoch launch that failed is retried epoch by epoch: each of those counts for itself)
+    return TMA_OK;
+}
+
+int tma_ppo_train_epochs_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch0, int n_epochs,
+                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr,
+                               double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream) {
+    int rc = enter(d);
+    if (rc) return rc;
+    if (!params || !rb || !hp || !grad || !exp_avg || !exp_avg_sq || !workspace) return fail(TMA_ERR_INVALID, "tma_ppo_train_epochs_local: null argument");
+    if (rb->T < 1 || rb->N < 1 || batch_size < 1 || first_step < 1 || n_epochs < 1)
+        return fail(TMA_ERR_INVALID, "tma_ppo_train_epochs_local: T, N, batch_size, first_step and n_epochs must be >= 1");
+    const int64_t total = (int64_t)rb->T * rb->N, n_mb = ceil_div(total, batch_size);
+    const PLayout L = layout_of(d);
+    int e = 0;
+    // as many epochs per persistent launch as the offsets cache holds (all of them for the reference's own 1- and 8-env schedules: 4 or 32
+    // optimizer steps an epoch, where a launch per epoch was mostly launch)
+    const int per = (int)(total > 0 && OFFS_CAP / total >= 1 ? (OFFS_CAP / total < n_epochs ? OFFS_CAP / total : n_epochs) : 0);
+    while (per >= 1 && e < n_epochs) {
+        const int n = n_epochs - e < per ? n_epochs - e : per;
+        int ran = 0;
+        rc = persistent_epochs(params, d, rb, L, perm_seed, perm_epoch0 + (uint32_t)e, n, batch_size, hp, exp_avg, exp_avg_sq, first_step + e * n_mb, lr, beta1, beta2,
+                               eps, max_grad_norm, workspace, stream, &ran);
+        if (rc) return rc;
+        if (!ran) break;
+        e += n;
+    }
+    for (; e < n_epochs; e++) {  // not eligible (or handed back): epoch by epoch (which tries the single-epoch persistent launch first, then the launches)
+        rc = tma_ppo_train_epoch_local(params, d, rb, perm_seed, perm_epoch0 + (uint32_t)e, batch_size, hp, grad, exp_avg, exp_avg_sq, first_step + e * n_mb, lr,
+                                       beta1, beta2, eps, max_grad_norm, workspace, stream);
+        if (rc) return rc;
+    }
+    return TMA_OK;
+}
+
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch, int64_t batch_size,
                               const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step, double lr, double beta1,
                               double beta2, double eps, double max_grad_norm, void *workspace, void *stream) {
@@ -2577,57 +2678,18 @@ int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma
     if (rb->T < 1 || rb->N < 1 || batch_size < 1 || first_step < 1) return fail(TMA_ERR_INVALID, "tma_ppo_train_epoch_local: T, N, batch_size and first_step must be >= 1");
     const int64_t total = (int64_t)rb->T * rb->N;
     const bool prepared = total <= OFFS_CAP && batch_size >= 256;
+    const PLayout L = layout_of(d);
     if (prepared) {
+        // the reference's literal batch_size = 256: the whole epoch as one persistent launch (H = 64: tma_h64p.hip; the reference's default
+        // 256 x 256 policy: tma_h256p.hip)
+        int ran = 0;
+        rc = persistent_epochs(params, d, rb, L, perm_seed, perm_epoch, 1, batch_size, hp, exp_avg, exp_avg_sq, first_step, lr, beta1, beta2, eps, max_grad_norm,
+                               workspace, stream, &ran);
+        if (rc) return rc;
+        if (ran) return TMA_OK;
         const tma_minibatch ep{nullptr, perm_seed, perm_epoch, 0, total, 0, 0};
         rc = tma_ppo_epoch_prepare(rb, &ep, batch_size, d, workspace, stream);
         if (rc) return rc;
-    }
-    const PLayout L = layout_of(d);
-    const bool p64 = prepared && total % batch_size == 0 && tma_epoch_h64p_eligible(L, batch_size, total);
-    const bool p256 = !p64 && prepared && h256p_layout(L) && tma_epoch_h256p_eligible(L, batch_size, total);
-    if (p64 || p256) {
-        // the reference's literal batch_size = 256: the whole epoch as one persistent launch (H = 64: tma_h64p.hip; the reference's default
-        // 256 x 256 policy: tma_h256p.hip)
-        if (!rb->obs || !rb->actions || !rb->log_probs || !rb->advantages || !rb->returns) return fail(TMA_ERR_INVALID, "rollout view has a null buffer");
-        char *ws = static_cast<char *>(workspace);
-        const int64_t offs_base = WS_SLABS + (int64_t)slab_cap(L) * L.P * 4;
-        const Rollout R{rb->obs, rb->actions, rb->log_probs, rb->advantages, rb->returns, rb->T, rb->N, rb->packed};
-        const HParams hpar{(float)hp->clip_range, (float)hp->ent_coef, (float)hp->vf_coef, hp->normalize_advantage ? 1 : 0, 0};
-        int stride = (int)ceil_div(batch_size, 1024);
-        if (stride > ADV_BLOCKS) stride = ADV_BLOCKS;
-        // Snapshot of what the launch may commit (trainable parameters, both moments, its 64 statistic slots) in the idle half of the AdamFold
-        // double buffer: "commit nothing after an abort" is a per-block decision inside the kernel, so a block that gives up on its LAST wait
-        // can raise the abort word after another block has already written its net -- the fallback below restores the snapshot first and is
-        // therefore the same results whatever the kernel managed to write (4 small device copies per ~10^5 us epoch).
-        hipStream_t ps = (hipStream_t)stream;
-        const int64_t Pp = ((int64_t)L.P + 3) & ~(int64_t)3;
-        float *snap = reinterpret_cast<float *>(ws + fold_state_offset(L));
-        TMA_HIP(hipMemcpyAsync(snap, params, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(snap + Pp, exp_avg, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(snap + 2 * Pp, exp_avg_sq, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(ws + WS_PERSIST_SNAP, ws + WS_STATS, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
-        rc = (p64 ? tma_launch_epoch_h64p : tma_launch_epoch_h256p)(params, L, R, hpar, reinterpret_cast<const int32_t *>(ws + offs_base),
-                                                                    reinterpret_cast<const double *>(ws + offs_base + OFFS_CAP * 4), stride, total, batch_size,
-                                                                    exp_avg, exp_avg_sq, first_step, lr, beta1, beta2, eps, max_grad_norm, ws, (hipStream_t)stream);
-        if (rc) return rc;
-        // The persistent kernels need their workgroups resident together on one XCD per group (H = 64: eight on one; 256-wide: 32 on each of
-        // two); a concurrent kernel, a CU mask or a preempted wave can deny that, in which case they give up on a bounded wait and commit
-        // NOTHING.  Check per epoch (one 4-byte read-back: the epoch is ~10^5 times longer) and, on failure, run this epoch through the
-        // per-minibatch launches below -- training goes on, the event is counted (tma_ppo_persist_fallbacks) and reported once on stderr.
-        int persist_err = 0;
-        TMA_HIP(hipMemcpyAsync(&persist_err, ws + WS_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-        TMA_HIP(hipStreamSynchronize((hipStream_t)stream));
-        if (const char *ff = getenv("TMA_PERSIST_FORCE_FAIL"))  // test hook "late": the launch ran and committed EVERYTHING, then is declared failed
-            if (!strcmp(ff, "late")) persist_err = 1;
-        if (!persist_err) return p256 ? launch_sync(params, L, ps) : TMA_OK;  // (the 256-wide kernel writes the trainable region; its derived images follow here)
-        TMA_HIP(hipMemsetAsync(ws + WS_PERSIST_ERR, 0, sizeof(int), ps));
-        TMA_HIP(hipMemcpyAsync(params, snap, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(exp_avg, snap + Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(exp_avg_sq, snap + 2 * Pp, (size_t)L.P * 4, hipMemcpyDeviceToDevice, ps));
-        TMA_HIP(hipMemcpyAsync(ws + WS_STATS, ws + WS_PERSIST_SNAP, 8 * 8 * 8, hipMemcpyDeviceToDevice, ps));
-        rc = launch_sync(params, L, ps);  // derived copies and weight images of the restored parameters
-        if (rc) return rc;
-        persist_fallback_note(ws, ps);
     }
     int64_t step = first_step;
     const bool no_fold = getenv("TMA_NO_ADAM_FOLD") != nullptr;  // test / measurement switch: one optimizer launch per minibatch (read per epoch)

@@ -525,14 +525,18 @@ class PPO:
         if self.world_size == 1 and not os.environ.get("TMA_DP_PATH"):  # (TMA_DP_PATH=1: time the data-parallel host loop on one GPU)
             # one GPU: a whole epoch (prepare + every minibatch's gradient and optimizer step) is issued natively by ONE call -- at the
             # reference's literal batch_size = 256 that is 16 384 optimizer steps without a host-language round trip in between
+            # (round 6: ALL the epochs by one call -- where a persistent epoch kernel takes the shape and the epochs' sample offsets fit the
+            #  workspace, tma_ppo_train_epochs_local runs them as ONE launch: the reference's own 1- / 8-env schedules are 4 / 32 optimizer
+            #  steps an epoch.  TMA_EPOCH_PER_CALL=1: one call per epoch, round 5's loop, the A/B switch)
             n_mb = (total + self.batch_size - 1) // self.batch_size
-            for _ in range(self.n_epochs):
-                _lib.check(L.tma_ppo_train_epoch_local(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view), perm_seed,
-                                                       self._epoch_counter & 0xFFFFFFFF, self.batch_size, C.byref(self._hp), _lib.ptr(self.grad),
-                                                       _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self._adam_step + 1, self.learning_rate, 0.9,
-                                                       0.999, 1e-5, self.max_grad_norm, _lib.ptr(self.workspace), self._stream()))
-                self._adam_step += n_mb
-                self._epoch_counter += 1
+            per_call = 1 if os.environ.get("TMA_EPOCH_PER_CALL") or (self._epoch_counter & 0xFFFFFFFF) + self.n_epochs > 0xFFFFFFFF else self.n_epochs
+            for _ in range(0, self.n_epochs, per_call):
+                _lib.check(L.tma_ppo_train_epochs_local(_lib.ptr(self.policy.params), C.byref(self.policy.dims), C.byref(self._rollout_view), perm_seed,
+                                                        self._epoch_counter & 0xFFFFFFFF, per_call, self.batch_size, C.byref(self._hp), _lib.ptr(self.grad),
+                                                        _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self._adam_step + 1, self.learning_rate, 0.9,
+                                                        0.999, 1e-5, self.max_grad_norm, _lib.ptr(self.workspace), self._stream()))
+                self._adam_step += n_mb * per_call
+                self._epoch_counter += per_call
             self._n_updates += self.n_epochs
             self._mark_update_done()
             return

@@ -13,7 +13,7 @@ cp $(ls -t gpurun_out/r06_literal256_h256/*/*kernel_stats.csv | head -1) gpurun_
 # ... and the same epoch as per-minibatch launches (TMA_NO_PERSIST=1: round 5's path, the fallback)
 TMA_NO_PERSIST=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_literal256_h256_launches -- python tools/time_literal256.py gridworld 4096 256 256 > gpurun_out/r06_literal256_h256_launches.log 2>&1
 cp $(ls -t gpurun_out/r06_literal256_h256_launches/*/*kernel_stats.csv | head -1) gpurun_out/r06_literal256_h256_launches_kernel_stats.csv
-( tail -1 gpurun_out/r06_literal256_h256.log; tail -1 gpurun_out/r06_literal256_h256_launches.log; python tools/time_literal256.py basic 8 1024 256 2>&1 | tail -1; TMA_NO_PERSIST=1 python tools/time_literal256.py basic 8 1024 256 2>&1 | tail -1 ) > gpurun_out/r06_literal256_time.txt
+( grep "optimizer steps" gpurun_out/r06_literal256_h256.log; grep "optimizer steps" gpurun_out/r06_literal256_h256_launches.log; python tools/time_literal256.py basic 8 1024 256 2>&1 | tail -1; TMA_NO_PERSIST=1 python tools/time_literal256.py basic 8 1024 256 2>&1 | tail -1 ) > gpurun_out/r06_literal256_time.txt
 python tools/h256p_ticks.py gridworld 1024 256 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_h256p_ticks.txt
 [ -f three-mlagents_amd/csrc/libtma_hip_ticks.so ] && TMA_LIB_PATH=three-mlagents_amd/csrc/libtma_hip_ticks.so python tools/h64_ticks.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_h64_ticks.txt
 cat gpurun_out/r06_literal256_time.txt gpurun_out/r06_h256p_ticks.txt
