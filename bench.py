@@ -189,15 +189,24 @@ def grad_kernel_roofline(model, task, hidden, mfma, batch, reps=24):
     split = mfma == "bf16x3" and wide and mb.count >= 4096
     kname = ("tma::ppo_grad_split3_kernel" if split else "tma::ppo_grad_wide_bf_kernel" if bf else "tma::ppo_grad_h64_kernel" if fast else
              "tma::ppo_grad_wide_kernel" if wide else "tma::ppo_grad_kernel")
+    f32_equiv = None
+    if split:
+        # the three-term split ISSUES bf16 MFMAs: six products on every chain GEMM (forward and input-gradient), three on the weight gradients
+        # -- (6 + 6 + 3) / 3 = 5 x the f32-equivalent flops (csrc/tma_split3.h; the SQ counters of profiles/r06_gradsplit3_sq_pmc.json give the
+        # measured count) -- and its roofline is the bf16 pipe's.  The f32-equivalent rate against the f32 peak stays as a second pair.
+        f32_equiv = {"achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "frac": tf / MFMA_F32_PEAK_TFLOPS, "note": "f32-EQUIVALENT flops (SURVEY.md 8d formula) against the f32 MFMA peak: "
+                     "what the update is worth, not a roofline of the pipe it runs on"}
+        tf, peak = 5.0 * tf, MFMA_BF16_PEAK_TFLOPS
     return {
         "kernel": kname, "launch_group_us": g_grp, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+        "f32_equivalent": f32_equiv,
         "launch_us": g_med, "launch_us_source": "HIP events recorded by the library around the kernel launch on its stream (median)" if ks else
                      "HIP events around the whole tma_ppo_minibatch_grad call",
         "samples_per_launch": int(mb.count), "flops_per_sample_fwd_bwd": flops_fb,
         # what follows the gradient kernel inside one tma_ppo_minibatch_grad call: the slab reduction launch and the boundary in front of it
         "slab_reduce_us": (g_grp - g_med) if ks else None,
-        "note": ("three-term bf16 split of the f32 update (six bf16 MFMAs per f32-class product; csrc/tma_split3.h): f32-EQUIVALENT flops against the f32 MFMA peak "
-                 "-- the work runs on the bf16 pipe, so frac may approach or pass 1" if split else
+        "note": ("three-term bf16 split of the f32 update (csrc/tma_split3.h): ISSUED bf16 MFMA flops = 5 x the f32-equivalent flops (six bf16 products per chain "
+                 "GEMM, three per weight gradient) against the bf16 MFMA peak; `f32_equivalent` carries the rate the update is worth" if split else
                  "bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate; ~2.5 PFLOP/s dense peak)" if bf else
                  "exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak)") + "; flops = SURVEY.md 8d formula, fwd + bwd = 3 x fwd",
     }
@@ -429,7 +438,7 @@ def run_extra(cfg, args, dev):
                "dtype": cfg["mfma"], "batch_size": batch, "n_epochs": args.n_epochs, "steps": steps, "warmup": warm,
                "env_steps_per_sec": steps * total / el, "ms_per_step": el / steps * 1e3, "rollout_ms": t_roll / steps * 1e3,
                "update_ms": (el - t_roll) / steps * 1e3, "ppo_updates_per_sec": updates / max(el - t_roll, 1e-9),
-               "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic")},
+               "roofline": {k: roof[k] for k in ("kernel", "launch_us", "achieved", "peak", "unit", "frac", "samples_per_launch", "traffic", "f32_equivalent")},
                "slab_reduce_us": roof.get("slab_reduce_us"), "grad_kernel_spilled_vgprs": spill_summary(roof["kernel"])}
         log(f"extra {cfg['name']}: {res['env_steps_per_sec'] / 1e6:.2f} M env-steps/s, {res['ms_per_step']:.1f} ms/iter, grad {roof['launch_us']:.0f} us")
         return res

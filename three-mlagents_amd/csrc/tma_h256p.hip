@@ -954,7 +954,14 @@ int tma_launch_epoch_h256p(float *params, const PLayout &L, const Rollout &R, co
                                                                                       beta1, beta2);
     TMA_LAUNCH_CHECK();
     auto launch = [&](auto k) -> int {
-        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        static bool attr_set = false;  // (one static per instantiation of this lambda's operator(): the attribute call costs ~0.1 ms and is sticky per device function)
+        static int attr_dev = -1;
+        int dev = 0;
+        TMA_HIP(hipGetDevice(&dev));
+        if (!attr_set || attr_dev != dev) {
+            TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true, attr_dev = dev;
+        }
         k<<<dim3(QGRID), dim3(QT), smem, s>>>(a);
         return TMA_OK;
     };
