@@ -53,10 +53,17 @@ out = {"kernel_match": "ppo_grad_split3_kernel", "command": "python tools/prof_g
 if m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
     # MOPS counters are in units of 512 operations (MI355X_MICROARCH.md); issued bf16 flops per launch = MOPS x 512
     out["issued_bf16_flops_per_launch"] = m["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
+    out["issued_over_f32_equivalent"] = out["issued_bf16_flops_per_launch"] / (131072 * 807936)
 if m.get("SQ_INSTS_MFMA") and m.get("SQ_INSTS_VALU"):
-    out["valu_per_mfma"] = m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"]
+    out["valu_per_mfma"] = (m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"]
 if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("SQ_BUSY_CYCLES"):
-    out["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"] / 4.0
+    # SQ_BUSY_CYCLES is summed over the 32 shader engines; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (tools/prof_round.sh)
+    out["kernel_cycles"] = m["SQ_BUSY_CYCLES"] / 32
+    out["mfma_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / out["kernel_cycles"]
+if m.get("SQ_WAVE_CYCLES"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+        if m.get(k):
+            out[k.lower() + "_frac_of_wave_cycles"] = m[k] / m["SQ_WAVE_CYCLES"]
 if m.get("SQ_LDS_BANK_CONFLICT") and m.get("SQ_LDS_IDX_ACTIVE"):
     out["lds_bank_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
 json.dump(out, open("gpurun_out/r06_gradsplit3_sq_pmc.json", "w"), indent=1)
