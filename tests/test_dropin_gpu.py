@@ -435,3 +435,35 @@ def test_stats_window_size_selects_sb3s_last_100_episode_window(tmp_path):
     assert abs(model.logger_values["rollout/ep_rew_mean"] - win) < 1e-12
     assert min(rows) - 1e-9 <= win <= max(rows) + 1e-9 and all(any(abs(x - r) < 1e-6 for r in set(round(v, 6) for v in rows)) for x in set(model._ep_info_r))
     env.close()
+
+
+def test_per_env_monitor_files_above_64_envs_are_opt_in(tmp_path):
+    """The reference wraps EVERY env of the vector in its own Monitor (`<rank>.monitor.csv`, training.py:84-86).  Up to 64 envs the engine
+    writes those files by default; above that it writes one file for the vector unless the limit is raised (PPO.monitor_per_env_limit /
+    TMA_MONITOR_PER_ENV_LIMIT): then every env gets its file, its rows are that env's episodes in the order they finished, and all files
+    together hold what the single file would -- the same multiset of (return, length) rows."""
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(sub, limit):
+        env = make_vector_env("gridworld", n_envs=160, seed=5, monitor_dir=str(tmp_path / sub))
+        model = PPO("MlpPolicy", env, n_steps=64, batch_size=1024, n_epochs=1, seed=5, policy_kwargs={"net_arch": [64, 64]})
+        if limit:
+            model.monitor_per_env_limit = limit
+        model.learn(160 * 64 * 3)
+        env.close()
+        files = sorted((tmp_path / sub).iterdir(), key=lambda p: int(p.name.split(".")[0]))
+        rows = {}
+        for p in files:
+            lines = p.read_text().splitlines()
+            assert lines[0].startswith("#{") and lines[1] == "r,l,t"
+            rows[int(p.name.split(".")[0])] = [tuple(ln.split(",")[:2]) for ln in lines[2:] if not ln.startswith("#")]
+        return rows
+
+    one = run("single", None)
+    per = run("per_env", 4096)
+    assert list(one) == [0] and list(per) == list(range(160))
+    assert sorted(x for v in per.values() for x in v) == sorted(one[0]) and len(one[0]) > 300
+    assert sum(1 for v in per.values() if v) > 100  # (most envs finished at least one episode in 192 steps)
+    ts = [float(ln.split(",")[2]) for ln in (tmp_path / "per_env" / "7.monitor.csv").read_text().splitlines()[2:] if not ln.startswith("#")]
+    assert ts == sorted(ts)

@@ -820,7 +820,9 @@ class PPO:
     monitor_log_capacity = 1 << 20  # episode records the device keeps between two log intervals
     monitor_max_rows = 100_000      # rows written per log interval (an evenly strided subsample beyond that)
 
-    monitor_per_env_limit = 64      # up to this many envs: one `<rank>.monitor.csv` per env, as the reference writes them (training.py:84-86)
+    # up to this many envs: one `<rank>.monitor.csv` per env, as the reference writes them (training.py:84-86); TMA_MONITOR_PER_ENV_LIMIT raises it
+    # (round 6: any vector size -- 4096 envs are 4096 files appended per log interval on the writer thread, which is why it is not the default)
+    monitor_per_env_limit = int(os.environ.get("TMA_MONITOR_PER_ENV_LIMIT") or 64)
 
     def _write_monitor(self, sum_ret: float, sum_len: float, count: float, t_begin: float, t_end: float, t_start: float, log=None) -> None:
         """SB3 Monitor files under the directory make_vector_env passes (reference training.py:84-86: env `rank` of the vector is wrapped in
@@ -848,6 +850,9 @@ class PPO:
             written = getattr(self, "_monitor_files", None)
             if written is None:
                 written = self._monitor_files = set()
+            # rows grouped by env with ONE stable sort (the order inside an env stays the order the kernels logged them): any vector size
+            order = np.argsort(e[keep], kind="stable")
+            bounds = np.searchsorted(e[keep][order], np.arange(self.n_envs + 1))
             for rank in range(self.n_envs):  # the reference creates every env's file at construction, finished episodes or not
                 path = os.path.join(str(mdir), f"{rank}.monitor.csv")
                 if rank not in written:
@@ -855,9 +860,9 @@ class PPO:
                         if f.tell() == 0:
                             f.write(header(rank))
                     written.add(rank)
-                rows = keep[e[keep] == rank]
-                if len(rows):
-                    pos = np.searchsorted(keep, rows)
+                pos = np.sort(order[bounds[rank]:bounds[rank + 1]])
+                if len(pos):
+                    rows = keep[pos]
                     jobs.append((path, np.ascontiguousarray(r[rows], np.float64), np.ascontiguousarray(l[rows], np.int32),
                                  np.ascontiguousarray(ts_all[pos], np.float64)))
         else:
