@@ -436,7 +436,9 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
         f32x4 h2;
         {
             const float bv = b2s[16 * j + r16];
-            f32x4 acc = f32x4{bv, bv, bv, bv};
+            // TWO accumulator chains per wave (k-groups alternate between them, summed at the end): a dependent 16x16x4 chain issues once per
+            // ~45 cycles, so one chain per wave leaves the pipe to the SIMD's other wave only -- two keep it at its 32-cycle cadence
+            f32x4 acc = f32x4{bv, bv, bv, bv}, accB = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const float *pa = H1 + (16 * t + r16) * H1_LD + 4 * g, *pb = W2s + (j * 4 + g) * W2S_LD + r16 * 4;
             // four k-groups (16 k each) per batch: their eight 16-byte LDS reads in flight together, fenced so that the scheduler does not hoist all 32
             f32x4 a4[2][4], b4[2][4];
@@ -452,11 +454,15 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 4; u += 2)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc = mfma16(a4[qq & 1][u][i], b4[qq & 1][u][i], acc);
+                    for (int i = 0; i < 4; i++) {
+                        acc = mfma16(a4[qq & 1][u][i], b4[qq & 1][u][i], acc);
+                        accB = mfma16(a4[qq & 1][u + 1][i], b4[qq & 1][u + 1][i], accB);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            acc += accB;
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 h2[rr] = tma_tanh(acc[rr]);
@@ -580,11 +586,20 @@ __device__ __forceinline__ void epoch256_body(const Epoch256Args &a, int cu0, fl
             for (int ks = 0; ks < 8; ks++) av[ks] = DZ2[(16 * t + r16) * DZ2_LD + 4 * ks + g];
             const float *pb = W2s + (r16 >> 2) * W2S_LD + g * 4 + (r16 & 3);
 #pragma unroll
-            for (int nt = 0; nt < 8; nt++) {
-                f32x4 accn = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int nt = 0; nt < 8; nt += 2) {  // two column tiles at a time: two independent chains (see P2)
+                f32x4 accn = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, accm = accn;
+                float bw[2][8];
 #pragma unroll
-                for (int ks = 0; ks < 8; ks++) accn = mfma16(av[ks], pb[(((8 * j + nt) * 2 + (ks >> 2)) * 4) * W2S_LD + (ks & 3) * 16], accn);
-                dh1[nt] = accn;
+                for (int ks = 0; ks < 8; ks++) {
+                    bw[0][ks] = pb[(((8 * j + nt) * 2 + (ks >> 2)) * 4) * W2S_LD + (ks & 3) * 16];
+                    bw[1][ks] = pb[(((8 * j + nt + 1) * 2 + (ks >> 2)) * 4) * W2S_LD + (ks & 3) * 16];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) {
+                    accn = mfma16(av[ks], bw[0][ks], accn);
+                    accm = mfma16(av[ks], bw[1][ks], accm);
+                }
+                dh1[nt] = accn, dh1[nt + 1] = accm;
             }
         }
         __syncthreads();  // (every wave is done reading h1)
