@@ -8,7 +8,8 @@ one of them is trained twice through harness.train_task with the reference's PPO
   scaled   4096 envs, batch_size 256 * 4096 / 8 (the same minibatches per epoch), a few PPO iterations.
 Measured on MI355X (tools/threshold_runs.py, profiles/r06_thresholds.json): every run takes 0.7 - 6 s of wall time.  The literal GridWorld
 run is the one whose FINAL evaluation sits at its threshold rather than above it (PPO with one env and 100 k timesteps, where the reference's
-own default for this task is DQN; 100 evaluation episodes with a standard deviation of 0.6: +-0.06 on a mean): per seed 0.64 - 0.88, every
+own default for this task is DQN; 100 evaluation episodes with a standard deviation of 0.6: +-0.06 on a mean): per seed 0.64 - 0.88 over the
+builds of round 6 (any change of a summation order reshuffles the seeds: 0.78 / 0.68 / 0.64 / 0.76 / 0.88, then 0.66 / 0.74 / 0.86 / 0.80 / 0.80), every
 seed passing 0.75 at some evaluation from 10 - 20 k steps on.  It is therefore asserted over FIVE seeds: every seed's best evaluation (the
 policy the reference's EvalCallback keeps as best_model.zip) at or above the threshold, and the MEDIAN of the five final evaluations at or
 above it -- one seed may end low, the schedule may not (a regression of the median to 0.66 fails).  All other cases: one seed, final >=
