@@ -162,6 +162,10 @@ def test_peer_exchange_entry_points_refuse_bad_use_without_touching_a_gpu():
         with pytest.raises(ValueError):
             _lib.check(L.tma_comm_p2p_attach(h, None))  # prepare first
         with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_attach_local(h, None))  # (round 6: the in-process form has the same precondition)
+        with pytest.raises(ValueError):
+            _lib.check(L.tma_comm_p2p_attach_local(h, (C.c_void_p * 2)(h, h)))  # still not prepared
+        with pytest.raises(ValueError):
             _lib.check(L.tma_comm_p2p_prepare(h, 0, (C.c_ubyte * 128)()))  # empty slots
         with pytest.raises(ValueError):
             _lib.check(L.tma_comm_p2p_set_timeout(h, 0.0))
@@ -172,3 +176,23 @@ def test_peer_exchange_entry_points_refuse_bad_use_without_touching_a_gpu():
         assert L.tma_comm_allreduce_cb(h, buf, 16) != 0  # the callback form reports failure instead of raising through C frames
     finally:
         _lib.check(L.tma_comm_destroy(h))
+
+
+def test_round_6_entry_points_refuse_bad_arguments_without_touching_a_gpu():
+    """include/tma.h, ABI 208: tma_ppo_train_epochs_local (all epochs of an update in one call) and the capacity argument of
+    tma_env_set_reward64 validate before any HIP work."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+
+    L = _lib.lib()
+    assert L.tma_version() >= 208
+    dims = _lib.PolicyDims(4, 256, 5, 0, 0, -1)
+    hp = _lib.PPOHParams(0.2, 0.01, 0.5, 1)
+    rv = _lib.Rollout(None, None, None, None, None, 16, 64)
+    args = lambda n_epochs, params: (params, C.byref(dims), C.byref(rv), 1, 0, n_epochs, 256, C.byref(hp), None, None, None, 1, 3e-4, 0.9, 0.999, 1e-5, 0.5, None, None)  # noqa: E731
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_ppo_train_epochs_local(*args(3, None)))  # null buffers
+    assert "null argument" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(L.tma_env_set_reward64(None, None, 0))  # null handle
