@@ -936,7 +936,8 @@ using namespace tma;
 
 bool tma_epoch_h256p_eligible(const PLayout &L, int64_t batch_size, int64_t total) {
     const bool off = getenv("TMA_NO_PERSIST") != nullptr || getenv("TMA_NO_PERSIST256") != nullptr;  // (read per call: tests switch paths inside one process)
-    if (off || L.bf16 || L.split || L.fr_pi < 0 || L.H != QH || L.cont || L.A > 16 || L.D > 32 || batch_size != QB) return false;
+    // (mfma_dtype 2 policies included: their three-term split update takes minibatches of >= 4 096 samples; at 256 they run the exact-f32 path anyway)
+    if (off || L.bf16 || L.fr_pi < 0 || L.H != QH || L.cont || L.A > 16 || L.D > 32 || batch_size != QB) return false;
     if (total < 2 * batch_size || total % batch_size != 0) return false;
     const int64_t n_mb = total / batch_size;
     return n_mb <= 65535 && R_TABLE + n_mb * 8 <= (int64_t)slab_cap(L) * L.P * 4;
