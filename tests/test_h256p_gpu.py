@@ -204,3 +204,36 @@ def test_all_epochs_in_one_persistent_launch_equal_a_launch_per_epoch(hidden, mo
     assert n2 == 40 and s2["train/persist_fallbacks"] == 10.0  # (two train() calls x five epochs, each epoch counted once)
     assert torch.equal(p2, ref.policy.params.cpu()) and torch.equal(m2, ref.exp_avg.cpu())
     env.close()
+
+
+def test_h256p_takes_bf16x3_policies_at_the_literal_batch(monkeypatch):
+    """mfma_dtype "bf16x3" (opt-in: the f32 256 x 256 update as a three-term bf16 split) only changes minibatches of >= 4 096 samples; at the
+    reference's literal batch_size = 256 such a policy runs the exact-f32 update -- the persistent kernel when it can, and its three-plane weight
+    images are rebuilt behind the launch like every other derived copy (tma_policy_sync afterwards changes nothing)."""
+    import ctypes as C
+
+    from three_mlagents_amd import _lib
+    from three_mlagents_amd.harness import make_vector_env
+    from three_mlagents_amd.ppo import PPO
+
+    def run(persist):
+        if persist:
+            monkeypatch.delenv("TMA_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("TMA_NO_PERSIST", "1")
+        env = make_vector_env("gridworld", n_envs=64, seed=2)
+        m = PPO("MlpPolicy", env, n_steps=32, batch_size=256, n_epochs=2, seed=2, policy_kwargs={"net_arch": [256, 256], "mfma_dtype": "bf16x3"})
+        m.collect_rollouts()
+        m.train()
+        st = m.pop_train_stats()
+        after = m.policy.params.clone()
+        _lib.check(_lib.lib().tma_policy_sync(_lib.ptr(m.policy.params), C.byref(m.policy.dims), _lib.stream_ptr()))
+        assert torch.equal(after, m.policy.params)
+        out = (after[: m.policy.n_trainable].cpu(), st)
+        env.close()
+        return out
+
+    p0, s0 = run(True)
+    p1, s1 = run(False)
+    assert "train/persist_fallbacks" not in s0 and torch.isfinite(p0).all()
+    assert torch.allclose(p0, p1, rtol=0, atol=2e-6), float((p0 - p1).abs().max())
