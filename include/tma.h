@@ -253,9 +253,16 @@ int tma_ppo_adam_step_local(float *params, float *grad, float *exp_avg, float *e
  * per-minibatch calls -- except on H = 64 policies at batch_size = 256 with T*N a multiple of it, where the epoch runs as ONE persistent
  * launch (csrc/tma_h64p.hip: weights in LDS, Adam moments in registers, eight workgroups of one XCD exchanging partial gradients through
  * the L2): same gradient sums and Adam arithmetic, the clip norm's f64 sum in another fixed order (parameters agree to the last bit or
- * two).  TMA_NO_PERSIST=1 in the environment selects the per-minibatch launches.  Should the kernel fail to place or synchronise its
- * workgroups (it needs eight of them resident on one XCD) it commits nothing; this call notices (it waits for the persistent launch and
- * reads one status word back), re-runs the epoch through the per-minibatch launches and counts the event (tma_ppo_persist_fallbacks). */
+ * two) -- and, since ABI 208, on the reference's DEFAULT policy (two 256 x 256 tanh nets, f32 weights: mfma_dtype 0 or 2; Discrete head of
+ * <= 16 actions, <= 32 observations; backend/mlagents/training.py:363-365) at batch_size = 256, where the epoch is ONE persistent launch of
+ * csrc/tma_h256p.hip: each net on the 32 CUs of one XCD as 4 row groups x 8 column slices, weights of a slice in LDS, Adam moments in
+ * registers, four same-XCD exchanges of activations and partial gradients per optimizer step; its sums have their own fixed order, so it is
+ * run-to-run bit-identical and equal to the per-minibatch launches to rounding (2e-6 on the parameters after three epochs; 18.9 us per
+ * optimizer step where the three launches take 34.2).  TMA_NO_PERSIST=1 in the environment selects the per-minibatch launches
+ * (TMA_NO_PERSIST256=1: for the 256-wide kernel only).  Should a persistent kernel fail to place or synchronise its workgroups (eight
+ * resident on one XCD; 32 on each of two for the 256-wide one) it commits nothing; this call notices (it waits for the persistent launch and
+ * reads one status word back), restores its snapshot, re-runs the epoch through the per-minibatch launches and counts the event
+ * (tma_ppo_persist_fallbacks). */
 int tma_ppo_train_epoch_local(float *params, const tma_policy_dims *d, const tma_rollout *rb, uint32_t perm_seed, uint32_t perm_epoch,
                               int64_t batch_size, const tma_ppo_hparams *hp, float *grad, float *exp_avg, float *exp_avg_sq, int64_t first_step,
                               double lr, double beta1, double beta2, double eps, double max_grad_norm, void *workspace, void *stream);
@@ -323,8 +330,8 @@ int tma_comm_pop_timing(tma_comm *comm, float *us_out, int capacity, int *n_out,
  * peers' inboxes, the sum-of-squares pass in front of the optimizer step reads the sum: no collective launch in the minibatch chain at all.
  * tma_comm_create_p2p: a communicator WITHOUT an RCCL side (several ranks on one GPU, which RCCL does not allow: the one-GPU tests); its
  * all-reduces must fit the exchange.  A receiver that waits longer than TMA_P2P_TIMEOUT_S (default 120) for a peer's words raises a flag:
- * the all-reduce that was waiting returns garbage, every later one fails with TMA_ERR_HIP, tma_comm_p2p_status reports it -- nothing spins
- * for ever.  tma_comm_timing brackets the RECEIVING kernel of an exchange (what the chain waits for once the sender kernel is done). */
+ * the all-reduce that was waiting returns NaN (ABI 208; never a sum of stale words), every later one fails with TMA_ERR_HIP,
+ * tma_comm_p2p_status reports it -- nothing spins for ever.  tma_comm_timing brackets the RECEIVING kernel of an exchange (what the chain waits for once the sender kernel is done). */
 int tma_comm_create_p2p(int world, int rank, int device, tma_comm **out);
 int tma_comm_p2p_prepare(tma_comm *comm, int64_t max_words, unsigned char *ticket_out128);
 int tma_comm_p2p_attach(tma_comm *comm, const unsigned char *tickets_world_x_128);
