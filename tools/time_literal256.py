@@ -21,4 +21,6 @@ for _ in range(3):
     t0 = time.perf_counter(); m.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
 n_mb = N * T // 256 * E
-print(f"{task} {N}x{T} H={H}: {n_mb} optimizer steps per {'train() of ' + str(E) + ' epochs' if E > 1 else 'epoch'}, {best / n_mb * 1e6:.2f} us per step = {n_mb / best:.0f} steps/s; approx_kl {m.pop_train_stats()['train/approx_kl']:.5f}")
+import hashlib
+digest = hashlib.sha256(b"".join(v.detach().cpu().contiguous().numpy().tobytes() for _, v in sorted(m.policy.state_dict().items()))).hexdigest()[:16]
+print(f"{task} {N}x{T} H={H}: {n_mb} optimizer steps per {'train() of ' + str(E) + ' epochs' if E > 1 else 'epoch'}, {best / n_mb * 1e6:.2f} us per step = {n_mb / best:.0f} steps/s; approx_kl {m.pop_train_stats()['train/approx_kl']:.5f}; parameters sha256 {digest}")
