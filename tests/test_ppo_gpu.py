@@ -346,8 +346,10 @@ def test_gae_flags_equals_sb3_layout(monkeypatch, T, N, scan):
                                                 ("ball3d", 256, 200, "bf16"), ("gridworld", 256, 200, "bf16"), ("push", 256, 96, "bf16"), ("basic", 256, 40, "bf16"),
                                                 ("walljump", 256, 64, "bf16"), ("ball3d", 256, 200, "f32"),
                                                 # the f32 256-wide fused chunk (the reference's default net and dtype: policy net only, values / bootstrap in batches;
-                                                # 16-env tiles: 8 = the reference's own env count, 200 = a ragged last tile, 40 with Basic's inline resets)
-                                                ("basic", 256, 8, "f32"), ("basic", 256, 40, "f32"), ("gridworld", 256, 200, "f32"), ("push", 256, 72, "f32"),
+                                                # up to 2048 envs in tiles of 8 on the broadcast 4x4x1 MFMA: 8 = the reference's own env count, 200 / 5 = full tiles / a
+                                                # ragged one, 40 with Basic's inline resets; beyond that 16-env tiles: 2100 = 131 full tiles + a ragged one)
+                                                ("basic", 256, 8, "f32"), ("basic", 256, 40, "f32"), ("basic", 256, 5, "f32"), ("gridworld", 256, 200, "f32"),
+                                                ("gridworld", 256, 2100, "f32"), ("push", 256, 72, "f32"),
                                                 ("walljump", 256, 64, "f32"), ("bicycle", 256, 40, "f32"), ("glider", 256, 40, "f32"),
                                                 # the Box-action fused chunk (Crawler shape: layer-1 fragments streamed, env state in LDS); 72 = a ragged group
                                                 ("crawler", 256, 72, "bf16"), ("crawler", 256, 40, "f32"), ("ant", 256, 72, "bf16"), ("ant", 256, 40, "f32"),

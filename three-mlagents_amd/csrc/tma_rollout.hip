@@ -1143,24 +1143,70 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
 // and log-probabilities are bit-identical to the per-step composition, which pays two launches, the observation's HBM round trip and
 // the whole weight matrix from L2 per vector step (28 us per step at 8 envs, 13 us at 4096).
 // ------------------------------------------------------------------------------------------
-template <class T>
+#ifdef TMA_ROLL_TICKS  // diagnostic build (make libtma_hip_rticks.so, tools/roll_ticks.py): cycles per phase of a vector step, thread 0 of block 0
+__device__ unsigned long long g_roll_ticks[8];
+#define TMA_RTICK(i)                                                                  \
+    do {                                                                              \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_roll_ticks[i] += tn_ - rt_last;    \
+        rt_last = tn_;                                                                \
+    } while (0)
+#else
+#define TMA_RTICK(i)
+#endif
+template <class T, int MROWS>
 __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
                                                                         float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,
                                                                         uint32_t rng_step0, int det) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int M = 16, H = 256, NTW = 4, D = T::OBS, ldx = ((D + 3) & ~3) + 2, ld = H + 2, KS1 = (D + 3) >> 2, KS2 = H / 4;
+    // MROWS = 8 (round 6): tiles of EIGHT envs -- the reference's own 8-env runs, and every run of up to 2048 envs (256 blocks).  A 16 x 16 x 4
+    // tile pads 8 envs to 16 rows: half the matrix pipe's work is zeros.  v_mfma_f32_4x4x1_16b_f32 with the A operand of one block broadcast to
+    // all sixteen (CBSZ = 4, ABID = e) is 4 envs x 64 columns x 1 k in 8 cycles: a wave's 64 columns of both hidden layers are two such
+    // chains (envs 0-3, envs 4-7), which issue back to back (8.3 cycles an instruction: tools/mfma_bcast_probe.hip) -- 512 x 8.3 = 4.2 k cycles for
+    // layer 2 instead of 256 x 32 = 8.2 k.  Same bits: a k-step of the 16 x 16 x 4 instruction is its four products added to the accumulator
+    // one after the other in k order, each a fused multiply-add (the same probe: 512 of 512 outputs identical, and identical to fmaf on the
+    // host), which is exactly what the k-by-k chain does.  The head, the sampling and the env step read the same 16-row LDS images as before
+    // (rows 8 .. 15 stay zero).
+    constexpr bool M8 = MROWS == 8;
+    constexpr int M = MROWS, H = 256, NTW = 4, D = T::OBS, ldx = ((D + 3) & ~3) + (M8 ? 4 : 2), ld = H + (M8 ? 4 : 2), KS1 = (D + 3) >> 2, KS2 = H / 4;
     static_assert(D <= 32 && T::NACT > 0, "fused f32 wide rollout: observations of up to 32 floats, Discrete actions");
+    static_assert(MROWS == 16 || MROWS == 8, "tiles of 16 or 8 envs");
+    // M8 with up to 8 actions: the head as ONE fused-multiply-add chain per (env, action) on the vector ALU -- lane 8 a + e runs
+    // acc = fma(h2[e][k], W3[k][a], acc) for k = 0 .. 255, the very operations (and order) of the 64 dependent 16 x 16 x 4 MFMAs, which
+    // issue once per ~50 cycles where a dependent v_fma_f32 issues once per ~5.  The logits cross to the sampling code's layout through
+    // LDS; there a lane group takes TWO rows instead of four (row 2 g + r: eight rows over four groups), which halves the serial
+    // softmax / scan chains of a step.
+    constexpr bool VH = M8 && T::NACT <= 8;
+    constexpr int RG = VH ? 2 : 4;  // rows of the tile per 16-lane group in the sampling code
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int A = L.A, n_base = wave * 16 * NTW;
-    float *X = smem_f, *h1 = X + M * ldx, *h2 = h1 + M * ld;
+    float *X = smem_f, *h1 = X + M * ldx, *h2 = h1 + M * ld;  // (h2: 16 rows in either form -- the head's A operand)
+    float *w3l = h2 + 16 * ld, *lgt = w3l + 8 * ld;            // VH: W3 as [action][k] rows (zero rows beyond A); logits [env][8]
     const int64_t N = v.N;
     const int64_t row0 = (int64_t)blockIdx.x * M;
     // ---- this wave's weights: registers for the whole launch (the operands policy_fwd_wide_kernel fetches per step) ----
     const Net P = pi_net(params, L);
-    float w1v[NTW][KS1], w2v[NTW][KS2], b1v[NTW], b2v[NTW];
+    float w1v[M8 ? 1 : NTW][M8 ? 1 : KS1], w2v[M8 ? 1 : NTW][M8 ? 1 : KS2], b1v[NTW], b2v[NTW];
+    float w1s[M8 ? D : 1], w2s[M8 ? H : 1];  // M8: column n_base + lane of W1t / W2t, one register per k
+    if constexpr (M8) {
 #pragma unroll
-    for (int j = 0; j < NTW; j++) {
+        for (int kk = 0; kk < D; kk++) w1s[kk] = P.W1t[(int64_t)kk * H + n_base + lane];
+#pragma unroll
+        for (int kk = 0; kk < H; kk++) w2s[kk] = P.W2t[(int64_t)kk * H + n_base + lane];
+#pragma unroll
+        for (int kk = 128; kk < H; kk++) asm volatile("" : "+a"(w2s[kk]));  // the upper half lives in accumulator registers: an MFMA reads its B operand from either file
+        b1v[0] = P.b1[n_base + lane], b2v[0] = P.b2[n_base + lane];
+        for (int e = threadIdx.x; e < 8 * ld; e += blockDim.x) h2[8 * ld + e] = 0.0f;  // rows 8 .. 15 of the head's operand
+        if constexpr (VH) {
+            for (int e = threadIdx.x; e < 8 * ld; e += blockDim.x) {
+                const int a = e / ld, kk = e - a * ld;
+                w3l[e] = (a < A && kk < H) ? P.W3t[(int64_t)kk * A + a] : 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (M8 ? 0 : NTW); j++) {
         const int col = n_base + 16 * j + r16;
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) {
@@ -1173,17 +1219,18 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
         b1v[j] = P.b1[col];
         b2v[j] = P.b2[col];
     }
-    float w3v[KS2];  // head operands of wave 0 (dense_head<1>: column r16 of W3t, zero beyond the A outputs)
+    float w3v[VH ? 1 : KS2];  // head operands of wave 0 (dense_head<1>: column r16 of W3t, zero beyond the A outputs)
 #pragma unroll
-    for (int ks = 0; ks < KS2; ks++) {
+    for (int ks = 0; ks < (VH ? 0 : KS2); ks++) {
         const float w = P.W3t[(int64_t)(4 * ks + g) * A + (r16 < A ? r16 : 0)];
         w3v[ks] = r16 < A ? w : 0.0f;
     }
     const float b3v = r16 < A ? P.b3[r16] : 0.0f;
     // ---- env state of the 16 owner lanes (wave 0, lanes r16 < 4: row = 4 g + r16, where the head's C layout leaves that row's action) ----
-    const int my_row = g * 4 + r16;
+    const int my_row = g * RG + r16;
     const int64_t i = row0 + my_row;
-    const bool owner = wave == 0 && r16 < 4 && i < N;
+    const bool owner = wave == 0 && r16 < RG && my_row < M && i < N;
+    const float b3h = VH ? ((lane >> 3) < A ? P.b3[lane >> 3] : 0.0f) : 0.0f;  // VH: lane 8 a + e
     typename T::S s;
     double er = 0.0;
     uint32_t ce = 0;
@@ -1198,9 +1245,28 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
     }
     __syncthreads();
     double sret = 0.0, slen = 0.0, scnt = 0.0;
+#ifdef TMA_ROLL_TICKS
+    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k;
-        {  // layer 1: c = b1; c = mfma(X[:, 4 ks + g], W1t[4 ks + g][col], c) for ks = 0 .. KS1 - 1 -- one chain per column tile
+        TMA_RTICK(0);
+        if constexpr (M8) {  // layer 1, k by k: lane l < 8 supplies env l's activation, block e of them is broadcast
+            f32x4 c0 = f32x4{b1v[0], b1v[0], b1v[0], b1v[0]}, c1 = c0;
+            const float *xr = X + (lane & 7) * ldx;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(xr + 4 * ks);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (4 * ks + u < D) {
+                        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[u], w1s[4 * ks + u], c0, 4, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[u], w1s[4 * ks + u], c1, 4, 1, 0);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) h1[r * ld + n_base + lane] = tma_tanh(c0[r]), h1[(4 + r) * ld + n_base + lane] = tma_tanh(c1[r]);
+        } else {  // layer 1: c = b1; c = mfma(X[:, 4 ks + g], W1t[4 ks + g][col], c) for ks = 0 .. KS1 - 1 -- one chain per column tile
             f32x4 c[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) c[j] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
@@ -1216,7 +1282,27 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
                 for (int r = 0; r < 4; r++) h1[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c[j][r]);
         }
         __syncthreads();
-        {  // layer 2 (the A operand of a k-step serves the four column tiles: a quarter of the LDS reads of a tile-by-tile walk)
+        TMA_RTICK(1);
+        if constexpr (M8) {
+            f32x4 c0 = f32x4{b2v[0], b2v[0], b2v[0], b2v[0]}, c1 = c0;
+            const float *hr = h1 + (lane & 7) * ld;
+            f32x4 a4[4];  // activations three reads ahead (fenced per k-step: left to itself the scheduler reads each quad right in front of its MFMAs)
+#pragma unroll
+            for (int q = 0; q < 3; q++) a4[q] = *reinterpret_cast<const f32x4 *>(hr + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                if (ks + 3 < KS2) a4[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(hr + 4 * (ks + 3));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 3][u], w2s[4 * ks + u], c0, 4, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 3][u], w2s[4 * ks + u], c1, 4, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[r * ld + n_base + lane] = tma_tanh(c0[r]), h2[(4 + r) * ld + n_base + lane] = tma_tanh(c1[r]);
+        } else {  // layer 2 (the A operand of a k-step serves the four column tiles: a quarter of the LDS reads of a tile-by-tile walk)
             f32x4 c[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) c[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
@@ -1232,15 +1318,41 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
                 for (int r = 0; r < 4; r++) h2[(g * 4 + r) * ld + n_base + 16 * j + r16] = tma_tanh(c[j][r]);
         }
         __syncthreads();
+        TMA_RTICK(2);
         if (wave == 0) {
             f32x4 acc = f32x4{b3v, b3v, b3v, b3v};
+            if constexpr (VH) {
+                float hacc = b3h;
+                const float *hr = h2 + (lane & 7) * ld, *wr = w3l + (lane >> 3) * ld;
+                f32x4 hq[4], wq[4];  // operands three quads ahead of the chain
 #pragma unroll
-            for (int ks = 0; ks < KS2; ks++) acc = mfma16(h2[r16 * ld + 4 * ks + g], w3v[ks], acc);
+                for (int q = 0; q < 3; q++) hq[q] = *reinterpret_cast<const f32x4 *>(hr + 4 * q), wq[q] = *reinterpret_cast<const f32x4 *>(wr + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS2; ks++) {
+                    if (ks + 3 < KS2) hq[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(hr + 4 * (ks + 3)), wq[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(wr + 4 * (ks + 3));
+#pragma unroll
+                    for (int u = 0; u < 4; u++) hacc = __builtin_fmaf(hq[ks & 3][u], wq[ks & 3][u], hacc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                lgt[(lane & 7) * 8 + (lane >> 3)] = hacc;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < RG; r++) acc[r] = lgt[(g * RG + r) * 8 + (r16 & 7)];  // (columns 8 .. 15 are masked below: A <= 8)
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS2; ks++) acc = mfma16(h2[r16 * ld + 4 * ks + g], w3v[ks], acc);
+            }
+#ifdef TMA_ROLL_TICKS
+            asm volatile("" : "+v"(acc));
+#endif
+            TMA_RTICK(3);
             int my_act = 0;
             float my_lp = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int64_t row = row0 + g * 4 + r;
+            for (int r = 0; r < RG; r++) {
+                const int64_t row = row0 + g * RG + r;
                 const bool colok = r16 < A;
                 const float x = colok ? acc[r] : -INFINITY;
                 const float m = gmax16(x);
@@ -1260,6 +1372,10 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
                 const float lpa = gsum16((r16 == act) ? lp : 0.0f);
                 if (r16 == r) my_act = act, my_lp = lpa;
             }
+#ifdef TMA_ROLL_TICKS
+            asm volatile("" : "+v"(my_act), "+v"(my_lp));
+#endif
+            TMA_RTICK(4);
             if (owner) {
                 const int64_t off = (int64_t)t * N + i;
                 b.actions[off] = my_act;
@@ -1310,8 +1426,10 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
 #pragma unroll
                 for (int c = 0; c < D; c++) X[my_row * ldx + c] = o[c];  // (every read of this step's tile is behind the two barriers above)
             }
+            TMA_RTICK(5);
         }
         __syncthreads();
+        TMA_RTICK(6);
     }
     if (owner) {
         T::pack(v.st, N, i, s);
@@ -1338,7 +1456,17 @@ template <class T>
 static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n, uint32_t rng_seed,
                                  uint32_t rng_step0, int det, hipStream_t s) {
     if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
-        auto k = rollout_chunk_wide_f32_kernel<T>;
+        // tiles of eight envs while they give every env its own block round (up to 2048 envs); TMA_WIDE_F32_ROWS=16 / 8 forces a form (A/B, tests)
+        static const int force = getenv("TMA_WIDE_F32_ROWS") ? atoi(getenv("TMA_WIDE_F32_ROWS")) : 0;
+        const bool m8 = force ? force == 8 : env->v.N <= 2048;
+        if (m8) {
+            constexpr int ldx = ((T::OBS + 3) & ~3) + 4;
+            const int smem = (8 * ldx + 8 * 260 + 16 * 260 + 8 * 260 + 64) * 4;  // X, h1, h2 (16 rows), W3 rows, logits
+            rollout_chunk_wide_f32_kernel<T, 8><<<dim3((unsigned)ceil_div(env->v.N, 8)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+            TMA_LAUNCH_CHECK();
+            return TMA_OK;
+        }
+        auto k = rollout_chunk_wide_f32_kernel<T, 16>;
         constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
         const int smem = 16 * (ldx + 2 * 258) * 4;
         k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
@@ -1674,3 +1802,14 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     }
     return TMA_OK;
 }
+
+#ifdef TMA_ROLL_TICKS
+// diagnostic build only: read (reset != 0: clear) the per-phase cycle sums of the f32 wide rollout kernel
+extern "C" int tma_debug_roll_ticks(unsigned long long *out8, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(tma::g_roll_ticks), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(tma::g_roll_ticks), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
+#endif
