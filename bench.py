@@ -251,7 +251,7 @@ def spill_summary(family, pick=None):
 def attach_pmc_traffic(roof, name):
     """HBM bytes per launch from the committed rocprofv3 --pmc summaries (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2
     corrected as MI355X_MICROARCH.md prescribes); newest round first."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc.json")
         if os.path.exists(path):
             with open(path) as f:
