@@ -1216,6 +1216,10 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
         }
 #pragma unroll
         for (int ks = 0; ks < KS2; ks++) w2v[j][ks] = P.W2t[(int64_t)(4 * ks + g) * H + col];
+        if (j >= 2) {  // half of the layer-2 operands live in accumulator registers (an MFMA reads its B operand from either file)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) asm volatile("" : "+a"(w2v[j][ks]));
+        }
         b1v[j] = P.b1[col];
         b2v[j] = P.b2[col];
     }
@@ -1306,11 +1310,19 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
             f32x4 c[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) c[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+            // (round 6, as in the 8-env form: the A operands are read eight k-steps ahead behind scheduling fences -- left to the scheduler every
+            //  ds_read sat in front of its four MFMAs with a full wait)
+            float av[16];
+            const float *hr = h1 + r16 * ld + g;
+#pragma unroll
+            for (int q = 0; q < 8; q++) av[q] = hr[4 * q];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
-                const float a = h1[r16 * ld + 4 * ks + g];
+                if (ks + 8 < KS2) av[(ks + 8) & 15] = hr[4 * (ks + 8)];
 #pragma unroll
-                for (int j = 0; j < NTW; j++) c[j] = mfma16(a, w2v[j][ks], c[j]);
+                for (int j = 0; j < NTW; j++) c[j] = mfma16(av[ks & 15], w2v[j][ks], c[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
