@@ -61,7 +61,7 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         // selects the four-wave kernel)
         static const bool nw8 = getenv("TMA_BF_NW4") == nullptr;
         if (nw8 && MTc == 4 && variant == 0 && !L.cont && L.H == 256) {
-            const int smem8 = smemw + (L.H / 32) * 1024 + 4 * 4 * 5 * 8;  // + the head fragments + the statistics of four more waves
+            const int smem8 = smemw + (L.H / 32) * 1024 + 12 * 4 * 5 * 8;  // + the head fragments + the statistics slots of the row-lane loss (64 in all)
             auto launch8 = [&](auto k) -> int {
                 TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
                 k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, nullptr, DZ1_CAP * L.H);

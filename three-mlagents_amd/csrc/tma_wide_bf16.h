@@ -359,6 +359,76 @@ __device__ __forceinline__ void bf_head(const bf16_t *A2, int ld, int row0, int 
     }
 }
 
+// ---- Categorical loss with ONE ROW PER LANE (round 6; the eight-wave 64-row-group kernel) ----
+// policy_loss_tile works in the head's C layout: a lane is one action column of four rows, every row-wise quantity (max, sum of exponentials,
+// log-probability of the taken action, entropy) is a DPP reduction over sixteen lanes, and a wave spends ~140 vector instructions on two rows
+// of each lane group -- eight waves, two per SIMD, 1 120 wave-instructions for the 64 rows of a group, 3.4 k cycles of a policy-net group's
+// 28 k.  Transposed through LDS (the f32 dz3 tile doubles as the logit tile) a lane owns a row: the reductions are straight-line code over
+// the row's A logits, ~45 + 35 A instructions for sixteen rows at once.  SAME BITS as policy_loss_tile: sums in gsum16's tree order
+// ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) ... with the padding terms' zeros, the same expression for every intermediate.
+// AP: the tree's width (4, 8 or 16 >= A).  x: the row's logits (LDS, f32); out: the row's dz3 entries [0, A) (the same LDS words).
+template <int AP>
+__device__ __forceinline__ float bf_tree_sum(const float (&v)[AP]) {
+    float t[AP];
+#pragma unroll
+    for (int i = 0; i < AP; i++) t[i] = v[i];
+#pragma unroll
+    for (int w = 1; w < AP; w *= 2)
+#pragma unroll
+        for (int i = 0; i < AP; i += 2 * w) t[i] = t[i] + t[i + w];
+    return t[0];  // (+ the zeros of the lanes beyond AP: x + 0 == x)
+}
+template <int AP>
+__device__ __forceinline__ void discrete_loss_row(float *xrow, const f32x4 mrow, bool valid, int A, float amean, float astd, const HParams &hp, float invB,
+                                                  double *sl /* this row lane's five statistics sums in LDS, or nullptr */) {
+    float x[AP], e[AP];  // logits -> log-probabilities, exponentials -> probabilities, in place (the accumulators of the whole launch are live around this)
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < AP; a++) {
+        x[a] = a < A ? xrow[a] : -INFINITY;
+        m = fmaxf(m, x[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < AP; a++) e[a] = a < A ? expf(x[a] - m) : 0.0f;
+    const float s = bf_tree_sum<AP>(e);
+    const float lse = m + logf(s);
+    const int act = __float_as_int(mrow[3]);
+    float lpa = 0.0f, ent;
+    {
+        float plp[AP];
+#pragma unroll
+        for (int a = 0; a < AP; a++) {
+            x[a] = a < A ? x[a] - lse : 0.0f;
+            e[a] = e[a] / s;
+            plp[a] = e[a] * x[a];
+            lpa = (a == act) ? x[a] : lpa;
+        }
+        ent = -bf_tree_sum<AP>(plp);
+    }
+    const float old = mrow[0];
+    const float advn = (mrow[1] - amean) / (astd + 1e-8f);
+    const float ratio = expf(lpa - old);
+    const float pl1 = advn * ratio;
+    const float rc = fminf(fmaxf(ratio, 1.0f - hp.clip_range), 1.0f + hp.clip_range);
+    const float pl2 = advn * rc;
+    const float g_lp = (valid && pl1 <= pl2) ? -(advn * ratio) * invB : 0.0f;
+#pragma unroll
+    for (int a = 0; a < AP; a++) {
+        if (a < A) {
+            float dl = g_lp * (((a == act) ? 1.0f : 0.0f) - e[a]);
+            dl += valid ? (hp.ent_coef * invB) * (e[a] * (x[a] + ent)) : 0.0f;
+            xrow[a] = dl;
+        }
+    }
+    if (sl && valid) {  // (read-add-write one after the other: no five doubles live beside the launch's accumulators)
+        sl[0] += (double)(-fminf(pl1, pl2));
+        sl[1] += (double)ent;
+        sl[2] += (double)((ratio - 1.0f) - (lpa - old));
+        sl[3] += fabsf(ratio - 1.0f) > hp.clip_range ? 1.0 : 0.0;
+        sl[4] += 1.0;
+    }
+}
+
 struct BfNetPtr {
     const bf16_t *fW1, *fW2, *bW2, *fW3, *bW3;
 };
@@ -423,6 +493,11 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     static_assert(NW == 4 || (NW == 8 && ((MT == 4 && KS1C == 1 && PASS == 0 && !CONT) || (MT == 2 && KS1C > 2 && KT1C == 0))),
                   "eight waves: 64-row groups of the single-k-step Discrete layouts, or 32-row groups of the wide-observation two-pass layouts");
     constexpr bool W8 = NW == 8;
+#ifndef TMA_BF_ROW_LOSS
+#define TMA_BF_ROW_LOSS 1  // 0: the C-layout loss on all eight waves (A/B builds)
+#endif
+    constexpr bool RL = W8 && MT == 4 && !CONT && TMA_BF_ROW_LOSS;  // head, loss (a row per lane) and both dz3 images of row tile w on wave w alone: one block barrier in P3 instead of two
+    constexpr int SLN = RL ? 64 : NW * 4;                           // statistics slots in LDS (RL: one per row lane of waves 0 .. 3)
 #ifndef TMA_BF_W8_BIAS_VALU
 #define TMA_BF_W8_BIAS_VALU 1
 #endif
@@ -497,7 +572,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     float *hpart = scratch + 128;              // MT = 2: [4 waves][MT][2][64 lanes][4] split-K partial head outputs (MT = 4: none)
     float *bias = hpart + (MT == 4 ? 0 : 4 * MT * 2 * 256);  // b1[H], b2[H], b3[32] (zero padded): LDS copies, no global load in front of a phase
     double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [4 waves][4][5] loss statistics (lanes r16 == 0)
-    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + NW * 4 * 5), *row_off_next = row_off + M;
+    int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + SLN * 5), *row_off_next = row_off + M;
     bf16_t *W3lds = reinterpret_cast<bf16_t *>(row_off_next + M);  // W8: [KS2 * NT3] head fragments of 1 KiB (grad_wide_bf_smem_bytes adds them)
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
     const float invB = 1.0f / (float)mb.count;
@@ -548,7 +623,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     }
     for (int e = threadIdx.x; e < 2 * H + 32; e += blockDim.x)
         bias[e] = e < H ? Q.b1[e] : (e < 2 * H ? Q.b2[e - H] : (e - 2 * H < NOUT ? Q.b3[e - 2 * H] : 0.0f));
-    if (threadIdx.x < NW * 4 * 5) stat_lds[threadIdx.x] = 0.0;
+    if (threadIdx.x < SLN * 5) stat_lds[threadIdx.x] = 0.0;
     // ---- weight operands: ring over the two H x H streams, resident small fragments ----
     int nt0l = nt0;  // laundered copy (see the asm in the group loop): keeps the fragment address arithmetic scalar and inside the loop
     auto sload = [&](int s) -> bf16x8 {  // s in [0, SL): position in the per-group stream (compile-time after unrolling)
@@ -1107,6 +1182,73 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             // Eight waves: waves w and w + 4 share row tile w -- both run its head (8 MFMAs), each takes two of the four rows of every lane
             // group through the loss (the expensive part: exp / log per row), then a barrier, then waves 0-3 build the row-major and
             // waves 4-7 the transposed bf16 image of dz3
+            const bool row_loss = RL && (!IS_PI || A <= 8);  // (block-uniform; wider heads keep the C-layout loss on all eight waves)
+            if (row_loss) {
+                if (!(dbg & 4) && wave < 4) {
+                    const int mt = wave;
+                    f32x4 part[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) part[w] = z4;
+#pragma unroll
+                    for (int i = 0; i < HK; i++)
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const int ks = BLOCKK ? w * HK + i : w + 4 * i;
+                            if (ks < KS2) part[w] = mfma_bf(act_frag<MT>(A2, lda, T2, mt, ks, lane), *reinterpret_cast<const bf16x8 *>(W3lds + (ks * 64 + lane) * 8), part[w]);
+                        }
+                    const float bv = bias[2 * H + r16];
+                    f32x4 out = f32x4{bv, bv, bv, bv};
+#pragma unroll
+                    for (int w = 0; w < 4; w++) out += part[w];
+                    float *dzt = dz3 + mt * 16 * ld3;
+                    // the tile's outputs, row-major in LDS (columns beyond NOUT are exact zeros: zero weights, zero bias -- they are the padding of dz3 too)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dzt[(4 * g + r) * ld3 + r16] = out[r];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    TMA_TICK(10);
+                    if (lane < 16) {  // lane = row of the tile
+                        const int row = mt * 16 + lane;
+                        const bool valid = row_off[row] >= 0;
+                        const f32x4 mrow = *reinterpret_cast<const f32x4 *>(meta + row * 4);
+                        float *xrow = dzt + lane * ld3;
+                        double *sl = MAIN ? stat_lds + (wave * 16 + lane) * 5 : nullptr;
+                        if constexpr (IS_PI) {
+                            discrete_loss_row<8>(xrow, mrow, valid, A, amean, astd, hp, invB, sl);
+                        } else {
+                            const float diff = xrow[0] - mrow[2];
+                            xrow[0] = valid ? (hp.vf_coef * 2.0f * invB) * diff : 0.0f;
+                            if (MAIN && valid) sl[0] += (double)(diff * diff);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    TMA_TICK(11);
+                    {  // dz3 of the tile as bf16, row-major (Z3a) ...
+                        bf16x8 v;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int a = 8 * g + j;
+                            v[j] = (bf16_t)(a < 16 * NT3 ? dzt[r16 * ld3 + a] : 0.0f);
+                        }
+                        *reinterpret_cast<bf16x8 *>(Z3a + (16 * mt + r16) * ldz + 8 * g) = v;
+                    }
+                    {  // ... and transposed (Z3t); the f32 column sums feed the head bias gradient
+                        const int a = lane & 31, half = lane >> 5;
+                        bf16x8 v;
+                        float c = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const float x = a < 16 * NT3 ? dzt[(8 * half + j) * ld3 + a] : 0.0f;
+                            c += x;
+                            v[j] = (bf16_t)x;
+                        }
+                        ab3 += c;
+                        *reinterpret_cast<bf16x8 *>(Z3t + t_off<MT>(a, 16 * mt + 8 * half)) = v;
+                    }
+                    TMA_TICK(12);
+                }
+            } else
             if (!(dbg & 4)) {
                 const int mt = W8 ? (wave & 3) : wave, r_lo = W8 ? 2 * (wave >> 2) : 0, r_hi = W8 ? r_lo + 2 : 4;
                 f32x4 part[4][NT3];
@@ -1134,6 +1276,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #pragma unroll
                     for (int w = 0; w < 4; w++) out[q] += part[w][q];
                 }
+                TMA_TICK(10);
                 LossStats st;
                 float *dzt = dz3 + mt * 16 * ld3;
                 if constexpr (IS_PI) {
@@ -1160,7 +1303,9 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     double *sl = stat_lds + (wave * 4 + g) * 5;
                     sl[0] += st.a, sl[1] += st.ent, sl[2] += st.kl, sl[3] += st.clip, sl[4] += st.n;
                 }
+                TMA_TICK(11);
                 if constexpr (W8) __syncthreads();  // (block-uniform: dbg is) both halves of every tile's dz3 are in LDS
+                TMA_TICK(12);
                 // dz3 of this tile as bf16, row-major (Z3a) and transposed (Z3t); the f32 column sums feed the head bias gradient.
                 // (four waves: dzt was written by this wave -- LDS operations of one wave execute in order, no barrier needed)
                 if (!W8 || wave < 4) {
@@ -1579,7 +1724,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         v0 += __shfl_xor(v0, 16, 64), v0 += __shfl_xor(v0, 32, 64);
         v1 += __shfl_xor(v1, 16, 64), v1 += __shfl_xor(v1, 32, 64);
         if constexpr (MT == 4) {  // every (head) wave holds the column sums of its row tile
-            if (lane < 32 && (W8 ? wave >= 4 : true)) scratch[(wave & 3) * 32 + lane] = v;
+            if (lane < 32 && (W8 ? ((RL && (!IS_PI || A <= 8)) ? wave < 4 : wave >= 4) : true)) scratch[(wave & 3) * 32 + lane] = v;
         } else if (wave >= 2 && wave < 4) {  // the Z3t waves hold the head-bias column sums (tile wave - 2)
             if (lane < 32) scratch[(wave - 2) * 32 + lane] = v;
         }
@@ -1604,7 +1749,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     __syncthreads();
     if (MAIN && threadIdx.x < 5) {
         double ssum = 0.0;
-        for (int w = 0; w < NW * 4; w++) ssum += stat_lds[w * 5 + threadIdx.x];
+        for (int w = 0; w < SLN; w++) ssum += stat_lds[w * 5 + threadIdx.x];
         const int q = IS_PI ? (threadIdx.x == 0 ? 0 : threadIdx.x + 1) : (threadIdx.x == 0 ? 1 : -1);
         if (q >= 0) stat_slot[q] += ssum;
     }

@@ -40,9 +40,10 @@ else:
         grad()
 torch.cuda.synchronize()
 L.tma_debug_bf_ticks(out, 0)
-names = ["loop top", "P0 commit", "P1 layer 1", "P2 layer 2", "P3 head / loss", "P3c dz3 images", "P4 dW3 + dz2", "P5 dW2 + dh1", "tail (after the loop)", "P6 dz1 + dW1"]
+names = ["loop top", "P0 commit", "P1 layer 1", "P2 layer 2", "P3 fragment requests", "P3 dz3 images + barrier", "P4 dW3 + dz2", "P5 dW2 (+ barrier)", "tail (after the loop)", "dh1 + dz1 + dW1",
+         "P3 head MFMAs + output sums (64-row groups)", "P3 loss", "P3 barrier behind the loss"]
 for net, o in (("pi", 0), ("vf", 16)):
-    v = [out[o + i] / reps for i in range(10)]
+    v = [out[o + i] / reps for i in range(13)]
     tot = sum(v)
     print(net, "cycles per launch (block 0):", {n: round(x) for n, x in zip(names, v)}, "sum", round(tot))
     print("    share:", {n: f"{100 * x / tot:.1f}%" for n, x in zip(names, v)})
