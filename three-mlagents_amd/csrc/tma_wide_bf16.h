@@ -534,14 +534,21 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     if (threadIdx.x < 16) tick_lds[threadIdx.x] = 0;
     long long tlast = clock64();
     const bool tick_on = threadIdx.x == 0 && block_net == 0;
-#define TMA_TICK(i)                                                        \
+#define TMA_TICK_DO(i)                                                     \
     do {                                                                   \
         const long long tn = clock64();                                    \
         if (tick_on) tick_lds[i] += (unsigned long long)(tn - tlast);      \
         tlast = clock64();                                                 \
     } while (0)
+#ifdef TMA_BF_TICK_P3_ONLY  // stamps of the loss phase only (the full set costs the eight-wave kernel 64 spilled registers, whose reloads wait for the HBM gathers in flight)
+#define TMA_TICK(i)
+#else
+#define TMA_TICK(i) TMA_TICK_DO(i)
+#endif
+#define TMA_TICK3(i) TMA_TICK_DO(i)
 #else
 #define TMA_TICK(i)
+#define TMA_TICK3(i)
 #endif
 #define TMA_RELANE()                                              \
     do {                                                          \
@@ -1178,7 +1185,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         if constexpr (MT == 4) {
             // ---- P3 (64-row groups): wave w owns row tile w -- whole head (the split-K summation order of bf_head, so the rollout's
             // log-probabilities still match bit for bit), loss, and both bf16 images of dz3, with no block barrier in between ----
-            TMA_TICK(4);
+            TMA_TICK3(4);
             // Eight waves: waves w and w + 4 share row tile w -- both run its head (8 MFMAs), each takes two of the four rows of every lane
             // group through the loss (the expensive part: exp / log per row), then a barrier, then waves 0-3 build the row-major and
             // waves 4-7 the transposed bf16 image of dz3
@@ -1206,7 +1213,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     for (int r = 0; r < 4; r++) dzt[(4 * g + r) * ld3 + r16] = out[r];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    TMA_TICK(10);
+                    TMA_TICK3(10);
                     if (lane < 16) {  // lane = row of the tile
                         const int row = mt * 16 + lane;
                         const bool valid = row_off[row] >= 0;
@@ -1223,7 +1230,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    TMA_TICK(11);
+                    TMA_TICK3(11);
                     {  // dz3 of the tile as bf16, row-major (Z3a) ...
                         bf16x8 v;
 #pragma unroll
@@ -1246,7 +1253,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                         ab3 += c;
                         *reinterpret_cast<bf16x8 *>(Z3t + t_off<MT>(a, 16 * mt + 8 * half)) = v;
                     }
-                    TMA_TICK(12);
+                    TMA_TICK3(12);
                 }
             } else
             if (!(dbg & 4)) {
@@ -1404,7 +1411,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
         }
         }
         __syncthreads();
-        TMA_TICK(5);
+        TMA_TICK3(5);
         TMA_RELANE();
         if constexpr (PFD) {
             if (has_next) {  // (nobody reads the observation images after layer 1 in this pass)
@@ -1675,6 +1682,8 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
 #endif
 #undef TMA_RELANE
 #undef TMA_TICK
+#undef TMA_TICK3
+#undef TMA_TICK_DO
     // ---- store this block's slab (every parameter of the net has exactly one owning wave) ----
     float *gW1 = slab + (IS_PI ? L.pW1t : L.vW1t), *gb1 = slab + (IS_PI ? L.pb1 : L.vb1);
     float *gW2 = slab + (IS_PI ? L.pW2t : L.vW2t), *gb2 = slab + (IS_PI ? L.pb2 : L.vb2);
