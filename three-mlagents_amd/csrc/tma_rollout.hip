@@ -1464,6 +1464,278 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: the Box-action chunk (Crawler / Ant shapes) for the reference's own dtype -- MLP(256, 256) in f32 -- in tiles of EIGHT envs.
+// Until now these shapes had a fused chunk on the bf16 MFMA only; in f32 every vector step was policy_fwd_wide_kernel + the env step kernel
+// + their launch gaps: 72 us per step at 2048 envs, a fifth of the Crawler shard's f32 iteration.  The block is the 8-env form of
+// rollout_chunk_wide_f32_kernel (4 waves, 64 columns each, the POLICY net only; values and the timeout bootstrap are one batched launch
+// each per chunk): both hidden layers k by k on v_mfma_f32_4x4x1_16b_f32 with the A operand broadcast (4 envs x 64 columns x 1 k in 8
+// cycles, no padding rows; the bits of the 16 x 16 x 4 chain), layer-2 weights in registers (half of them accumulator registers), the
+// layer-1 weights -- 172 x 256 f32 at the Crawler width, no room beside them -- streamed from L2 a k-quad ahead (176 KB per block and step,
+// the same 176 KB for every block), the mean head as ONE fused-multiply-add chain per (env, action dim) over all four waves (dense_head's
+// order: bias, then k ascending), DiagGaussian sampling and the env step on eight lanes per env on wave 0 (the code of
+// rollout_chunk_wide_cont_pi_kernel).  Bit-identical to the per-step composition (test_native_rollout_equals_stepwise_composition).
+// ------------------------------------------------------------------------------------------
+struct ObsDualF {  // one observation element to its global row and to its f32 LDS row
+    float *gl, *img;
+    struct Ref {
+        float *gl, *img;
+        __device__ __forceinline__ void operator=(float x) const { *gl = x, *img = x; }
+    };
+    __device__ __forceinline__ Ref operator[](int k) const { return Ref{gl + k, img + k}; }
+    __device__ __forceinline__ ObsDualF operator+(int k) const { return ObsDualF{gl + k, img + k}; }
+};
+template <class T>
+struct WideContF32Lds {
+    static constexpr int M = 8, H = 256, LD = H + 4, LDX = ((T::OBS + 3) & ~3) + 4, AP = 32;
+    // observation rows, two activation images, the head's weights as [action dim][k] rows, means and sampled actions [M][32], env state
+    // [SW][M], truncated / done flags, per-joint terms of the multi-lane env step
+    static constexpr int floats() { return M * LDX + 2 * M * LD + AP * LD + 2 * M * 32 + T::SW * M + 64 + M * T::NJ * 5; }
+};
+template <class T>
+__global__ __launch_bounds__(256, 1) void rollout_chunk_wide_cont_f32_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
+                                                                             float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,
+                                                                             uint32_t rng_step0, int det) {
+    extern __shared__ __attribute__((aligned(16))) float smem_cf[];
+    using W = WideContF32Lds<T>;
+    constexpr int M = W::M, H = W::H, ld = W::LD, ldx = W::LDX, D = T::OBS, AD = T::ADIM, KQ1 = (D + 3) >> 2, KS2 = H / 4;
+    static_assert(T::NACT == 0 && AD <= 32 && !T::USES_MT, "fused f32 wide rollout, Box actions: <= 32 action dims, inline resets");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4, n_base = 64 * wave;
+    float *X = smem_cf, *h1 = X + M * ldx, *h2 = h1 + M * ld, *w3l = h2 + M * ld, *means = w3l + W::AP * ld, *actl = means + M * 32;
+    uint32_t *stl = reinterpret_cast<uint32_t *>(actl + M * 32);  // [SW][M] env state words
+    int *trf = reinterpret_cast<int *>(stl + T::SW * M), *dnf = trf + 32;
+    float *termsl = reinterpret_cast<float *>(dnf + 32);  // [M][NJ][5]
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x * M;
+    float *act_out = reinterpret_cast<float *>(b.actions);
+    const Net P = pi_net(params, L);
+    // ---- layer-2 weights: column n_base + lane, one register per k (the upper half in accumulator registers) ----
+    float w2s[H];
+#pragma unroll
+    for (int kk = 0; kk < H; kk++) w2s[kk] = P.W2t[(int64_t)kk * H + n_base + lane];
+#pragma unroll
+    for (int kk = H / 2; kk < H; kk++) asm volatile("" : "+a"(w2s[kk]));
+    const float b1s = P.b1[n_base + lane], b2s = P.b2[n_base + lane];
+    const float *w1col = P.W1t + n_base + lane;  // layer 1: W1t[k][col], streamed
+    for (int e = threadIdx.x; e < W::AP * ld; e += blockDim.x) {  // head weights as [action dim][k] rows (zero rows beyond AD)
+        const int a = e / ld, kk = e - a * ld;
+        w3l[e] = (a < AD && kk < H) ? P.W3t[(int64_t)kk * AD + a] : 0.0f;
+    }
+    const int hp = wave * 64 + lane, he = hp & 7, ha = hp >> 3;  // head pair of this lane: env he, action dim ha (live below AD)
+    const float b3h = ha < AD ? P.b3[ha] : 0.0f;
+    // ---- env state -> LDS; eight lanes per env on wave 0 ----
+    const int my_row = lane >> 3, sub = lane & 7;
+    const int64_t i = row0 + my_row;
+    const bool grp_ok = wave == 0 && i < N;
+    const bool owner = grp_ok && sub == 0;
+    double er = 0.0;
+    uint32_t ce = 0;
+    static_assert(sizeof(typename T::S) <= T::SW * 4, "state struct fits its LDS slot");
+    typename T::S *sl = reinterpret_cast<typename T::S *>(stl);
+    if (owner) {
+        T::unpack(v.st, N, i, sl[my_row]);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    for (int e = threadIdx.x; e < M * ldx; e += blockDim.x) {  // observation rows of step t0 (columns >= D stay zero for the whole launch)
+        const int row = e / ldx, c = e - row * ldx;
+        X[e] = (row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f;
+    }
+    if (threadIdx.x < 64) trf[threadIdx.x] = 0;  // (trf and dnf)
+    __syncthreads();
+    const float *ls = params + L.log_std;
+    float lsd_v[2], sd_v[2];  // log_std and exp(log_std) of this lane's two action columns: constant over the launch
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        lsd_v[j] = (16 * j + r16 < AD) ? ls[16 * j + r16] : 0.0f;
+        sd_v[j] = expf(lsd_v[j]);
+    }
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+#ifdef TMA_ROLL_TICKS
+    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k;
+        TMA_RTICK(0);
+        {  // layer 1, k by k: lane l < 8 supplies env l's observation, block e of them is broadcast; weights four k-quads ahead of their use
+            f32x4 c0 = f32x4{b1s, b1s, b1s, b1s}, c1 = c0;
+            const float *xr = X + (lane & 7) * ldx;
+            constexpr int PF = 4;
+            f32x4 a4[PF];
+            float wq[PF][4];
+#pragma unroll
+            for (int q = 0; q < PF - 1; q++) {
+                a4[q] = *reinterpret_cast<const f32x4 *>(xr + 4 * q);
+#pragma unroll
+                for (int u = 0; u < 4; u++) wq[q][u] = w1col[(int64_t)(4 * q + u < D ? 4 * q + u : 0) * H];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 4
+            for (int q = 0; q < KQ1; q++) {
+                const int qn = q + PF - 1;
+                if (qn < KQ1) {
+                    a4[qn % PF] = *reinterpret_cast<const f32x4 *>(xr + 4 * qn);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) wq[qn % PF][u] = w1col[(int64_t)(4 * qn + u < D ? 4 * qn + u : 0) * H];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (4 * q + u < D) {
+                        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q % PF][u], wq[q % PF][u], c0, 4, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q % PF][u], wq[q % PF][u], c1, 4, 1, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) h1[r * ld + n_base + lane] = tma_tanh(c0[r]), h1[(4 + r) * ld + n_base + lane] = tma_tanh(c1[r]);
+        }
+        __syncthreads();
+        TMA_RTICK(1);
+        {  // layer 2 (rollout_chunk_wide_f32_kernel<T, 8>'s loop)
+            f32x4 c0 = f32x4{b2s, b2s, b2s, b2s}, c1 = c0;
+            const float *hr = h1 + (lane & 7) * ld;
+            f32x4 a4[4];
+#pragma unroll
+            for (int q = 0; q < 3; q++) a4[q] = *reinterpret_cast<const f32x4 *>(hr + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                if (ks + 3 < KS2) a4[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(hr + 4 * (ks + 3));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 3][u], w2s[4 * ks + u], c0, 4, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[ks & 3][u], w2s[4 * ks + u], c1, 4, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[r * ld + n_base + lane] = tma_tanh(c0[r]), h2[(4 + r) * ld + n_base + lane] = tma_tanh(c1[r]);
+        }
+        __syncthreads();
+        TMA_RTICK(2);
+        if (ha < AD) {  // mean head: one fused-multiply-add chain per (env, action dim) -- dense_head's operations in dense_head's order
+            float hacc = b3h;
+            const float *hr = h2 + he * ld, *wr = w3l + ha * ld;
+            f32x4 hq[4], wq[4];
+#pragma unroll
+            for (int q = 0; q < 3; q++) hq[q] = *reinterpret_cast<const f32x4 *>(hr + 4 * q), wq[q] = *reinterpret_cast<const f32x4 *>(wr + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) {
+                if (ks + 3 < KS2) hq[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(hr + 4 * (ks + 3)), wq[(ks + 3) & 3] = *reinterpret_cast<const f32x4 *>(wr + 4 * (ks + 3));
+#pragma unroll
+                for (int u = 0; u < 4; u++) hacc = __builtin_fmaf(hq[ks & 3][u], wq[ks & 3][u], hacc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            means[he * 32 + ha] = hacc;
+        }
+        __syncthreads();
+        TMA_RTICK(3);
+        if (wave == 0) {
+            // DiagGaussian sample + log-prob: policy_fwd_wide_kernel<CONT>'s streams and arithmetic; a lane group takes rows 2 g, 2 g + 1
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int lrow = 2 * g + r;
+                const int64_t row = row0 + lrow;
+                const uint32_t gi = v.env_offset + (uint32_t)row;
+                const uint32_t rstep = rng_step0 + (uint32_t)t;
+                float lpsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = 16 * j + r16;
+                    if (col < AD) {
+                        const float mu = means[lrow * 32 + col], lsd = lsd_v[j], sd = sd_v[j];
+                        const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
+                        const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
+                        const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+                        const float a = det ? mu : mu + sd * z;  // deterministic evaluation: the mean (policy_fwd_wide_kernel)
+                        const float dd = a - mu;
+                        lpsum += -(dd * dd) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                        actl[lrow * 32 + col] = a;
+                        if (row < N) act_out[((int64_t)t * N + row) * AD + col] = a;
+                    }
+                }
+                lpsum = gsum16(lpsum);
+                if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            TMA_RTICK(4);
+            // env step on eight lanes per env (rollout_chunk_wide_cont_pi_kernel's sequence)
+            typename T::S &s = sl[my_row];
+            double r = 0.0;
+            bool done = false;
+            if (grp_ok) T::template step_lanes<8>(s, actl + my_row * 32, termsl + my_row * (T::NJ * 5), sub, r, done);
+            if (owner) {
+                const int64_t off = (int64_t)t * N + i;
+                const bool hit = T::steps(s) >= T::MAXSTEPS;  // adapter rule, backend/mlagents/envs.py:139-145
+                const bool te = done && !hit, tr = hit;
+                er += r;
+                b.rewards[off] = (float)r;  // (the timeout bootstrap is added by the caller's batched tma_policy_bootstrap)
+                b.terminated[off] = (uint8_t)te;
+                b.truncated[off] = (uint8_t)tr;
+                trf[my_row] = tr ? 1 : 0;
+                dnf[my_row] = (te || tr) ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool g_tr = grp_ok && trf[my_row] != 0, g_dn = grp_ok && dnf[my_row] != 0;
+            if (g_tr) T::template obs_lanes<8>(s, sub, term_obs + ((int64_t)k * N + i) * D);  // terminal observation: slot (t - t0) of the chunk
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (g_dn && sub == 0) {
+                const int steps = T::steps(s);
+                sret += er, slen += (double)steps, scnt += 1.0;
+                log_episode(v, i, er, steps);
+                er = 0.0;
+                ce += 1;
+                T::reset_inline(episode_seed(v.seed_base, v.env_offset + (uint32_t)i, ce), s);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (grp_ok) T::template obs_lanes<8>(s, sub, ObsDualF{b.obs + ((int64_t)(t + 1) * N + i) * D, X + my_row * ldx});
+            TMA_RTICK(5);
+        }
+        __syncthreads();
+        TMA_RTICK(6);
+    }
+    if (owner) {
+        T::pack(v.st, N, i, sl[my_row]);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sret += __shfl_down(sret, o, 64);
+            slen += __shfl_down(slen, o, 64);
+            scnt += __shfl_down(scnt, o, 64);
+        }
+        if (lane == 0 && scnt > 0.0) {
+            double *slot = v.stats + (row0 >> 8) * 3;
+            atomicAdd(slot + 0, sret);
+            atomicAdd(slot + 1, slen);
+            atomicAdd(slot + 2, scnt);
+        }
+    }
+}
+
+template <class T>
+static int launch_chunk_wide_cont_f32(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n,
+                                      uint32_t rng_seed, uint32_t rng_step0, int det, hipStream_t s) {
+    if constexpr (T::FUSED_ROLLOUT && T::NACT == 0 && T::ADIM <= 32 && !T::USES_MT && T::OBS <= 192) {
+        auto k = rollout_chunk_wide_cont_f32_kernel<T>;
+        const int smem = WideContF32Lds<T>::floats() * 4;
+        TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        k<<<dim3((unsigned)ceil_div(env->v.N, 8)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    } else {
+        return fail(TMA_ERR_INVALID, "no fused f32 wide rollout for this Box-action task");
+    }
+}
+
 template <class T>
 static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n, uint32_t rng_seed,
                                  uint32_t rng_step0, int det, hipStream_t s) {
@@ -1611,10 +1883,14 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     // ... and on the Crawler shape (Box actions, 172 observations): layer-1 fragments streamed per step, env state in LDS
     const bool fused_cont = d->continuous && (env->task == TMA_TASK_CRAWLER || env->task == TMA_TASK_ANT) && d->act_dim == tma_task_act_dim(env->task);
     const bool fused_wide = !no_wide_fused && L.bf16 && L.H == 256 && env->is_reset && d->obs_dim == tma_task_obs_dim(env->task) && (fused_disc || fused_cont);
+    // ... and in f32 (the reference's dtype), round 6: tiles of eight envs, up to 4096 envs (two block rounds; beyond that the per-step composition)
+    static const bool no_cont_f32 = getenv("TMA_NO_CONT_F32_FUSED") != nullptr;  // A/B switch
+    const bool fused_cont_f32 = !no_wide_fused && !no_cont_f32 && !L.bf16 && L.img_pi < 0 && L.H == 256 && env->is_reset && fused_cont &&
+                                d->obs_dim == tma_task_obs_dim(env->task) && env->v.N <= 4096;
     // Box-action tasks (Crawler / Ant shapes), round 4: policy-only fused chunk + ONE batched value launch + ONE batched bootstrap launch per
     // chunk of up to terminal_obs_slots steps (TMA_CONT_TWO_NET=1: the round-2 chunk with both nets in the step loop)
     static const bool cont_two_net = getenv("TMA_CONT_TWO_NET") != nullptr;
-    if (fused_wide && fused_cont && !cont_two_net) {
+    if ((fused_wide && fused_cont && !cont_two_net) || fused_cont_f32) {
         TMA_HIP(hipSetDevice(env->device));
         ChunkPtrs cp{b->obs, static_cast<int32_t *>(b->actions), b->rewards, b->values, b->log_probs, b->terminated, b->truncated};
         const int D = d->obs_dim;
@@ -1649,6 +1925,7 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
                 TMA_HIP(hipStreamWaitEvent(mainS, env->ev_side[half], 0));
             rc = dispatch_task(env->task, [&](auto task) {
                 using TT = decltype(task);
+                if (fused_cont_f32) return launch_chunk_wide_cont_f32<TT>(env, params, L, cp, tobs, t, n, rng_seed, rng_step0, det, mainS);
                 return launch_chunk_wide_cont_pi<TT>(env, params, L, cp, tobs, t, n, rng_seed, rng_step0, det, mainS);
             });
             if (rc) return rc;

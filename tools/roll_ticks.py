@@ -21,7 +21,7 @@ L.tma_debug_roll_ticks(None, 1)
 m.collect_rollouts(); torch.cuda.synchronize()
 out = (C.c_ulonglong * 8)()
 L.tma_debug_roll_ticks(out, 0)
-names = ["loop top", "layer 1 + tanh + barrier", "layer 2 + tanh + barrier", "head chain (wave 0)", "softmax + sampling", "env step + observation", "last barrier"]
+names = ["loop top", "layer 1 + tanh + barrier", "layer 2 + tanh + barrier", "head chain (+ barrier on the Box tasks)", "softmax / Gaussian sampling", "env step + observation", "last barrier"]
 v = [out[i] / T for i in range(7)]
 print(f"{task} N={N}: cycles per vector step (s_memtime: shader cycles)")
 for n, x in zip(names, v):
