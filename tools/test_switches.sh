@@ -26,3 +26,4 @@ run "TMA_NO_PERSIST256=1" "tests/test_h256p_gpu.py tests/test_ppo_gpu.py" "not f
 run "TMA_EPOCH_PER_CALL=1" "tests/test_h256p_gpu.py"                          # one persistent launch per epoch instead of per train()
 run "TMA_WIDE_F32_ROWS=16" "tests/test_ppo_gpu.py tests/test_rollout_oracle_gpu.py"   # the f32 256-wide fused rollout in 16-env tiles at every env count
 run "TMA_WIDE_F32_ROWS=8" "tests/test_ppo_gpu.py"                             # ... and in 8-env tiles beyond 2048 envs
+run "TMA_NO_CONT_F32_FUSED=1" "tests/test_ppo_gpu.py" "crawler or ant"   # the f32 Box-action rollouts step by step
