@@ -353,6 +353,8 @@ def test_gae_flags_equals_sb3_layout(monkeypatch, T, N, scan):
                                                 ("walljump", 256, 64, "f32"), ("bicycle", 256, 40, "f32"), ("glider", 256, 40, "f32"),
                                                 # the Box-action fused chunk (Crawler shape: layer-1 fragments streamed, env state in LDS); 72 = a ragged group
                                                 ("crawler", 256, 72, "bf16"), ("crawler", 256, 40, "f32"), ("ant", 256, 72, "bf16"), ("ant", 256, 40, "f32"),
+                                                # (f32: 8-env tiles since round 6 -- 12 = a ragged second tile)
+                                                ("crawler", 256, 12, "f32"),
                                                 # the float64-physics tasks of SURVEY 8f: fused on 64-wide and 256-wide bf16 nets (Bicycle, Glider), per-step otherwise
                                                 ("bicycle", 64, 200, "f32"), ("glider", 64, 200, "f32"), ("bicycle", 256, 72, "bf16"), ("glider", 256, 72, "bf16"),
                                                 ("brickbreak", 64, 100, "f32")])
