@@ -466,6 +466,65 @@ __device__ __forceinline__ void h64t_forward(const float *wimg, const float *b1,
         }
 }
 
+// The same forward pass with every operand of the net in REGISTERS (round 6; the fused rollout kernels, whose weights do not change during a
+// launch and whose waves have 512 registers to themselves): 64 registers of layer-2 weights, 16 of the head, the layer-1 rows and the
+// biases are read from the LDS image once per launch instead of ~40 LDS reads per vector step -- the head's sixteen operands had been
+// coming out as eight dependent read-wait-multiply round trips.  Instruction for instruction h64t_forward's arithmetic: same bits.
+template <int KS1C>
+struct H64FwdRegs {
+    f32x4 b1[4], b2[4], w1[KS1C], w2[16], b3o;
+    float w3[16];
+};
+template <int KS1C>
+__device__ __forceinline__ void h64t_load_fwd(const float *wimg, const float *b1, const float *b2, const float *b3, int KS1, H64FwdRegs<KS1C> &R, int lane) {
+    const int r16 = lane & 15, g = lane >> 4, acol = (r16 >> 2) + 4 * (r16 & 3);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) R.b1[mt] = *reinterpret_cast<const f32x4 *>(b1 + 16 * mt + 4 * g), R.b2[mt] = *reinterpret_cast<const f32x4 *>(b2 + 16 * mt + 4 * g);
+#pragma unroll
+    for (int ks = 0; ks < KS1C; ks++) R.w1[ks] = *reinterpret_cast<const f32x4 *>(wimg + IMG_W1 + (4 * (ks < KS1 ? ks : 0) + g) * 64 + r16 * 4);
+    const float *wrow = wimg + IMG_W2F + 4 * g * 64 + r16 * 4;
+#pragma unroll
+    for (int i = 0; i < 16; i++) R.w2[i] = *reinterpret_cast<const f32x4 *>(wrow + (16 * (i >> 2) + (i & 3)) * 64);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) R.w3[4 * j + r] = wimg[IMG_W3F + (16 * j + 4 * g + r) * 16 + acol];
+    R.b3o = f32x4{b3[g], b3[g + 4], b3[g + 8], b3[g + 12]};
+}
+template <int KS1C>
+__device__ __forceinline__ void h64t_forward_r(const H64FwdRegs<KS1C> &R, const float (&xb)[KS1C], int KS1, f32x4 &o0, f32x4 &o1) {
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) h1[mt] = R.b1[mt];
+#pragma unroll
+    for (int ks = 0; ks < KS1C; ks++) {
+        if (ks < KS1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(R.w1[ks][mt], xb[ks], h1[mt]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) h2[mt] = R.b2[mt];
+    // chain64_act's order: the activations of tile j + 1 are formed under the MFMAs of tile j
+#pragma unroll
+    for (int r = 0; r < 4; r++) h1[0][r] = tma_tanh(h1[0][r]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) h2[mt] = mfma16(R.w2[i][mt], h1[i >> 2][i & 3], h2[mt]);
+        if (i + 4 < 16) h1[(i + 4) >> 2][(i + 4) & 3] = tma_tanh(h1[(i + 4) >> 2][(i + 4) & 3]);
+    }
+    o0 = R.b3o, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            h2[j][r] = tma_tanh(h2[j][r]);
+            if ((4 * j + r) & 1) o1 = mfma16(R.w3[4 * j + r], h2[j][r], o1);
+            else o0 = mfma16(R.w3[4 * j + r], h2[j][r], o0);
+        }
+}
+
 __device__ __forceinline__ float xg_min(float v) { return xg_reduce(v, [](float a, float b) { return fminf(a, b); }); }
 
 // Categorical action and its log-probability from the head outputs of h64t_forward (output a = g + 4 r in register r of lane group g).

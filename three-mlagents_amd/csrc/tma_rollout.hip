@@ -208,6 +208,9 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     __syncthreads();
     double sret = 0.0, slen = 0.0, scnt = 0.0;
     const float *img = wave == 1 ? vimg : pimg;
+    // this wave's net in registers for the whole launch (h64t_forward_r: the arithmetic of h64t_forward, no LDS weight reads in the step loop)
+    H64FwdRegs<KS1> FR;
+    h64t_load_fwd<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, KS1, FR, lane);
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k, p = k & 1, q = p ^ 1;
         const float *X = X0 + p * 16 * CH_LDX;
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) xb[ks] = X[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
         f32x4 o0, o1;
-        h64t_forward<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, xb, KS1, o0, o1, lane);
+        h64t_forward_r<KS1>(FR, xb, KS1, o0, o1);
         if (wave == 1) {
             if (active) b.values[(int64_t)t * N + i] = o0[0] + o1[0];
             if (k > 0 && flag[q]) {  // timeout bootstrap of step t-1: rewards = reward + gamma * V(terminal_obs) where truncated
                 float xt[KS1];
 #pragma unroll
                 for (int ks = 0; ks < KS1; ks++) xt[ks] = XT0[q * 16 * CH_LDX + r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];
-                h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xt, KS1, o0, o1, lane);
+                h64t_forward_r<KS1>(FR, xt, KS1, o0, o1);  // (wave 1 holds the value net)
                 if (active && trf[q * 16 + r16]) {
                     const float gv = gamma * (o0[0] + o1[0]);
                     b.rewards[(int64_t)(t - 1) * N + i] = rw[q * 16 + r16] + gv;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) xt[ks] = XT0[q * 16 * CH_LDX + r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];
             f32x4 o0, o1;
-            h64t_forward<KS1>(vimg, vimg + IMG_FWD_FLOATS, vimg + IMG_FWD_FLOATS + 64, vimg + IMG_FWD_FLOATS + 128, xt, KS1, o0, o1, lane);
+            h64t_forward_r<KS1>(FR, xt, KS1, o0, o1);
             if (active && trf[q * 16 + r16]) {
                 const float gv = gamma * (o0[0] + o1[0]);
                 b.rewards[(int64_t)t * N + i] = rw[q * 16 + r16] + gv;
