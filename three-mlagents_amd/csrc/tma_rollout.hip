@@ -388,11 +388,17 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
             f32x4 acc[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; j++) acc[j] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+            // (round 6: the A fragments two k-steps ahead behind scheduling fences -- left to the scheduler every ds_read_b128 sat in front of
+            //  its four MFMAs behind a full wait: an LDS round trip per k-step with the matrix pipe idle)
+            bf16x8 af[3];
+            af[0] = a_frag(A1, lda, 16 * m2 + r16, 0, g), af[1] = a_frag(A1, lda, 16 * m2 + r16, 1, g);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
-                const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+                if (ks + 2 < KS2) af[(ks + 2) % 3] = a_frag(A1, lda, 16 * m2 + r16, ks + 2, g);
 #pragma unroll
-                for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(a, w2[j][ks], acc[j]);
+                for (int j = 0; j < NTW; j++) acc[j] = mfma_bf(af[ks % 3], w2[j][ks], acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
@@ -405,13 +411,20 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_bf_kernel(EnvView v
         f32x4 part[4];
 #pragma unroll
         for (int wq = 0; wq < 4; wq++) part[wq] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // (all sixteen operands requested before the first product: eight dependent read-wait-multiply round trips otherwise)
 #pragma unroll
-        for (int i2 = 0; i2 < 2; i2++)
+        for (int i2 = 0; i2 < 2; i2++) {  // (the four k-steps of a pass in one batch of reads: 32 registers)
+            bf16x8 ha[4], hw[4];
 #pragma unroll
             for (int wq = 0; wq < 4; wq++) {
                 const int ks = wq * 2 + i2;
-                part[wq] = mfma_bf(a_frag(A2, lda, 16 * mt + r16, ks, g), *reinterpret_cast<const bf16x8 *>(W3l + (ks * 64 + lane) * 8), part[wq]);
+                ha[wq] = a_frag(A2, lda, 16 * mt + r16, ks, g), hw[wq] = *reinterpret_cast<const bf16x8 *>(W3l + (ks * 64 + lane) * 8);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++) part[wq] = mfma_bf(ha[wq], hw[wq], part[wq]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x4 out = f32x4{b3v, b3v, b3v, b3v};
 #pragma unroll
         for (int wq = 0; wq < 4; wq++) out += part[wq];
