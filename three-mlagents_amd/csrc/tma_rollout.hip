@@ -929,6 +929,7 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
     using W = WideContPiLds<T, MROWS>;
     constexpr int M = W::M, MT2 = M / 16, NTW = 2, KS2 = W::KS2, lda = W::LDA, ldx = W::LDX, KS1 = W::KS1, NT3 = W::NT3, D = T::OBS, AD = T::ADIM;
     static_assert(MROWS == 32 || MROWS == 16, "one or two 16-row tiles per block");
+    constexpr bool AHEAD = KS1 <= 4;  // operand fragments requested ahead of their MFMAs (see layer 1): the Ant width yes, the Crawler width (KS1 = 6) no
     static_assert(T::NACT == 0 && AD <= 32 && !T::USES_MT, "fused wide rollout, Box actions: <= 32 action dims, inline resets");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -1000,14 +1001,32 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int m2 = 0; m2 < MT2; m2++) acc[j][m2] = f32x4{b1v[j], b1v[j], b1v[j], b1v[j]};
+            // (round 6: A fragments two ahead behind scheduling fences -- an LDS round trip per fragment with the matrix pipe idle otherwise.  Only
+            //  where the registers allow it: at the Crawler width the wave's 112 weight registers leave no room, and the ring spilled: 6.0 -> 7.5 us)
+            if constexpr (AHEAD) {
+                constexpr int NF1 = KS1 * MT2;
+                bf16x8 af[3];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ks++)
+                for (int f = 0; f < 2 && f < NF1; f++) af[f] = a_frag(Xa, ldx, 16 * (f % MT2) + r16, f / MT2, g);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m2 = 0; m2 < MT2; m2++) {
-                    const bf16x8 a = a_frag(Xa, ldx, 16 * m2 + r16, ks, g);
+                for (int f = 0; f < NF1; f++) {
+                    const int ks = f / MT2, m2 = f % MT2;
+                    if (f + 2 < NF1) af[(f + 2) % 3] = a_frag(Xa, ldx, 16 * ((f + 2) % MT2) + r16, (f + 2) / MT2, g);
 #pragma unroll
-                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w1[j][ks], acc[j][m2]);
+                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(af[f % 3], w1[j][ks], acc[j][m2]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++)
+#pragma unroll
+                    for (int m2 = 0; m2 < MT2; m2++) {
+                        const bf16x8 a = a_frag(Xa, ldx, 16 * m2 + r16, ks, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w1[j][ks], acc[j][m2]);
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1021,14 +1040,30 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
             for (int j = 0; j < NTW; j++)
 #pragma unroll
                 for (int m2 = 0; m2 < MT2; m2++) acc[j][m2] = f32x4{b2v[j], b2v[j], b2v[j], b2v[j]};
+            if constexpr (AHEAD) {
+                constexpr int NF2 = KS2 * MT2;
+                bf16x8 af[3];
 #pragma unroll
-            for (int ks = 0; ks < KS2; ks++)
+                for (int f = 0; f < 2; f++) af[f] = a_frag(A1, lda, 16 * (f % MT2) + r16, f / MT2, g);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m2 = 0; m2 < MT2; m2++) {
-                    const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+                for (int f = 0; f < NF2; f++) {
+                    const int ks = f / MT2, m2 = f % MT2;
+                    if (f + 2 < NF2) af[(f + 2) % 3] = a_frag(A1, lda, 16 * ((f + 2) % MT2) + r16, (f + 2) / MT2, g);
 #pragma unroll
-                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
+                    for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(af[f % 3], w2[j][ks], acc[j][m2]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+                    for (int m2 = 0; m2 < MT2; m2++) {
+                        const bf16x8 a = a_frag(A1, lda, 16 * m2 + r16, ks, g);
+#pragma unroll
+                        for (int j = 0; j < NTW; j++) acc[j][m2] = mfma_bf(a, w2[j][ks], acc[j][m2]);
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < NTW; j++)
 #pragma unroll
@@ -1043,15 +1078,35 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
             for (int wq = 0; wq < 4; wq++)
 #pragma unroll
                 for (int q = 0; q < NT3; q++) part[wq][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (AHEAD) {
 #pragma unroll
-            for (int i2 = 0; i2 < 2; i2++)
+                for (int i2 = 0; i2 < 2; i2++) {  // (the four k-steps of a pass: their twelve reads in one batch)
+                    bf16x8 ha[4], hw[4][NT3];
 #pragma unroll
-                for (int wq = 0; wq < 4; wq++) {
-                    const int ks = wq * 2 + i2;
-                    const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+                    for (int wq = 0; wq < 4; wq++) {
+                        const int ks = wq * 2 + i2;
+                        ha[wq] = a_frag(A2, lda, 16 * mt + r16, ks, g);
 #pragma unroll
-                    for (int q = 0; q < NT3; q++) part[wq][q] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W3l + ((q * KS2 + ks) * 64 + lane) * 8), part[wq][q]);
+                        for (int q = 0; q < NT3; q++) hw[wq][q] = *reinterpret_cast<const bf16x8 *>(W3l + ((q * KS2 + ks) * 64 + lane) * 8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int wq = 0; wq < 4; wq++)
+#pragma unroll
+                        for (int q = 0; q < NT3; q++) part[wq][q] = mfma_bf(ha[wq], hw[wq][q], part[wq][q]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+                    for (int wq = 0; wq < 4; wq++) {
+                        const int ks = wq * 2 + i2;
+                        const bf16x8 a = a_frag(A2, lda, 16 * mt + r16, ks, g);
+#pragma unroll
+                        for (int q = 0; q < NT3; q++) part[wq][q] = mfma_bf(a, *reinterpret_cast<const bf16x8 *>(W3l + ((q * KS2 + ks) * 64 + lane) * 8), part[wq][q]);
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < NT3; q++) {
                 acc[q] = f32x4{b3v[q], b3v[q], b3v[q], b3v[q]};
