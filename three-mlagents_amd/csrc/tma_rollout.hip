@@ -81,6 +81,17 @@ __device__ __forceinline__ void chunk_env_step(const EnvView &v, const ChunkPtrs
 
 constexpr int CH_LDX = 17;  // observation tiles [16 envs][17]: the odd row stride spreads the 16 rows of a feature column over the banks
 
+#ifdef TMA_ROLL_TICKS  // diagnostic build (make libtma_hip_rticks.so, tools/roll_ticks.py): cycles per phase of a vector step, thread 0 of block 0
+__device__ unsigned long long g_roll_ticks[8];
+#define TMA_RTICK(i)                                                                  \
+    do {                                                                              \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_roll_ticks[i] += tn_ - rt_last;    \
+        rt_last = tn_;                                                                \
+    } while (0)
+#else
+#define TMA_RTICK(i)
+#endif
 template <class T>
 __global__ __launch_bounds__(256) void rollout_chunk_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
@@ -211,14 +222,22 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
     // this wave's net in registers for the whole launch (h64t_forward_r: the arithmetic of h64t_forward, no LDS weight reads in the step loop)
     H64FwdRegs<KS1> FR;
     h64t_load_fwd<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, KS1, FR, lane);
+#ifdef TMA_ROLL_TICKS
+    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k, p = k & 1, q = p ^ 1;
+        TMA_RTICK(0);
         const float *X = X0 + p * 16 * CH_LDX;
         float xb[KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) xb[ks] = X[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
         f32x4 o0, o1;
         h64t_forward_r<KS1>(FR, xb, KS1, o0, o1);
+#ifdef TMA_ROLL_TICKS
+        asm volatile("" : "+v"(o0), "+v"(o1));
+#endif
+        TMA_RTICK(1);
         if (wave == 1) {
             if (active) b.values[(int64_t)t * N + i] = o0[0] + o1[0];
             if (k > 0 && flag[q]) {  // timeout bootstrap of step t-1: rewards = reward + gamma * V(terminal_obs) where truncated
@@ -235,6 +254,10 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
             int act;
             float lp;
             h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
+#ifdef TMA_ROLL_TICKS
+            asm volatile("" : "+v"(act), "+v"(lp));
+#endif
+            TMA_RTICK(2);
             bool tr_flag = false;
             if (active) {
                 float rew32;
@@ -245,8 +268,10 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
             }
             const bool any = __ballot(tr_flag) != 0ull;
             if (lane == 0) flag[p] = any ? 1 : 0;
+            TMA_RTICK(3);
         }
         __syncthreads();
+        TMA_RTICK(4);
     }
     if (wave == 1) {  // bootstrap of the chunk's last step
         const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
@@ -1214,17 +1239,6 @@ __global__ __launch_bounds__(512, 2) void rollout_chunk_wide_cont_pi_kernel(EnvV
 // and log-probabilities are bit-identical to the per-step composition, which pays two launches, the observation's HBM round trip and
 // the whole weight matrix from L2 per vector step (28 us per step at 8 envs, 13 us at 4096).
 // ------------------------------------------------------------------------------------------
-#ifdef TMA_ROLL_TICKS  // diagnostic build (make libtma_hip_rticks.so, tools/roll_ticks.py): cycles per phase of a vector step, thread 0 of block 0
-__device__ unsigned long long g_roll_ticks[8];
-#define TMA_RTICK(i)                                                                  \
-    do {                                                                              \
-        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();                  \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_roll_ticks[i] += tn_ - rt_last;    \
-        rt_last = tn_;                                                                \
-    } while (0)
-#else
-#define TMA_RTICK(i)
-#endif
 template <class T, int MROWS>
 __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b,
                                                                         float *__restrict__ term_obs, int t0, int n_steps, uint32_t rng_seed,

@@ -13,7 +13,8 @@ task = sys.argv[1] if len(sys.argv) > 1 else "basic"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 T = 1024
 env = make_vector_env(task, n_envs=N, seed=1)
-m = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=1, policy_kwargs={"net_arch": [256, 256]})
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+m = PPO("MlpPolicy", env, n_steps=T, batch_size=256, n_epochs=1, seed=1, policy_kwargs={"net_arch": [H, H]})
 m.collect_rollouts(); torch.cuda.synchronize()
 L = _lib.lib()
 L.tma_debug_roll_ticks.argtypes = [C.c_void_p, C.c_int]
@@ -21,7 +22,10 @@ L.tma_debug_roll_ticks(None, 1)
 m.collect_rollouts(); torch.cuda.synchronize()
 out = (C.c_ulonglong * 8)()
 L.tma_debug_roll_ticks(out, 0)
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 names = ["loop top", "layer 1 + tanh + barrier", "layer 2 + tanh + barrier", "head chain (+ barrier on the Box tasks)", "softmax / Gaussian sampling", "env step + observation", "last barrier"]
+if H == 64:  # rollout_chunk2_h64_kernel: thread 0 = the policy wave
+    names = ["loop top + observation read", "forward (layer 1, layer 2, head)", "action (Gumbel-max, log-prob)", "env step + stores", "barrier", "-", "-"]
 v = [out[i] / T for i in range(7)]
 print(f"{task} N={N}: cycles per vector step (s_memtime: shader cycles)")
 for n, x in zip(names, v):
