@@ -384,7 +384,11 @@ typedef struct {
                                rewards[t] += gamma * V(terminal_obs[t]) of K consecutive steps in ONE launch over K*N rows
                                instead of one small launch per vector step */
 } tma_rollout_buffers;
-/* deterministic != 0: actions are the distribution's mode (first maximal logit / Gaussian mean) instead of samples -- what SB3's
+/* One launch advances every env by many vector steps ("fused chunk") for: 64-wide f32 policies on GridWorld / Push / Ball3D / WallJump /
+ * Bicycle / Glider; 256-wide policies, bf16 or f32, on the Discrete tasks with up to 32 observations and on the Box-action tasks (Crawler /
+ * Ant shapes; f32: up to 4096 envs, round 6).  Every other shape runs policy forward + env step launch by launch -- the same results bit for bit
+ * (tests/test_ppo_gpu.py::test_native_rollout_equals_stepwise_composition); TMA_NO_WIDE_FUSED=1 / TMA_NO_CONT_F32_FUSED=1 force that path.
+ * deterministic != 0: actions are the distribution's mode (first maximal logit / Gaussian mean) instead of samples -- what SB3's
  * evaluate_policy(deterministic=True) asks of the policy (backend/mlagents/training.py:177-184,240-247); evaluation.py runs whole evaluation
  * chunks through this entry point and reads the finished episodes from the env's episode log. */
 int tma_rollout_collect(tma_env *env, const float *params, const tma_policy_dims *d, const tma_rollout_buffers *b, int t_begin, int t_end,
