@@ -99,7 +99,8 @@ struct LossStats {
 template <bool CONT, int RLO = -1, int RHI = -1>
 __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1], const float *meta, const int64_t *row_off, const void *actions,
                                                  const float *log_std, int A, float amean, float astd, const HParams &hp, float invB, float *dz3,
-                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4) {
+                                                 int ld3, float (&dlsd)[2], LossStats &st, int lane, int r_lo = 0, int r_hi = 4,
+                                                 const float *act_tile = nullptr /* CONT: the tile's actions [16][32] in LDS (gathered with the observation rows, a phase ahead) instead of a global load here */) {
     const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -136,7 +137,7 @@ __device__ __forceinline__ void policy_loss_tile(const f32x4 (&acc)[CONT ? 2 : 1
                 if (col < A) {
                     const float lsd = log_std[col];
                     sd[j] = expf(lsd);
-                    const float a = valid ? static_cast<const float *>(actions)[off * A + col] : 0.0f;
+                    const float a = valid ? (act_tile ? act_tile[row * 32 + col] : static_cast<const float *>(actions)[off * A + col]) : 0.0f;
                     d[j] = a - acc[j][r];
                     lpsum += -(d[j] * d[j]) / (2.0f * (sd[j] * sd[j])) - lsd - 0.9189385332046727f;
                     entsum += 1.4189385332046727f + lsd;

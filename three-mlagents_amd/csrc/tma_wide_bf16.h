@@ -451,7 +451,7 @@ __host__ __device__ inline int grad_wide_bf_smem_bytes(int D, int H, int MT) {
     }
     const int bf = M * (Kp1 + 16) + Kp1 * M + 2 * M * (H + 16) + 2 * H * M + M * 48 + 32 * M;
     // + f32: dz3, meta, scratch, head partial sums [4 waves][MT][2][64][4], biases [2H + 32]; f64: stats [MT][4][5]; i64: row offsets x2
-    return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + 4 * 4 * 5 * 8 + 2 * M * 8;
+    return bf * 2 + (M * 34 + M * 4 + 128 + 4 * MT * 2 * 256 + 2 * H + 32) * 4 + 4 * 4 * 5 * 8 + 2 * M * 8 + 4 * 4 * 5 * 8 + M * 32 * 4;  // (+ eight-wave statistics, + the action tile)
 }
 __host__ __device__ inline int fwd_wide_bf_smem_bytes(int D, int H) {
     const int Kp1 = (D + 31) & ~31;
@@ -581,6 +581,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
     double *stat_lds = reinterpret_cast<double *>(bias + 2 * H + 32);  // [4 waves][4][5] loss statistics (lanes r16 == 0)
     int64_t *row_off = reinterpret_cast<int64_t *>(stat_lds + SLN * 5), *row_off_next = row_off + M;
     bf16_t *W3lds = reinterpret_cast<bf16_t *>(row_off_next + M);  // W8: [KS2 * NT3] head fragments of 1 KiB (grad_wide_bf_smem_bytes adds them)
+    // Box heads, 32-row groups with the direct observation gather (round 6): the group's actions [M][32] f32, gathered with the observation rows --
+    // the loss read them from global memory where it needed them, a cache-missing round trip in the middle of the phase whose MFMAs are idle
+    constexpr bool ACT_TILE = CONT && IS_PI && MT == 2 && !(KS1C > 0 && KS1C <= 2) && PASS != 2;
+    float *act_tile = reinterpret_cast<float *>(reinterpret_cast<char *>(row_off_next + M) + 4 * 4 * 5 * 8);  // (behind the statistics of four more waves: MT == 2 layouts have no W3lds)
     const int n_base = wave * 16 * NTW, nt0 = wave * NTW;
     const float invB = 1.0f / (float)mb.count;
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
@@ -895,6 +899,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             typedef const float __attribute__((address_space(1))) *gf_ptr;
             gf_ptr rbase[RW];
             bool rok[RW];
+            [[maybe_unused]] float actv[RW];
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 const int64_t off = row_off[wave * RW + i];
@@ -902,6 +907,10 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                 const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
                 rok[i] = offu >= 0;
                 rbase[i] = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (rok[i] ? offu * D : 0)));
+                if constexpr (ACT_TILE) {  // (issue only: stored to LDS behind the observation chunks)
+                    gf_ptr ab = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(static_cast<const float *>(rb.actions) + (rok[i] ? offu * A : 0)));
+                    actv[i] = ab[lane < A ? lane : 0];
+                }
             }
             constexpr int KCC = KS1C > 0 ? (32 * KS1C + 63) / 64 : 1;  // compile-time width: every column chunk in one batch
             const int c_end = KS1C > 0 ? 64 * KCC : Kp1;
@@ -931,6 +940,12 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
                             *reinterpret_cast<uint2 *>(Xt + t_off<MT>(c, wave * RW)) = uint2{pk[0], pk[1]};
                         }
                     }
+                }
+            }
+            if constexpr (ACT_TILE) {
+                if (lane < 32) {
+#pragma unroll
+                    for (int i = 0; i < RW; i++) act_tile[(wave * RW + i) * 32 + lane] = (rok[i] && lane < A) ? actv[i] : 0.0f;
                 }
             }
         }
@@ -1364,7 +1379,7 @@ __device__ __forceinline__ void grad_wide_bf_body(const float *__restrict__ para
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                       lane, r_lo, r_lo + r_n);
+                                       lane, r_lo, r_lo + r_n, ACT_TILE ? act_tile + mt * 16 * 32 : nullptr);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
