@@ -926,7 +926,9 @@ import ctypes as C, sys, torch
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
 import test_ppo_gpu as t
 out = {{}}
-for (D, A, cont, B) in [(6, 5, False, 256), (21, 3, False, 1000), (8, 2, True, 512), (4, 5, False, 200)]:  # (>= 128 samples: below that the generic kernel with float atomics runs)
+# (>= 128 samples: below that the generic kernel with float atomics runs; 105 / 8 = the reference's `ant` task, 60: another width between 32 and 112 --
+#  round 6: half groups with dW1 in registers, against the runtime-width kernel with dW1 accumulated in the slab)
+for (D, A, cont, B) in [(6, 5, False, 256), (21, 3, False, 1000), (8, 2, True, 512), (4, 5, False, 200), (105, 8, True, 256), (105, 8, True, 700), (60, 4, False, 300)]:
     pol, sd = t._policy(D, 256, A, cont)
     T, N = 16, 80
     obs, actions, old_lp, adv, ret = t._rollout(pol, sd, D, A, cont, T, N)
@@ -963,7 +965,10 @@ def test_small_wide_minibatch_deferred_dw2_equals_the_slab_path(tmp_path):
         (ga, sa), (gb, sb) = res[0][key], res[1][key]
         scale = float(gb.abs().max())
         assert float((ga - gb).abs().max()) <= 2e-6 * max(scale, 1.0), key
-        assert sa == sb, key
         D, A, cont, B = key
+        if D <= 32:
+            assert sa == sb, key
+        else:  # (eight waves against four: the head's split-K partial sums are added in another order, so log-probs differ in their last bits)
+            assert all(abs(x - y) <= 1e-5 * max(1.0, abs(y)) for x, y in zip(sa, sb)), (key, sa, sb)
         w2 = slice(D * 256 + 256, D * 256 + 256 + 65536)
         assert float(ga[w2].abs().max()) > 0 and not torch.equal(ga[w2], gb[w2]) or B <= 16, key  # (the W2 block really took another route)

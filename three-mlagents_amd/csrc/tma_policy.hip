@@ -780,25 +780,28 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else if constexpr (KT1C == 1 || KT1C == 2) {  // D <= 32: at most 8 k-steps, all weight loads issued together
-                constexpr int KSC = 4 * KT1C;
-                float w1[KSC][NTW];
+            } else if constexpr (KT1C >= 1 && KT1C <= 8) {  // D <= 32 (or, round 6, <= 112 on half groups): all weight loads issued together
+                constexpr int KSC = 4 * KT1C, KB = KSC <= 8 ? KSC : 8;  // (wider inputs: eight k-steps of weights per batch of loads)
 #pragma unroll
-                for (int ks = 0; ks < KSC; ks++)
+                for (int k0 = 0; k0 < KSC; k0 += KB) {
+                    float w1[KB][NTW];
 #pragma unroll
-                    for (int j = 0; j < NTW; j++) {
-                        const int k = 4 * ks + g;
-                        w1[ks][j] = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
-                    }
-#pragma unroll
-                for (int ks = 0; ks < KSC; ks++) {
-                    if (ks < KS1) {
-                        const int k = 4 * ks + g;
-                        const float a0 = X[r16 * ldx + k], a1 = HALF ? 0.0f : X[(16 + r16) * ldx + k];
+                    for (int ks = 0; ks < KB; ks++)
 #pragma unroll
                         for (int j = 0; j < NTW; j++) {
-                            acc[j][0] = mfma16(a0, w1[ks][j], acc[j][0]);
-                            if constexpr (!HALF) acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
+                            const int k = 4 * (k0 + ks) + g;
+                            w1[ks][j] = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
+                        }
+#pragma unroll
+                    for (int ks = 0; ks < KB; ks++) {
+                        if (k0 + ks < KS1) {
+                            const int k = 4 * (k0 + ks) + g;
+                            const float a0 = X[r16 * ldx + k], a1 = HALF ? 0.0f : X[(16 + r16) * ldx + k];
+#pragma unroll
+                            for (int j = 0; j < NTW; j++) {
+                                acc[j][0] = mfma16(a0, w1[ks][j], acc[j][0]);
+                                if constexpr (!HALF) acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
+                            }
                         }
                     }
                 }
@@ -1013,7 +1016,8 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             // rank-16 contribution would leave as a 256 KB slab that sixteen to sixty-four blocks write and slab_reduce_kernel reads back.  The group's
             // h1 and dz2 rows (16 KB each) go to the buffer instead and wide_small_reduce_kernel forms H1^T . DZ2 over the whole minibatch as ONE
             // GEMM spread over 128 workgroups, straight into the gradient.
-            const bool defer_w2 = HALF && dz1c != nullptr;  // (block-uniform)
+            constexpr bool ALWAYS_DEFER = HALF && KT1C > 2;  // (wider inputs: dW1's k-tiles take the registers dW2 would need -- the launch guarantees the buffer)
+            const bool defer_w2 = ALWAYS_DEFER || (HALF && dz1c != nullptr);  // (block-uniform)
             if (defer_w2) {
                 float *bh = dz1c, *bz = bh + (int64_t)W2_DEFER_ROWS * H;  // (dz1c: this net's [h1 | dz2] pair -- the launch passes the net stride)
                 for (int e = threadIdx.x; e < 16 * (H / 4); e += 64 * NW) {
@@ -1138,7 +1142,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     for (int j = 0; j < NTW; j++) {
         const int col = n_base + 16 * j + r16;
         if constexpr (MAIN) {
-            if (!(HALF && dz1c != nullptr)) {  // (deferred: wide_small_reduce_kernel writes dW2 straight into the gradient)
+            if (!(HALF && (KT1C > 2 || dz1c != nullptr))) {  // (deferred: wide_small_reduce_kernel writes dW2 straight into the gradient)
 #pragma unroll
                 for (int kt = 0; kt < KT2; kt++)
 #pragma unroll
@@ -2450,7 +2454,13 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         const int smemw = grad_wide_smem_bytes(L);
         // small minibatches on single-pass shapes (D <= 32): 16-row half groups, so that the reference's literal batch_size = 256 runs on 32
         // workgroups instead of 16 (TMA_NO_HALF_GROUPS=1: 32-row groups throughout)
-        const bool half = L.D <= 32 && mbi->count <= 1024 && getenv("TMA_NO_HALF_GROUPS") == nullptr;  // (at 2048 samples the doubled slab count costs more than the shorter groups save: 79.6 against 76.6 us per call)
+        // Round 6: ... and observations of up to 112 floats (the reference's `ant` task: Ant-v5, 105 observations, batch_size 256) on the same
+        // half groups with dW1 in registers (7 k-tiles: the eight-wave half-group kernel defers dW2, so it has them) -- that width took the
+        // runtime-width kernel with dW1 accumulated in the slab: 99.5 us per 256-sample gradient launch
+        static const bool no_half = getenv("TMA_NO_HALF_GROUPS") != nullptr;
+        const bool small7 = L.H == 256 && L.D > 32 && L.D <= 112 && mbi->count <= 1024 && !no_half && getenv("TMA_WIDE_NW4") == nullptr && getenv("TMA_NO_DEFER_W2") == nullptr &&
+                            (int64_t)64 * L.P + 4 * (int64_t)W2_DEFER_ROWS * L.H <= (int64_t)slab_cap(L) * L.P;  // (the deferral buffer must fit: that kernel has no dW2 accumulators)
+        const bool half = (L.D <= 32 || small7) && mbi->count <= 1024 && !no_half;  // (at 2048 samples the doubled slab count costs more than the shorter groups save: 79.6 against 76.6 us per call)
         const int64_t groups = ceil_div(mbi->count, half ? 16 : 32);  // one row group per block while there are CUs to spare, then grid-stride
         const int cap_pi = d->continuous ? 136 : 128, cap_vf = 256 - cap_pi;  // measured: the Categorical head leaves the two nets balanced
         const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
@@ -2458,7 +2468,7 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         // dW1: D <= 32 in registers; D in 161..176 (Crawler's 172: 11 k-tiles) by a second pass that keeps only dW1 in registers;
         // any other width accumulates it in place in the slab
-        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : ((L.D > 160 && L.D <= 176) ? 11 : 0));
+        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : (small7 ? 7 : ((L.D > 160 && L.D <= 176) ? 11 : 0)));
         if (kt1 == 0) {
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
             TMA_LAUNCH_CHECK();
@@ -2468,7 +2478,7 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             k<<<dim3((unsigned)(n_pi + n_vf)), dim3(256), smemw, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
             return TMA_OK;
         };
-        const bool eight = L.H == 256 && (kt1 == 1 || kt1 == 2) && getenv("TMA_WIDE_NW4") == nullptr;
+        const bool eight = L.H == 256 && (kt1 == 1 || kt1 == 2 || kt1 == 7) && getenv("TMA_WIDE_NW4") == nullptr;
         const int smem8 = grad_wide_smem_bytes(L, 8);
         // half groups on the eight-wave kernel (<= 1024 samples: <= 64 slabs in use): dW2 deferred to wide_small_reduce_kernel through a buffer behind
         // slab 64 of the workspace's slab area (TMA_NO_DEFER_W2=1: the slab path throughout)
@@ -2490,6 +2500,7 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
                 if constexpr (NTWc == 4) {  // H = 256, single-pass shapes: eight waves of 32 columns (TMA_WIDE_NW4=1: four of 64)
                     if (eight && kt1 == 1) return half ? launch8(ppo_grad_wide_kernel<C, 2, 1, 0, 0, true, 8>) : launch8(ppo_grad_wide_kernel<C, 2, 1, 0, 0, false, 8>);
                     if (eight && kt1 == 2) return half ? launch8(ppo_grad_wide_kernel<C, 2, 2, 0, 0, true, 8>) : launch8(ppo_grad_wide_kernel<C, 2, 2, 0, 0, false, 8>);
+                    if (eight && kt1 == 7) return launch8(ppo_grad_wide_kernel<C, 2, 7, 0, 0, true, 8>);  // (small7 implies half groups)
                 }
                 if (kt1 == 1) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 1, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 1>);
                 if (kt1 == 2) return half ? launch(ppo_grad_wide_kernel<C, NTWc, 2, 0, 0, true>) : launch(ppo_grad_wide_kernel<C, NTWc, 2>);
