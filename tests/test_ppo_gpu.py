@@ -188,7 +188,9 @@ def test_large_minibatch_register_accumulating_kernel(D, A):
     assert torch.allclose(g_full, 0.5 * (g_a + g_b), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("D,H,A,cont", [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 256, 3, False)])
+@pytest.mark.parametrize("D,H,A,cont", [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 256, 3, False),
+                                        (105, 256, 8, True),    # the reference's ant task (Ant-v5): two passes with seven k-tiles (round 6)
+                                        (105, 256, 6, False)])  # the same width with a Discrete head: the runtime-width kernel
 def test_wide_policy_column_parallel_kernel(D, H, A, cont):
     """B >= 32768 with H in {128, 256} takes the column-parallel register-accumulating kernel (slab reduction, no atomics
     except none at all for D <= 32)."""
@@ -211,7 +213,7 @@ def test_wide_policy_column_parallel_kernel(D, H, A, cont):
     assert abs(-st[2] / B - stats_ref["entropy_loss"]) < 1e-4 and abs(st[4] / B - stats_ref["clip_fraction"]) < 1e-6
 
 
-@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (165, 128, 4, False), (176, 192, 3, False)])
+@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (165, 128, 4, False), (176, 192, 3, False), (105, 256, 8, True), (98, 256, 3, True)])
 def test_wide_dw1_from_cached_dz1_equals_recompute_pass(D, H, A, cont, monkeypatch):
     """Crawler-width observations (161..176): the second launch computes dW1 from the dz1 operands the first one left in the
     workspace; beyond the cache (or with the test hook) it recomputes the chain instead -- the two must agree bit for bit."""

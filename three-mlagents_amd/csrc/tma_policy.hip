@@ -2468,7 +2468,8 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
         float *slabs = reinterpret_cast<float *>(ws + WS_SLABS);
         // dW1: D <= 32 in registers; D in 161..176 (Crawler's 172: 11 k-tiles) by a second pass that keeps only dW1 in registers;
         // any other width accumulates it in place in the slab
-        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : (small7 ? 7 : ((L.D > 160 && L.D <= 176) ? 11 : 0)));
+        // (round 6: 97..112 observations with a Box head at H = 256 -- Ant-v5's 105 -- by the same two passes with seven k-tiles: kt1 = 107, "7 in two passes")
+        const int kt1 = L.D <= 16 ? 1 : (L.D <= 32 ? 2 : (small7 ? 7 : ((L.D > 160 && L.D <= 176) ? 11 : ((f32_two_pass(L) && L.D <= 112) ? 107 : 0))));
         if (kt1 == 0) {
             slab_zero_w1_kernel<<<dim3(256), dim3(256), 0, s>>>(slabs, (int)pairs, L);
             TMA_LAUNCH_CHECK();
@@ -2491,7 +2492,7 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
             return TMA_OK;
         };
         // (as on the bf16 path) minibatches that fit the dz1 cache: chain pass + dW1 from the cached operands; else chain + recompute
-        float *const dz1_cache = (f32_two_pass(L) && kt1 == 11 && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
+        float *const dz1_cache = (f32_two_pass(L) && (kt1 == 11 || kt1 == 107) && mbi->count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
             ? reinterpret_cast<float *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
         auto pick = [&](auto ntw) -> int {
             constexpr int NTWc = decltype(ntw)::value;
@@ -2508,6 +2509,13 @@ static int minibatch_grad_impl(const float *params, const tma_policy_dims *d, co
                     const int rc2 = launch(ppo_grad_wide_kernel<C, NTWc, -1, 0, 11>, dz1_cache);
                     if (rc2) return rc2;
                     return dz1_cache ? launch(ppo_grad_wide_kernel<C, NTWc, 11, 2, 11>, dz1_cache) : launch(ppo_grad_wide_kernel<C, NTWc, 11, 1, 11>);
+                }
+                if constexpr (C && NTWc == 4) {
+                    if (kt1 == 107) {
+                        const int rc2 = launch(ppo_grad_wide_kernel<true, 4, -1, 0, 7>, dz1_cache);
+                        if (rc2) return rc2;
+                        return dz1_cache ? launch(ppo_grad_wide_kernel<true, 4, 7, 2, 7>, dz1_cache) : launch(ppo_grad_wide_kernel<true, 4, 7, 1, 7>);
+                    }
                 }
                 return launch(ppo_grad_wide_kernel<C, NTWc, 0>);
             };

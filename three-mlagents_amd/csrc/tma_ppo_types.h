@@ -22,7 +22,10 @@ constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_k
 
 constexpr int64_t DZ1_CAP = 1 << 18;  // samples per minibatch whose dz1 images fit the workspace cache (bf16 two-pass layouts only)
 static inline bool bf_two_pass(const PLayout &L) { return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192)); }
-static inline bool f32_two_pass(const PLayout &L) { return !L.bf16 && L.fr_pi >= 0 && L.D > 160 && L.D <= 176; }
+// (round 6: ... and 97 .. 112 observations -- the reference's ant task, Ant-v5's 105 -- with Box heads at H = 256: seven k-tiles)
+static inline bool f32_two_pass(const PLayout &L) {
+    return !L.bf16 && L.fr_pi >= 0 && ((L.D > 160 && L.D <= 176) || (L.D > 96 && L.D <= 112 && L.cont && L.H == 256));
+}
 static inline int64_t dz1_cache_bytes(const PLayout &L) {  // both nets; bf16 images or f32 MFMA operands
     return bf_two_pass(L) ? 2 * DZ1_CAP * L.H * 2 : (f32_two_pass(L) ? 2 * DZ1_CAP * L.H * 4 : 0);
 }
