@@ -14,7 +14,8 @@ from test_ppo_gpu import HP, _flatten_env_major, _hip_grad, _ref_grad_flat, _rol
 
 pytestmark = pytest.mark.gpu
 
-BF_CONFIGS = [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 192, 3, False), (40, 256, 7, True), (100, 128, 4, False)]
+BF_CONFIGS = [(6, 256, 5, False), (172, 256, 20, True), (4, 128, 5, False), (21, 192, 3, False), (40, 256, 7, True), (100, 128, 4, False),
+              (105, 256, 8, True)]  # (the reference's ant task, Ant-v5: the two-pass layout with four layer-1 k-steps, round 6)
 
 
 def _bf(x):
@@ -180,7 +181,7 @@ def test_bf16_minibatch_gradient(D, H, A, cont, B):
     assert abs(-st[2] / n - stats_emu["entropy_loss"]) < 2e-3 and abs(st[4] / n - stats_emu["clip_fraction"]) < 2e-3
 
 
-@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (40, 256, 7, True), (172, 128, 20, True), (50, 192, 4, False)])
+@pytest.mark.parametrize("D,H,A,cont", [(172, 256, 20, True), (40, 256, 7, True), (172, 128, 20, True), (50, 192, 4, False), (105, 256, 8, True), (128, 256, 3, True)])
 def test_bf16_dw1_from_cached_dz1_equals_recompute_pass(D, H, A, cont, monkeypatch):
     """Two-pass layouts (observations 33..64 / 161..192 wide): dW1 from the dz1 images PASS 0 leaves in the workspace (PASS 2)
     is bit-identical to dW1 from the recomputed chain (PASS 1, the path minibatches beyond the cache take)."""

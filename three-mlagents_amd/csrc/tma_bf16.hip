@@ -31,7 +31,8 @@ using namespace tma;
 
 int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout &R, const Minibatch &M, const HParams &hpar, const float *ws_adv,
                             float *slabs, double *slots, char *ws, int *n_pi_out, int *n_vf_out, hipStream_t s) {
-        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : 4)));
+        // (variant 5, round 6: 97..128 observations with a Box head at H = 256 -- the reference's ant task -- on the two-pass layout with four k-steps)
+        const int variant = L.D <= 16 ? 0 : (L.D <= 32 ? 1 : (L.D <= 64 ? 2 : ((L.D > 160 && L.D <= 192) ? 3 : ((L.D > 96 && L.D <= 128 && L.cont && L.H == 256) ? 5 : 4))));
         // observations of up to 32 floats: 64-row groups (half the weight bytes, barriers and latency chains per sample); wider ones keep
         // 32-row groups (their observation images would not fit next to 64-row activation images)
         static const bool force_mt2 = getenv("TMA_BF_MT2") != nullptr;  // development switch: the 32-row-group kernel
@@ -47,7 +48,8 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
         // (Categorical loss is cheaper than the DiagGaussian one; the eight-wave kernel shares a tile's loss between two waves: swept 124 .. 160, best 136 .. 140)
         const int cap_pi = npi_env > 0 ? npi_env : (L.cont ? 144 : (eight ? 140 : 136)), cap_vf = 256 - cap_pi;
         const int n_pi = (int)(groups < cap_pi ? groups : cap_pi), n_vf = (int)(groups < cap_vf ? groups : cap_vf);
-        if (variant == 4) {  // runtime observation width: dW1 accumulates in place in the slab
+        static const bool nw8_early = getenv("TMA_BF_NW4") == nullptr;
+        if (variant == 4 || (variant == 5 && !nw8_early)) {  // runtime observation width: dW1 accumulates in place in the slab
             const int zrc = tma_launch_slab_zero_w1(slabs, n_pi, L, s);
             if (zrc) return zrc;
         }
@@ -74,6 +76,23 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
             return TMA_OK;
         }
         // ... and the Crawler width (Box head, 161 .. 192 observations, two launches): 32-row groups on eight waves
+        if (nw8 && variant == 5) {  // the Ant width: the same two launches with four layer-1 k-steps
+            bf16_t *const dz1c8 = (bf_two_pass(L) && M.count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
+                ? reinterpret_cast<bf16_t *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
+            const int smem8 = smemw + 4 * 4 * 5 * 8;
+            auto launch8 = [&](auto k, bf16_t *dz1) -> int {
+                TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
+                k<<<dim3((unsigned)(n_pi + n_vf)), dim3(512), smem8, s>>>(params, L, R, M, hpar, ws_adv, slabs, slots, n_pi, dz1, DZ1_CAP * L.H);
+                return TMA_OK;
+            };
+            int rc8 = launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 4, 0, 8>, dz1c8);
+            if (rc8) return rc8;
+            rc8 = dz1c8 ? launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 4, 2, 8>, dz1c8) : launch8(ppo_grad_wide_bf_kernel<true, 2, 2, 0, 4, 1, 8>, nullptr);
+            if (rc8) return rc8;
+            TMA_LAUNCH_CHECK();
+            *n_pi_out = n_pi, *n_vf_out = n_vf;
+            return TMA_OK;
+        }
         if (nw8 && variant == 3 && L.cont && L.H == 256) {
             bf16_t *const dz1c8 = (bf_two_pass(L) && M.count <= DZ1_CAP && !getenv("TMA_NO_DZ1_CACHE"))
                 ? reinterpret_cast<bf16_t *>(ws + WS_SLABS + (int64_t)slab_cap(L) * L.P * 4 + OFFS_CAP * 4 + EPOCH_PART_BYTES + WIDE_SQ_SLOTS * 8) : nullptr;
@@ -117,7 +136,7 @@ int tma_launch_grad_wide_bf(const float *params, const PLayout &L, const Rollout
                         return dz1_cache ? launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 2>, dz1_cache)
                                          : launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 6, 1>, nullptr);
                     }
-                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>, nullptr);
+                    default: return launch(ppo_grad_wide_bf_kernel<C, NTWc, 2, 0, 0, 0>, nullptr);  // (also variant 5 with TMA_BF_NW4=1)
                 }
             };
 #ifdef TMA_BF_DEV  // development builds: discrete heads only (a third of the instantiations)

@@ -21,7 +21,10 @@ constexpr int64_t EPOCH_PART_BYTES = ((OFFS_CAP / 1024) + (OFFS_CAP / 256)) * 16
 constexpr int WIDE_SQ_SLOTS = 8192;  // sum-of-squares partials of slab_reduce_kernel for policies beyond the 256 slots at WS_NORM_PART  // sample offsets of one minibatch cached behind the slabs (int32 each) when count <= OFFS_CAP
 
 constexpr int64_t DZ1_CAP = 1 << 18;  // samples per minibatch whose dz1 images fit the workspace cache (bf16 two-pass layouts only)
-static inline bool bf_two_pass(const PLayout &L) { return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192)); }
+// (round 6: ... and 97 .. 128 observations with a Box head at H = 256 -- Ant-v5's 105 -- as four layer-1 k-steps)
+static inline bool bf_two_pass(const PLayout &L) {
+    return L.bf16 && ((L.D > 32 && L.D <= 64) || (L.D > 160 && L.D <= 192) || (L.D > 96 && L.D <= 128 && L.cont && L.H == 256));
+}
 // (round 6: ... and 97 .. 112 observations -- the reference's ant task, Ant-v5's 105 -- with Box heads at H = 256: seven k-tiles)
 static inline bool f32_two_pass(const PLayout &L) {
     return !L.bf16 && L.fr_pi >= 0 && ((L.D > 160 && L.D <= 176) || (L.D > 96 && L.D <= 112 && L.cont && L.H == 256));
