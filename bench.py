@@ -410,6 +410,11 @@ EXTRA_CONFIGS = [
          steps=6, warmup=1),
     dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="f32",
          steps=6, warmup=1),
+    # the task the reference's registry actually binds to "crawler": gym Ant-v5, 105 observations / 8 torques (backend/mlagents/envs.py:274-277) --
+    # build-defined chain dynamics at that shape (parity unpinned, as configs[4]); its literal schedule (8 envs, batch 256) and a 2048-env shard
+    dict(name="reference 'ant' shape 105/8 (Ant-v5), 8 envs, MLP(256,256) f32, the reference's literal batch 256", task="ant", n_envs=8, n_steps=1024, hidden=256, mfma="f32",
+         batch=256, steps=6, warmup=1),
+    dict(name="reference 'ant' shape 105/8, 2048 envs/GPU, MLP(256,256) f32", task="ant", n_envs=2048, n_steps=2048, hidden=256, mfma="f32", steps=4, warmup=1),
     dict(name="configs[4] Crawler-shape 172/20, 2048 envs/GPU, MLP(256,256) f32 (the reference's dtype)", task="crawler", n_envs=2048, n_steps=2048, hidden=256,
          mfma="f32", steps=6, warmup=1),
     dict(name="configs[3] Push 2048 envs/GPU, MLP(256,256) f32 weights, bf16x3 update (opt-in)", task="push", n_envs=2048, n_steps=2048, hidden=256, mfma="bf16x3",
