@@ -656,16 +656,95 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
         for (int s = 0; s < R; s++) ring[s] = sload(s);
     }
     const int64_t n_groups = (mb.count + MG - 1) / MG;
-    TMA_WTICK(0);  // prologue
-    for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
-        f32x4 zc[NTW][2];  // PASS 2: cached dz1 operands of this wave, in flight under the gathers of P0
+    // PASS 2 (round 6): a group is its observation rows and its cached dz1 operands, then 32 MFMAs per k-tile -- the rows and operands of the NEXT
+    // group are requested in front of this group's MFMAs and committed to LDS at the top of the next iteration, the row offsets a group
+    // further ahead (the gather had been two dependent round trips -- offsets, then rows -- in front of every group's MFMAs).  Same operands in
+    // the same order: the bits of PASS 1.  Measured at the Crawler width: 299 -> 288 us, of which the MFMAs are 194 (one k-tile instead of
+    // eleven: 112 us; no requests: 241 us) -- the requests still cost 47 us because their 56 destination registers do not fit beside the 176
+    // accumulators this file's -amdgpu-mfma-vgpr-form=1 puts into architectural registers: the compiler parks them in accumulator registers
+    // as they arrive, behind counted waits INSIDE the MFMA block.  Not pursued further.
+    [[maybe_unused]] float tq[3][RW];
+    [[maybe_unused]] f32x4 zq[NTW][2];
+    [[maybe_unused]] bool qok[RW];
+    [[maybe_unused]] int64_t noff2 = -1;
+    auto p2_issue = [&](int64_t g2) {  // (row_off_next holds the offsets of group g2, published by a barrier)
         if constexpr (PASS == 2) {
-            const float *gi = dz1c + (grp * 4 + wave) * (int64_t)(NTW * 512);
+            typedef const float __attribute__((address_space(1))) *gf_ptr;
+            const int Dp = (D + 3) & ~3;
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                const int64_t off = row_off_next[wave * RW + i];
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)off >> 32));
+                const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
+                qok[i] = offu >= 0;
+                gf_ptr rb_i = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (qok[i] ? offu * D : 0)));
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int c = 64 * k + lane0;
+                    if (64 * k < Dp) tq[k][i] = rb_i[c < D ? c : 0];
+                }
+            }
+            const float *gi = dz1c + (g2 * 4 + wave) * (int64_t)(NTW * 512);
 #pragma unroll
             for (int j = 0; j < NTW; j++) {
-                zc[j][0] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8);
-                zc[j][1] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8 + 4);
+                zq[j][0] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8);
+                zq[j][1] = *reinterpret_cast<const f32x4 *>(gi + (j * 64 + lane0) * 8 + 4);
             }
+        }
+    };
+    if constexpr (PASS == 2) {
+        static_assert(NW == 4, "PASS 2: the dz1 cache is laid out for four waves");
+        if (block_net < n_groups) {
+            if (threadIdx.x < M) noff2 = block_net + n_blocks_net < n_groups ? next_off(block_net + n_blocks_net) : -1;
+            p2_issue(block_net);  // (the prologue's barrier published row_off_next)
+            __syncthreads();  // every wave has read its rows' offsets
+            if (threadIdx.x < M) row_off_next[threadIdx.x] = noff2;  // (published by the loop's first barrier)
+        }
+    }
+    TMA_WTICK(0);  // prologue
+    for (int64_t grp = block_net; grp < n_groups; grp += n_blocks_net) {
+        f32x4 zc[NTW][2];  // PASS 2: cached dz1 operands of this wave (requested a group ago)
+        if constexpr (PASS == 2) {
+            const int Dp = (D + 3) & ~3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int c = 64 * k + lane0;
+                if (64 * k < Dp && c < Dp) {
+#pragma unroll
+                    for (int i = 0; i < RW; i++) X[(wave * RW + i) * ldx + c] = (qok[i] && c < D) ? tq[k][i] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; j++) zc[j][0] = zq[j][0], zc[j][1] = zq[j][1];
+            __syncthreads();  // the group's rows are in LDS; row_off_next names the next group's
+            // (the offset load in front of the row requests: it is consumed at the end of this iteration, and a wait for it must not wait for them --
+            //  vmcnt retires in order)
+            if (threadIdx.x < M) noff2 = grp + 2 * (int64_t)n_blocks_net < n_groups ? next_off(grp + 2 * (int64_t)n_blocks_net) : -1;
+            if (grp + n_blocks_net < n_groups) p2_issue(grp + n_blocks_net);
+            TMA_RELANE();
+            // (per accumulator the same sidx order as P6 of PASS 1; the A operands of k-tile kt + 1 are read under the MFMAs of k-tile kt)
+            float a[2][8];
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) a[0][sidx] = r16 < D ? X[(4 * sidx + g) * ldx + r16] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < KT1A; kt++) {
+                if (kt + 1 < KT1A) {
+                    const int krow = (kt + 1) * 16 + r16;
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; sidx++) a[(kt + 1) & 1][sidx] = krow < D ? X[(4 * sidx + g) * ldx + krow] : 0.0f;
+                }
+                // (sample step outer, column tile inner: consecutive MFMAs go to different accumulators -- with the tile outermost eight
+                //  dependent MFMAs in a row issued once per ~45 cycles instead of 32: 305 us for this pass at the Crawler width)
+#pragma unroll
+                for (int sidx = 0; sidx < 8; sidx++)
+#pragma unroll
+                    for (int j = 0; j < NTW; j++) aW1[kt][j] = mfma16(a[kt & 1][sidx], zc[j][sidx >> 2][sidx & 3], aW1[kt][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();  // X and row_off_next are read
+            if (threadIdx.x < M) row_off_next[threadIdx.x] = noff2;
+            continue;
         }
         {
             const float *pl = launder_uniform(params);
