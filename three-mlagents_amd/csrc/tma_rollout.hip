@@ -1717,35 +1717,36 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_cont_f32_kernel(Env
         }
         __syncthreads();
         TMA_RTICK(3);
-        if (wave == 0) {
-            // DiagGaussian sample + log-prob: policy_fwd_wide_kernel<CONT>'s streams and arithmetic; a lane group takes rows 2 g, 2 g + 1
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int lrow = 2 * g + r;
-                const int64_t row = row0 + lrow;
-                const uint32_t gi = v.env_offset + (uint32_t)row;
-                const uint32_t rstep = rng_step0 + (uint32_t)t;
-                float lpsum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int col = 16 * j + r16;
-                    if (col < AD) {
-                        const float mu = means[lrow * 32 + col], lsd = lsd_v[j], sd = sd_v[j];
-                        const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
-                        const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
-                        const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
-                        const float a = det ? mu : mu + sd * z;  // deterministic evaluation: the mean (policy_fwd_wide_kernel)
-                        const float dd = a - mu;
-                        lpsum += -(dd * dd) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
-                        actl[lrow * 32 + col] = a;
-                        if (row < N) act_out[((int64_t)t * N + row) * AD + col] = a;
-                    }
-                }
-                lpsum = gsum16(lpsum);
-                if (r16 == r && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
+        {
+            // DiagGaussian sample + log-prob: policy_fwd_wide_kernel<CONT>'s streams and arithmetic, ONE sample per lane over all four waves --
+            // wave w takes rows 2 w and 2 w + 1, lane group g row 2 w + (g & 1) and action columns 16 (g >> 1) + r16 (on wave 0 alone this was
+            // four samples a lane, 2.9 k cycles of a Crawler step with three waves waiting).  The two column tiles' terms of a row meet through
+            // a cross-lane read (0 + t0) + t1, then the 16-lane sum: the order of the reference loop.
+            const int lrow = 2 * wave + (g & 1), jt = g >> 1, col = 16 * jt + r16;
+            const int64_t row = row0 + lrow;
+            const uint32_t gi = v.env_offset + (uint32_t)row;
+            const uint32_t rstep = rng_step0 + (uint32_t)t;
+            float term = 0.0f;
+            if (col < AD) {
+                const float mu = means[lrow * 32 + col], lsd = lsd_v[jt], sd = sd_v[jt];
+                const float u1 = fmaxf(uniform01(mix32(rng_seed ^ (0x68E31DA4u + (uint32_t)col * 0x9E3779B9u), gi, rstep)), 5.9604645e-08f);
+                const float u2 = uniform01(mix32(rng_seed ^ (0xB5297A4Du + (uint32_t)col * 0x85EBCA77u), gi, rstep));
+                const float z = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+                const float a = det ? mu : mu + sd * z;  // deterministic evaluation: the mean (policy_fwd_wide_kernel)
+                const float dd = a - mu;
+                term = -(dd * dd) / (2.0f * (sd * sd)) - lsd - 0.9189385332046727f;
+                actl[lrow * 32 + col] = a;
+                if (row < N) act_out[((int64_t)t * N + row) * AD + col] = a;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            const float t1 = __shfl(term, (lane + 32) & 63, 64);  // (lanes of column tile 0 read their row's tile-1 term)
+            float lpsum = 0.0f;
+            lpsum += term;
+            if (16 + r16 < AD) lpsum += t1;
+            lpsum = gsum16(lpsum);
+            if (jt == 0 && r16 == 0 && row < N) b.log_probs[(int64_t)t * N + row] = lpsum;
+        }
+        __syncthreads();  // the sampled actions of every row are in LDS
+        if (wave == 0) {
             TMA_RTICK(4);
             // env step on eight lanes per env (rollout_chunk_wide_cont_pi_kernel's sequence)
             typename T::S &s = sl[my_row];
