@@ -359,7 +359,9 @@ def test_gae_flags_equals_sb3_layout(monkeypatch, T, N, scan):
                                                 ("crawler", 256, 12, "f32"),
                                                 # the float64-physics tasks of SURVEY 8f: fused on 64-wide and 256-wide bf16 nets (Bicycle, Glider), per-step otherwise
                                                 ("bicycle", 64, 200, "f32"), ("glider", 64, 200, "f32"), ("bicycle", 256, 72, "bf16"), ("glider", 256, 72, "bf16"),
-                                                ("brickbreak", 64, 100, "f32")])
+                                                ("brickbreak", 64, 100, "f32"),
+                                                # BrickBreak (45 observations) on the 8-env tiles of the f32 256-wide chunk (round 6); 2100 envs: per-step
+                                                ("brickbreak", 256, 8, "f32"), ("brickbreak", 256, 44, "f32"), ("brickbreak", 256, 2100, "f32")])
 def test_native_rollout_equals_stepwise_composition(task, hidden, N, mfma):
     """tma_rollout_collect (fused multi-step kernels: H=64 on gridworld/push/ball3d/walljump, 256-wide bf16 on every Discrete task;
     per-step launches otherwise) == policy.act -> env.step -> bootstrap composed step by step: bit-identical (same arithmetic, same

@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256, 1) void rollout_chunk_wide_f32_kernel(EnvView 
     // (rows 8 .. 15 stay zero).
     constexpr bool M8 = MROWS == 8;
     constexpr int M = MROWS, H = 256, NTW = 4, D = T::OBS, ldx = ((D + 3) & ~3) + (M8 ? 4 : 2), ld = H + (M8 ? 4 : 2), KS1 = (D + 3) >> 2, KS2 = H / 4;
-    static_assert(D <= 32 && T::NACT > 0, "fused f32 wide rollout: observations of up to 32 floats, Discrete actions");
+    static_assert(D <= (MROWS == 8 ? 64 : 32) && T::NACT > 0, "fused f32 wide rollout: observations of up to 32 floats (8-env tiles: 64), Discrete actions");
     static_assert(MROWS == 16 || MROWS == 8, "tiles of 16 or 8 envs");
     // M8 with up to 8 actions: the head as ONE fused-multiply-add chain per (env, action) on the vector ALU -- lane 8 a + e runs
     // acc = fma(h2[e][k], W3[k][a], acc) for k = 0 .. 255, the very operations (and order) of the 64 dependent 16 x 16 x 4 MFMAs, which
@@ -1825,7 +1825,8 @@ static int launch_chunk_wide_cont_f32(tma_env *env, const float *params, const P
 template <class T>
 static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayout &L, const ChunkPtrs &b, float *term_obs, int t0, int n, uint32_t rng_seed,
                                  uint32_t rng_step0, int det, hipStream_t s) {
-    if constexpr (T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) {
+    // (round 6: BrickBreak -- 45 observations, one of the reference's PPO-default tasks -- on the 8-env tiles, whose layer-1 weights are one register per k)
+    if constexpr ((T::FUSED_ROLLOUT && T::OBS <= 32 && T::NACT > 0) || T::ID == TMA_TASK_BRICKBREAK) {
         // tiles of eight envs while they give every env its own block round (up to 2048 envs); TMA_WIDE_F32_ROWS=16 / 8 forces a form (A/B, tests)
         static const int force = getenv("TMA_WIDE_F32_ROWS") ? atoi(getenv("TMA_WIDE_F32_ROWS")) : 0;
         const bool m8 = force ? force == 8 : env->v.N <= 2048;
@@ -1836,10 +1837,14 @@ static int launch_chunk_wide_f32(tma_env *env, const float *params, const PLayou
             TMA_LAUNCH_CHECK();
             return TMA_OK;
         }
-        auto k = rollout_chunk_wide_f32_kernel<T, 16>;
-        constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
-        const int smem = 16 * (ldx + 2 * 258) * 4;
-        k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        if constexpr (T::OBS <= 32) {
+            auto k = rollout_chunk_wide_f32_kernel<T, 16>;
+            constexpr int ldx = ((T::OBS + 3) & ~3) + 2;
+            const int smem = 16 * (ldx + 2 * 258) * 4;
+            k<<<dim3((unsigned)ceil_div(env->v.N, 16)), dim3(256), smem, s>>>(env->v, params, L, b, term_obs, t0, n, rng_seed, rng_step0, det);
+        } else {
+            return fail(TMA_ERR_INVALID, "fused f32 wide rollout: this task runs on 8-env tiles only (up to 2048 envs)");
+        }
         TMA_LAUNCH_CHECK();
         return TMA_OK;
     } else {
@@ -2066,7 +2071,9 @@ extern "C" int tma_rollout_collect(tma_env *env, const float *params, const tma_
     }
     // the reference's default MLP(256, 256) in f32 on the Discrete tasks (observations of up to 32 floats): policy-only fused chunk + ONE
     // batched value launch + ONE batched bootstrap launch per chunk of up to terminal_obs_slots steps
-    const bool fused_wide_f32 = !no_wide_fused && !L.bf16 && L.img_pi < 0 && L.H == 256 && env->is_reset && fused_disc &&
+    static const int rows_forced = getenv("TMA_WIDE_F32_ROWS") ? atoi(getenv("TMA_WIDE_F32_ROWS")) : 0;
+    const bool fused_bb = env->task == TMA_TASK_BRICKBREAK && !d->continuous && d->act_dim == tma_task_num_actions(env->task) && env->v.N <= 2048 && rows_forced != 16;
+    const bool fused_wide_f32 = !no_wide_fused && !L.bf16 && L.img_pi < 0 && L.H == 256 && env->is_reset && (fused_disc || fused_bb) &&
                                 d->obs_dim == tma_task_obs_dim(env->task);
     if (fused_wide_f32) {
         TMA_HIP(hipSetDevice(env->device));
