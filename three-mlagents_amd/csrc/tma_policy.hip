@@ -860,29 +860,37 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (KT1C >= 1 && KT1C <= 8) {  // D <= 32 (or, round 6, <= 112 on half groups): all weight loads issued together
-                constexpr int KSC = 4 * KT1C, KB = KSC <= 8 ? KSC : 8;  // (wider inputs: eight k-steps of weights per batch of loads)
-#pragma unroll
-                for (int k0 = 0; k0 < KSC; k0 += KB) {
-                    float w1[KB][NTW];
+                constexpr int KSC = 4 * KT1C, KB = KSC <= 8 ? KSC : 8, NB = (KSC + KB - 1) / KB;  // (wider inputs: eight k-steps of weights per batch of loads,
+                float w1[2][KB][NTW];                                                    //  the next batch requested while this one multiplies)
+                auto w1_load = [&](int b) {
 #pragma unroll
                     for (int ks = 0; ks < KB; ks++)
 #pragma unroll
                         for (int j = 0; j < NTW; j++) {
-                            const int k = 4 * (k0 + ks) + g;
-                            w1[ks][j] = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
+                            const int k = 4 * (b * KB + ks) + g;
+                            w1[b & 1][ks][j] = k < D ? Q.W1t[(int64_t)k * H + n_base + 16 * j + r16] : 0.0f;
                         }
+                };
+                w1_load(0);
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    if (b + 1 < NB) {
+                        w1_load(b + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KB; ks++) {
-                        if (k0 + ks < KS1) {
-                            const int k = 4 * (k0 + ks) + g;
+                        if (b * KB + ks < KS1) {
+                            const int k = 4 * (b * KB + ks) + g;
                             const float a0 = X[r16 * ldx + k], a1 = HALF ? 0.0f : X[(16 + r16) * ldx + k];
 #pragma unroll
                             for (int j = 0; j < NTW; j++) {
-                                acc[j][0] = mfma16(a0, w1[ks][j], acc[j][0]);
-                                if constexpr (!HALF) acc[j][1] = mfma16(a1, w1[ks][j], acc[j][1]);
+                                acc[j][0] = mfma16(a0, w1[b & 1][ks][j], acc[j][0]);
+                                if constexpr (!HALF) acc[j][1] = mfma16(a1, w1[b & 1][ks][j], acc[j][1]);
                             }
                         }
                     }
+                    if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
                 }
             } else
             for (int ks = 0; ks < KS1; ks++) {
