@@ -580,6 +580,10 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
     // buffer offsets of the NEXT group's rows (round 5): fetched during the current group, so that a group starts with ONE memory round trip --
     // metadata and observation rows together -- instead of three dependent ones (offset -> metadata -> barrier -> observation rows)
     int64_t *row_off_next = reinterpret_cast<int64_t *>(bias + 2 * H + 32);
+    // Box heads (round 6): the group's actions [M][32], gathered with the observation rows -- the loss had read them from global memory
+    // where it needed them (a cache-missing round trip in the middle of its phase: 5.5 k of a 256-sample launch's 65 k cycles at the Ant width)
+    constexpr bool ACT_TILE = CONT && IS_PI && PASS != 2;
+    float *act_tile = reinterpret_cast<float *>(row_off_next + M);
     const int n_base = wave * 16 * NTW;
     const float invB = 1.0f / (float)mb.count;
     // minibatch advantage statistics: folded here from the partials (the order of adv_final_kernel, so the same bits) instead of by a
@@ -763,6 +767,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             typedef const float __attribute__((address_space(1))) *gf_ptr;
             gf_ptr rbase[RW];
             bool rok[RW];
+            [[maybe_unused]] float actv[RW];
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 const int64_t off = row_off_next[wave * RW + i];
@@ -770,6 +775,10 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
                 const int64_t offu = (int64_t)(((uint64_t)hi << 32) | lo);
                 rok[i] = offu >= 0;
                 rbase[i] = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(rb.obs + (rok[i] ? offu * D : 0)));
+                if constexpr (ACT_TILE) {  // (issue only; stored behind the observation chunks)
+                    gf_ptr ab = reinterpret_cast<gf_ptr>(reinterpret_cast<uintptr_t>(static_cast<const float *>(rb.actions) + (rok[i] ? offu * A : 0)));
+                    actv[i] = ab[lane < A ? lane : 0];
+                }
             }
             // the metadata of row threadIdx.x: issued in front of the observation loads, consumed behind them (one round trip for both)
             int64_t moff = -1;
@@ -807,6 +816,12 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             if (threadIdx.x < M) {
                 meta[threadIdx.x * 4 + 0] = m0, meta[threadIdx.x * 4 + 1] = m1, meta[threadIdx.x * 4 + 2] = m2, meta[threadIdx.x * 4 + 3] = m3;
                 row_off[threadIdx.x] = moff;
+            }
+            if constexpr (ACT_TILE) {
+                if (lane < 32) {
+#pragma unroll
+                    for (int i = 0; i < RW; i++) act_tile[(wave * RW + i) * 32 + lane] = (rok[i] && lane < A) ? actv[i] : 0.0f;
+                }
             }
         }
         __syncthreads();
@@ -998,7 +1013,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
             }
             float *dzt = dz3 + mt * 16 * ld3;
             if constexpr (LOSS8) {
-#define TMA_WLOSS_ARGS out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane
+#define TMA_WLOSS_ARGS out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st, lane, 0, 4, (ACT_TILE ? act_tile + mt * 16 * 32 : nullptr)
                 if (loss_part == 0) policy_loss_tile<CONT, 0, 1>(TMA_WLOSS_ARGS);
                 else if (loss_part == 1) policy_loss_tile<CONT, 1, 2>(TMA_WLOSS_ARGS);
                 else if (loss_part == 2) policy_loss_tile<CONT, 2, 3>(TMA_WLOSS_ARGS);
@@ -1006,7 +1021,7 @@ __device__ __forceinline__ void grad_wide_body(const float *__restrict__ params,
 #undef TMA_WLOSS_ARGS
             } else if constexpr (IS_PI) {
                 policy_loss_tile<CONT>(out, meta + mt * 64, row_off + mt * 16, rb.actions, params + L.log_std, A, amean, astd, hp, invB, dzt, ld3, dlsd, st,
-                                       lane);
+                                       lane, 0, 4, ACT_TILE ? act_tile + mt * 16 * 32 : nullptr);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1336,7 +1351,7 @@ __global__ void slab_zero_w1_kernel(float *slabs, int n_slabs, PLayout L) {
 
 static int grad_wide_smem_bytes(const PLayout &L, int nw = 4) {
     const int ldx = ((L.D + 3) & ~3) + 2, ld = L.H + 2;
-    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + nw * 2 * 2 * 256 + 2 * L.H + 32 + 2 * 32) * 4;  // (last term: row_off_next)
+    return (32 * (ldx + 2 * ld + 34 + 4) + 2 * 32 + 64 + nw * 2 * 2 * 256 + 2 * L.H + 32 + 2 * 32 + 32 * 32) * 4;  // (last terms: row_off_next, the Box heads' action tile)
 }
 
 // grad[e] += sum over blocks of slab[b][e].  64 params x 4 slab quarters per block, partial sums folded through LDS in a
