@@ -525,6 +525,51 @@ __device__ __forceinline__ void h64t_forward_r(const H64FwdRegs<KS1C> &R, const 
         }
 }
 
+// The same forward pass split over TWO waves of a net (round 6, rollout_chunk4_h64_kernel): both form layer 1 (four MFMAs), wave `half` runs
+// layer 2 for output tiles 2 half and 2 half + 1 (32 of the 64 MFMAs) and hands their activations to the other through LDS; the head then
+// runs on half 0.  Per accumulator the operations and their order are h64t_forward's: same bits.
+template <int KS1C>
+__device__ __forceinline__ void h64t_forward_half(const H64FwdRegs<KS1C> &R, const float (&xb)[KS1C], int KS1, int half, f32x4 (&t2)[2]) {
+    f32x4 h1[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) h1[mt] = R.b1[mt];
+#pragma unroll
+    for (int ks = 0; ks < KS1C; ks++) {
+        if (ks < KS1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) h1[mt] = mfma16(R.w1[ks][mt], xb[ks], h1[mt]);
+        }
+    }
+    f32x4 h2[2];
+    h2[0] = half ? R.b2[2] : R.b2[0], h2[1] = half ? R.b2[3] : R.b2[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) h1[0][r] = tma_tanh(h1[0][r]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float wa = half ? R.w2[i][2] : R.w2[i][0], wb = half ? R.w2[i][3] : R.w2[i][1];
+        h2[0] = mfma16(wa, h1[i >> 2][i & 3], h2[0]);
+        h2[1] = mfma16(wb, h1[i >> 2][i & 3], h2[1]);
+        if (i + 4 < 16) h1[(i + 4) >> 2][(i + 4) & 3] = tma_tanh(h1[(i + 4) >> 2][(i + 4) & 3]);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) t2[m][r] = tma_tanh(h2[m][r]);
+}
+// the head over the four activated tiles (tiles 0, 1: this wave's; 2, 3: the partner's)
+template <int KS1C>
+__device__ __forceinline__ void h64t_head_r(const H64FwdRegs<KS1C> &R, const f32x4 (&ta)[2], const f32x4 (&tb)[2], f32x4 &o0, f32x4 &o1) {
+    o0 = R.b3o, o1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float h = j < 2 ? ta[j][r] : tb[j - 2][r];
+            if ((4 * j + r) & 1) o1 = mfma16(R.w3[4 * j + r], h, o1);
+            else o0 = mfma16(R.w3[4 * j + r], h, o0);
+        }
+}
+
 __device__ __forceinline__ float xg_min(float v) { return xg_reduce(v, [](float a, float b) { return fminf(a, b); }); }
 
 // Categorical action and its log-probability from the head outputs of h64t_forward (output a = g + 4 r in register r of lane group g).

@@ -308,6 +308,138 @@ __global__ __launch_bounds__(128) void rollout_chunk2_h64_kernel(EnvView v, cons
 }
 
 
+// Four-wave variant of the two-wave kernel above (round 6): each net on TWO waves -- layer 1 on both, layer 2 split by output tiles (32 MFMAs a
+// wave instead of 64), the partner's activated tiles through LDS, head / action / env step on the net's first wave.  One more workgroup barrier
+// per step (the hand-over), 1 k cycles less layer 2 on the policy chain.  Same arithmetic per element (h64t_forward_half).  TMA_ROLL2=1 selects
+// the two-wave kernel (A/B).
+template <class T>
+__global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, const float *__restrict__ params, PLayout L, ChunkPtrs b, int t0, int n_steps,
+                                                                 uint32_t rng_seed, uint32_t rng_step0, float gamma, int det) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int net = wave >> 1, half = wave & 1;  // net 0: policy, 1: value
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int D = T::OBS, KS1 = (D + 3) >> 2;
+    const int A = L.A;
+    float *vimg = smem, *pimg = smem + FWD_IMG;
+    float *X0 = smem + 2 * FWD_IMG;                    // [2][16][CH_LDX] observation tile, by step parity
+    float *XT0 = X0 + 2 * 16 * CH_LDX;                 // [2][16][CH_LDX] terminal observations of truncated rows
+    float *rw = XT0 + 2 * 16 * CH_LDX;                 // [2][16] reward of a truncated row (before the bootstrap)
+    int *trf = reinterpret_cast<int *>(rw + 32);       // [2][16] row truncated at this parity's step
+    int *flag = trf + 32;                              // [2] any row truncated
+    float *xch = reinterpret_cast<float *>(flag + 4);  // [2 nets][2 tiles][64 lanes][4]: the second wave's activated tiles; then [2][64][4] for the bootstrap pass
+    stage_fwd_image(params + L.img_vf, vimg);
+    stage_fwd_image(params + L.img_pi, pimg);
+    const int64_t N = v.N;
+    const int64_t row0 = (int64_t)blockIdx.x << 4;
+    const int64_t i = row0 + r16;
+    const bool active = g == 0 && i < N;
+    typename T::S s;
+    double er = 0.0;
+    uint32_t ce = 0;
+    if (wave == 0 && active) {
+        T::unpack(v.st, N, i, s);
+        er = v.ep_ret[i];
+        ce = v.cur_ep[i];
+    }
+    if (wave == 0) {
+        for (int e = lane; e < 2 * 16 * CH_LDX; e += 64) {
+            const int row = e / CH_LDX, c = e - row * CH_LDX;
+            X0[e] = (row < 16 && row0 + row < N && c < D) ? b.obs[((int64_t)t0 * N + row0 + row) * D + c] : 0.0f;
+            XT0[e] = 0.0f;
+        }
+        if (lane < 2) flag[lane] = 0;
+        if (lane < 32) trf[lane] = 0;
+    }
+    __syncthreads();
+    double sret = 0.0, slen = 0.0, scnt = 0.0;
+    const float *img = net == 1 ? vimg : pimg;
+    H64FwdRegs<KS1> FR;
+    h64t_load_fwd<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, KS1, FR, lane);
+    float *xq = xch + net * 512, *xq2 = xch + 1024;  // hand-over slots: [2 tiles][64][4] per net; the bootstrap pass's own
+    // one forward pass of this wave's net on the tile at `Xp`: layer-2 halves, hand-over, head on the net's first wave (o0 / o1 valid there).
+    // EVERY wave of the block must call it (one barrier inside).
+    auto forward = [&](const float *Xp, float *slot, bool mine, f32x4 &o0, f32x4 &o1) {
+        f32x4 t2[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        if (mine) {
+            float xb[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) xb[ks] = Xp[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
+            h64t_forward_half<KS1>(FR, xb, KS1, half, t2);
+            if (half == 1) {
+                *reinterpret_cast<f32x4 *>(slot + lane * 4) = t2[0];
+                *reinterpret_cast<f32x4 *>(slot + 256 + lane * 4) = t2[1];
+            }
+        }
+        __syncthreads();
+        if (mine && half == 0) {
+            f32x4 tb[2];
+            tb[0] = *reinterpret_cast<const f32x4 *>(slot + lane * 4), tb[1] = *reinterpret_cast<const f32x4 *>(slot + 256 + lane * 4);
+            h64t_head_r<KS1>(FR, t2, tb, o0, o1);
+        }
+    };
+    for (int k = 0; k < n_steps; k++) {
+        const int t = t0 + k, p = k & 1, q = p ^ 1;
+        f32x4 o0, o1;
+        forward(X0 + p * 16 * CH_LDX, xq, true, o0, o1);
+        if (wave == 2 && active) b.values[(int64_t)t * N + i] = o0[0] + o1[0];
+        const bool boot = k > 0 && flag[q];  // (block-uniform: written before the previous step's last barrier)
+        if (wave == 0) {
+            int act;
+            float lp;
+            h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
+            bool tr_flag = false;
+            if (active) {
+                float rew32;
+                chunk_env_step<T>(v, b, s, er, ce, N, i, t, act, lp, X0 + q * 16 * CH_LDX + r16 * CH_LDX, XT0 + p * 16 * CH_LDX + r16 * CH_LDX, rew32, tr_flag,
+                                  false, sret, slen, scnt);  // truncated rows: the value net writes reward + bootstrap after the barrier
+                if (tr_flag) rw[p * 16 + r16] = rew32;
+                trf[p * 16 + r16] = tr_flag ? 1 : 0;
+            }
+            const bool any = __ballot(tr_flag) != 0ull;
+            if (lane == 0) flag[p] = any ? 1 : 0;
+        }
+        if (boot) {  // timeout bootstrap of step t - 1 on the value net's waves (the policy waves only take part in the barrier)
+            f32x4 b0, b1;
+            forward(XT0 + q * 16 * CH_LDX, xq2, net == 1, b0, b1);
+            if (wave == 2 && active && trf[q * 16 + r16]) {
+                const float gv = gamma * (b0[0] + b1[0]);
+                b.rewards[(int64_t)(t - 1) * N + i] = rw[q * 16 + r16] + gv;
+            }
+        }
+        __syncthreads();
+    }
+    {  // bootstrap of the chunk's last step
+        const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
+        if (n_steps > 0 && flag[q]) {
+            f32x4 b0, b1;
+            forward(XT0 + q * 16 * CH_LDX, xq2, net == 1, b0, b1);
+            if (wave == 2 && active && trf[q * 16 + r16]) {
+                const float gv = gamma * (b0[0] + b1[0]);
+                b.rewards[(int64_t)t * N + i] = rw[q * 16 + r16] + gv;
+            }
+        }
+    }
+    if (wave != 0) return;
+    if (active) {
+        T::pack(v.st, N, i, s);
+        v.ep_ret[i] = er;
+        v.cur_ep[i] = ce;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sret += __shfl_down(sret, o, 64);
+        slen += __shfl_down(slen, o, 64);
+        scnt += __shfl_down(scnt, o, 64);
+    }
+    if (lane == 0 && scnt > 0.0) {
+        double *slot = v.stats + (row0 >> 8) * 3;
+        atomicAdd(slot + 0, sret);
+        atomicAdd(slot + 1, slen);
+        atomicAdd(slot + 2, scnt);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused rollout chunk for the reference's default 256 x 256 policy on the bf16 MFMA (BASELINE configs[2] / [3] shapes: Ball3D, Push, ...
 // with observations of up to 32 floats and a Discrete head): ONE launch advances every env by n_steps vector steps.
@@ -1915,6 +2047,15 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
     const int64_t tiles = ceil_div(env->v.N, 16);
     const int wpb = tiles >= 1024 ? 4 : 1;  // BASELINE shape (256 tiles): one wave per block so all 256 CUs take part
     const int smem = (2 * FWD_IMG + wpb * 2 * 16 * CH_LDX) * 4;
+    static const bool roll2 = getenv("TMA_ROLL2") != nullptr;  // A/B switch: the two-wave kernel
+    if (wpb == 1 && !roll2) {  // one tile per CU: each net on two waves (round 6)
+        const int smem4 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4 + 1024 + 512) * 4;
+        auto k4 = rollout_chunk4_h64_kernel<T>;
+        if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
+        k4<<<dim3((unsigned)tiles), dim3(256), smem4, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
+        TMA_LAUNCH_CHECK();
+        return TMA_OK;
+    }
     if (wpb == 1) {  // one tile per CU: split the policy and the value net of a tile over two waves
         const int smem2 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4) * 4;
         auto k2 = rollout_chunk2_h64_kernel<T>;
