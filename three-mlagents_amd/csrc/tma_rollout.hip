@@ -378,16 +378,28 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
             h64t_head_r<KS1>(FR, t2, tb, o0, o1);
         }
     };
+#ifdef TMA_ROLL_TICKS
+    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k, p = k & 1, q = p ^ 1;
         f32x4 o0, o1;
+        TMA_RTICK(0);
         forward(X0 + p * 16 * CH_LDX, xq, true, o0, o1);
+#ifdef TMA_ROLL_TICKS
+        asm volatile("" : "+v"(o0), "+v"(o1));
+#endif
+        TMA_RTICK(1);
         if (wave == 2 && active) b.values[(int64_t)t * N + i] = o0[0] + o1[0];
         const bool boot = k > 0 && flag[q];  // (block-uniform: written before the previous step's last barrier)
         if (wave == 0) {
             int act;
             float lp;
             h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
+#ifdef TMA_ROLL_TICKS
+            asm volatile("" : "+v"(act), "+v"(lp));
+#endif
+            TMA_RTICK(2);
             bool tr_flag = false;
             if (active) {
                 float rew32;
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
             }
             const bool any = __ballot(tr_flag) != 0ull;
             if (lane == 0) flag[p] = any ? 1 : 0;
+            TMA_RTICK(3);
         }
         if (boot) {  // timeout bootstrap of step t - 1 on the value net's waves (the policy waves only take part in the barrier)
             f32x4 b0, b1;
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
             }
         }
         __syncthreads();
+        TMA_RTICK(4);
     }
     {  // bootstrap of the chunk's last step
         const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
