@@ -27,3 +27,4 @@ run "TMA_EPOCH_PER_CALL=1" "tests/test_h256p_gpu.py"                          # 
 run "TMA_WIDE_F32_ROWS=16" "tests/test_ppo_gpu.py tests/test_rollout_oracle_gpu.py"   # the f32 256-wide fused rollout in 16-env tiles at every env count
 run "TMA_WIDE_F32_ROWS=8" "tests/test_ppo_gpu.py"                             # ... and in 8-env tiles beyond 2048 envs
 run "TMA_NO_CONT_F32_FUSED=1" "tests/test_ppo_gpu.py" "crawler or ant"   # the f32 Box-action rollouts step by step
+run "TMA_ROLL2=1" "tests/test_ppo_gpu.py tests/test_rollout_oracle_gpu.py" "rollout"   # the headline rollout on two waves per tile (round 5) instead of four
