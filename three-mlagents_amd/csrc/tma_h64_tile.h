@@ -578,8 +578,23 @@ __device__ __forceinline__ float xg_min(float v) { return xg_reduce(v, [](float 
 // under the head's MFMAs and the action needs two cross-lane-group reductions instead of a prefix scan over the probabilities.
 // deterministic: the first maximal logit (SB3 predict(deterministic=True)).  Softmax / log-prob arithmetic = h64t_loss's.
 // Every lane of the sample's four lane groups returns the same (action, log-prob).
-__device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A, uint32_t rng_seed, uint32_t global_env, uint32_t rng_step, int det,
-                                         int &act_out, float &lp_out, int lane) {
+// (the Gumbel noise of a lane's four outputs depends on the counters only: h64t_gumbel forms it -- a step ahead on an idle wave in
+//  rollout_chunk4_h64_kernel -- and h64t_act_n takes it; h64t_act = the two in sequence, the same values either way)
+__device__ __forceinline__ f32x4 h64t_gumbel(uint32_t rng_seed, uint32_t global_env, uint32_t rng_step, int det, int lane) {
+    const int g = lane >> 4;
+    f32x4 noise = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (!det) {
+            const uint32_t h = mix32(rng_seed ^ (0x9E3779B9u * (uint32_t)(g + 4 * r + 1)), global_env, rng_step);
+            // 23 bits: k + 0.5 is exact for k < 2^23, so u <= 1 - 2^-24 < 1 (with 24 bits k = 0xFFFFFF rounds to 2^24: u == 1, noise == +inf)
+            const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
+            noise[r] = -__logf(-__logf(u));
+        }
+    }
+    return noise;
+}
+__device__ __forceinline__ void h64t_act_n(const f32x4 &o0, const f32x4 &o1, int A, const f32x4 &noise, int &act_out, float &lp_out, int lane) {
     const int g = lane >> 4;
     float x[4], key[4];
     bool ok[4];
@@ -594,14 +609,7 @@ __device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A
     float km = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        float noise = 0.0f;
-        if (!det) {
-            const uint32_t h = mix32(rng_seed ^ (0x9E3779B9u * (uint32_t)(g + 4 * r + 1)), global_env, rng_step);
-            // 23 bits: k + 0.5 is exact for k < 2^23, so u <= 1 - 2^-24 < 1 (with 24 bits k = 0xFFFFFF rounds to 2^24: u == 1, noise == +inf)
-            const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
-            noise = -__logf(-__logf(u));
-        }
-        key[r] = ok[r] ? x[r] + noise : -INFINITY;
+        key[r] = ok[r] ? x[r] + noise[r] : -INFINITY;
         km = fmaxf(km, key[r]);
     }
     km = xg_max(km);
@@ -619,6 +627,10 @@ __device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A
     for (int r = 0; r < 4; r++) lpa += (g + 4 * r == act) ? (ok[r] ? x[r] - lse : 0.0f) : 0.0f;
     act_out = act;
     lp_out = xg_sum(lpa);
+}
+__device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A, uint32_t rng_seed, uint32_t global_env, uint32_t rng_step, int det,
+                                         int &act_out, float &lp_out, int lane) {
+    h64t_act_n(o0, o1, A, h64t_gumbel(rng_seed, global_env, rng_step, det, lane), act_out, lp_out, lane);
 }
 
 // accumulator register idx (0..104) of a NetAcc, and the flat parameter index it holds in lane `lane`

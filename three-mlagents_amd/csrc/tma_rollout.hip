@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
     int *trf = reinterpret_cast<int *>(rw + 32);       // [2][16] row truncated at this parity's step
     int *flag = trf + 32;                              // [2] any row truncated
     float *xch = reinterpret_cast<float *>(flag + 4);  // [2 nets][2 tiles][64 lanes][4]: the second wave's activated tiles; then [2][64][4] for the bootstrap pass
+    float *gnz = xch + 1536;                           // [2][64 lanes][4] Gumbel noise of a step, by step parity: formed a step ahead by wave 1
     stage_fwd_image(params + L.img_vf, vimg);
     stage_fwd_image(params + L.img_pi, pimg);
     const int64_t N = v.N;
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
         if (lane < 2) flag[lane] = 0;
         if (lane < 32) trf[lane] = 0;
     }
+    const uint32_t genv = v.env_offset + (uint32_t)i;
+    if (wave == 1) *reinterpret_cast<f32x4 *>(gnz + lane * 4) = h64t_gumbel(rng_seed, genv, rng_step0 + (uint32_t)t0, det, lane);
     __syncthreads();
     double sret = 0.0, slen = 0.0, scnt = 0.0;
     const float *img = net == 1 ? vimg : pimg;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
         if (wave == 0) {
             int act;
             float lp;
-            h64t_act(o0, o1, A, rng_seed, v.env_offset + (uint32_t)i, rng_step0 + (uint32_t)t, det, act, lp, lane);
+            h64t_act_n(o0, o1, A, *reinterpret_cast<const f32x4 *>(gnz + p * 256 + lane * 4), act, lp, lane);
 #ifdef TMA_ROLL_TICKS
             asm volatile("" : "+v"(act), "+v"(lp));
 #endif
@@ -412,6 +415,8 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
             if (lane == 0) flag[p] = any ? 1 : 0;
             TMA_RTICK(3);
         }
+        // the next step's noise on the policy net's second wave, idle from the hand-over to the end of the step (read behind the step's last barrier)
+        if (wave == 1) *reinterpret_cast<f32x4 *>(gnz + q * 256 + lane * 4) = h64t_gumbel(rng_seed, genv, rng_step0 + (uint32_t)(t + 1), det, lane);
         if (boot) {  // timeout bootstrap of step t - 1 on the value net's waves (the policy waves only take part in the barrier)
             f32x4 b0, b1;
             forward(XT0 + q * 16 * CH_LDX, xq2, net == 1, b0, b1);
@@ -2063,7 +2068,7 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
     const int smem = (2 * FWD_IMG + wpb * 2 * 16 * CH_LDX) * 4;
     static const bool roll2 = getenv("TMA_ROLL2") != nullptr;  // A/B switch: the two-wave kernel
     if (wpb == 1 && !roll2) {  // one tile per CU: each net on two waves (round 6)
-        const int smem4 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4 + 1024 + 512) * 4;
+        const int smem4 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4 + 1024 + 512 + 512) * 4;
         auto k4 = rollout_chunk4_h64_kernel<T>;
         if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
         k4<<<dim3((unsigned)tiles), dim3(256), smem4, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
