@@ -322,7 +322,7 @@ def step_kernel_rooflines(out, args, env, model, world):
         tf = N * fwd_flops / (per_step_us * 1e-6) / 1e12
         wbytes = N * (4 * D + 4 * (A_ if model.policy.continuous else 1) + 16)
         peak = MFMA_BF16_PEAK_TFLOPS if args.mfma_dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        fused = {64: "tma::rollout_chunk2_h64_kernel", 256: "tma::rollout_chunk_wide_bf_kernel" if args.mfma_dtype == "bf16" else "tma::rollout_chunk_wide_f32_kernel"}
+        fused = {64: "tma::rollout_chunk2_h64_kernel" if os.environ.get("TMA_ROLL2") else "tma::rollout_chunk4_h64_kernel", 256: "tma::rollout_chunk_wide_bf_kernel" if args.mfma_dtype == "bf16" else "tma::rollout_chunk_wide_f32_kernel"}
         out["roofline_rollout_kernel"] = {
             "kernel": f"{fused.get(args.hidden, 'per-step policy_fwd + step_kernel launches')}<{args.task}> (policy + value forward, sampling, env step with auto-reset, "
                       f"buffer writes; up to one reset-ring window = {eng.ring_depth} vector steps per launch)",
@@ -330,9 +330,10 @@ def step_kernel_rooflines(out, args, env, model, world):
             "us_per_vector_step": per_step_us, "collect_call_us": roll_us, "vector_steps_per_call": T, "flops_per_env_step_fwd": fwd_flops,
             "buffer_bytes_per_vector_step": wbytes, "buffer_write_GBps": wbytes / (per_step_us * 1e-6) / 1e9,
             "note": "HIP events around tma_rollout_collect over the whole rollout (chunk launches + MT19937 ring refills) / n_steps; flops = SURVEY.md 8d forward "
-                    "formula (both nets) x envs, bytes = 8d's rollout-buffer write (4D + 4A' + 16) x envs.  A vector step is ONE 16-env tile per CU running a "
-                    "dependent chain of ~84 MFMAs with a tanh between layers: bound by that chain's latency (DESIGN.md section 5), not by the pipe or by HBM; the "
-                    "rocprofv3 mean of the chunk kernel is in profiles/r04_bench_n1_kernel_stats.csv"}
+                    "formula (both nets) x envs, bytes = 8d's rollout-buffer write (4D + 4A' + 16) x envs.  A vector step is ONE 16-env tile per CU: each net on two "
+                    "waves (round 6), a dependent chain of 4 + 32 + 16 MFMAs with a tanh between layers, then the action and the env step on one wave: bound by "
+                    "that chain's latency (DESIGN.md section 5.1), not by the pipe or by HBM; the rocprofv3 mean of the chunk kernel is in "
+                    "profiles/r06_bench_n1_kernel_stats.csv"}
     except Exception as exc:  # noqa: BLE001
         out["roofline_rollout_kernel"] = {"error": repr(exc)}
     # GAE over the rollout that was just collected (20 B per (t, env) in SB3's layout; the engine's flag bytes make it 18)

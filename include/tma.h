@@ -387,7 +387,8 @@ typedef struct {
 /* One launch advances every env by many vector steps ("fused chunk") for: 64-wide f32 policies on GridWorld / Push / Ball3D / WallJump /
  * Bicycle / Glider; 256-wide policies, bf16 or f32, on the Discrete tasks with up to 32 observations and on the Box-action tasks (Crawler /
  * Ant shapes; f32: up to 4096 envs, round 6).  Every other shape runs policy forward + env step launch by launch -- the same results bit for bit
- * (tests/test_ppo_gpu.py::test_native_rollout_equals_stepwise_composition); TMA_NO_WIDE_FUSED=1 / TMA_NO_CONT_F32_FUSED=1 force that path.
+ * (tests/test_ppo_gpu.py::test_native_rollout_equals_stepwise_composition); TMA_NO_WIDE_FUSED=1 / TMA_NO_CONT_F32_FUSED=1 force that path;
+ * TMA_ROLL2=1 runs the 64-wide fused chunk on two waves per 16-env tile (round 5's kernel) instead of four.
  * deterministic != 0: actions are the distribution's mode (first maximal logit / Gaussian mean) instead of samples -- what SB3's
  * evaluate_policy(deterministic=True) asks of the policy (backend/mlagents/training.py:177-184,240-247); evaluation.py runs whole evaluation
  * chunks through this entry point and reads the finished episodes from the env's episode log. */

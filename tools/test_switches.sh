@@ -22,7 +22,7 @@ run "TMA_P2P_NO_FUSE=1" "tests/test_dist_gpu.py"   # the peer exchange as push /
 run "TMA_NO_SPLIT3=1" "tests/test_dist_gpu.py"      # mfma_dtype 2 on the exact-f32 kernels
 run "TMA_NO_DEFER_W2=1" "tests/test_ppo_gpu.py"            # small f32 256-wide minibatches on the slab path
 # round 6
-run "TMA_NO_PERSIST256=1" "tests/test_h256p_gpu.py tests/test_ppo_gpu.py" "not falls_back"   # the 256-wide literal-batch epoch as per-minibatch launches
+run "TMA_NO_PERSIST256=1" "tests/test_h256p_gpu.py tests/test_ppo_gpu.py" "not falls_back and not all_epochs_in_one_persistent_launch"   # the 256-wide literal-batch epoch as per-minibatch launches
 run "TMA_EPOCH_PER_CALL=1" "tests/test_h256p_gpu.py"                          # one persistent launch per epoch instead of per train()
 run "TMA_WIDE_F32_ROWS=16" "tests/test_ppo_gpu.py tests/test_rollout_oracle_gpu.py"   # the f32 256-wide fused rollout in 16-env tiles at every env count
 run "TMA_WIDE_F32_ROWS=8" "tests/test_ppo_gpu.py"                             # ... and in 8-env tiles beyond 2048 envs
