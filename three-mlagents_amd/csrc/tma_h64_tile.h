@@ -628,6 +628,57 @@ __device__ __forceinline__ void h64t_act_n(const f32x4 &o0, const f32x4 &o1, int
     act_out = act;
     lp_out = xg_sum(lpa);
 }
+// h64t_act_n in two parts for rollout_chunk4_h64_kernel, whose policy wave only needs the ACTION before it can step the envs: xs = o0 + o1.
+// h64t_argmax: the Gumbel-max draw as ONE cross-lane-group reduction over (key, index) pairs -- the greatest key, the lowest index among
+// equal keys: what h64t_act_n's max-then-first-index pair of reductions returns.
+__device__ __forceinline__ int h64t_argmax(const f32x4 &xs, int A, const f32x4 &noise, int lane) {
+    const int g = lane >> 4;
+    float kb = -INFINITY;
+    uint32_t ib = 99u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float key = (g + 4 * r < A) ? xs[r] + noise[r] : -INFINITY;
+        if (key > kb) kb = key, ib = (uint32_t)(g + 4 * r);
+    }
+    {
+        const auto k = __builtin_amdgcn_permlane16_swap(__float_as_uint(kb), __float_as_uint(kb), false, false);
+        const auto i = __builtin_amdgcn_permlane16_swap(ib, ib, false, false);
+        const float k0 = __uint_as_float(k[0]), k1 = __uint_as_float(k[1]);
+        const bool t1 = k1 > k0 || (k1 == k0 && i[1] < i[0]);
+        kb = t1 ? k1 : k0, ib = t1 ? i[1] : i[0];
+    }
+    {
+        const auto k = __builtin_amdgcn_permlane32_swap(__float_as_uint(kb), __float_as_uint(kb), false, false);
+        const auto i = __builtin_amdgcn_permlane32_swap(ib, ib, false, false);
+        const float k0 = __uint_as_float(k[0]), k1 = __uint_as_float(k[1]);
+        const bool t1 = k1 > k0 || (k1 == k0 && i[1] < i[0]);
+        ib = t1 ? i[1] : i[0];
+    }
+    return (int)ib;
+}
+// h64t_logp: log-probability of action `act` under softmax(xs): h64t_act_n's operations in its order (any wave with the same lane layout)
+__device__ __forceinline__ float h64t_logp(const f32x4 &xs, int A, int act, int lane) {
+    const int g = lane >> 4;
+    float x[4];
+    bool ok[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        ok[r] = g + 4 * r < A;
+        x[r] = ok[r] ? xs[r] : -INFINITY;
+        m = fmaxf(m, x[r]);
+    }
+    m = xg_max(m);
+    float ssum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) ssum += ok[r] ? __expf(x[r] - m) : 0.0f;
+    ssum = xg_sum(ssum);
+    const float lse = m + __logf(ssum);
+    float lpa = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) lpa += (g + 4 * r == act) ? (ok[r] ? x[r] - lse : 0.0f) : 0.0f;
+    return xg_sum(lpa);
+}
 __device__ __forceinline__ void h64t_act(const f32x4 &o0, const f32x4 &o1, int A, uint32_t rng_seed, uint32_t global_env, uint32_t rng_step, int det,
                                          int &act_out, float &lp_out, int lane) {
     h64t_act_n(o0, o1, A, h64t_gumbel(rng_seed, global_env, rng_step, det, lane), act_out, lp_out, lane);

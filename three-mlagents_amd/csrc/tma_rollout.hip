@@ -36,14 +36,18 @@ struct ChunkPtrs {
 // lane (g, s) works for env s of the tile, the observation features go straight from LDS words into MFMA B operands, no activation is
 // written to LDS, the action comes out of two cross-lane-group reductions (h64t_act) in every lane of the env's column, and the 16 lanes
 // of lane group 0 own the env states.  The LDS round-trip chain this replaces cost 3.6 us per vector step at 4096 envs.
-template <class T>
+template <class T, bool STORE = true>
 __device__ __forceinline__ void chunk_env_step(const EnvView &v, const ChunkPtrs &b, typename T::S &s, double &er, uint32_t &ce, int64_t N, int64_t i,
                                                int t, int act, float lp, float *Xn, float *XT, float &rew32, bool &tr_out, bool write_reward_if_trunc,
-                                               double &sret, double &slen, double &scnt) {
+                                               double &sret, double &slen, double &scnt, bool *te_out = nullptr) {
+    // STORE = false (rollout_chunk4_h64_kernel): the step's rollout-buffer rows are written by another wave from what this one leaves in LDS
+    // (action, reward, flags: the caller; next observation: Xn) -- everything else is the same
     constexpr int D = T::OBS;
     const int64_t off = (int64_t)t * N + i;
-    b.actions[off] = act;
-    b.log_probs[off] = lp;
+    if constexpr (STORE) {
+        b.actions[off] = act;
+        b.log_probs[off] = lp;
+    }
     double r;
     bool done;
     T::step(s, act, nullptr, r, done);
@@ -52,8 +56,11 @@ __device__ __forceinline__ void chunk_env_step(const EnvView &v, const ChunkPtrs
     const bool te = done && !hit, tr = hit;
     er += r;
     rew32 = (float)r;
-    b.terminated[off] = (uint8_t)te;
-    b.truncated[off] = (uint8_t)tr;
+    if constexpr (STORE) {
+        b.terminated[off] = (uint8_t)te;
+        b.truncated[off] = (uint8_t)tr;
+    }
+    if (te_out != nullptr) *te_out = te;
     float o[D];
     if (te || tr) {
         if (tr) {
@@ -72,10 +79,12 @@ __device__ __forceinline__ void chunk_env_step(const EnvView &v, const ChunkPtrs
         T::from_rec(rec, s);
     }
     T::obs(s, o);
-    store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
+    if constexpr (STORE) store_obs<D>(b.obs + ((int64_t)(t + 1) * N + i) * D, o);
 #pragma unroll
     for (int c = 0; c < D; c++) Xn[c] = o[c];
-    if (!tr || write_reward_if_trunc) b.rewards[off] = rew32;
+    if constexpr (STORE) {
+        if (!tr || write_reward_if_trunc) b.rewards[off] = rew32;
+    }
     tr_out = tr;
 }
 
@@ -329,6 +338,9 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
     int *flag = trf + 32;                              // [2] any row truncated
     float *xch = reinterpret_cast<float *>(flag + 4);  // [2 nets][2 tiles][64 lanes][4]: the second wave's activated tiles; then [2][64][4] for the bootstrap pass
     float *gnz = xch + 1536;                           // [2][64 lanes][4] Gumbel noise of a step, by step parity: formed a step ahead by wave 1
+    float *lgt = gnz + 512;                            // [2][64 lanes][4] the step's logits (o0 + o1), by step parity: wave 3 forms the log-probability
+    int *acts = reinterpret_cast<int *>(lgt + 512);    // [2][16] action, [2][16] reward bits, [2][16] terminated | truncated << 1 of the step
+    int *orw = acts + 32, *ofl = orw + 32;
     stage_fwd_image(params + L.img_vf, vimg);
     stage_fwd_image(params + L.img_pi, pimg);
     const int64_t N = v.N;
@@ -381,6 +393,26 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
             h64t_head_r<KS1>(FR, t2, tb, o0, o1);
         }
     };
+    // wave 3 (idle from the hand-over on): log-probability and rollout-buffer rows of step tt, left in LDS at parity `par` by wave 0 a step
+    // earlier -- h64t_logp is h64t_act_n's arithmetic on the same lane layout; the next observation is the tile the step after reads
+    auto flush_rows = [&](int tt, int par) {
+        const int a_ = acts[par * 16 + r16];
+        const float lp_ = h64t_logp(*reinterpret_cast<const f32x4 *>(lgt + par * 256 + lane * 4), A, a_, lane);
+        if (active) {
+            const int64_t off = (int64_t)tt * N + i;
+            const int fl = ofl[par * 16 + r16];
+            b.actions[off] = a_;
+            b.log_probs[off] = lp_;
+            b.terminated[off] = (uint8_t)(fl & 1);
+            b.truncated[off] = (uint8_t)(fl >> 1);
+            if (!(fl >> 1)) b.rewards[off] = __int_as_float(orw[par * 16 + r16]);
+            float o[D];
+            const float *Xr = X0 + (par ^ 1) * 16 * CH_LDX + r16 * CH_LDX;
+#pragma unroll
+            for (int c = 0; c < D; c++) o[c] = Xr[c];
+            store_obs<D>(b.obs + ((int64_t)(tt + 1) * N + i) * D, o);
+        }
+    };
 #ifdef TMA_ROLL_TICKS
     unsigned long long rt_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -398,18 +430,24 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
         if (wave == 0) {
             int act;
             float lp;
-            h64t_act_n(o0, o1, A, *reinterpret_cast<const f32x4 *>(gnz + p * 256 + lane * 4), act, lp, lane);
+            // only the action is on this wave's chain: the logits go to wave 3, which forms the log-probability and writes the step's rows
+            const f32x4 xs = o0 + o1;
+            *reinterpret_cast<f32x4 *>(lgt + p * 256 + lane * 4) = xs;
+            act = h64t_argmax(xs, A, *reinterpret_cast<const f32x4 *>(gnz + p * 256 + lane * 4), lane);
+            lp = 0.0f;
 #ifdef TMA_ROLL_TICKS
-            asm volatile("" : "+v"(act), "+v"(lp));
+            asm volatile("" : "+v"(act));
 #endif
             TMA_RTICK(2);
             bool tr_flag = false;
             if (active) {
                 float rew32;
-                chunk_env_step<T>(v, b, s, er, ce, N, i, t, act, lp, X0 + q * 16 * CH_LDX + r16 * CH_LDX, XT0 + p * 16 * CH_LDX + r16 * CH_LDX, rew32, tr_flag,
-                                  false, sret, slen, scnt);  // truncated rows: the value net writes reward + bootstrap after the barrier
+                bool te_flag = false;
+                chunk_env_step<T, false>(v, b, s, er, ce, N, i, t, act, lp, X0 + q * 16 * CH_LDX + r16 * CH_LDX, XT0 + p * 16 * CH_LDX + r16 * CH_LDX, rew32,
+                                         tr_flag, false, sret, slen, scnt, &te_flag);  // truncated rows: the value net writes reward + bootstrap after the barrier
                 if (tr_flag) rw[p * 16 + r16] = rew32;
                 trf[p * 16 + r16] = tr_flag ? 1 : 0;
+                acts[p * 16 + r16] = act, orw[p * 16 + r16] = __float_as_int(rew32), ofl[p * 16 + r16] = (te_flag ? 1 : 0) | (tr_flag ? 2 : 0);
             }
             const bool any = __ballot(tr_flag) != 0ull;
             if (lane == 0) flag[p] = any ? 1 : 0;
@@ -417,6 +455,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
         }
         // the next step's noise on the policy net's second wave, idle from the hand-over to the end of the step (read behind the step's last barrier)
         if (wave == 1) *reinterpret_cast<f32x4 *>(gnz + q * 256 + lane * 4) = h64t_gumbel(rng_seed, genv, rng_step0 + (uint32_t)(t + 1), det, lane);
+        if (wave == 3 && k > 0) flush_rows(t - 1, q);
         if (boot) {  // timeout bootstrap of step t - 1 on the value net's waves (the policy waves only take part in the barrier)
             f32x4 b0, b1;
             forward(XT0 + q * 16 * CH_LDX, xq2, net == 1, b0, b1);
@@ -430,6 +469,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
     }
     {  // bootstrap of the chunk's last step
         const int q = (n_steps - 1) & 1, t = t0 + n_steps - 1;
+        if (wave == 3 && n_steps > 0) flush_rows(t, q);  // (the rows of the last step)
         if (n_steps > 0 && flag[q]) {
             f32x4 b0, b1;
             forward(XT0 + q * 16 * CH_LDX, xq2, net == 1, b0, b1);
@@ -2068,7 +2108,7 @@ static int launch_chunk(tma_env *env, const float *params, const PLayout &L, con
     const int smem = (2 * FWD_IMG + wpb * 2 * 16 * CH_LDX) * 4;
     static const bool roll2 = getenv("TMA_ROLL2") != nullptr;  // A/B switch: the two-wave kernel
     if (wpb == 1 && !roll2) {  // one tile per CU: each net on two waves (round 6)
-        const int smem4 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4 + 1024 + 512 + 512) * 4;
+        const int smem4 = (2 * FWD_IMG + 4 * 16 * CH_LDX + 32 + 32 + 4 + 1024 + 512 + 512 + 512 + 96) * 4;
         auto k4 = rollout_chunk4_h64_kernel<T>;
         if (smem4 > 64 * 1024) TMA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
         k4<<<dim3((unsigned)tiles), dim3(256), smem4, s>>>(env->v, params, L, b, t0, n, rng_seed, rng_step0, gamma, det);
