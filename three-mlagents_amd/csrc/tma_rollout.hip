@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
     H64FwdRegs<KS1> FR;
     h64t_load_fwd<KS1>(img, img + IMG_FWD_FLOATS, img + IMG_FWD_FLOATS + 64, img + IMG_FWD_FLOATS + 128, KS1, FR, lane);
     float *xq = xch + net * 512, *xq2 = xch + 1024;  // hand-over slots: [2 tiles][64][4] per net; the bootstrap pass's own
+#ifdef TMA_ROLL_TICKS
+    unsigned long long rt_last = 0;
+#endif
     // one forward pass of this wave's net on the tile at `Xp`: layer-2 halves, hand-over, head on the net's first wave (o0 / o1 valid there).
     // EVERY wave of the block must call it (one barrier inside).
     auto forward = [&](const float *Xp, float *slot, bool mine, f32x4 &o0, f32x4 &o1) {
@@ -381,12 +384,19 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) xb[ks] = Xp[r16 * CH_LDX + ((4 * ks + g < D) ? 4 * ks + g : 16)];  // (column 16: a zero)
             h64t_forward_half<KS1>(FR, xb, KS1, half, t2);
+#ifdef TMA_ROLL_TICKS
+            asm volatile("" : "+v"(t2[0]), "+v"(t2[1]));
+            if (slot == xq) TMA_RTICK(5);
+#endif
             if (half == 1) {
                 *reinterpret_cast<f32x4 *>(slot + lane * 4) = t2[0];
                 *reinterpret_cast<f32x4 *>(slot + 256 + lane * 4) = t2[1];
             }
         }
         __syncthreads();
+#ifdef TMA_ROLL_TICKS
+        if (slot == xq) TMA_RTICK(6);
+#endif
         if (mine && half == 0) {
             f32x4 tb[2];
             tb[0] = *reinterpret_cast<const f32x4 *>(slot + lane * 4), tb[1] = *reinterpret_cast<const f32x4 *>(slot + 256 + lane * 4);
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) void rollout_chunk4_h64_kernel(EnvView v, cons
         }
     };
 #ifdef TMA_ROLL_TICKS
-    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+    rt_last = __builtin_amdgcn_s_memtime();
 #endif
     for (int k = 0; k < n_steps; k++) {
         const int t = t0 + k, p = k & 1, q = p ^ 1;

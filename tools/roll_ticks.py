@@ -25,7 +25,7 @@ L.tma_debug_roll_ticks(out, 0)
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 names = ["loop top", "layer 1 + tanh + barrier", "layer 2 + tanh + barrier", "head chain (+ barrier on the Box tasks)", "softmax / Gaussian sampling", "env step + observation", "last barrier"]
 if H == 64:  # rollout_chunk2_h64_kernel: thread 0 = the policy wave
-    names = ["loop top + observation read", "forward (layer 1, layer 2, head)", "action (Gumbel-max, log-prob)", "env step + stores", "barrier", "-", "-"]
+    names = ["loop top + observation read", "forward (whole; with slots 5, 6 stamped: the head)", "action (Gumbel-max argmax)", "env step", "barrier", "(forward: layer 1 + layer 2 half)", "(forward: hand-over barrier)"]
 v = [out[i] / T for i in range(7)]
 print(f"{task} N={N}: cycles per vector step (s_memtime: shader cycles)")
 for n, x in zip(names, v):
