@@ -334,6 +334,13 @@ def step_kernel_rooflines(out, args, env, model, world):
                     "waves (round 6), a dependent chain of 4 + 32 + 16 MFMAs with a tanh between layers, then the action and the env step on one wave: bound by "
                     "that chain's latency (DESIGN.md section 5.1), not by the pipe or by HBM; the rocprofv3 mean of the chunk kernel is in "
                     "profiles/r06_bench_n1_kernel_stats.csv"}
+        if args.hidden == 64 and args.task == "gridworld" and N == 4096:  # the committed counter summary is of this shape (tools/r06_rollout_pmc.sh)
+            pmc = os.path.join(ROOT, "profiles", "r06_rollout_kernel_pmc.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    out["roofline_rollout_kernel"]["traffic"] = json.load(f).get("traffic_bytes_per_vector_step")
+                out["roofline_rollout_kernel"]["traffic_source"] = ("profiles/r06_rollout_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                                                    "FETCH_SIZE x2; per vector step like buffer_bytes_per_vector_step)")
     except Exception as exc:  # noqa: BLE001
         out["roofline_rollout_kernel"] = {"error": repr(exc)}
     # GAE over the rollout that was just collected (20 B per (t, env) in SB3's layout; the engine's flag bytes make it 18)
